@@ -1,0 +1,201 @@
+"""ChainGraph / ChainGraphBatch: the tensor containers of the LF-MMI path.
+
+Mirror of the reference's pychain/graph.py (same class names, constructor
+signatures, attribute names, shapes, dtypes and error behaviour; §8(a) rows A4
+and A5 of SURVEY.md), re-implemented for a device-resident, shared-graph hot
+path:
+
+  * `ChainGraphBatch(one_graph, B)` keeps stride-0 *views* of the single graph
+    instead of B physical copies (reference: `.repeat(B, ...)`,
+    pychain/graph.py:101-120) and remembers the source graph, so the HIP
+    denominator reads ONE compiled plan instead of B replicas;
+  * a `ChainGraph` lazily owns its compiled device plan (see
+    `pychain_amd/_plan.py`), built once and cached per device, instead of an
+    H2D copy of every tensor on every call (chain-computation.cc:77-89).
+
+All tensors live on the CPU exactly as in the reference.
+"""
+import torch
+
+from . import simplefst
+
+__all__ = ["ChainGraph", "ChainGraphBatch"]
+
+
+class ChainGraph(object):
+    """One FST as 7 tensors + leaky/initial probs (pychain/graph.py:23-70)."""
+
+    def __init__(self, fst, initial_mode="fst", final_mode="fst", log_domain=False):
+        self.num_states = fst.num_states()
+        assert initial_mode in ["fst", "leaky"]
+        assert final_mode in ["fst", "ones"]
+        self.log_domain = log_domain
+        sfst = type(fst) if hasattr(type(fst), "fst_to_tensor") else simplefst.StdVectorFst
+        (self.forward_transitions,
+         self.forward_transition_probs,
+         self.forward_transition_indices,
+         self.backward_transitions,
+         self.backward_transition_probs,
+         self.backward_transition_indices,
+         self.final_probs) = sfst.fst_to_tensor(fst, log_domain)
+        self.num_transitions = self.forward_transitions.size(0)
+        self.is_empty = (self.num_transitions == 0)
+        self.start_state = sfst.start_state(fst)
+        if self.is_empty:
+            raise Exception("An empty graph encountered!")
+        ptype = self.forward_transition_probs.dtype
+        if log_domain:
+            self.leaky_probs = None  # no leaky-HMM in the log domain
+            assert initial_mode == "fst", "'leaky' mode is incompatible with log domain"
+            self.initial_probs = torch.full([self.num_states], float("-inf"), dtype=ptype)
+            self.initial_probs[self.start_state] = 0.0
+            if final_mode == "ones":
+                self.final_probs.fill_(0.0)
+        else:
+            self.leaky_probs = sfst.set_leaky_probs(fst)
+            if initial_mode == "fst":
+                self.initial_probs = torch.zeros([self.num_states], dtype=ptype)
+                self.initial_probs[self.start_state] = 1.0
+            else:
+                self.initial_probs = self.leaky_probs.clone()
+            if final_mode == "ones":
+                self.final_probs.fill_(1.0)
+        self._plan_cache = {}
+
+    @classmethod
+    def from_tensors(cls, forward_transitions, forward_transition_probs, forward_transition_indices,
+                     backward_transitions, backward_transition_probs, backward_transition_indices,
+                     final_probs, initial_probs, leaky_probs=None, start_state=0, log_domain=False):
+        """Build from already-laid-out tensors (what `fst_to_tensor` returns)."""
+        g = cls.__new__(cls)
+        g.num_states = int(final_probs.numel())
+        g.log_domain = bool(log_domain)
+        g.forward_transitions = forward_transitions
+        g.forward_transition_probs = forward_transition_probs
+        g.forward_transition_indices = forward_transition_indices
+        g.backward_transitions = backward_transitions
+        g.backward_transition_probs = backward_transition_probs
+        g.backward_transition_indices = backward_transition_indices
+        g.final_probs = final_probs
+        g.num_transitions = forward_transitions.size(0)
+        g.is_empty = (g.num_transitions == 0)
+        if g.is_empty:
+            raise Exception("An empty graph encountered!")
+        g.start_state = int(start_state)
+        g.leaky_probs = None if log_domain else leaky_probs
+        g.initial_probs = initial_probs
+        g._plan_cache = {}
+        return g
+
+
+_TENSORS = ("forward_transitions", "forward_transition_indices", "forward_transition_probs",
+            "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+            "final_probs", "leaky_probs", "initial_probs", "start_state")
+
+
+class ChainGraphBatch(object):
+    """B graphs as batched tensors (pychain/graph.py:73-194)."""
+
+    def __init__(self, graphs, batch_size=None, max_num_transitions=None, max_num_states=None):
+        self.shared_graph = None     # set when every row is the same ChainGraph
+        self._device_cache = {}
+        if isinstance(graphs, ChainGraph):
+            if not batch_size:
+                raise ValueError("batch size should be specified to expand a single graph")
+            self.batch_size = batch_size
+            self.initialized_by_one(graphs)
+        elif isinstance(graphs, list):
+            if not max_num_transitions:
+                raise ValueError(
+                    "max_num_transitions should be specified if given a "
+                    "a list of ChainGraph objects to initialize from")
+            if not max_num_states:
+                raise ValueError(
+                    "max_num_states should be specified if given a "
+                    "a list of ChainGraph objects to initialize from")
+            self.batch_size = len(graphs)
+            self.initialized_by_list(graphs, max_num_transitions, max_num_states)
+        else:
+            raise ValueError(
+                "ChainGraphBatch should be either initialized by a "
+                "single ChainGraph object or a list of ChainGraph objects "
+                "but given {}".format(type(graphs)))
+
+    def initialized_by_one(self, graph):
+        # Same shapes/values as the reference's .repeat(B, ...) but zero-stride
+        # views: no B-fold host copy per training step (graph.py:101-120).
+        B = self.batch_size
+        self.log_domain = graph.log_domain
+        self.num_states = graph.num_states
+        self.forward_transitions = graph.forward_transitions.unsqueeze(0).expand(B, -1, -1)
+        self.forward_transition_indices = graph.forward_transition_indices.unsqueeze(0).expand(B, -1, -1)
+        self.forward_transition_probs = graph.forward_transition_probs.unsqueeze(0).expand(B, -1)
+        self.backward_transitions = graph.backward_transitions.unsqueeze(0).expand(B, -1, -1)
+        self.backward_transition_indices = graph.backward_transition_indices.unsqueeze(0).expand(B, -1, -1)
+        self.backward_transition_probs = graph.backward_transition_probs.unsqueeze(0).expand(B, -1)
+        self.final_probs = graph.final_probs.unsqueeze(0).expand(B, -1)
+        self.leaky_probs = (graph.leaky_probs.unsqueeze(0).expand(B, -1)
+                            if not self.log_domain else None)
+        self.initial_probs = graph.initial_probs.unsqueeze(0).expand(B, -1)
+        self.start_state = graph.start_state * torch.ones(B, dtype=torch.long)
+        self.shared_graph = graph
+
+    def initialized_by_list(self, graphs, max_num_transitions, max_num_states):
+        ttype = graphs[0].forward_transitions.dtype
+        ptype = graphs[0].forward_transition_probs.dtype
+        B, K, H = self.batch_size, max_num_transitions, max_num_states
+        self.log_domain = graphs[0].log_domain
+        self.num_states = H
+        self.num_transitions = K
+        self.forward_transitions = torch.zeros([B, K, 3], dtype=ttype)
+        self.forward_transition_indices = torch.zeros([B, H, 2], dtype=ttype)
+        self.forward_transition_probs = torch.zeros([B, K], dtype=ptype)
+        self.backward_transitions = torch.zeros([B, K, 3], dtype=ttype)
+        self.backward_transition_indices = torch.zeros([B, H, 2], dtype=ttype)
+        self.backward_transition_probs = torch.zeros([B, K], dtype=ptype)
+        if self.log_domain:
+            self.leaky_probs = None
+            pad = float("-inf")   # padded states are unreachable (graph.py:140-145)
+        else:
+            self.leaky_probs = torch.zeros([B, H], dtype=ptype)
+            pad = 0.0
+        self.initial_probs = torch.full([B, H], pad, dtype=ptype)
+        self.final_probs = torch.full([B, H], pad, dtype=ptype)
+        self.start_state = torch.zeros([B], dtype=torch.long)
+        for i, g in enumerate(graphs):
+            k, h = g.num_transitions, g.num_states
+            self.forward_transitions[i, :k].copy_(g.forward_transitions)
+            self.forward_transition_indices[i, :h].copy_(g.forward_transition_indices)
+            self.forward_transition_probs[i, :k].copy_(g.forward_transition_probs)
+            self.backward_transitions[i, :k].copy_(g.backward_transitions)
+            self.backward_transition_indices[i, :h].copy_(g.backward_transition_indices)
+            self.backward_transition_probs[i, :k].copy_(g.backward_transition_probs)
+            if self.leaky_probs is not None:
+                self.leaky_probs[i, :h].copy_(g.leaky_probs)
+            self.initial_probs[i, :h].copy_(g.initial_probs)
+            self.final_probs[i, :h].copy_(g.final_probs)
+            self.start_state[i] = g.start_state
+
+    def reorder(self, new_order):
+        """Permute the batch (pychain/graph.py:177-194)."""
+        for name in _TENSORS:
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t.index_select(0, new_order))
+        self._device_cache = {}
+        # every row of a shared batch is the same graph: still shared
+
+    # ---- device staging for the HIP path (not in the reference API) -------
+    def device_tensors(self, device):
+        """Contiguous device copies of the per-sequence tensors, cached until
+        `reorder`.  Replaces the per-call `.cuda()` of chain-computation.cc:77-89."""
+        key = str(device)
+        hit = self._device_cache.get(key)
+        if hit is None:
+            hit = {}
+            for name in _TENSORS[:-1]:
+                t = getattr(self, name)
+                if t is not None:
+                    hit[name] = t.contiguous().to(device, non_blocking=True)
+            self._device_cache = {key: hit}
+        return hit
