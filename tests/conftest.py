@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+ORACLE = os.path.join(REPO, "oracle")
+if ORACLE not in sys.path:
+    sys.path.insert(0, ORACLE)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load

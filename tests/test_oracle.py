@@ -1,0 +1,108 @@
+"""The CPU restatement (oracle/chain_oracle.c) against the golden fixtures that were
+produced by running the reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from helpers import batch_from_npz, graph_from_npz, rel_err
+from pychain_amd import synthetic as syn
+from pychain_amd.graph import ChainGraphBatch
+
+OBJF_TOL = 1e-6   # |d objf| / |objf|
+GRAD_TOL = 1e-5   # max|d grad| / max|grad|
+
+
+def _check(objf, grad, ref_objf, ref_grad, otol=OBJF_TOL, gtol=GRAD_TOL):
+    assert abs(float(objf) - float(ref_objf)) <= otol * abs(float(ref_objf)) + 1e-6
+    assert rel_err(grad, ref_grad) <= gtol
+
+
+def test_g1_c1_den(golden):
+    z = golden("g1_c1_den")
+    den = graph_from_npz(z, "den_")
+    o, g = orc.chain_function(z["x"], z["lengths"], ChainGraphBatch(den, 2), float(z["leaky_coefficient"]))
+    _check(o, g, z["objf"], z["grad"])
+    assert np.all(g[1, 37:] == 0.0)            # padded frames are exactly zero
+
+
+def test_g2_c1_chainloss(golden):
+    z = golden("g2_c1_chainloss")
+    den = graph_from_npz(z, "den_")
+    numb = batch_from_npz(z, "numbatch_")
+    o, g = orc.chain_function(z["x"], z["lengths"], numb)
+    _check(o, g, z["num_objf"], z["num_grad"])
+    for avg in (1, 0):
+        loss, grad = orc.chain_loss(torch.from_numpy(z["x"]), torch.from_numpy(z["lengths"]), den, numb,
+                                    avg=bool(avg))
+        _check(loss, grad, z["loss_avg%d" % avg], z["xgrad_avg%d" % avg], otol=2e-6, gtol=2e-5)
+
+
+@pytest.mark.parametrize("case", ["leaky_ones", "fst_fst", "leaky_fst_coef01", "fst_ones_clamp"])
+def test_g3_den_variants(golden, case):
+    z = golden("g3_den_variants")
+    p = case + "__"
+    den = graph_from_npz(z, p + "den_")
+    B = z[p + "x"].shape[0]
+    o, g = orc.chain_function(z[p + "x"], z[p + "lengths"], ChainGraphBatch(den, B), float(z[p + "coef"]))
+    _check(o, g, z[p + "objf"], z[p + "grad"])
+
+
+@pytest.mark.parametrize("case", ["fst", "ones", "clamp"])
+def test_g3_num_variants(golden, case):
+    z = golden("g3_num_variants")
+    p = case + "__"
+    gb = batch_from_npz(z, p + "batch_")
+    o, g = orc.chain_function(z[p + "x"], z[p + "lengths"], gb)
+    _check(o, g, z[p + "objf"], z[p + "grad"])
+
+
+def test_g4_den_medium(golden):
+    z = golden("g4_den_medium")
+    den = syn.make_den_graph(int(z["H"]), int(z["K"]), int(z["D"]), seed=int(z["graph_seed"]))
+    x = syn.make_input(int(z["B"]), int(z["T"]), int(z["D"]), seed=int(z["x_seed"]))
+    gb = ChainGraphBatch(den, int(z["B"]))
+    per_seq, grad, ok = orc.den(gb, x.clamp(-30, 30).exp(), z["lengths"])
+    assert ok
+    np.testing.assert_allclose(per_seq, z["objf_per_seq"], rtol=2e-6)
+    assert abs(per_seq.sum() - z["objf"]) <= 2e-6 * abs(z["objf"])
+    np.testing.assert_allclose(grad.astype(np.float64).sum(-1), z["grad_rowsum"], atol=2e-5)
+    r = z["sample_rows"]
+    assert rel_err(grad[r[:, 0], r[:, 1]], z["grad_rows"]) <= GRAD_TOL
+    w = syn.uniform(99, grad.size).reshape(grad.shape)
+    assert abs((grad.astype(np.float64) * w).sum() - z["grad_checksum"]) <= 1e-5 * abs(z["grad_checksum"])
+
+
+def test_g4_num_medium(golden):
+    z = golden("g4_num_medium")
+    gb = syn.make_num_graphs(z["lengths"].tolist(), int(z["D"]), seed=int(z["graph_seed"]))
+    x = syn.make_input(int(z["B"]), int(z["T"]), int(z["D"]), seed=int(z["x_seed"]))
+    o, g = orc.chain_function(x, z["lengths"], gb)
+    assert abs(o - z["objf"]) <= 2e-6 * abs(z["objf"])
+    np.testing.assert_allclose(g.astype(np.float64).sum(-1), z["grad_rowsum"], atol=3e-5)
+    r = z["sample_rows"]
+    assert rel_err(g[r[:, 0], r[:, 1]], z["grad_rows"]) <= GRAD_TOL
+
+
+def test_g5_raw(golden):
+    z = golden("g5_raw_pychain_C")
+    db = batch_from_npz(z, "den_")
+    o, g, ok = orc.den(db, np.exp(z["x_clamped"]), z["lengths"], shared=False)
+    assert ok and bool(z["den_ok"][0])
+    _check(o.sum(), g, z["den_objf"], z["den_grad"])
+    nb = batch_from_npz(z, "num_")
+    o, lg, ok = orc.num(nb, z["x_clamped"], z["lengths"])
+    assert ok and bool(z["num_ok"][0])
+    assert abs(o.sum() - z["num_objf"]) <= OBJF_TOL * abs(z["num_objf"])
+    ref = z["num_log_grad"]
+    assert np.array_equal(np.isneginf(lg), np.isneginf(ref))     # same -inf pattern
+    fin = ~np.isneginf(ref)
+    np.testing.assert_allclose(lg[fin], ref[fin], atol=2e-5)
+
+
+def test_f64_second_opinion(golden):
+    """The same equations in float64 stay within fp32 rounding of the reference."""
+    z = golden("g1_c1_den")
+    den = graph_from_npz(z, "den_")
+    o, g = orc.chain_function(z["x"], z["lengths"], ChainGraphBatch(den, 2), flavour="f64")
+    _check(o, g, z["objf"], z["grad"], otol=2e-6, gtol=2e-5)
