@@ -1,0 +1,145 @@
+/*
+ * pychain_hip.h - C ABI of libpychain_hip.so, the MI355X (gfx950) LF-MMI
+ * forward-backward.  This library replaces the reference's native extension
+ * `pychain_C` (pytorch_binding/src, built by pytorch_binding/setup.py:4-14)
+ * wholesale.  Plain pointers and sizes only: no torch / pybind types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PYCHAIN_HIP_E* code on
+ *     error; pychain_hip_last_error() then holds a message (thread-local);
+ *   - "dev" pointers are device memory, "host" pointers host memory;
+ *   - all launches go to the caller's stream (`void* stream` is a hipStream_t);
+ *     nothing synchronises with the host and nothing allocates: scratch memory
+ *     is a caller-provided workspace sized by the *_workspace_bytes queries;
+ *   - float = IEEE fp32, indices int32, lengths int64 (the reference's dtypes,
+ *     openfst_binding/src/fstext.cc:81-104, pychain/loss.py:41).
+ *
+ * Reference boundary being replaced (pytorch_binding/src/pychain.cc):
+ *   pychain_C.forward_backward            :26-79   -> pychain_hip_den_*  (probability domain, leaky-HMM)
+ *   pychain_C.forward_backward_log_domain :81-129  -> pychain_hip_num_*  (log domain)
+ *   pychain_C.set_verbose_level           :134     -> pychain_hip_set_verbose_level
+ */
+#ifndef PYCHAIN_HIP_H_
+#define PYCHAIN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYCHAIN_HIP_ABI_VERSION 1
+
+#define PYCHAIN_HIP_OK            0
+#define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
+#define PYCHAIN_HIP_EUNSUPPORTED (-2) /* shape outside what the kernels were built for */
+#define PYCHAIN_HIP_EWORKSPACE  (-3)  /* workspace / blob too small */
+#define PYCHAIN_HIP_ELAUNCH     (-4)  /* HIP runtime reported a launch error */
+
+int         pychain_hip_abi_version(void);
+const char* pychain_hip_last_error(void);
+/* base.h:34-42 / pychain.cc:134.  The reference re-runs its invariant checks on
+ * every frame when level >= 1; here level >= 1 makes the kernels count every
+ * non-finite normaliser instead of only flagging the call. */
+void        pychain_hip_set_verbose_level(int level);
+int         pychain_hip_get_verbose_level(void);
+
+/* ------------------------------------------------------------------------
+ * Denominator graph plan  (host side, no GPU work).
+ *
+ * Compiles ONE probability-domain graph, given in the reference layout
+ * (pychain/graph.py:36-44; fstext.cc:49-116), into the device format the
+ * kernels consume: three degree-sorted, wave-tiled arc orderings
+ *   by destination state (alpha recursion; = reference backward_transitions),
+ *   by source state      (beta recursion;  = reference forward_transitions),
+ *   by pdf-id            (occupancy pass;  replaces the reference's atomicAdd
+ *                         scatter, chain-kernels.cu:53-87,230-240)
+ * plus the permuted leaky / initial / final vectors.
+ *
+ * Returns the number of bytes the plan needs (> 0).  If `blob` is NULL or
+ * `blob_bytes` is too small nothing is written (call once to size, once to
+ * fill).  The filled blob is position independent: copy it to the device with
+ * any allocator and pass the device address to pychain_hip_den_forward_backward.
+ * Negative return = error.
+ */
+int64_t pychain_hip_den_plan_build(
+    const int32_t* forward_transitions,        /* host [K,3] (src,dst,pdf)          */
+    const int32_t* forward_transition_indices, /* host [H,2] (begin,end) by source   */
+    const float*   forward_transition_probs,   /* host [K]   probabilities           */
+    const int32_t* backward_transitions,       /* host [K,3] grouped by destination  */
+    const int32_t* backward_transition_indices,/* host [H,2]                         */
+    const float*   backward_transition_probs,  /* host [K]                           */
+    const float*   leaky_probs,                /* host [H]                           */
+    const float*   initial_probs,              /* host [H]                           */
+    const float*   final_probs,                /* host [H]                           */
+    int num_states, int num_transitions, int num_pdfs,
+    void* blob, size_t blob_bytes);
+
+/* ------------------------------------------------------------------------
+ * Denominator forward-backward on the GPU (replaces pychain.cc:26-79 and all
+ * of chain-computation.cc / chain-kernels.cu).
+ *
+ * plans_dev/plan_stride_bytes: device address of the first plan and the byte
+ *   distance between the plans of consecutive sequences; 0 = every sequence
+ *   shares one graph (the ChainLoss denominator, pychain/loss.py:99).
+ * nnet_output: dev [B,T,D].  input_is_exp = 0: raw network output, clamp(-30,30)
+ *   and exp are fused into the kernels (pychain/loss.py:30,43);
+ *   input_is_exp = 1: already exp(clamp(.)) as pychain_C.forward_backward gets it.
+ * seq_lengths: dev [B] int64, 1 <= len <= T.  Any order (the reference needs
+ *   them sorted descending for pack_padded_sequence, loss.py:37-40).
+ * objf_per_seq: dev [B], log-probability of each sequence (reference returns
+ *   their sum, chain-computation.cc:229).
+ * grad: dev [B,T,D], d objf / d nnet_output, every element written (rows
+ *   t >= len are zero), multiplied by grad_scale.
+ * bad_count: dev int32[1]; zeroed by the call, incremented by every frame or
+ *   sequence whose normaliser is not finite-positive (the reference's `ok`
+ *   flag, chain-computation.cc:367-390, without a host sync).
+ */
+size_t pychain_hip_den_workspace_bytes(int B, int T, int num_states, int num_pdfs);
+int pychain_hip_den_forward_backward(
+    const void* plans_dev, int64_t plan_stride_bytes, int num_states, int num_pdfs,
+    const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+    int B, int T, float leaky_hmm_coefficient, float grad_scale,
+    float* objf_per_seq, float* grad, int32_t* bad_count,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Numerator forward-backward, log domain, one graph per sequence (replaces
+ * pychain.cc:81-129 and chain-log-domain-computation.cc / -kernels.cu).
+ * Graph tensors are the batched, zero-padded ChainGraphBatch tensors
+ * (pychain/graph.py:122-175) already on the device; graph_batch_stride = 1
+ * for per-sequence graphs, 0 when all sequences share row 0.
+ * nnet_output: dev [B,T,D] raw (clamped to [-30,30] in-kernel).
+ * grad_mode:
+ *   PYCHAIN_HIP_GRAD_LOG    grad[b,t,n] = log occupancy, -inf where zero (what
+ *                           forward_backward_log_domain returns, :57,:265)
+ *   PYCHAIN_HIP_GRAD_LINEAR grad[b,t,n] = grad_scale * occupancy (loss.py:77 fused)
+ *   PYCHAIN_HIP_GRAD_ACCUM  grad[b,t,n] += grad_scale * occupancy on the touched
+ *                           pdfs only (fused ChainLoss: pass grad_scale < 0 to
+ *                           subtract the numerator from the denominator grad)
+ */
+#define PYCHAIN_HIP_GRAD_LOG    0
+#define PYCHAIN_HIP_GRAD_LINEAR 1
+#define PYCHAIN_HIP_GRAD_ACCUM  2
+size_t pychain_hip_num_workspace_bytes(int B, int T, int num_states, int num_transitions, int num_pdfs);
+int pychain_hip_num_forward_backward(
+    const int32_t* forward_transitions,         /* dev [G,K,3] */
+    const int32_t* forward_transition_indices,  /* dev [G,H,2] */
+    const float*   forward_transition_probs,    /* dev [G,K] log-probs */
+    const int32_t* backward_transitions,        /* dev [G,K,3] */
+    const int32_t* backward_transition_indices, /* dev [G,H,2] */
+    const float*   backward_transition_probs,   /* dev [G,K] */
+    const float*   initial_probs,               /* dev [G,H] log */
+    const float*   final_probs,                 /* dev [G,H] log */
+    int graph_batch_stride,
+    const float* nnet_output, const int64_t* seq_lengths,
+    int B, int T, int num_pdfs, int num_states, int num_transitions,
+    int grad_mode, float grad_scale,
+    float* objf_per_seq, float* grad, int32_t* bad_count,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* PYCHAIN_HIP_H_ */

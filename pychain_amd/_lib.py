@@ -1,0 +1,63 @@
+"""ctypes binding of libpychain_hip.so (include/pychain_hip.h).
+
+There is NO fallback: if the shared library is missing, or a call is made with
+tensors that are not on a HIP device, this raises.  The product path never
+touches oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpychain_hip.so")
+ABI_VERSION = 1
+
+GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
+
+_lib = None
+
+_vp, _i, _f, _sz, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
+
+_SIGNATURES = {
+    "pychain_hip_abi_version": (_i, []),
+    "pychain_hip_last_error": (ctypes.c_char_p, []),
+    "pychain_hip_set_verbose_level": (None, [_i]),
+    "pychain_hip_get_verbose_level": (_i, []),
+    "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),
+    "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _f, _f,
+                                              _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pychain_hip_num_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "pychain_hip_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
+                                              _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "pychain_amd: %s is missing. Build it with `python -m pychain_amd.build_ext` "
+                "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback."
+                % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        v = l.pychain_hip_abi_version()
+        if v != ABI_VERSION:
+            raise ImportError("pychain_amd: libpychain_hip.so has ABI %d, expected %d" % (v, ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+class PychainHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc < 0:
+        raise PychainHipError("%s failed (%d): %s" % (what, rc, lib().pychain_hip_last_error().decode()))
+    return rc

@@ -1,0 +1,73 @@
+"""Compiled denominator plans: host build (C++) + device residency (cached).
+
+Replaces the reference's per-call `.cuda()` of eleven graph tensors
+(chain-computation.cc:77-89): a graph is compiled once and its plan stays on
+the device for as long as the ChainGraph object lives.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _np(t, dtype):
+    return np.ascontiguousarray(t.detach().cpu().numpy(), dtype=dtype)
+
+
+def build_plan_blob(forward_transitions, forward_transition_indices, forward_transition_probs,
+                    backward_transitions, backward_transition_indices, backward_transition_probs,
+                    leaky_probs, initial_probs, final_probs, num_pdfs):
+    """Host tensors of ONE graph -> numpy uint8 plan blob (pychain_hip_den_plan_build)."""
+    arrs = [_np(forward_transitions, np.int32), _np(forward_transition_indices, np.int32),
+            _np(forward_transition_probs, np.float32),
+            _np(backward_transitions, np.int32), _np(backward_transition_indices, np.int32),
+            _np(backward_transition_probs, np.float32),
+            _np(leaky_probs, np.float32), _np(initial_probs, np.float32), _np(final_probs, np.float32)]
+    H = arrs[1].shape[0]
+    K = arrs[0].shape[0]
+    ptrs = [a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
+    L = _lib.lib()
+    need = _lib.check(L.pychain_hip_den_plan_build(*ptrs, H, K, int(num_pdfs), None, 0), "den_plan_build")
+    blob = np.zeros(int(need), dtype=np.uint8)
+    _lib.check(L.pychain_hip_den_plan_build(*ptrs, H, K, int(num_pdfs),
+                                            blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes),
+               "den_plan_build")
+    return blob
+
+
+def graph_plan(graph, num_pdfs, device):
+    """Device plan of a ChainGraph (shared denominator), cached on the graph."""
+    key = (str(device), int(num_pdfs))
+    hit = graph._plan_cache.get(key) if hasattr(graph, "_plan_cache") else None
+    if hit is None:
+        blob = build_plan_blob(graph.forward_transitions, graph.forward_transition_indices,
+                               graph.forward_transition_probs, graph.backward_transitions,
+                               graph.backward_transition_indices, graph.backward_transition_probs,
+                               graph.leaky_probs, graph.initial_probs, graph.final_probs, num_pdfs)
+        hit = torch.from_numpy(blob).to(device)
+        if not hasattr(graph, "_plan_cache"):
+            graph._plan_cache = {}
+        graph._plan_cache[key] = hit
+    return hit
+
+
+def batch_plans(tensors, num_pdfs, device):
+    """Per-sequence probability-domain graphs ([B,...] tensors) -> (device blob, stride).
+    Rows that are all identical collapse to one shared plan (stride 0)."""
+    names = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
+             "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+             "leaky_probs", "initial_probs", "final_probs"]
+    ts = [tensors[n].detach().cpu() for n in names]
+    B = ts[0].shape[0]
+    same = all(bool((t[1:] == t[:1]).all()) for t in ts) if B > 1 else True
+    rows = [0] if same else range(B)
+    blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
+    if same:
+        return torch.from_numpy(blobs[0]).to(device), 0
+    stride = (max(b.nbytes for b in blobs) + 255) // 256 * 256
+    allb = np.zeros(stride * B, dtype=np.uint8)
+    for i, b in enumerate(blobs):
+        allb[i * stride:i * stride + b.nbytes] = b
+    return torch.from_numpy(allb).to(device), stride

@@ -1,0 +1,132 @@
+// api.hip - the C ABI of libpychain_hip.so (include/pychain_hip.h): argument checks,
+// workspace carving, launches.  No allocation, no host synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/pychain_hip.h"
+#include "common.h"
+#include "den_kernels.h"
+#include "num_kernels.h"
+
+namespace pychain_hip {
+int g_verbose_level = 0;
+char* last_error_buffer() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+namespace {
+size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+int roundup64(int x) { return (x + 63) / 64 * 64; }
+}  // namespace
+}  // namespace pychain_hip
+
+using namespace pychain_hip;
+
+extern "C" int pychain_hip_abi_version(void) { return PYCHAIN_HIP_ABI_VERSION; }
+extern "C" const char* pychain_hip_last_error(void) { return last_error_buffer(); }
+extern "C" void pychain_hip_set_verbose_level(int level) { g_verbose_level = level; }
+extern "C" int pychain_hip_get_verbose_level(void) { return g_verbose_level; }
+
+extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
+  (void)D;
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  const size_t Hp = roundup64(H);
+  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + 256;
+}
+
+extern "C" int pychain_hip_den_forward_backward(
+    const void* plans_dev, int64_t plan_stride_bytes, int H, int D,
+    const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+    int B, int T, float leaky_hmm_coefficient, float grad_scale,
+    float* objf_per_seq, float* grad, int32_t* bad_count,
+    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!plans_dev || !nnet_output || !seq_lengths || !objf_per_seq || !grad || !bad_count || !workspace)
+    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: null pointer argument");
+  if (B <= 0 || T <= 0 || H <= 0 || D <= 0)
+    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: bad sizes B=%d T=%d H=%d D=%d", B, T, H, D);
+  if (H > 65535 || D > 65535)
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "den_forward_backward: num_states and num_pdfs must be <= 65535");
+  // chain-computation.cc:68 asserts 0 < coefficient < 1 (compiled out under NDEBUG); here it is an error
+  if (!(leaky_hmm_coefficient > 0.f && leaky_hmm_coefficient < 1.f))
+    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: leaky_hmm_coefficient must be in (0,1), got %g",
+                (double)leaky_hmm_coefficient);
+  if (plan_stride_bytes < 0 || (plan_stride_bytes & 15))
+    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: plan stride must be a non-negative multiple of 16");
+  if (((uintptr_t)plans_dev | (uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)workspace) & 15)
+    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: plan, nnet_output, grad and workspace must be 16-byte aligned");
+  if (workspace_bytes < pychain_hip_den_workspace_bytes(B, T, H, D))
+    return fail(PYCHAIN_HIP_EWORKSPACE, "den_forward_backward: workspace too small (%zu < %zu)", workspace_bytes,
+                pychain_hip_den_workspace_bytes(B, T, H, D));
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
+    return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: hipMemsetAsync failed");
+  DenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.plans = (const char*)plans_dev; a.plan_stride = plan_stride_bytes;
+  a.x = nnet_output; a.lengths = seq_lengths; a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
+  a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H);
+  a.input_is_exp = input_is_exp ? 1 : 0;
+  a.frames_per_block = 8;
+  a.coef = leaky_hmm_coefficient; a.grad_scale = grad_scale;
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.alpha_store = (float*)ws;
+  a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
+  const char* why = nullptr;
+  hipError_t e = launch_den(a, (D + 63) / 64, st, &why);
+  if (e != hipSuccess)
+    return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "den_forward_backward: %s",
+                why ? why : hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
+extern "C" size_t pychain_hip_num_workspace_bytes(int B, int T, int H, int K, int D) {
+  (void)K; (void)D;
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  return align256(4 * (size_t)B * (T + 1) * H) + align256(4 * (size_t)B * (T + 1)) + 256;
+}
+
+extern "C" int pychain_hip_num_forward_backward(
+    const int32_t* ft, const int32_t* fi, const float* fp,
+    const int32_t* bt, const int32_t* bi, const float* bp,
+    const float* initial, const float* final_, int graph_batch_stride,
+    const float* nnet_output, const int64_t* seq_lengths,
+    int B, int T, int D, int H, int K, int grad_mode, float grad_scale,
+    float* objf_per_seq, float* grad, int32_t* bad_count,
+    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ft || !fi || !fp || !bt || !bi || !bp || !initial || !final_ || !nnet_output || !seq_lengths ||
+      !objf_per_seq || !grad || !bad_count || !workspace)
+    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: null pointer argument");
+  if (B <= 0 || T <= 0 || H <= 0 || D <= 0 || K <= 0)
+    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: bad sizes B=%d T=%d H=%d K=%d D=%d", B, T, H, K, D);
+  if (H > 65535 || D > 65535)
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "num_forward_backward: num_states and num_pdfs must be <= 65535");
+  if (graph_batch_stride != 0 && graph_batch_stride != 1)
+    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: graph_batch_stride must be 0 or 1");
+  if (grad_mode < PYCHAIN_HIP_GRAD_LOG || grad_mode > PYCHAIN_HIP_GRAD_ACCUM)
+    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: unknown grad_mode %d", grad_mode);
+  if (((uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)fi | (uintptr_t)bi) & 15)
+    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: nnet_output, grad and index tensors must be 16-byte aligned");
+  if (workspace_bytes < pychain_hip_num_workspace_bytes(B, T, H, K, D))
+    return fail(PYCHAIN_HIP_EWORKSPACE, "num_forward_backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
+    return fail(PYCHAIN_HIP_ELAUNCH, "num_forward_backward: hipMemsetAsync failed");
+  NumArgs a;
+  memset(&a, 0, sizeof(a));
+  a.fwd_trans = ft; a.fwd_idx = fi; a.fwd_probs = fp; a.bwd_trans = bt; a.bwd_idx = bi; a.bwd_probs = bp;
+  a.initial = initial; a.final_ = final_; a.x = nnet_output; a.lengths = seq_lengths;
+  a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
+  a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
+  a.grad_mode = grad_mode; a.grad_scale = grad_scale;
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.alpha_ws = (float*)ws;
+  a.logtot_ws = (float*)(ws + align256(4 * (size_t)B * (T + 1) * H));
+  const char* why = nullptr;
+  hipError_t e = launch_num(a, st, &why);
+  if (e != hipSuccess)
+    return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "num_forward_backward: %s",
+                why ? why : hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}

@@ -1,0 +1,189 @@
+// plan.cpp - host-side compiler from the reference graph layout to the device plan.
+// See plan_format.h for the format and include/pychain_hip.h for the contract.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/pychain_hip.h"
+#include "common.h"
+#include "plan_format.h"
+
+namespace {
+
+struct Arc { uint32_t i0, i1; float p; };
+
+struct BuiltTile {
+  std::vector<WaveEntry> waves;
+  std::vector<GroupEntry> groups;   // wave order
+  std::vector<uint32_t> slots;      // 2 words per lane per slot-row
+  int total_slot_rows = 0, max_wave = 0, nrows = 0;
+  std::vector<int> row_order;       // sorted position -> original row id
+};
+
+// rows[r] = arcs of original row r.  `order` = row ids sorted by descending degree
+// (stable), rows beyond order.size() do not exist.  npos = number of row positions
+// (multiple of 64) the output vector has.
+BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vector<int>& order,
+                     int npos, int nwaves) {
+  BuiltTile t;
+  t.row_order = order;
+  t.nrows = (int)order.size();
+  const int ngroups = npos / 64;
+  std::vector<int> gsl(ngroups, 0);
+  for (int g = 0; g < ngroups; g++)
+    for (int l = 0; l < 64; l++) {
+      const int pos = g * 64 + l;
+      if (pos < (int)order.size()) gsl[g] = std::max(gsl[g], (int)rows[order[pos]].size());
+    }
+  // longest-processing-time-first: groups are already in descending slot order
+  std::vector<std::vector<int>> per_wave(nwaves);
+  std::vector<int> load(nwaves, 0);
+  for (int g = 0; g < ngroups; g++) {
+    int w = 0;
+    for (int i = 1; i < nwaves; i++) if (load[i] < load[w]) w = i;
+    per_wave[w].push_back(g);
+    load[w] += gsl[g] + 1;        // +1: the per-group store/bookkeeping cost
+  }
+  t.waves.resize(nwaves);
+  int row_cursor = 0;
+  for (int w = 0; w < nwaves; w++) {
+    WaveEntry& we = t.waves[w];
+    we.first_group = (int)t.groups.size();
+    we.ngroups = (int)per_wave[w].size();
+    we.slot_row_begin = row_cursor;
+    int n = 0;
+    for (int g : per_wave[w]) {
+      t.groups.push_back(GroupEntry{g * 64, gsl[g]});
+      for (int j = 0; j < gsl[g]; j++)
+        for (int l = 0; l < 64; l++) {
+          const int pos = g * 64 + l;
+          uint32_t idx = 0; float p = 0.f;
+          if (pos < (int)order.size() && j < (int)rows[order[pos]].size()) {
+            const Arc& a = rows[order[pos]][j];
+            idx = a.i0 | (a.i1 << 16); p = a.p;
+          }
+          uint32_t pb; memcpy(&pb, &p, 4);
+          t.slots.push_back(idx); t.slots.push_back(pb);
+        }
+      n += gsl[g];
+    }
+    we.nslot_rows = n;
+    row_cursor += n;
+    t.max_wave = std::max(t.max_wave, n);
+  }
+  t.total_slot_rows = row_cursor;
+  return t;
+}
+
+std::vector<int> sort_by_degree(const std::vector<int>& deg, const std::vector<int>& ids) {
+  std::vector<int> o = ids;
+  std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return deg[a] > deg[b]; });
+  return o;
+}
+
+size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+
+}  // namespace
+
+extern "C" int64_t pychain_hip_den_plan_build(
+    const int32_t* ft, const int32_t* fi, const float* fp,
+    const int32_t* bt, const int32_t* bi, const float* bp,
+    const float* leaky, const float* initial, const float* final_,
+    int H, int K, int D, void* blob, size_t blob_bytes) {
+  if (!ft || !fi || !fp || !bt || !bi || !bp || !leaky || !initial || !final_)
+    return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: null graph pointer");
+  if (H <= 0 || K <= 0 || D <= 0)
+    return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: empty graph (H=%d K=%d D=%d)", H, K, D);
+  if (H > 65535 || D > 65535)
+    return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED,
+                             "den_plan_build: packed arc format needs num_states and num_pdfs <= 65535 "
+                             "(got H=%d D=%d)", H, D);
+  for (int h = 0; h < H; h++) {
+    if (fi[2 * h] < 0 || fi[2 * h + 1] < fi[2 * h] || fi[2 * h + 1] > K ||
+        bi[2 * h] < 0 || bi[2 * h + 1] < bi[2 * h] || bi[2 * h + 1] > K)
+      return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: transition_indices of state %d out of range", h);
+  }
+  for (int k = 0; k < K; k++) {
+    const int32_t* a = ft + 3 * k; const int32_t* b = bt + 3 * k;
+    if (a[0] < 0 || a[0] >= H || a[1] < 0 || a[1] >= H || a[2] < 0 || a[2] >= D ||
+        b[0] < 0 || b[0] >= H || b[1] < 0 || b[1] >= H || b[2] < 0 || b[2] >= D)
+      return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: transition %d has a state or pdf out of range", k);
+  }
+  const int Hp = (H + 63) / 64 * 64;
+  std::vector<int> indeg(H), outdeg(H), ids(H);
+  std::iota(ids.begin(), ids.end(), 0);
+  for (int h = 0; h < H; h++) { indeg[h] = bi[2 * h + 1] - bi[2 * h]; outdeg[h] = fi[2 * h + 1] - fi[2 * h]; }
+  const std::vector<int> order_a = sort_by_degree(indeg, ids), order_b = sort_by_degree(outdeg, ids);
+  std::vector<int> pa(H), pb(H);
+  for (int i = 0; i < H; i++) { pa[order_a[i]] = i; pb[order_b[i]] = i; }
+
+  // alpha rows: arcs entering h, in the reference's order (fstext.cc:63-76)
+  std::vector<std::vector<Arc>> rows_a(H), rows_b(H), rows_g(D);
+  for (int h = 0; h < H; h++) {
+    for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++) {
+      if (bt[3 * k + 1] != h)
+        return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: backward transition %d is not grouped under its destination", k);
+      rows_a[h].push_back(Arc{(uint32_t)pa[bt[3 * k]], (uint32_t)bt[3 * k + 2], bp[k]});
+    }
+    for (int k = fi[2 * h]; k < fi[2 * h + 1]; k++) {
+      if (ft[3 * k] != h)
+        return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: forward transition %d is not grouped under its source", k);
+      rows_b[h].push_back(Arc{(uint32_t)pb[ft[3 * k + 1]], (uint32_t)ft[3 * k + 2], fp[k]});
+      // gamma rows keep the (state, arc) order the reference accumulates in (chain-computation.cc:293-305)
+      rows_g[ft[3 * k + 2]].push_back(Arc{(uint32_t)pa[h], (uint32_t)pb[ft[3 * k + 1]], fp[k]});
+    }
+  }
+  std::vector<int> gdeg(D), gids;
+  for (int n = 0; n < D; n++) { gdeg[n] = (int)rows_g[n].size(); if (gdeg[n] > 0) gids.push_back(n); }
+  const std::vector<int> order_g = sort_by_degree(gdeg, gids);
+  const int gpos = ((int)order_g.size() + 63) / 64 * 64;
+
+  BuiltTile ta = build_tile(rows_a, order_a, Hp, PLAN_REC_WAVES);
+  BuiltTile tb = build_tile(rows_b, order_b, Hp, PLAN_REC_WAVES);
+  BuiltTile tg = build_tile(rows_g, order_g, gpos, PLAN_GAM_WAVES);
+
+  // ---- lay the blob out
+  size_t off = align16(sizeof(PlanHeader));
+  PlanHeader hd;
+  memset(&hd, 0, sizeof(hd));
+  hd.magic = PLAN_MAGIC; hd.version = PLAN_VERSION;
+  hd.H = H; hd.K = K; hd.D = D; hd.Hp = Hp;
+  auto place_tile = [&](TilePlan& tp, const BuiltTile& t) {
+    tp.ngroups = (int)t.groups.size(); tp.nwaves = (int)t.waves.size();
+    tp.total_slot_rows = t.total_slot_rows; tp.max_wave_slot_rows = t.max_wave; tp.nrows = t.nrows;
+    tp.off_wave_tab = (int32_t)off; off = align16(off + t.waves.size() * sizeof(WaveEntry));
+    tp.off_group_tab = (int32_t)off; off = align16(off + std::max<size_t>(1, t.groups.size()) * sizeof(GroupEntry));
+    tp.off_slots = (int32_t)off; off = align16(off + std::max<size_t>(1, t.slots.size()) * 4);
+  };
+  place_tile(hd.alpha, ta); place_tile(hd.beta, tb); place_tile(hd.gamma, tg);
+  auto place_vec = [&](int32_t& o, size_t n) { o = (int32_t)off; off = align16(off + n * 4); };
+  place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
+  place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
+  place_vec(hd.off_row_pdf, std::max(gpos, 64));
+  if (off > (size_t)INT32_MAX)
+    return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED, "den_plan_build: plan larger than 2 GiB");
+  hd.total_bytes = (int32_t)off;
+  if (!blob || blob_bytes < off) return (int64_t)off;
+
+  char* base = (char*)blob;
+  memset(base, 0, off);
+  memcpy(base, &hd, sizeof(hd));
+  auto write_tile = [&](const TilePlan& tp, const BuiltTile& t) {
+    memcpy(base + tp.off_wave_tab, t.waves.data(), t.waves.size() * sizeof(WaveEntry));
+    memcpy(base + tp.off_group_tab, t.groups.data(), t.groups.size() * sizeof(GroupEntry));
+    memcpy(base + tp.off_slots, t.slots.data(), t.slots.size() * 4);
+  };
+  write_tile(hd.alpha, ta); write_tile(hd.beta, tb); write_tile(hd.gamma, tg);
+  float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
+  float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
+  float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);
+  for (int h = 0; h < H; h++) {
+    init_a[pa[h]] = initial[h]; leaky_a[pa[h]] = leaky[h]; final_a[pa[h]] = final_[h];
+    leaky_b[pb[h]] = leaky[h]; final_b[pb[h]] = final_[h];
+  }
+  for (int i = 0; i < std::max(gpos, 64); i++) row_pdf[i] = i < (int)order_g.size() ? order_g[i] : -1;
+  return (int64_t)off;
+}

@@ -1,0 +1,74 @@
+// plan_format.h - device-side layout of a compiled denominator graph ("plan").
+//
+// A plan holds three *tile plans*.  A tile plan evaluates, once per frame,
+//
+//     out[row] = sum_{k in row}  p_k * U[i0_k] * V[i1_k]
+//
+// for every row, where U and V are two vectors resident in LDS:
+//
+//   alpha plan: row = destination state, U = alpha'(t-1,.) , V = exp x(t-1,.)   (i0 = source state, i1 = pdf)
+//   beta  plan: row = source state,      U = beta(t+1,.)   , V = exp x(t,.)     (i0 = dest state,   i1 = pdf)
+//   gamma plan: row = pdf-id,            U = alpha'(t,.)   , V = beta(t+1,.)    (i0 = source state, i1 = dest state)
+//
+// Rows are sorted by descending arc count and cut into groups of 64 (one row per
+// lane of a wave64).  A group is stored as `nslots` slot-rows; slot-row j holds
+// the j-th arc of each of the 64 rows (zero-probability padding where a row is
+// shorter), 8 bytes per lane, lane-contiguous, so a wave reads 512 contiguous
+// bytes per slot-row.  Groups are dealt to `nwaves` waves by longest-processing
+// -time-first so every wave of the workgroup owns about the same number of
+// slot-rows.  States are renumbered by sorted position, so lane l of a group
+// writes out[out_base + l]: stores are conflict-free and need no index.
+//
+// State numbering: the alpha side numbers states by descending in-degree
+// (position "pa"), the beta side by descending out-degree ("pb").  Vectors in
+// the plan are stored in the numbering of the side that uses them and padded
+// with zeros to Hp = roundup(H, 64).
+#ifndef PYCHAIN_HIP_PLAN_FORMAT_H_
+#define PYCHAIN_HIP_PLAN_FORMAT_H_
+
+#include <stdint.h>
+
+#define PLAN_MAGIC 0x4C504843  // "CHPL"
+#define PLAN_VERSION 2
+#define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
+#define PLAN_GAM_WAVES 16      // same for the gamma plan
+
+struct TilePlan {              // all offsets are bytes from the start of the blob
+  int32_t ngroups;
+  int32_t nwaves;
+  int32_t off_wave_tab;        // WaveEntry[nwaves]
+  int32_t off_group_tab;       // GroupEntry[ngroups], in wave order
+  int32_t off_slots;           // uint2[total_slot_rows * 64]
+  int32_t total_slot_rows;
+  int32_t max_wave_slot_rows;  // max over waves of the slot-rows a wave owns
+  int32_t nrows;               // real rows (states / pdfs with arcs)
+};
+
+struct WaveEntry {
+  int32_t first_group;         // index into the group table
+  int32_t ngroups;
+  int32_t slot_row_begin;      // first slot-row of this wave in the slot stream
+  int32_t nslot_rows;
+};
+
+struct GroupEntry {
+  int32_t out_base;            // lane l writes out[out_base + l]
+  int32_t nslots;              // slot-rows in this group (may be 0)
+};
+
+struct PlanHeader {
+  int32_t magic, version;
+  int32_t H, K, D, Hp;
+  int32_t total_bytes;
+  int32_t reserved0;
+  TilePlan alpha, beta, gamma;
+  int32_t off_init_a;          // float[Hp]  initial_probs, alpha numbering
+  int32_t off_leaky_a;         // float[Hp]  leaky_probs,   alpha numbering
+  int32_t off_final_a;         // float[Hp]  final_probs,   alpha numbering
+  int32_t off_leaky_b;         // float[Hp]  leaky_probs,   beta numbering
+  int32_t off_final_b;         // float[Hp]  final_probs,   beta numbering
+  int32_t off_row_pdf;         // int32[gamma.ngroups*64] natural pdf-id of each gamma row, -1 = padding
+  int32_t reserved1[2];
+};
+
+#endif

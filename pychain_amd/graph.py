@@ -196,6 +196,8 @@ class ChainGraphBatch(object):
             for name in _TENSORS[:-1]:
                 t = getattr(self, name)
                 if t is not None:
+                    if self.shared_graph is not None:
+                        t = t[:1]            # every row is the same graph: ship one (stride 0)
                     hit[name] = t.contiguous().to(device, non_blocking=True)
             self._device_cache = {key: hit}
         return hit

@@ -1,0 +1,83 @@
+"""ChainFunction / ChainLoss: the LF-MMI autograd API of pychain on MI355X.
+
+Mirror of the reference's pychain/loss.py (same names, signatures, defaults and
+error behaviour).  What differs is underneath:
+
+  * no extra passes over [B,T,D]: clamp(-30,30) and exp (loss.py:30,43) are fused
+    into the HIP kernels, the log-domain gradient is produced in the linear
+    domain directly (loss.py:77);
+  * the denominator graph is compiled once to a device-resident plan that all B
+    sequences share (no B-fold replication, no per-call H2D; graph.py:99-120,
+    chain-computation.cc:77-89);
+  * lengths may be given in any order and on any device (the reference needs
+    them sorted descending on the CPU for pack_padded_sequence, loss.py:37-40).
+
+There is no CPU implementation here: CPU tensors raise.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib, _plan, native
+from .graph import ChainGraphBatch
+
+__all__ = ["ChainFunction", "ChainLoss"]
+
+
+class ChainFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, input_lengths, graphs, leaky_coefficient=1e-5):
+        B = input.size(0)
+        if B != graphs.batch_size:
+            raise ValueError(
+                "input batch size ({}) does not equal to graph batch size ({})"
+                .format(B, graphs.batch_size))
+        x = input.detach()
+        D = x.size(2)
+        if not graphs.log_domain:   # usually the denominator
+            if graphs.shared_graph is not None:
+                plan, stride = _plan.graph_plan(graphs.shared_graph, D, x.device), 0
+            else:
+                key = ("den_plans", str(x.device), D)
+                hit = graphs._device_cache.get(key)
+                if hit is None:
+                    hit = _plan.batch_plans({n: getattr(graphs, n) for n in (
+                        "forward_transitions", "forward_transition_indices", "forward_transition_probs",
+                        "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+                        "leaky_probs", "initial_probs", "final_probs")}, D, x.device)
+                    graphs._device_cache[key] = hit
+                plan, stride = hit
+            objf, input_grad, bad = native.den_forward_backward(
+                plan, stride, graphs.num_states, x, input_lengths, leaky_coefficient, input_is_exp=False)
+        else:                       # usually the numerator
+            gt = graphs.device_tensors(x.device)
+            gstride = 0 if graphs.shared_graph is not None else 1
+            objf, input_grad, bad = native.num_forward_backward(
+                gt, gstride, graphs.num_states, x, input_lengths, grad_mode=_lib.GRAD_LINEAR)
+        ctx.save_for_backward(input_grad)
+        ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
+        ChainFunction.last_bad_count = bad
+        return objf.sum()
+
+    @staticmethod
+    def backward(ctx, objf_grad):
+        input_grad, = ctx.saved_tensors
+        # clamp is inside the Function and therefore not differentiated (loss.py:30,82-87)
+        return torch.mul(input_grad, objf_grad), None, None, None
+
+
+class ChainLoss(nn.Module):
+    def __init__(self, den_graph, leaky_coefficient=1e-5, avg=True):
+        super(ChainLoss, self).__init__()
+        self.den_graph = den_graph
+        self.avg = avg
+        self.leaky_coefficient = leaky_coefficient
+
+    def forward(self, x, x_lengths, num_graphs):
+        batch_size = x.size(0)
+        den_graphs = ChainGraphBatch(self.den_graph, batch_size)
+        den_objf = ChainFunction.apply(x, x_lengths, den_graphs, self.leaky_coefficient)
+        num_objf = ChainFunction.apply(x, x_lengths, num_graphs)
+        objf = -(num_objf - den_objf)
+        if self.avg:
+            objf = objf / x_lengths.sum()
+        return objf

@@ -1,0 +1,161 @@
+"""Tensor-level entry points over the C ABI: the drop-in for the reference's
+`pychain_C` module (pytorch_binding/src/pychain.cc:131-135).
+
+`forward_backward` / `forward_backward_log_domain` / `set_verbose_level` keep the
+reference's positional signatures and return `[objf, grad, ok]`; the `den_*` /
+`num_*` functions are what `pychain_amd.loss` calls (device-resident plans, fused
+clamp/exp, per-sequence objf).
+"""
+import torch
+
+from . import _lib, _plan
+
+_ws_cache = {}
+
+
+def _require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "pychain_amd: %s must live on a HIP device (got %s). The MI355X path has no CPU "
+            "fallback by design." % (what, t.device))
+
+
+def _workspace(nbytes, device):
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _lengths_dev(lengths, device):
+    return torch.as_tensor(lengths).to(device=device, dtype=torch.int64, non_blocking=True).contiguous()
+
+
+def _check_lengths(lengths, B, T):
+    lc = torch.as_tensor(lengths)
+    if lc.numel() != B:
+        raise ValueError("sequence_lengths has %d entries for a batch of %d" % (lc.numel(), B))
+    if not lc.is_cuda:   # cheap host-side validation only when it costs no sync
+        if int(lc.min()) < 1 or int(lc.max()) > T:
+            raise ValueError("sequence lengths must be in [1, %d]" % T)
+
+
+def den_forward_backward(plan, plan_stride, num_states, x, lengths, leaky_coefficient=1e-5,
+                         input_is_exp=False, grad_scale=1.0):
+    """Denominator on the GPU.  Returns (objf_per_seq[B], grad[B,T,D], bad_count[1])."""
+    _require_device(x, "nnet_output")
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, T, D = x.shape
+    _check_lengths(lengths, B, T)
+    L = _lib.lib()
+    dev = x.device
+    with torch.cuda.device(dev):
+        ld = _lengths_dev(lengths, dev)
+        objf = torch.empty(B, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(x)
+        bad = torch.empty(1, dtype=torch.int32, device=dev)
+        nws = L.pychain_hip_den_workspace_bytes(B, T, int(num_states), D)
+        ws = _workspace(nws, dev)
+        _lib.check(L.pychain_hip_den_forward_backward(
+            plan.data_ptr(), int(plan_stride), int(num_states), D, x.data_ptr(), int(bool(input_is_exp)),
+            ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
+            objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+            "pychain_hip_den_forward_backward")
+    return objf, grad, bad
+
+
+def num_forward_backward(gt, graph_stride, num_states, x, lengths, grad_mode=_lib.GRAD_LINEAR,
+                         grad_scale=1.0, grad_out=None):
+    """Numerator on the GPU.  `gt`: dict of device graph tensors.  Returns
+    (objf_per_seq[B], grad[B,T,D], bad_count[1])."""
+    _require_device(x, "nnet_output")
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, T, D = x.shape
+    _check_lengths(lengths, B, T)
+    K = gt["forward_transitions"].shape[1]
+    L = _lib.lib()
+    dev = x.device
+    with torch.cuda.device(dev):
+        ld = _lengths_dev(lengths, dev)
+        objf = torch.empty(B, dtype=torch.float32, device=dev)
+        if grad_mode == _lib.GRAD_ACCUM:
+            if grad_out is None:
+                raise ValueError("GRAD_ACCUM needs grad_out")
+            grad = grad_out
+        else:
+            grad = torch.empty_like(x)
+        bad = torch.empty(1, dtype=torch.int32, device=dev)
+        nws = L.pychain_hip_num_workspace_bytes(B, T, int(num_states), K, D)
+        ws = _workspace(nws, dev)
+        _lib.check(L.pychain_hip_num_forward_backward(
+            gt["forward_transitions"].data_ptr(), gt["forward_transition_indices"].data_ptr(),
+            gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
+            gt["backward_transition_indices"].data_ptr(), gt["backward_transition_probs"].data_ptr(),
+            gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
+            x.data_ptr(), ld.data_ptr(), B, T, D, int(num_states), K, int(grad_mode), float(grad_scale),
+            objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+            "pychain_hip_num_forward_backward")
+    return objf, grad, bad
+
+
+# ---------------------------------------------------------------------------
+# pychain_C-compatible surface (positional signatures of pychain.cc:26-41, :81-94)
+# ---------------------------------------------------------------------------
+_GRAPH6 = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
+           "backward_transitions", "backward_transition_indices", "backward_transition_probs"]
+
+
+def _check_contiguous(**named):
+    for n, t in named.items():   # pychain.cc:24,42-54
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % n)
+
+
+def forward_backward(forward_transitions, forward_transition_indices, forward_transition_probs,
+                     backward_transitions, backward_transition_indices, backward_transition_probs,
+                     leaky_probs, initial_probs, final_probs, start_state, exp_nnet_output,
+                     batch_sizes, sequence_lengths, num_states, leaky_hmm_coefficient=1.0e-05):
+    """Same contract as `pychain_C.forward_backward`: pre-exponentiated input, returns
+    [objf (0-dim), nnet_output_grad [B,T,D], ok (bool[1])]."""
+    _check_contiguous(exp_nnet_output=exp_nnet_output, batch_sizes=batch_sizes,
+                      sequence_lengths=sequence_lengths)
+    tensors = dict(zip(_GRAPH6 + ["leaky_probs", "initial_probs", "final_probs"],
+                       [forward_transitions, forward_transition_indices, forward_transition_probs,
+                        backward_transitions, backward_transition_indices, backward_transition_probs,
+                        leaky_probs, initial_probs, final_probs]))
+    D = exp_nnet_output.shape[2]
+    plan, stride = _plan.batch_plans(tensors, D, exp_nnet_output.device)
+    objf, grad, bad = den_forward_backward(plan, stride, num_states, exp_nnet_output, sequence_lengths,
+                                           leaky_hmm_coefficient, input_is_exp=True)
+    return [objf.sum(), grad, bad == 0]
+
+
+def forward_backward_log_domain(forward_transitions, forward_transition_indices, forward_transition_probs,
+                                backward_transitions, backward_transition_indices, backward_transition_probs,
+                                initial_probs, final_probs, start_state, nnet_output,
+                                batch_sizes, sequence_lengths, num_states):
+    """Same contract as `pychain_C.forward_backward_log_domain`: returns
+    [objf, log-grad [B,T,D] (-inf where zero), ok]."""
+    _check_contiguous(nnet_output=nnet_output, batch_sizes=batch_sizes, sequence_lengths=sequence_lengths)
+    dev = nnet_output.device
+    vals = [forward_transitions, forward_transition_indices, forward_transition_probs,
+            backward_transitions, backward_transition_indices, backward_transition_probs,
+            initial_probs, final_probs]
+    gt = {n: t.contiguous().to(dev) for n, t in zip(_GRAPH6 + ["initial_probs", "final_probs"], vals)}
+    objf, lgrad, bad = num_forward_backward(gt, 1, num_states, nnet_output, sequence_lengths,
+                                            grad_mode=_lib.GRAD_LOG)
+    return [objf.sum(), lgrad, bad == 0]
+
+
+def set_verbose_level(level):
+    _lib.lib().pychain_hip_set_verbose_level(int(level))

@@ -1,0 +1,92 @@
+"""NumPy emulation of what the HIP denominator kernels compute from a compiled plan.
+
+Test infrastructure: lets the CPU suite validate the host-side plan compiler
+(pychain_amd/csrc/plan.cpp) and the kernel decomposition (independent alpha/beta
+normalisers + per-frame-normalised occupancies, pychain_amd/csrc/den_kernels.hip)
+against the oracle without a GPU.  Mirrors the kernels step by step.
+"""
+import numpy as np
+
+HDR_INTS = 8 + 3 * 8 + 8
+
+
+def parse(blob):
+    b = np.asarray(blob, dtype=np.uint8)
+    h = b[:HDR_INTS * 4].view(np.int32)
+    assert h[0] == 0x4C504843, "bad magic"
+    hd = dict(version=int(h[1]), H=int(h[2]), K=int(h[3]), D=int(h[4]), Hp=int(h[5]), total_bytes=int(h[6]))
+
+    def tile(o):
+        t = dict(zip(["ngroups", "nwaves", "off_wave_tab", "off_group_tab", "off_slots",
+                      "total_slot_rows", "max_wave_slot_rows", "nrows"], [int(v) for v in h[o:o + 8]]))
+        t["waves"] = b[t["off_wave_tab"]:t["off_wave_tab"] + 16 * t["nwaves"]].view(np.int32).reshape(-1, 4)
+        t["groups"] = b[t["off_group_tab"]:t["off_group_tab"] + 8 * t["ngroups"]].view(np.int32).reshape(-1, 2)
+        n = t["total_slot_rows"] * 64
+        s = b[t["off_slots"]:t["off_slots"] + 8 * n].view(np.uint32).reshape(-1, 64, 2)
+        t["idx"] = s[:, :, 0].copy()
+        t["p"] = s[:, :, 1].copy().view(np.float32)
+        return t
+    hd["alpha"], hd["beta"], hd["gamma"] = tile(8), tile(16), tile(24)
+    offs = [int(v) for v in h[32:38]]
+    Hp = hd["Hp"]
+    vec = lambda o: b[o:o + 4 * Hp].view(np.float32).copy()
+    hd["init_a"], hd["leaky_a"], hd["final_a"], hd["leaky_b"], hd["final_b"] = [vec(o) for o in offs[:5]]
+    ng = max(hd["gamma"]["ngroups"] * 64, 64)
+    hd["row_pdf"] = b[offs[5]:offs[5] + 4 * ng].view(np.int32).copy()
+    return hd
+
+
+def tile_rows(t, U, V, nout, dtype):
+    """out[row] = sum_k p_k U[i0_k] V[i1_k], evaluated wave by wave / group by group."""
+    out = np.zeros(nout, dtype=dtype)
+    for w in range(t["nwaves"]):
+        first, ng, row, _ = t["waves"][w]
+        for g in range(first, first + ng):
+            base, ns = t["groups"][g]
+            acc = np.zeros(64, dtype=dtype)
+            for j in range(ns):
+                idx = t["idx"][row + j]
+                acc += t["p"][row + j].astype(dtype) * U[idx & 0xffff] * V[idx >> 16]
+            row += ns
+            out[base:base + 64] = acc
+    return out
+
+
+def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.float64):
+    """Returns (objf_per_seq[B], grad[B,T,D]) exactly as den_kernels.hip computes them."""
+    hd = parse(blob)
+    H, Hp, D = hd["H"], hd["Hp"], hd["D"]
+    B, T, _ = x.shape
+    ex = x.astype(dtype) if input_is_exp else np.exp(np.clip(x.astype(dtype), -30, 30))
+    objf = np.zeros(B, dtype=dtype)
+    grad = np.zeros((B, T, D), dtype=dtype)
+    mask = (np.arange(Hp) < H).astype(dtype)
+    la, lb = hd["leaky_a"].astype(dtype), hd["leaky_b"].astype(dtype)
+    for b in range(B):
+        L = int(lengths[b])
+        A = np.zeros((L + 1, Hp), dtype=dtype)
+        Bt = np.zeros((L + 1, Hp), dtype=dtype)
+        v = hd["init_a"].astype(dtype)
+        tot = v.sum()
+        logsum = np.log(tot)
+        A[0] = v / tot + coef * la
+        for t in range(1, L + 1):
+            v = tile_rows(hd["alpha"], A[t - 1], ex[b, t - 1], Hp, dtype)
+            tot = v.sum()
+            logsum += np.log(tot)
+            A[t] = v / tot + coef * la
+        objf[b] = logsum + np.log((A[L] * hd["final_a"].astype(dtype)).sum())
+        v = hd["final_b"].astype(dtype)
+        Bt[L] = (v + coef * (v * lb).sum()) / v.sum() * mask
+        for t in range(L - 1, 0, -1):
+            v = tile_rows(hd["beta"], Bt[t + 1], ex[b, t], Hp, dtype)
+            Bt[t] = (v + coef * (v * lb).sum()) / v.sum() * mask
+        g = hd["gamma"]
+        for t in range(L):
+            st = tile_rows(g, A[t], Bt[t + 1], max(g["ngroups"] * 64, 64), dtype)
+            q = np.zeros(D, dtype=dtype)
+            ok = hd["row_pdf"][:len(st)] >= 0
+            q[hd["row_pdf"][:len(st)][ok]] = st[ok]
+            gm = ex[b, t] * q
+            grad[b, t] = gm / gm.sum()
+    return objf, grad

@@ -1,0 +1,82 @@
+"""Host-side plan compiler + kernel decomposition, checked on the CPU against the oracle
+and the reference-generated goldens (no GPU needed)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+import plan_emulator as emu
+from helpers import graph_from_npz, rel_err
+from pychain_amd import _lib, _plan, synthetic as syn
+from pychain_amd.graph import ChainGraphBatch
+
+
+def _blob(g, D):
+    return _plan.build_plan_blob(g.forward_transitions, g.forward_transition_indices, g.forward_transition_probs,
+                                 g.backward_transitions, g.backward_transition_indices,
+                                 g.backward_transition_probs, g.leaky_probs, g.initial_probs, g.final_probs, D)
+
+
+def test_plan_structure():
+    g = syn.make_den_graph(200, 2000, 1000, seed=3)
+    hd = emu.parse(_blob(g, 1000))
+    assert hd["H"] == 200 and hd["K"] == 2000 and hd["Hp"] == 256
+    for name, nreal in (("alpha", 2000), ("beta", 2000), ("gamma", 2000)):
+        t = hd[name]
+        assert int((t["p"] != 0).sum()) == nreal                  # every arc exactly once
+        assert t["waves"][:, 3].sum() == t["total_slot_rows"]
+        assert t["waves"][:, 3].max() == t["max_wave_slot_rows"]
+        assert sorted(t["groups"][:, 0].tolist()) == list(range(0, t["ngroups"] * 64, 64))
+        # longest-processing-time balance: no wave carries more than ~2 groups above the mean
+        assert t["waves"][:, 3].max() <= t["total_slot_rows"] / t["nwaves"] + 2 * t["groups"][:, 1].max()
+    assert abs(hd["leaky_a"].sum() - g.leaky_probs.sum().item()) < 1e-6
+    assert set(hd["row_pdf"][hd["row_pdf"] >= 0].tolist()) == set(g.forward_transitions[:, 2].tolist())
+
+
+@pytest.mark.parametrize("case", ["leaky_ones", "fst_fst", "leaky_fst_coef01", "fst_ones_clamp"])
+def test_decomposition_matches_reference(golden, case):
+    """alpha/beta with independent normalisers + normalised gamma == reference numbers."""
+    z = golden("g3_den_variants")
+    p = case + "__"
+    g = graph_from_npz(z, p + "den_")
+    x = z[p + "x"]
+    objf, grad = emu.den_forward_backward(_blob(g, x.shape[2]), x, z[p + "lengths"], float(z[p + "coef"]))
+    assert abs(objf.sum() - z[p + "objf"]) <= 2e-6 * abs(z[p + "objf"])
+    assert rel_err(grad, z[p + "grad"]) <= 1e-5
+
+
+def test_decomposition_c1(golden):
+    z = golden("g1_c1_den")
+    g = graph_from_npz(z, "den_")
+    objf, grad = emu.den_forward_backward(_blob(g, 40), z["x"], z["lengths"], 1e-5)
+    assert abs(objf.sum() - z["objf"]) <= 2e-6 * abs(z["objf"])
+    assert rel_err(grad, z["grad"]) <= 1e-5
+    # float32 evaluation of the same scheme stays inside the 1e-4 bar with margin
+    objf32, grad32 = emu.den_forward_backward(_blob(g, 40), z["x"], z["lengths"], 1e-5, dtype=np.float32)
+    assert abs(objf32.sum() - z["objf"]) <= 1e-5 * abs(z["objf"])
+    assert rel_err(grad32, z["grad"]) <= 5e-5
+
+
+def test_plan_errors():
+    g = syn.make_den_graph(20, 60, 40, seed=0)
+    L = _lib.lib()
+    bad = g.forward_transitions.clone()
+    bad[3, 2] = 40    # pdf out of range
+    with pytest.raises(_lib.PychainHipError, match="out of range"):
+        _plan.build_plan_blob(bad, g.forward_transition_indices, g.forward_transition_probs,
+                              g.backward_transitions, g.backward_transition_indices,
+                              g.backward_transition_probs, g.leaky_probs, g.initial_probs, g.final_probs, 40)
+    assert L.pychain_hip_den_plan_build(None, None, None, None, None, None, None, None, None, 1, 1, 1, None, 0) < 0
+    assert b"null" in L.pychain_hip_last_error()
+
+
+def test_batch_plans_shared_detection():
+    g = syn.make_den_graph(20, 60, 40, seed=0)
+    gb = ChainGraphBatch(g, 3)
+    names = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
+             "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+             "leaky_probs", "initial_probs", "final_probs"]
+    blob, stride = _plan.batch_plans({n: getattr(gb, n) for n in names}, 40, "cpu")
+    assert stride == 0 and np.array_equal(blob.numpy(), _blob(g, 40))
