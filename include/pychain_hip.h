@@ -44,6 +44,11 @@ const char* pychain_hip_last_error(void);
  * non-finite normaliser instead of only flagging the call. */
 void        pychain_hip_set_verbose_level(int level);
 int         pychain_hip_get_verbose_level(void);
+/* Measurement aid (bench.py): restrict pychain_hip_den_forward_backward to a subset of
+ * its launches so each kernel can be bracketed by events on the caller's stream.
+ * bit 0 = alpha/beta recursion launch, bit 1 = occupancy launch; default 3 = both.
+ * With a partial mask the outputs of the call are NOT meaningful. */
+void        pychain_hip_set_den_phase_mask(int mask);
 
 /* ------------------------------------------------------------------------
  * Denominator graph plan  (host side, no GPU work).

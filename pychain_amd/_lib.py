@@ -22,6 +22,7 @@ _SIGNATURES = {
     "pychain_hip_last_error": (ctypes.c_char_p, []),
     "pychain_hip_set_verbose_level": (None, [_i]),
     "pychain_hip_get_verbose_level": (_i, []),
+    "pychain_hip_set_den_phase_mask": (None, [_i]),
     "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _f, _f,

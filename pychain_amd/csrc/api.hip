@@ -12,6 +12,7 @@
 
 namespace pychain_hip {
 int g_verbose_level = 0;
+int g_den_phase_mask = 3;
 char* last_error_buffer() {
   static thread_local char buf[512] = "";
   return buf;
@@ -28,6 +29,7 @@ extern "C" int pychain_hip_abi_version(void) { return PYCHAIN_HIP_ABI_VERSION; }
 extern "C" const char* pychain_hip_last_error(void) { return last_error_buffer(); }
 extern "C" void pychain_hip_set_verbose_level(int level) { g_verbose_level = level; }
 extern "C" int pychain_hip_get_verbose_level(void) { return g_verbose_level; }
+extern "C" void pychain_hip_set_den_phase_mask(int mask) { g_den_phase_mask = mask & 3; }
 
 extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   (void)D;
@@ -69,6 +71,7 @@ extern "C" int pychain_hip_den_forward_backward(
   a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H);
   a.input_is_exp = input_is_exp ? 1 : 0;
   a.frames_per_block = 8;
+  a.phase_mask = g_den_phase_mask;
   a.coef = leaky_hmm_coefficient; a.grad_scale = grad_scale;
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_store = (float*)ws;

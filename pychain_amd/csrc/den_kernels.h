@@ -20,6 +20,7 @@ struct DenArgs {
   int B, T, D, H, Hp;
   int input_is_exp;
   int frames_per_block;      // gamma kernel: frames one workgroup handles
+  int phase_mask;            // bit0 recursion launch, bit1 gamma launch (bench aid)
   float coef, grad_scale;
 };
 

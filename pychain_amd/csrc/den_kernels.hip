@@ -307,9 +307,11 @@ hipError_t launch_variant(const DenArgs& a, size_t lds_rec, size_t lds_gam, int 
   hipError_t e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(rec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gam), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gam)) != hipSuccess) return e;
-  hipLaunchKernelGGL(rec, dim3(2 * a.B), dim3(kNT), lds_rec, st, a);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(gam, dim3(gamma_grid_x, a.B), dim3(kNT), lds_gam, st, a);
+  if (a.phase_mask & 1) {
+    hipLaunchKernelGGL(rec, dim3(2 * a.B), dim3(kNT), lds_rec, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  if (a.phase_mask & 2) hipLaunchKernelGGL(gam, dim3(gamma_grid_x, a.B), dim3(kNT), lds_gam, st, a);
   return hipGetLastError();
 }
 

@@ -1,0 +1,82 @@
+"""Utterance sharding across the GPUs of a node.
+
+The reference has no distributed code; LF-MMI shards naturally because sequences are
+independent (chain-computation.h:33-35).  One process per GPU; the only coupling is the
+scalar sum of per-sequence log-probs (chain-computation.cc:229) and ChainLoss's frame
+normaliser (loss.py:104): ONE all-reduce of a 3-float buffer per step.  Each rank
+back-propagates its own [B_local,T,D] gradient shard; DDP all-reduces parameter
+gradients as usual.  (An all-reduce of the [B_global,T,D] gradient slab itself would
+move 10.6 GB per step at C5 - see DESIGN.md §6 - and is deliberately not on the path.)
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_indices", "shard_batch", "allreduce_stats", "ShardedChainLoss"]
+
+
+def shard_indices(lengths, world_size, rank):
+    """Global minibatch -> this rank's utterance indices.  Utterances are sorted by length
+    (descending) and dealt in serpentine order (0..R-1, R-1..0, 0..R-1, ...), so every
+    shard stays length-sorted (what the reference API wants, loss.py:37-40) and shards
+    carry near-equal frame counts and near-equal longest sequences (kernel time follows
+    the longest sequence)."""
+    lengths = torch.as_tensor(lengths).cpu()
+    order = torch.argsort(lengths, descending=True, stable=True)
+    n = order.numel()
+    pos = torch.arange(n)
+    row, col = pos // world_size, pos % world_size
+    owner = torch.where(row % 2 == 0, col, world_size - 1 - col)
+    return order[owner == rank]
+
+
+def shard_batch(x, lengths, num_graphs, world_size, rank):
+    """Slice (x, lengths, num_graphs) down to this rank's shard."""
+    from .graph import ChainGraphBatch
+    idx = shard_indices(lengths, world_size, rank)
+    lengths = torch.as_tensor(lengths)
+    xs = x.index_select(0, idx.to(x.device))
+    ls = lengths.index_select(0, idx.to(lengths.device))
+    gs = None
+    if num_graphs is not None:
+        gs = ChainGraphBatch.__new__(ChainGraphBatch)
+        gs.__dict__.update(num_graphs.__dict__)
+        gs._device_cache = {}
+        gs.reorder(idx)
+        gs.batch_size = int(idx.numel())
+    return xs, ls, gs, idx
+
+
+def allreduce_stats(objf, n_frames, bad_count=None, group=None):
+    """[objf, n_frames, n_bad] summed over all ranks with ONE collective (RCCL all_reduce
+    over xGMI on GPUs, gloo on CPU).  Returns the fp32[3] buffer; no host sync."""
+    dev = objf.device
+    buf = torch.zeros(3, dtype=torch.float32, device=dev)
+    buf[0] = objf.detach().float().reshape(())
+    buf[1] = torch.as_tensor(n_frames, device=dev).float().reshape(())
+    if bad_count is not None:
+        buf[2] = bad_count.to(dev).float().reshape(())
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+class ShardedChainLoss(torch.nn.Module):
+    """ChainLoss over a utterance-sharded global minibatch: each rank evaluates its shard,
+    the loss value is the global one (sum over ranks / global frame count when `avg`), and
+    autograd yields the correctly scaled gradient for the local shard."""
+
+    def __init__(self, den_graph, leaky_coefficient=1e-5, avg=True, group=None, loss_cls=None):
+        super().__init__()
+        if loss_cls is None:
+            from .loss import ChainLoss as loss_cls
+        self.local = loss_cls(den_graph, leaky_coefficient, avg=False)
+        self.avg = avg
+        self.group = group
+
+    def forward(self, x, x_lengths, num_graphs):
+        local = self.local(x, x_lengths, num_graphs)                  # sum over local utterances
+        frames = torch.as_tensor(x_lengths).sum()
+        stats = allreduce_stats(local, frames, None, self.group)
+        # value: global; gradient: d(local)/dx scaled by the global normaliser
+        denom = stats[1] if self.avg else torch.ones((), device=stats.device)
+        return (local - local.detach() + stats[0]) / denom

@@ -1,0 +1,85 @@
+"""N>1 path on CPU: world_size-2 gloo group exercising the sharding + single all-reduce
+(the same code bench.py runs over RCCL).  The loss itself is replaced by the CPU oracle
+here - the collective logic is what is under test."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pychain_amd import parallel, synthetic as syn
+
+
+def test_shard_indices_balanced_and_sorted():
+    L = syn.make_lengths(64, 1500, "ragged", seed=2)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(0))
+    L = L[perm]
+    shards = [parallel.shard_indices(L, 8, r) for r in range(8)]
+    allidx = torch.cat(shards).sort().values
+    assert torch.equal(allidx, torch.arange(64))
+    frames = [int(L[s].sum()) for s in shards]
+    assert (max(frames) - min(frames)) / max(frames) < 0.05
+    for s in shards:
+        ls = L[s]
+        assert bool((ls[:-1] >= ls[1:]).all())
+
+
+class _OracleLoss(torch.nn.Module):
+    """ChainLoss(avg=False) evaluated by the CPU oracle, with autograd (test stand-in)."""
+
+    def __init__(self, den_graph, leaky, avg=False):
+        super().__init__()
+        self.den_graph, self.leaky = den_graph, leaky
+
+    def forward(self, x, lengths, num_graphs):
+        import oracle as orc
+
+        class F(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, xx):
+                loss, grad = orc.chain_loss(xx, lengths, self.den_graph, num_graphs, self.leaky, avg=False)
+                ctx.save_for_backward(torch.from_numpy(np.asarray(grad, dtype=np.float32)))
+                return torch.tensor(float(loss))
+
+            @staticmethod
+            def backward(ctx, g):
+                return ctx.saved_tensors[0] * g
+        return F.apply(x)
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = syn.make_workload("C1")
+        L = torch.tensor([50, 37, 44, 50])
+        x = syn.make_input(4, 50, 40, seed=5)
+        numg = syn.make_num_graphs(L.tolist(), 40, seed=100, max_states=12)
+        xs, ls, gs, idx = parallel.shard_batch(x, L, numg, world, rank)
+        xs = xs.clone().requires_grad_(True)
+        loss = parallel.ShardedChainLoss(w["den_graph"], 1e-5, avg=True, loss_cls=_OracleLoss)(xs, ls, gs)
+        loss.backward()
+        out[rank] = (float(loss), idx.tolist(), xs.grad.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_loss_matches_single_process():
+    import oracle as orc
+    world, port = 2, 29731 + os.getpid() % 1000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    w = syn.make_workload("C1")
+    L = torch.tensor([50, 37, 44, 50])
+    x = syn.make_input(4, 50, 40, seed=5)
+    numg = syn.make_num_graphs(L.tolist(), 40, seed=100, max_states=12)
+    ref_loss, ref_grad = orc.chain_loss(x, L, w["den_graph"], numg, avg=True)
+    for r in range(world):
+        loss, idx, grad = out[r]
+        assert abs(loss - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
+        np.testing.assert_allclose(grad, ref_grad[idx], atol=1e-6)
