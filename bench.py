@@ -63,7 +63,7 @@ def kernel_rooflines(w, dev, iters):
     plan = _plan.graph_plan(w["den_graph"], D, dev)
     stream = torch.cuda.current_stream(dev)
     frames = int(w["lengths"].sum())
-    call = lambda: native.den_forward_backward(plan, 0, H, w["x"], w["lengths_dev"], 1e-5)
+    call = lambda: native.den_forward_backward(plan, w["x"], w["lengths_dev"], 1e-5)
     out = {}
     try:
         call(); torch.cuda.synchronize()

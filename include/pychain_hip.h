@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 1
+#define PYCHAIN_HIP_ABI_VERSION 2
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -81,6 +81,16 @@ int64_t pychain_hip_den_plan_build(
     int num_states, int num_transitions, int num_pdfs,
     void* blob, size_t blob_bytes);
 
+/* Facts about a filled HOST blob that the launcher needs (the blob itself lives on the
+ * device at call time and is never read back):
+ *   info[0] num_states  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes
+ *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers) of the
+ *           recursion plans in bits 0-15 and of the occupancy plan in bits 16-30; combine
+ *           several plans by taking the max of each half
+ *   info[5..7] reserved (0)
+ */
+int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]);
+
 /* ------------------------------------------------------------------------
  * Denominator forward-backward on the GPU (replaces pychain.cc:26-79 and all
  * of chain-computation.cc / chain-kernels.cu).
@@ -88,6 +98,10 @@ int64_t pychain_hip_den_plan_build(
  * plans_dev/plan_stride_bytes: device address of the first plan and the byte
  *   distance between the plans of consecutive sequences; 0 = every sequence
  *   shares one graph (the ChainLoss denominator, pychain/loss.py:99).
+ * resident_slot_rows: the launch hint info[4] of pychain_hip_den_plan_info (per-half max
+ *   over the passed plans); selects the kernel variant that keeps every wave's arcs
+ *   in registers for the whole launch.  0 = unknown (arcs are re-read from L2 each frame;
+ *   same results, slower).
  * nnet_output: dev [B,T,D].  input_is_exp = 0: raw network output, clamp(-30,30)
  *   and exp are fused into the kernels (pychain/loss.py:30,43);
  *   input_is_exp = 1: already exp(clamp(.)) as pychain_C.forward_backward gets it.
@@ -103,7 +117,8 @@ int64_t pychain_hip_den_plan_build(
  */
 size_t pychain_hip_den_workspace_bytes(int B, int T, int num_states, int num_pdfs);
 int pychain_hip_den_forward_backward(
-    const void* plans_dev, int64_t plan_stride_bytes, int num_states, int num_pdfs,
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows,
+    int num_states, int num_pdfs,
     const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
     int B, int T, float leaky_hmm_coefficient, float grad_scale,
     float* objf_per_seq, float* grad, int32_t* bad_count,

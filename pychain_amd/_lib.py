@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpychain_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -25,7 +25,8 @@ _SIGNATURES = {
     "pychain_hip_set_den_phase_mask": (None, [_i]),
     "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _vp, _i, _vp, _i, _i, _f, _f,
+    "pychain_hip_den_plan_info": (_i, [_vp, _sz, _vp]),
+    "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _f,
                                               _vp, _vp, _vp, _vp, _sz, _vp]),
     "pychain_hip_num_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "pychain_hip_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,

@@ -11,6 +11,18 @@ import torch
 
 from . import _lib
 
+_NAMES = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
+          "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+          "leaky_probs", "initial_probs", "final_probs"]
+
+
+class DevicePlan(object):
+    """Device-resident plan(s): `blob` uint8 tensor, byte `stride` between per-sequence
+    plans (0 = shared), `slot_rows` = arcs per wave the kernels keep in registers."""
+
+    def __init__(self, blob, stride, slot_rows, num_states):
+        self.blob, self.stride, self.slot_rows, self.num_states = blob, int(stride), int(slot_rows), int(num_states)
+
 
 def _np(t, dtype):
     return np.ascontiguousarray(t.detach().cpu().numpy(), dtype=dtype)
@@ -37,37 +49,42 @@ def build_plan_blob(forward_transitions, forward_transition_indices, forward_tra
     return blob
 
 
+def plan_info(blob):
+    info = np.zeros(8, dtype=np.int32)
+    _lib.check(_lib.lib().pychain_hip_den_plan_info(blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes,
+                                                    info.ctypes.data_as(ctypes.c_void_p)), "den_plan_info")
+    return dict(num_states=int(info[0]), num_transitions=int(info[1]), num_pdfs=int(info[2]),
+                bytes=int(info[3]), slot_rows=int(info[4]))
+
+
 def graph_plan(graph, num_pdfs, device):
-    """Device plan of a ChainGraph (shared denominator), cached on the graph."""
+    """DevicePlan of a ChainGraph (shared denominator), cached on the graph."""
     key = (str(device), int(num_pdfs))
-    hit = graph._plan_cache.get(key) if hasattr(graph, "_plan_cache") else None
+    if not hasattr(graph, "_plan_cache"):
+        graph._plan_cache = {}
+    hit = graph._plan_cache.get(key)
     if hit is None:
-        blob = build_plan_blob(graph.forward_transitions, graph.forward_transition_indices,
-                               graph.forward_transition_probs, graph.backward_transitions,
-                               graph.backward_transition_indices, graph.backward_transition_probs,
-                               graph.leaky_probs, graph.initial_probs, graph.final_probs, num_pdfs)
-        hit = torch.from_numpy(blob).to(device)
-        if not hasattr(graph, "_plan_cache"):
-            graph._plan_cache = {}
+        blob = build_plan_blob(*[getattr(graph, n) for n in _NAMES], num_pdfs)
+        hit = DevicePlan(torch.from_numpy(blob).to(device), 0, plan_info(blob)["slot_rows"], graph.num_states)
         graph._plan_cache[key] = hit
     return hit
 
 
 def batch_plans(tensors, num_pdfs, device):
-    """Per-sequence probability-domain graphs ([B,...] tensors) -> (device blob, stride).
+    """Per-sequence probability-domain graphs ([B,...] tensors) -> DevicePlan.
     Rows that are all identical collapse to one shared plan (stride 0)."""
-    names = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
-             "backward_transitions", "backward_transition_indices", "backward_transition_probs",
-             "leaky_probs", "initial_probs", "final_probs"]
-    ts = [tensors[n].detach().cpu() for n in names]
+    ts = [tensors[n].detach().cpu() for n in _NAMES]
     B = ts[0].shape[0]
+    H = ts[1].shape[1]
     same = all(bool((t[1:] == t[:1]).all()) for t in ts) if B > 1 else True
     rows = [0] if same else range(B)
     blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
+    hints = [plan_info(b)["slot_rows"] for b in blobs]
+    slot_rows = max(h & 0xffff for h in hints) | (max(h >> 16 for h in hints) << 16)
     if same:
-        return torch.from_numpy(blobs[0]).to(device), 0
+        return DevicePlan(torch.from_numpy(blobs[0]).to(device), 0, slot_rows, H)
     stride = (max(b.nbytes for b in blobs) + 255) // 256 * 256
     allb = np.zeros(stride * B, dtype=np.uint8)
     for i, b in enumerate(blobs):
         allb[i * stride:i * stride + b.nbytes] = b
-    return torch.from_numpy(allb).to(device), stride
+    return DevicePlan(torch.from_numpy(allb).to(device), stride, slot_rows, H)

@@ -9,6 +9,7 @@
 #include "common.h"
 #include "den_kernels.h"
 #include "num_kernels.h"
+#include "plan_format.h"
 
 namespace pychain_hip {
 int g_verbose_level = 0;
@@ -31,6 +32,23 @@ extern "C" void pychain_hip_set_verbose_level(int level) { g_verbose_level = lev
 extern "C" int pychain_hip_get_verbose_level(void) { return g_verbose_level; }
 extern "C" void pychain_hip_set_den_phase_mask(int mask) { g_den_phase_mask = mask & 3; }
 
+extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]) {
+  if (!host_blob || !info || blob_bytes < sizeof(PlanHeader))
+    return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: null or truncated blob");
+  const PlanHeader* hd = (const PlanHeader*)host_blob;
+  if (hd->magic != PLAN_MAGIC || hd->version != PLAN_VERSION || (size_t)hd->total_bytes > blob_bytes)
+    return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: not a plan of this library version");
+  memset(info, 0, 8 * sizeof(int32_t));
+  info[0] = hd->H; info[1] = hd->K; info[2] = hd->D; info[3] = hd->total_bytes;
+  int m = hd->alpha.max_wave_slot_rows;
+  if (hd->beta.max_wave_slot_rows > m) m = hd->beta.max_wave_slot_rows;
+  int gmm = hd->gamma.max_wave_slot_rows;
+  if (m > 0x7fff) m = 0x7fff;
+  if (gmm > 0x7fff) gmm = 0x7fff;
+  info[4] = m | (gmm << 16);     // launch hint: recursion rows | occupancy rows << 16
+  return PYCHAIN_HIP_OK;
+}
+
 extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   (void)D;
   if (B <= 0 || T <= 0 || H <= 0) return 0;
@@ -39,7 +57,7 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
 }
 
 extern "C" int pychain_hip_den_forward_backward(
-    const void* plans_dev, int64_t plan_stride_bytes, int H, int D,
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int H, int D,
     const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
     int B, int T, float leaky_hmm_coefficient, float grad_scale,
     float* objf_per_seq, float* grad, int32_t* bad_count,
@@ -70,14 +88,14 @@ extern "C" int pychain_hip_den_forward_backward(
   a.x = nnet_output; a.lengths = seq_lengths; a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
   a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H);
   a.input_is_exp = input_is_exp ? 1 : 0;
-  a.frames_per_block = 8;
+  a.frames_per_block = 32;
   a.phase_mask = g_den_phase_mask;
   a.coef = leaky_hmm_coefficient; a.grad_scale = grad_scale;
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_store = (float*)ws;
   a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
   const char* why = nullptr;
-  hipError_t e = launch_den(a, (D + 63) / 64, st, &why);
+  hipError_t e = launch_den(a, (D + 63) / 64, resident_slot_rows, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "den_forward_backward: %s",
                 why ? why : hipGetErrorString(e));

@@ -26,7 +26,8 @@ struct DenArgs {
 
 // Enqueues the two launches on `st`.  On failure returns the HIP error and, when the
 // shape is unsupported, a reason in *why.
-hipError_t launch_den(const DenArgs& a, int gamma_max_groups, hipStream_t st, const char** why);
+hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,
+                      const char** why);
 
 }  // namespace pychain_hip
 #endif

@@ -36,44 +36,93 @@ namespace {
 constexpr int kNT = PLAN_REC_WAVES * 64;   // threads per workgroup (both kernels)
 constexpr int kNW = PLAN_REC_WAVES;
 static_assert(PLAN_REC_WAVES == PLAN_GAM_WAVES, "one workgroup shape for both kernels");
+constexpr int kMaxResident = 40;           // slot-rows per wave kept in VGPRs (2 VGPRs each) at 16 waves/CU
 
-// ---- one frame of a tile plan, arcs streamed from the plan (L2-resident) ----------
-// out[row] = sum_k p_k * U[i0_k] * V[i1_k]; returns this lane's sum of its rows in s0 and
-// the wvec-weighted sum in s1 (wvec == nullptr: s1 untouched).
-__device__ __forceinline__ void tile_rows_stream(const WaveEntry we, const GroupEntry* __restrict__ gtab,
-                                                 const uint2* __restrict__ slots, int lane,
-                                                 const float* U, const float* V, float* out,
-                                                 const float* wvec, float& s0, float& s1) {
-  const GroupEntry* gt = gtab + we.first_group;
-  const uint2* sp = slots + (size_t)we.slot_row_begin * 64 + lane;
-  for (int g = 0; g < we.ngroups; g++) {
-    const int out_base = gt[g].out_base, ns = gt[g].nslots;
-    float acc = 0.f;
-    int j = 0;
-    for (; j + 4 <= ns; j += 4) {
-      const uint2 a0 = sp[(j + 0) * 64], a1 = sp[(j + 1) * 64], a2 = sp[(j + 2) * 64], a3 = sp[(j + 3) * 64];
-      const float u0 = U[a0.x & 0xffffu], u1 = U[a1.x & 0xffffu], u2 = U[a2.x & 0xffffu], u3 = U[a3.x & 0xffffu];
-      const float v0 = V[a0.x >> 16], v1 = V[a1.x >> 16], v2 = V[a2.x >> 16], v3 = V[a3.x >> 16];
-      acc = fmaf(__uint_as_float(a0.y) * u0, v0, acc);
-      acc = fmaf(__uint_as_float(a1.y) * u1, v1, acc);
-      acc = fmaf(__uint_as_float(a2.y) * u2, v2, acc);
-      acc = fmaf(__uint_as_float(a3.y) * u3, v3, acc);
+// ---- one frame of a tile plan: out[row] = sum_k p_k * U[i0_k] * V[i1_k] ------------------
+// The first R slot-rows of a wave are held in registers (R = 0: everything is streamed
+// from the L2-resident plan).  The plan of a wave is loop-invariant over frames, so its arcs are loaded ONCE per
+// workgroup into VGPRs (2 per slot-row) and the per-frame inner loop touches only LDS.
+// Slot-rows beyond R (plans larger than the register budget) are streamed as above.
+template <int R>
+struct ArcRegs {
+  // 2 VGPRs per slot-row: the two LDS byte offsets packed 16:16 (so this variant needs
+  // 4*Hp and 4*D below 65536) and the arc probability.
+  uint32_t pk[R > 0 ? R : 1];
+  float p[R > 0 ? R : 1];
+  __device__ __forceinline__ void load(const WaveEntry we, const uint2* __restrict__ slots, int lane) {
+    const uint2* sp = slots + (size_t)we.slot_row_begin * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      uint2 a = make_uint2(0u, 0u);
+      if (s < we.nslot_rows) a = sp[s * 64];
+      pk[s] = ((a.x & 0xffffu) << 2) | ((a.x >> 16) << 18);
+      p[s] = __uint_as_float(a.y);
     }
-    for (; j < ns; j++) {
-      const uint2 a0 = sp[j * 64];
-      acc = fmaf(__uint_as_float(a0.y) * U[a0.x & 0xffffu], V[a0.x >> 16], acc);
-    }
-    sp += (size_t)ns * 64;
-    out[out_base + lane] = acc;
-    s0 += acc;
-    if (wvec) s1 += acc * wvec[out_base + lane];
   }
+};
+
+__device__ __forceinline__ float lds_at(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// MODE 0: out[out_base+lane] = acc (recursions).  MODE 1: out[row_map[out_base+lane]] = acc
+// (occupancy pass: plan order -> natural pdf order, row_map in LDS, -1 = padding row).
+#define PYCHAIN_TILE_FLUSH()                                                   \
+  do {                                                                         \
+    const int pos = cur_base + lane;                                           \
+    if constexpr (MODE == 0) {                                                 \
+      out[pos] = acc;                                                          \
+      s0 += acc;                                                               \
+      if (wvec) s1 += acc * wvec[pos];                                         \
+    } else {                                                                   \
+      const int n = row_map[pos];                                              \
+      if (n >= 0) out[n] = acc;                                                \
+    }                                                                          \
+    acc = 0.f;                                                                 \
+    g++;                                                                       \
+    cur_base = nxt_base; remaining = nxt_n;                                    \
+    if (g + 1 < ng) { nxt_base = gt[g + 1].out_base; nxt_n = gt[g + 1].nslots; } \
+    else { nxt_base = 0; nxt_n = 0; }                                          \
+  } while (0)
+
+template <int R, int MODE>
+__device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const WaveEntry we,
+                                          const GroupEntry* __restrict__ gtab, const uint2* __restrict__ slots,
+                                          int lane, const float* U, const float* V, float* out,
+                                          const int* row_map, const float* wvec, float& s0, float& s1) {
+  const GroupEntry* gt = gtab + we.first_group;
+  const int ng = we.ngroups, ns = we.nslot_rows;
+  int g = 0;
+  int cur_base = 0, remaining = 0, nxt_base = 0, nxt_n = 0;   // one group ahead: its scalar load is off the critical path
+  if (ng > 0) { cur_base = gt[0].out_base; remaining = gt[0].nslots; }
+  if (ng > 1) { nxt_base = gt[1].out_base; nxt_n = gt[1].nslots; }
+  float acc = 0.f;
+#pragma unroll
+  for (int s = 0; s < R; s++) {
+    if (s < ns) {
+      // Opaque to the optimiser: without this it hoists the two unpacked offsets of every
+      // slot out of the frame loop and the arcs cost 3 VGPRs each instead of 2.
+      asm volatile("" : "+v"(ar.pk[s]));
+      acc = fmaf(ar.p[s] * lds_at(U, ar.pk[s] & 0xffffu), lds_at(V, ar.pk[s] >> 16), acc);
+      if (--remaining == 0) PYCHAIN_TILE_FLUSH();
+    }
+  }
+  if (ns > R) {
+    const uint2* sp = slots + ((size_t)we.slot_row_begin + R) * 64 + lane;
+    for (int s = R; s < ns; s++) {
+      const uint2 a = *sp;
+      sp += 64;
+      acc = fmaf(__uint_as_float(a.y) * U[a.x & 0xffffu], V[a.x >> 16], acc);
+      if (--remaining == 0) PYCHAIN_TILE_FLUSH();
+    }
+  }
+  while (g < ng) PYCHAIN_TILE_FLUSH();           // trailing groups whose rows have no arcs: zeros
 }
 
 // ------------------------------------------------------------------------------------
 // launch 1: alpha and beta recursions
 // ------------------------------------------------------------------------------------
-template <int VEC, int XCH>
+template <int VEC, int XCH, int R>
 __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
@@ -89,6 +138,8 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
+  ArcRegs<R> arcs;
+  arcs.load(we, slots, lane);
 
   float* vec0 = reinterpret_cast<float*>(smem_raw);
   float* vec1 = vec0 + Hp;
@@ -152,7 +203,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     if (have_next) xq.load(xrow_next, D, tid);       // in flight during the arc work
 
     float s0 = 0.f, s1 = 0.f;
-    tile_rows_stream(we, gtab, slots, lane, vin, xcur, vout, fwd ? nullptr : lk, s0, s1);
+    tile_rows<R, 0>(arcs, we, gtab, slots, lane, vin, xcur, vout, nullptr, fwd ? nullptr : lk, s0, s1);
     s0 = wave_sum(s0);
     if (!fwd) s1 = wave_sum(s1);
     if (lane == 0) { red[wave] = s0; red[kNW + wave] = s1; }
@@ -199,7 +250,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 // ------------------------------------------------------------------------------------
 // launch 2: occupancies (time-parallel)
 // ------------------------------------------------------------------------------------
-template <int VEC, int XCH>
+template <int VEC, int XCH, int R>
 __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
@@ -210,6 +261,11 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const int Hp = a.Hp, D = a.D, Dp = (D + 3) & ~3;
   const int t_begin = blockIdx.x * a.frames_per_block;
   const int t_end = min(t_begin + a.frames_per_block, a.T);
+  float* gseq = a.grad + (size_t)b * a.T * D;
+  if (t_begin >= L) {                               // whole chunk is padding: exact zeros (zeros_like, :58)
+    for (size_t i = (size_t)t_begin * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
+    return;
+  }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
   const TilePlan tp = hd->gamma;
@@ -217,27 +273,26 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
   const int32_t* row_pdf = reinterpret_cast<const int32_t*>(plan + hd->off_row_pdf);
+  ArcRegs<R> arcs;
+  arcs.load(we, slots, lane);
 
   float* U = reinterpret_cast<float*>(smem_raw);   // alpha'(t,.)   [Hp]
   float* V = U + Hp;                                // beta(t+1,.)   [Hp]
   float* xr = V + Hp;                               // exp x(t,.)    [Dp]
   float* q = xr + Dp;                               // per-pdf arc sums, natural pdf order [Dp]
-  float* stage = q + Dp;                            // per-row sums in plan order [ngroups*64]
-  float* red = stage + tp.ngroups * 64;             // [kNW]
+  int* rmap = reinterpret_cast<int*>(q + Dp);       // plan row -> pdf-id [ngroups*64]
+  float* red = reinterpret_cast<float*>(rmap + tp.ngroups * 64);   // [kNW]
 
   const float* xseq = a.x + (size_t)b * a.T * D;
-  float* gseq = a.grad + (size_t)b * a.T * D;
   const float* aseq = a.alpha_store + (size_t)b * a.T * Hp;
   const float* bseq = a.beta_store + (size_t)b * (a.T + 1) * Hp;
 
   for (int i = tid; i < Dp; i += kNT) q[i] = 0.f;   // pdfs without arcs stay zero forever
+  for (int i = tid; i < tp.ngroups * 64; i += kNT) rmap[i] = row_pdf[i];
   int bad = 0;
-  for (int t = t_begin; t < t_end; t++) {
+  const int t_live_end = min(t_end, L);
+  for (int t = t_begin; t < t_live_end; t++) {
     float* grow = gseq + (size_t)t * D;
-    if (t >= L) {                                    // padded frame: exact zeros (zeros_like, :58)
-      for (int e = tid; e < D; e += kNT) grow[e] = 0.f;
-      continue;
-    }
     XRow<kNT, VEC, XCH> xq;
     xq.load(xseq + (size_t)t * D, D, tid);
     const float* ar = aseq + (size_t)t * Hp;
@@ -249,13 +304,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     xq.store(xr, xseq + (size_t)t * D, D, tid, a.input_is_exp);
     __syncthreads();
     float s0 = 0.f, s1 = 0.f;
-    tile_rows_stream(we, gtab, slots, lane, U, V, stage, nullptr, s0, s1);
-    __syncthreads();
-    // plan order -> natural pdf order (scattered LDS write, then everything below is coalesced)
-    for (int r = tid; r < tp.ngroups * 64; r += kNT) {
-      const int n = row_pdf[r];
-      if (n >= 0) q[n] = stage[r];
-    }
+    tile_rows<R, 1>(arcs, we, gtab, slots, lane, U, V, q, rmap, nullptr, s0, s1);
     __syncthreads();
     float g[(VEC * XCH) > 0 ? (VEC * XCH) : 1];
     float part = 0.f;
@@ -297,27 +346,59 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     }
     __syncthreads();   // U/V/xr/q are rewritten by the next frame
   }
+  // padded tail of a chunk that straddles the sequence end
+  if (t_live_end < t_end)
+    for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
-template <int VEC, int XCH>
-hipError_t launch_variant(const DenArgs& a, size_t lds_rec, size_t lds_gam, int gamma_grid_x, hipStream_t st) {
-  auto rec = den_recursion_kernel<VEC, XCH>;
-  auto gam = den_gamma_kernel<VEC, XCH>;
-  hipError_t e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(rec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gam), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gam)) != hipSuccess) return e;
-  if (a.phase_mask & 1) {
-    hipLaunchKernelGGL(rec, dim3(2 * a.B), dim3(kNT), lds_rec, st, a);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-  }
-  if (a.phase_mask & 2) hipLaunchKernelGGL(gam, dim3(gamma_grid_x, a.B), dim3(kNT), lds_gam, st, a);
+template <typename K>
+hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, grid, dim3(kNT), lds, st, a);
   return hipGetLastError();
+}
+
+// rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
+// than kMaxResident keep the first kMaxResident rows in registers and stream their tail.
+// The packed-offset register format needs 4*Hp and 4*D < 65536.
+inline int pick_r(const DenArgs& a, int rows) {
+  if (rows <= 0 || a.Hp * 4 > 65535 || a.D * 4 > 65535) return 0;
+  if (rows <= 16) return 16;
+  if (rows <= 32) return 32;
+  return kMaxResident;
+}
+
+template <int VEC, int XCH>
+hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, int gx, hipStream_t st) {
+  hipError_t e = hipSuccess;
+  if (a.phase_mask & 1) {
+    const dim3 grid(2 * a.B);
+    switch (pick_r(a, hint & 0xffff)) {
+      case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0>, a, grid, lds_rec, st); break;
+      case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16>, a, grid, lds_rec, st); break;
+      case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32>, a, grid, lds_rec, st); break;
+      default: e = launch_one(den_recursion_kernel<VEC, XCH, kMaxResident>, a, grid, lds_rec, st); break;
+    }
+    if (e != hipSuccess) return e;
+  }
+  if (a.phase_mask & 2) {
+    const dim3 grid(gx, a.B);
+    switch (pick_r(a, (hint >> 16) & 0x7fff)) {
+      case 0: e = launch_one(den_gamma_kernel<VEC, XCH, 0>, a, grid, lds_gam, st); break;
+      case 16: e = launch_one(den_gamma_kernel<VEC, XCH, 16>, a, grid, lds_gam, st); break;
+      case 32: e = launch_one(den_gamma_kernel<VEC, XCH, 32>, a, grid, lds_gam, st); break;
+      default: e = launch_one(den_gamma_kernel<VEC, XCH, kMaxResident>, a, grid, lds_gam, st); break;
+    }
+  }
+  return e;
 }
 
 }  // namespace
 
-hipError_t launch_den(const DenArgs& a, int gamma_max_groups, hipStream_t st, const char** why) {
+hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,
+                      const char** why) {
   const int Dp = (a.D + 3) & ~3;
   const size_t lds_rec = sizeof(float) * (3 * (size_t)a.Hp + 2 * (size_t)Dp + 2 * kNW);
   const size_t lds_gam = sizeof(float) * (2 * (size_t)a.Hp + 2 * (size_t)Dp + (size_t)gamma_max_groups * 64 + kNW);
@@ -326,16 +407,15 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, hipStream_t st, co
     return hipErrorInvalidValue;
   }
   const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
-  const int D = a.D;
+  const int D = a.D, r = resident_slot_rows;
   if (D % 4 == 0) {
-    if (D <= 4 * kNT) return launch_variant<4, 1>(a, lds_rec, lds_gam, gx, st);
-    if (D <= 8 * kNT) return launch_variant<4, 2>(a, lds_rec, lds_gam, gx, st);
-    if (D <= 16 * kNT) return launch_variant<4, 4>(a, lds_rec, lds_gam, gx, st);
-  } else {
-    if (D <= kNT) return launch_variant<1, 1>(a, lds_rec, lds_gam, gx, st);
-    if (D <= 4 * kNT) return launch_variant<1, 4>(a, lds_rec, lds_gam, gx, st);
+    if (D <= 4 * kNT) return launch_r<4, 1>(a, r, lds_rec, lds_gam, gx, st);
+    if (D <= 8 * kNT) return launch_r<4, 2>(a, r, lds_rec, lds_gam, gx, st);
+    if (D <= 16 * kNT) return launch_r<4, 4>(a, r, lds_rec, lds_gam, gx, st);
+  } else if (D <= 4 * kNT) {
+    return launch_r<1, 4>(a, r, lds_rec, lds_gam, gx, st);
   }
-  return launch_variant<1, 0>(a, lds_rec, lds_gam, gx, st);
+  return launch_r<1, 0>(a, r, lds_rec, lds_gam, gx, st);
 }
 
 }  // namespace pychain_hip

@@ -35,7 +35,7 @@ class ChainFunction(torch.autograd.Function):
         D = x.size(2)
         if not graphs.log_domain:   # usually the denominator
             if graphs.shared_graph is not None:
-                plan, stride = _plan.graph_plan(graphs.shared_graph, D, x.device), 0
+                plan = _plan.graph_plan(graphs.shared_graph, D, x.device)
             else:
                 key = ("den_plans", str(x.device), D)
                 hit = graphs._device_cache.get(key)
@@ -45,9 +45,9 @@ class ChainFunction(torch.autograd.Function):
                         "backward_transitions", "backward_transition_indices", "backward_transition_probs",
                         "leaky_probs", "initial_probs", "final_probs")}, D, x.device)
                     graphs._device_cache[key] = hit
-                plan, stride = hit
+                plan = hit
             objf, input_grad, bad = native.den_forward_backward(
-                plan, stride, graphs.num_states, x, input_lengths, leaky_coefficient, input_is_exp=False)
+                plan, x, input_lengths, leaky_coefficient, input_is_exp=False)
         else:                       # usually the numerator
             gt = graphs.device_tensors(x.device)
             gstride = 0 if graphs.shared_graph is not None else 1

@@ -46,9 +46,10 @@ def _check_lengths(lengths, B, T):
             raise ValueError("sequence lengths must be in [1, %d]" % T)
 
 
-def den_forward_backward(plan, plan_stride, num_states, x, lengths, leaky_coefficient=1e-5,
-                         input_is_exp=False, grad_scale=1.0):
-    """Denominator on the GPU.  Returns (objf_per_seq[B], grad[B,T,D], bad_count[1])."""
+def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=False, grad_scale=1.0):
+    """Denominator on the GPU.  `plan`: _plan.DevicePlan.
+    Returns (objf_per_seq[B], grad[B,T,D], bad_count[1])."""
+    num_states = plan.num_states
     _require_device(x, "nnet_output")
     x = x.contiguous()
     if x.dtype != torch.float32:
@@ -65,7 +66,8 @@ def den_forward_backward(plan, plan_stride, num_states, x, lengths, leaky_coeffi
         nws = L.pychain_hip_den_workspace_bytes(B, T, int(num_states), D)
         ws = _workspace(nws, dev)
         _lib.check(L.pychain_hip_den_forward_backward(
-            plan.data_ptr(), int(plan_stride), int(num_states), D, x.data_ptr(), int(bool(input_is_exp)),
+            plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(),
+            int(bool(input_is_exp)),
             ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
             objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
             "pychain_hip_den_forward_backward")
@@ -134,8 +136,8 @@ def forward_backward(forward_transitions, forward_transition_indices, forward_tr
                         backward_transitions, backward_transition_indices, backward_transition_probs,
                         leaky_probs, initial_probs, final_probs]))
     D = exp_nnet_output.shape[2]
-    plan, stride = _plan.batch_plans(tensors, D, exp_nnet_output.device)
-    objf, grad, bad = den_forward_backward(plan, stride, num_states, exp_nnet_output, sequence_lengths,
+    plan = _plan.batch_plans(tensors, D, exp_nnet_output.device)
+    objf, grad, bad = den_forward_backward(plan, exp_nnet_output, sequence_lengths,
                                            leaky_hmm_coefficient, input_is_exp=True)
     return [objf.sum(), grad, bad == 0]
 

@@ -78,5 +78,7 @@ def test_batch_plans_shared_detection():
     names = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
              "backward_transitions", "backward_transition_indices", "backward_transition_probs",
              "leaky_probs", "initial_probs", "final_probs"]
-    blob, stride = _plan.batch_plans({n: getattr(gb, n) for n in names}, 40, "cpu")
-    assert stride == 0 and np.array_equal(blob.numpy(), _blob(g, 40))
+    dp = _plan.batch_plans({n: getattr(gb, n) for n in names}, 40, "cpu")
+    assert dp.stride == 0 and np.array_equal(dp.blob.numpy(), _blob(g, 40))
+    info = _plan.plan_info(_blob(g, 40))
+    assert info["num_states"] == 20 and info["num_transitions"] == 60 and dp.slot_rows == info["slot_rows"] > 0
