@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpychain_hip.so")
+LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
 ABI_VERSION = 2
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2

@@ -33,6 +33,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-fno-slp-vectorize",   # v_pk_*_f32 pairs cost v_movs and lengthen the dependent chains here
            "-I", INCLUDE] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))

@@ -11,10 +11,12 @@
 //             the beta pass does not wait for the alpha pass because both carry their own
 //             per-frame normaliser ("arbitrary_scale" in chain-computation.h:91-98 - any
 //             per-frame scale gives the same posteriors).  The state vector of the previous
-//             frame and the exp'd nnet-output row live in LDS; arcs are read wave-tiled and
-//             coalesced from the compiled plan; per-state sums are lane-private (one state
-//             per lane), per-frame totals are wave64 shuffle reductions + one LDS hop.
-//             Every normalised alpha'(t,.) / beta(t,.) row is streamed to HBM once.
+//             frame and the exp'd nnet-output row live in LDS; every wave keeps its share of
+//             the arcs in VGPRs for the whole launch (LDS address of both operands + the
+//             probability), so the per-frame inner loop is 2 ds_read + 2 VALU per arc;
+//             per-state sums are lane-private (one state per lane), per-frame totals are
+//             wave64 DPP reductions + one LDS hop.  Every normalised alpha'(t,.) / beta(t,.)
+//             row is streamed to HBM once.
 //   launch 2  den_gamma_kernel       time-parallel over all (sequence, frame-chunk) pairs:
 //             gamma(t,n) = x(t,n) * sum_{arcs with pdf n} p * alpha'(t,src) * beta(t+1,dst),
 //             normalised so that each live frame sums to one (the invariant the reference
@@ -22,6 +24,11 @@
 //             occupancy is a lane-private sum: no atomics, deterministic, exact (the
 //             reference's CUDA path adds stochastically-thresholded atomics,
 //             chain-kernels.cu:53-87; parity target is its exact CPU path).
+//
+// What bounds these kernels (profiles/): the recursion is a chain of T
+// dependent frame steps per workgroup; a step is instruction-issue bound on its CU
+// (SQ_ACTIVE_INST_* ~80 % of SIMD cycles), not HBM- or LDS-bandwidth bound, so the design
+// minimises instructions per arc and per frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,37 +40,75 @@ namespace pychain_hip {
 
 namespace {
 
-constexpr int kNT = PLAN_REC_WAVES * 64;   // threads per workgroup (both kernels)
-constexpr int kNW = PLAN_REC_WAVES;
+constexpr int kNW = PLAN_REC_WAVES;        // waves per workgroup (both kernels)
+constexpr int kNT = kNW * 64;              // threads per workgroup
 static_assert(PLAN_REC_WAVES == PLAN_GAM_WAVES, "one workgroup shape for both kernels");
-constexpr int kMaxResident = 40;           // slot-rows per wave kept in VGPRs (2 VGPRs each) at 16 waves/CU
+static_assert(kNW <= 16, "block totals are reduced inside one 16-lane DPP row");
+constexpr int kMaxResident = 64;           // slot-rows per wave kept in VGPRs (3 VGPRs each; 2 waves/SIMD => 256 VGPRs)
 
 // ---- one frame of a tile plan: out[row] = sum_k p_k * U[i0_k] * V[i1_k] ------------------
-// The first R slot-rows of a wave are held in registers (R = 0: everything is streamed
-// from the L2-resident plan).  The plan of a wave is loop-invariant over frames, so its arcs are loaded ONCE per
-// workgroup into VGPRs (2 per slot-row) and the per-frame inner loop touches only LDS.
-// Slot-rows beyond R (plans larger than the register budget) are streamed as above.
+// The first R slot-rows of a wave are held in registers as ABSOLUTE LDS byte addresses of
+// the two operands plus the arc probability (R = 0: everything is streamed from the
+// L2-resident plan).  The plan of a wave is loop-invariant over frames, so this is loaded
+// ONCE per workgroup and the per-frame inner loop touches only LDS.
 template <int R>
 struct ArcRegs {
-  // 2 VGPRs per slot-row: the two LDS byte offsets packed 16:16 (so this variant needs
-  // 4*Hp and 4*D below 65536) and the arc probability.
-  uint32_t pk[R > 0 ? R : 1];
+  uint32_t o0[R > 0 ? R : 1];
+  uint32_t o1[R > 0 ? R : 1];
   float p[R > 0 ? R : 1];
-  __device__ __forceinline__ void load(const WaveEntry we, const uint2* __restrict__ slots, int lane) {
-    const uint2* sp = slots + (size_t)we.slot_row_begin * 64 + lane;
+  __device__ __forceinline__ void load(const int nslot_rows, const uint2* __restrict__ wave_slots,
+                                       uint32_t lds_u, uint32_t lds_v) {
 #pragma unroll
     for (int s = 0; s < R; s++) {
-      uint2 a = make_uint2(0u, 0u);
-      if (s < we.nslot_rows) a = sp[s * 64];
-      pk[s] = ((a.x & 0xffffu) << 2) | ((a.x >> 16) << 18);
+      uint2 a = make_uint2(0u, 0u);                    // rows past the plan: p = 0, harmless addresses
+      if (s < nslot_rows) a = wave_slots[s * 64];
+      o0[s] = lds_u + ((a.x & 0xffffu) << 2);
+      o1[s] = lds_v + ((a.x >> 16) << 2);
+#ifdef PYCHAIN_EXP_NOCONFLICT      // timing experiment: lane-linear gathers (wrong results)
+      o0[s] = lds_u + (((threadIdx.x & 63) + 64 * (s & 7)) << 2);
+      o1[s] = lds_v + (((threadIdx.x & 63) + 64 * (s & 7)) << 2);
+#endif
+#ifdef PYCHAIN_EXP_BROADCAST       // timing experiment: every lane reads the same word
+      o0[s] = lds_u + 4 * s; o1[s] = lds_v + 4 * s;
+#endif
       p[s] = __uint_as_float(a.y);
+      // Opaque: otherwise the optimiser keeps the packed word and re-derives both addresses
+      // (and / shift / add x2) in every frame to save a register.
+      asm volatile("" : "+v"(o0[s]), "+v"(o1[s]));
     }
   }
 };
 
-__device__ __forceinline__ float lds_at(const float* base, uint32_t byte_off) {
-  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
-}
+// The wave's group table lives in registers: lane i of `base` / `n` = output base and
+// slot-row count of the wave's i-th group (read back with v_readlane), `endmask` bit s =
+// resident slot-row s closes a group.  The frame loop issues NO memory instruction for
+// bookkeeping.  (A table in global memory costs a vmcnt wait per group, and vmcnt is
+// in-order: it would also wait for the nnet-output prefetch from HBM.)
+struct GroupRegs {
+  int base, n;
+  unsigned long long endmask;
+  int ngroups, nslots;      // of this wave
+  int tail_g, tail_rem;     // group / slot-rows left in it when the streamed tail (slot-row R) starts
+  template <int R>
+  __device__ __forceinline__ void load(const WaveEntry we, const GroupEntry* __restrict__ gtab, int lane) {
+    ngroups = __builtin_amdgcn_readfirstlane(we.ngroups);
+    nslots = __builtin_amdgcn_readfirstlane(we.nslot_rows);
+    const int first = __builtin_amdgcn_readfirstlane(we.first_group);
+    base = 0; n = 0;
+    if (lane < ngroups) { const GroupEntry e = gtab[first + lane]; base = e.out_base; n = e.nslots; }
+    endmask = 0ull; tail_g = 0; tail_rem = 0;
+    int cum = 0;
+    bool tail_set = false;
+    for (int gi = 0; gi < ngroups; gi++) {
+      const int cnt = __builtin_amdgcn_readlane(n, gi);
+      if (cnt > 0) {
+        if (!tail_set && cum + cnt > R) { tail_g = gi; tail_rem = cum + cnt - (cum > R ? cum : R); tail_set = true; }
+        cum += cnt;
+        if (cum - 1 < R && cum - 1 < 64) endmask |= 1ull << (cum - 1);
+      }
+    }
+  }
+};
 
 // MODE 0: out[out_base+lane] = acc (recursions).  MODE 1: out[row_map[out_base+lane]] = acc
 // (occupancy pass: plan order -> natural pdf order, row_map in LDS, -1 = padding row).
@@ -75,49 +120,103 @@ __device__ __forceinline__ float lds_at(const float* base, uint32_t byte_off) {
       s0 += acc;                                                               \
       if (wvec) s1 += acc * wvec[pos];                                         \
     } else {                                                                   \
-      const int n = row_map[pos];                                              \
-      if (n >= 0) out[n] = acc;                                                \
+      const int nat = row_map[pos];                                            \
+      if (nat >= 0) out[nat] = acc;                                            \
     }                                                                          \
     acc = 0.f;                                                                 \
     g++;                                                                       \
-    cur_base = nxt_base; remaining = nxt_n;                                    \
-    if (g + 1 < ng) { nxt_base = gt[g + 1].out_base; nxt_n = gt[g + 1].nslots; } \
-    else { nxt_base = 0; nxt_n = 0; }                                          \
+    cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);                     \
   } while (0)
 
 template <int R, int MODE>
-__device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const WaveEntry we,
-                                          const GroupEntry* __restrict__ gtab, const uint2* __restrict__ slots,
-                                          int lane, const float* U, const float* V, float* out,
-                                          const int* row_map, const float* wvec, float& s0, float& s1) {
-  const GroupEntry* gt = gtab + we.first_group;
-  const int ng = we.ngroups, ns = we.nslot_rows;
+__device__ __forceinline__ void tile_rows(const ArcRegs<R>& ar, const GroupRegs& gr,
+                                          const uint2* __restrict__ tail_slots, int lane,
+                                          const float* __restrict__ U, const float* __restrict__ V,
+                                          float* __restrict__ out, const int* __restrict__ row_map,
+                                          const float* __restrict__ wvec, float& s0, float& s1) {
   int g = 0;
-  int cur_base = 0, remaining = 0, nxt_base = 0, nxt_n = 0;   // one group ahead: its scalar load is off the critical path
-  if (ng > 0) { cur_base = gt[0].out_base; remaining = gt[0].nslots; }
-  if (ng > 1) { nxt_base = gt[1].out_base; nxt_n = gt[1].nslots; }
+  int cur_base = __builtin_amdgcn_readlane(gr.base, 0);
   float acc = 0.f;
+  // Group ends are tested with s_bitcmp1 on two 32-bit SGPRs.  The asm makes them opaque per
+  // call: otherwise the optimiser precomputes one 64-bit lane mask PER SLOT-ROW outside the
+  // frame loop, spills them, and every slot-row pays two v_readlane reloads.
+  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32);
+  asm volatile("" : "+s"(m_lo), "+s"(m_hi));
+  // Per chunk of kChunk slot-rows: all gathers first (2*kChunk independent ds_reads in flight),
+  // then all products (independent VALU, no branch in between so they pipeline), then the
+  // running row sums.  A chunk without a group end is one adder tree; group ends (a few per
+  // frame) take the per-slot path.  Products are rounded before they are added - the
+  // reference's CPU loop does the same (chain-computation.cc:161).
+  static_assert(32 % 8 == 0, "a chunk never straddles the two mask words");
+  constexpr int kChunk = 8;
 #pragma unroll
-  for (int s = 0; s < R; s++) {
-    if (s < ns) {
-      // Opaque to the optimiser: without this it hoists the two unpacked offsets of every
-      // slot out of the frame loop and the arcs cost 3 VGPRs each instead of 2.
-      asm volatile("" : "+v"(ar.pk[s]));
-      acc = fmaf(ar.p[s] * lds_at(U, ar.pk[s] & 0xffffu), lds_at(V, ar.pk[s] >> 16), acc);
-      if (--remaining == 0) PYCHAIN_TILE_FLUSH();
+  for (int c = 0; c < R; c += kChunk) {
+    if (c < gr.nslots) {
+      float pr[kChunk];
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) {
+        pr[k] = 0.f;
+#ifndef PYCHAIN_EXP_NOLDS
+        if (c + k < R) pr[k] = (ar.p[c + k] * lds_abs(ar.o0[c + k])) * lds_abs(ar.o1[c + k]);
+#else
+        if (c + k < R) pr[k] = (ar.p[c + k] * __uint_as_float(ar.o0[c + k])) * __uint_as_float(ar.o1[c + k]);
+#endif
+      }
+      const uint32_t ends = ((c < 32 ? m_lo : m_hi) >> (c & 31)) & ((1u << kChunk) - 1u);
+      if (__builtin_expect(ends == 0u, 1)) {
+        acc += ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
+      } else {
+#pragma unroll
+        for (int k = 0; k < kChunk; k++) {
+          acc += pr[k];
+          if ((ends >> k) & 1u) PYCHAIN_TILE_FLUSH();
+        }
+      }
     }
   }
-  if (ns > R) {
-    const uint2* sp = slots + ((size_t)we.slot_row_begin + R) * 64 + lane;
-    for (int s = R; s < ns; s++) {
+  if (gr.nslots > R) {                           // plan larger than the register budget: stream the tail
+    const uint2* sp = tail_slots;
+    g = gr.tail_g;
+    cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
+    int remaining = gr.tail_rem;
+    for (int s = R; s < gr.nslots; s++) {
       const uint2 a = *sp;
       sp += 64;
-      acc = fmaf(__uint_as_float(a.y) * U[a.x & 0xffffu], V[a.x >> 16], acc);
-      if (--remaining == 0) PYCHAIN_TILE_FLUSH();
+      acc += (__uint_as_float(a.y) * U[a.x & 0xffffu]) * V[a.x >> 16];
+      if (--remaining == 0) {
+        PYCHAIN_TILE_FLUSH();
+        remaining = __builtin_amdgcn_readlane(gr.n, g & 63);
+      }
     }
   }
-  while (g < ng) PYCHAIN_TILE_FLUSH();           // trailing groups whose rows have no arcs: zeros
+  while (g < gr.ngroups) PYCHAIN_TILE_FLUSH();   // trailing groups whose rows have no arcs: zeros
 }
+
+// Normalise the frame's raw sums into the gather operand and stream the row to HBM, 16 bytes
+// per lane:  alpha: v = raw/tot + coef*leaky   (AlphaSum/AlphaDash, chain-computation.cc:97-110,178-194)
+//            beta:  v = (raw + coef*sum_i leaky_i raw_i)/sum_i raw_i  (Beta, :313-330; unit-sum scale)
+__device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const float* lk, float* cur, float* row,
+                                              float inv, float coef, float add, int H, int Hp, int tid) {
+  for (int i = tid * 4; i < Hp; i += kNT * 4) {
+    const float4 r = *reinterpret_cast<const float4*>(raw + i);
+    float4 v;
+    if (fwd) {
+      const float4 l = *reinterpret_cast<const float4*>(lk + i);
+      v = make_float4(r.x * inv + coef * l.x, r.y * inv + coef * l.y, r.z * inv + coef * l.z, r.w * inv + coef * l.w);
+    } else {
+      v = make_float4(i + 0 < H ? (r.x + add) * inv : 0.f, i + 1 < H ? (r.y + add) * inv : 0.f,
+                      i + 2 < H ? (r.z + add) * inv : 0.f, i + 3 < H ? (r.w + add) * inv : 0.f);
+    }
+    *reinterpret_cast<float4*>(cur + i) = v;
+    if (row) *reinterpret_cast<float4*>(row + i) = v;
+  }
+}
+
+// natural log on the v_log_f32 unit (1 ulp of log2): all lanes, no divergent libm call
+__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.693147182464599609375f; }
+
+// block total of per-wave partials: red[16] in LDS (entries >= kNW stay zero)
+__device__ __forceinline__ float block_total(const float* red, int lane) { return dpp_row_sum(red[lane & 15]); }
 
 // ------------------------------------------------------------------------------------
 // launch 1: alpha and beta recursions
@@ -130,7 +229,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool fwd = blockIdx.x < (unsigned)a.B;
   const int b = fwd ? blockIdx.x : blockIdx.x - a.B;
-  const int L = (int)a.lengths[b];
+  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
   const int Hp = a.Hp, H = a.H, D = a.D, Dp = (D + 3) & ~3;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
@@ -138,15 +237,22 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
-  ArcRegs<R> arcs;
-  arcs.load(we, slots, lane);
 
-  float* vec0 = reinterpret_cast<float*>(smem_raw);
-  float* vec1 = vec0 + Hp;
-  float* lk = vec1 + Hp;             // leaky probs in this side's numbering
-  float* xr0 = lk + Hp;
-  float* xr1 = xr0 + Dp;
-  float* red = xr1 + Dp;             // [2*kNW]
+  // LDS: cur = normalised state vector of the previous frame (gather operand U), xr = exp'd
+  // nnet-output row (operand V), raw = this frame's un-normalised sums, lk = leaky probs.
+  float* cur = reinterpret_cast<float*>(smem_raw);
+  float* xr = cur + Hp;
+  float* raw = xr + Dp;
+  float* lk = raw + Hp;
+  float* red = lk + Hp;              // [2][16]
+  const uint32_t lds0 = lds_addr(smem_raw);
+
+  GroupRegs groups;
+  groups.load<R>(we, gtab, lane);
+  const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
+  ArcRegs<R> arcs;
+  arcs.load(groups.nslots, wave_slots, lds0, lds0 + 4u * (uint32_t)Hp);
+  const uint2* tail_slots = wave_slots + (size_t)R * 64;
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
   const float* start_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_init_a : hd->off_final_b));
@@ -155,91 +261,93 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const float coef = a.coef;
 
   // ---- frame 0 (alpha) / frame L (beta): chain-computation.cc:92-95,97-110,178-194 / :232-245,313-330
+  if (tid < 32) red[tid] = 0.f;
   float p0 = 0.f, p1 = 0.f;
   for (int i = tid; i < Hp; i += kNT) {
     const float l = leaky_g[i], s = start_g[i];
-    lk[i] = l; vec0[i] = s;
+    lk[i] = l; raw[i] = s;
     p0 += s; p1 += s * l;
   }
   p0 = wave_sum(p0); p1 = wave_sum(p1);
-  if (lane == 0) { red[wave] = p0; red[kNW + wave] = p1; }
   XRow<kNT, VEC, XCH> xq;
   {
     const int t0 = fwd ? 0 : L - 1;                 // first nnet-output row this side consumes
     xq.load(xseq + (size_t)t0 * D, D, tid);
-    xq.store(xr0, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
   }
+  __syncthreads();                                   // red zeroed
+  if (lane == 0) { red[wave] = p0; red[16 + wave] = p1; }
   __syncthreads();
-  float tot = 0.f, wtot = 0.f;
-#pragma unroll
-  for (int w = 0; w < kNW; w++) { tot += red[w]; wtot += red[kNW + w]; }
+  float tot = block_total(red, lane), wtot = block_total(red + 16, lane);
   double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229
   int bad = 0;
   {
-    const float inv = 1.f / tot;
+    const float inv = __builtin_amdgcn_rcpf(tot);
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
-    if (fwd && tid == 0) logsum += (double)logf(tot);
-    float* row = store + (size_t)(fwd ? 0 : L) * Hp;
-    for (int i = tid; i < Hp; i += kNT) {
-      float v = fwd ? vec0[i] * inv + coef * lk[i]                    // alpha'(0)/tot(0)
-                    : (i < H ? (vec0[i] + coef * wtot) * inv : 0.f);  // beta(L), unit sum
-      vec0[i] = v;
-      row[i] = v;
-    }
+    logsum += (double)fast_log(tot);
+    normalise_row(fwd, raw, lk, cur, store + (size_t)(fwd ? 0 : L) * Hp, inv, coef, coef * wtot, H, Hp, tid);
   }
   __syncthreads();
 
   // ---- general frames.  alpha: step j produces alpha'(j+1) from alpha'(j) and x(j), j = 0..L-1
   //                        beta:  step j produces beta(t) from beta(t+1) and x(t), t = L-1-j, j = 0..L-2
   const int nsteps = fwd ? L : L - 1;
+#ifdef PYCHAIN_PROFILE_PHASES
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define PH_T() __builtin_readcyclecounter()
+#define PH_ADD(i, t0) ph[i] += PH_T() - (t0)
+#else
+#define PH_T() 0ull
+#define PH_ADD(i, t0) (void)(t0)
+#endif
   for (int j = 0; j < nsteps; j++) {
-    const float* vin = (j & 1) ? vec1 : vec0;
-    float* vout = (j & 1) ? vec0 : vec1;
-    const float* xcur = (j & 1) ? xr1 : xr0;
-    float* xnext = (j & 1) ? xr0 : xr1;
+    unsigned long long pt = PH_T();
     const int tn = fwd ? j + 1 : L - 2 - j;          // nnet-output row of the NEXT step
     const bool have_next = fwd ? (tn < L) : (tn >= 1);
     const float* xrow_next = xseq + (size_t)(have_next ? tn : 0) * D;
     if (have_next) xq.load(xrow_next, D, tid);       // in flight during the arc work
 
     float s0 = 0.f, s1 = 0.f;
-    tile_rows<R, 0>(arcs, we, gtab, slots, lane, vin, xcur, vout, nullptr, fwd ? nullptr : lk, s0, s1);
+    tile_rows<R, 0>(arcs, groups, tail_slots, lane, cur, xr, raw, nullptr, fwd ? nullptr : lk, s0, s1);
+    PH_ADD(0, pt); pt = PH_T();
     s0 = wave_sum(s0);
     if (!fwd) s1 = wave_sum(s1);
-    if (lane == 0) { red[wave] = s0; red[kNW + wave] = s1; }
-    __syncthreads();
-    tot = 0.f; wtot = 0.f;
-#pragma unroll
-    for (int w = 0; w < kNW; w++) { tot += red[w]; wtot += red[kNW + w]; }
-    const float inv = 1.f / tot;
+    if (lane == 0) { red[wave] = s0; red[16 + wave] = s1; }
+    PH_ADD(1, pt); pt = PH_T();
+    __syncthreads();                                 // every gather of this frame is done
+    PH_ADD(2, pt); pt = PH_T();
+    tot = block_total(red, lane);
+    wtot = fwd ? 0.f : block_total(red + 16, lane);
+    const float inv = __builtin_amdgcn_rcpf(tot);
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
-    if (fwd && tid == 0) logsum += (double)logf(tot);
+    logsum += (double)fast_log(tot);
     const int tstore = fwd ? j + 1 : L - 1 - j;
     const bool do_store = fwd ? (tstore < L) : true;
-    float* row = store + (size_t)(do_store ? tstore : 0) * Hp;
-    for (int i = tid; i < Hp; i += kNT) {
-      float v = fwd ? vout[i] * inv + coef * lk[i]
-                    : (i < H ? (vout[i] + coef * wtot) * inv : 0.f);
-      vout[i] = v;
-      if (do_store) row[i] = v;
-    }
-    if (have_next) xq.store(xnext, xrow_next, D, tid, a.input_is_exp);
+    normalise_row(fwd, raw, lk, cur, do_store ? store + (size_t)tstore * Hp : nullptr, inv, coef, coef * wtot,
+                  H, Hp, tid);
+    PH_ADD(3, pt); pt = PH_T();
+    if (have_next) xq.store(xr, xrow_next, D, tid, a.input_is_exp);
+    PH_ADD(4, pt); pt = PH_T();
     __syncthreads();
+    PH_ADD(5, pt);
   }
+#ifdef PYCHAIN_PROFILE_PHASES
+  if (lane == 0 && (b == 0) && (wave == 0 || wave == kNW - 1))
+    printf("dir %d wave %d steps %d cycles/step: arcs %llu wsum %llu bar1 %llu update %llu xstore %llu bar2 %llu\n", (int)fwd, wave,
+           nsteps, ph[0] / nsteps, ph[1] / nsteps, ph[2] / nsteps, ph[3] / nsteps, ph[4] / nsteps, ph[5] / nsteps);
+#endif
 
   if (fwd) {
     // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i alpha'(L,i) final(i) + sum_t log tot(t)
-    const float* vL = (nsteps & 1) ? vec1 : vec0;
     const float* fin = reinterpret_cast<const float*>(plan + hd->off_final_a);
     float f = 0.f;
-    for (int i = tid; i < Hp; i += kNT) f += vL[i] * fin[i];
+    for (int i = tid; i < Hp; i += kNT) f += cur[i] * fin[i];
     f = wave_sum(f);
     if (lane == 0) red[wave] = f;
     __syncthreads();
+    const float fs = block_total(red, lane);
     if (tid == 0) {
-      float fs = 0.f;
-      for (int w = 0; w < kNW; w++) fs += red[w];
-      const float objf = (float)(logsum + (double)logf(fs));
+      const float objf = (float)(logsum + (double)fast_log(fs));
       a.objf[b] = objf;
       if (!(fs > 0.f) || !(objf - objf == 0.f)) bad = 1;
     }
@@ -257,7 +365,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
-  const int L = (int)a.lengths[b];
+  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
   const int Hp = a.Hp, D = a.D, Dp = (D + 3) & ~3;
   const int t_begin = blockIdx.x * a.frames_per_block;
   const int t_end = min(t_begin + a.frames_per_block, a.T);
@@ -273,20 +381,27 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
   const int32_t* row_pdf = reinterpret_cast<const int32_t*>(plan + hd->off_row_pdf);
-  ArcRegs<R> arcs;
-  arcs.load(we, slots, lane);
 
   float* U = reinterpret_cast<float*>(smem_raw);   // alpha'(t,.)   [Hp]
   float* V = U + Hp;                                // beta(t+1,.)   [Hp]
   float* xr = V + Hp;                               // exp x(t,.)    [Dp]
   float* q = xr + Dp;                               // per-pdf arc sums, natural pdf order [Dp]
   int* rmap = reinterpret_cast<int*>(q + Dp);       // plan row -> pdf-id [ngroups*64]
-  float* red = reinterpret_cast<float*>(rmap + tp.ngroups * 64);   // [kNW]
+  float* red = reinterpret_cast<float*>(rmap + tp.ngroups * 64);   // [16]
+  const uint32_t lds0 = lds_addr(smem_raw);
+
+  GroupRegs groups;
+  groups.load<R>(we, gtab, lane);
+  const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
+  ArcRegs<R> arcs;
+  arcs.load(groups.nslots, wave_slots, lds0, lds0 + 4u * (uint32_t)Hp);
+  const uint2* tail_slots = wave_slots + (size_t)R * 64;
 
   const float* xseq = a.x + (size_t)b * a.T * D;
   const float* aseq = a.alpha_store + (size_t)b * a.T * Hp;
   const float* bseq = a.beta_store + (size_t)b * (a.T + 1) * Hp;
 
+  if (tid < 16) red[tid] = 0.f;
   for (int i = tid; i < Dp; i += kNT) q[i] = 0.f;   // pdfs without arcs stay zero forever
   for (int i = tid; i < tp.ngroups * 64; i += kNT) rmap[i] = row_pdf[i];
   int bad = 0;
@@ -304,7 +419,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     xq.store(xr, xseq + (size_t)t * D, D, tid, a.input_is_exp);
     __syncthreads();
     float s0 = 0.f, s1 = 0.f;
-    tile_rows<R, 1>(arcs, we, gtab, slots, lane, U, V, q, rmap, nullptr, s0, s1);
+    tile_rows<R, 1>(arcs, groups, tail_slots, lane, U, V, q, rmap, nullptr, s0, s1);
     __syncthreads();
     float g[(VEC * XCH) > 0 ? (VEC * XCH) : 1];
     float part = 0.f;
@@ -323,9 +438,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     part = wave_sum(part);
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < kNW; w++) tot += red[w];
+    const float tot = block_total(red, lane);
     const float sc = a.grad_scale / tot;
     if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
     if constexpr (XCH > 0) {
@@ -362,11 +475,11 @@ hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream
 
 // rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
 // than kMaxResident keep the first kMaxResident rows in registers and stream their tail.
-// The packed-offset register format needs 4*Hp and 4*D < 65536.
-inline int pick_r(const DenArgs& a, int rows) {
-  if (rows <= 0 || a.Hp * 4 > 65535 || a.D * 4 > 65535) return 0;
+inline int pick_r(int rows) {
+  if (rows <= 0) return 0;
   if (rows <= 16) return 16;
   if (rows <= 32) return 32;
+  if (rows <= 48) return 48;
   return kMaxResident;
 }
 
@@ -375,20 +488,22 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
   hipError_t e = hipSuccess;
   if (a.phase_mask & 1) {
     const dim3 grid(2 * a.B);
-    switch (pick_r(a, hint & 0xffff)) {
+    switch (pick_r(hint & 0xffff)) {
       case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0>, a, grid, lds_rec, st); break;
       case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16>, a, grid, lds_rec, st); break;
       case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32>, a, grid, lds_rec, st); break;
+      case 48: e = launch_one(den_recursion_kernel<VEC, XCH, 48>, a, grid, lds_rec, st); break;
       default: e = launch_one(den_recursion_kernel<VEC, XCH, kMaxResident>, a, grid, lds_rec, st); break;
     }
     if (e != hipSuccess) return e;
   }
   if (a.phase_mask & 2) {
     const dim3 grid(gx, a.B);
-    switch (pick_r(a, (hint >> 16) & 0x7fff)) {
+    switch (pick_r((hint >> 16) & 0x7fff)) {
       case 0: e = launch_one(den_gamma_kernel<VEC, XCH, 0>, a, grid, lds_gam, st); break;
       case 16: e = launch_one(den_gamma_kernel<VEC, XCH, 16>, a, grid, lds_gam, st); break;
       case 32: e = launch_one(den_gamma_kernel<VEC, XCH, 32>, a, grid, lds_gam, st); break;
+      case 48: e = launch_one(den_gamma_kernel<VEC, XCH, 48>, a, grid, lds_gam, st); break;
       default: e = launch_one(den_gamma_kernel<VEC, XCH, kMaxResident>, a, grid, lds_gam, st); break;
     }
   }
@@ -400,8 +515,8 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,
                       const char** why) {
   const int Dp = (a.D + 3) & ~3;
-  const size_t lds_rec = sizeof(float) * (3 * (size_t)a.Hp + 2 * (size_t)Dp + 2 * kNW);
-  const size_t lds_gam = sizeof(float) * (2 * (size_t)a.Hp + 2 * (size_t)Dp + (size_t)gamma_max_groups * 64 + kNW);
+  const size_t lds_rec = sizeof(float) * (3 * (size_t)a.Hp + (size_t)Dp + 32);
+  const size_t lds_gam = sizeof(float) * (2 * (size_t)a.Hp + 2 * (size_t)Dp + (size_t)gamma_max_groups * 64 + 16);
   if (lds_rec > 160 * 1024 || lds_gam > 160 * 1024) {
     *why = "state vector + nnet-output row do not fit the 160 KiB LDS of one CU";
     return hipErrorInvalidValue;
@@ -409,11 +524,11 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
   const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   const int D = a.D, r = resident_slot_rows;
   if (D % 4 == 0) {
-    if (D <= 4 * kNT) return launch_r<4, 1>(a, r, lds_rec, lds_gam, gx, st);
-    if (D <= 8 * kNT) return launch_r<4, 2>(a, r, lds_rec, lds_gam, gx, st);
-    if (D <= 16 * kNT) return launch_r<4, 4>(a, r, lds_rec, lds_gam, gx, st);
-  } else if (D <= 4 * kNT) {
-    return launch_r<1, 4>(a, r, lds_rec, lds_gam, gx, st);
+    if (D <= 4 * 2 * kNT) return launch_r<4, 2>(a, r, lds_rec, lds_gam, gx, st);
+    if (D <= 4 * 4 * kNT) return launch_r<4, 4>(a, r, lds_rec, lds_gam, gx, st);
+    if (D <= 4 * 8 * kNT) return launch_r<4, 8>(a, r, lds_rec, lds_gam, gx, st);
+  } else if (D <= 8 * kNT) {
+    return launch_r<1, 8>(a, r, lds_rec, lds_gam, gx, st);
   }
   return launch_r<1, 0>(a, r, lds_rec, lds_gam, gx, st);
 }

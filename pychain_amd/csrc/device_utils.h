@@ -3,13 +3,52 @@
 #define PYCHAIN_HIP_DEVICE_UTILS_H_
 
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 
 namespace pychain_hip {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- LDS by absolute byte address (so an operand address is ONE VGPR, no base add) ----
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(lds_char*)(p);
+}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+__device__ __forceinline__ float lds_abs(uint32_t byte_addr) { return *(lds_cfloat*)(byte_addr); }
+#pragma clang diagnostic pop
+
+// ---- wave64 reductions on DPP (no LDS traffic, unlike __shfl_xor = ds_bpermute) --------
+#define PYCHAIN_DPP_ADD(v, ctrl) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true)))
+// sum over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ float dpp_row_sum(float v) {
+  v = PYCHAIN_DPP_ADD(v, 0xB1);    // quad_perm [1,0,3,2]
+  v = PYCHAIN_DPP_ADD(v, 0x4E);    // quad_perm [2,3,0,1]
+  v = PYCHAIN_DPP_ADD(v, 0x141);   // row_half_mirror
+  v = PYCHAIN_DPP_ADD(v, 0x140);   // row_mirror
   return v;
+}
+// sum over the wave, same value (an SGPR-derived one) in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_row_sum(v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
+// exp(c) for |c| <= 30 in 6 VALU ops: v_exp_f32 on a split product c*log2(e) = t + r,
+// exp(c) = 2^t * (1 + r ln2).  Relative error ~1e-7 (one v_exp ulp); the generic expf
+// spends ~25 instructions on range handling this input range never needs.
+__device__ __forceinline__ float exp_bounded(float c) {
+  const float kL2E = 1.44269502162933349609375f;       // fp32(log2 e)
+  const float kL2E_lo = 1.925963033500011e-8f;          // log2 e - fp32(log2 e)
+  const float t = c * kL2E;
+  const float r = fmaf(c, kL2E, -t) + c * kL2E_lo;
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147182464599609375f, e);
 }
 
 // How a raw nnet-output element enters LDS (pychain/loss.py:30,43):
@@ -19,8 +58,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 enum { kXExpClamp = 0, kXIdentity = 1, kXClamp = 2 };
 __device__ __forceinline__ float clamp_exp(float v, int mode) {
   if (mode == kXIdentity) return v;
-  const float c = fminf(fmaxf(v, -30.f), 30.f);
-  return mode == kXClamp ? c : expf(c);
+  const float c = __builtin_amdgcn_fmed3f(v, -30.f, 30.f);
+  return mode == kXClamp ? c : exp_bounded(c);
 }
 
 // ---- nnet-output row: global -> registers (early) -> LDS (late) ------------------

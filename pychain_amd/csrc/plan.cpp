@@ -42,8 +42,9 @@ BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vecto
   std::vector<std::vector<int>> per_wave(nwaves);
   std::vector<int> load(nwaves, 0);
   for (int g = 0; g < ngroups; g++) {
-    int w = 0;
-    for (int i = 1; i < nwaves; i++) if (load[i] < load[w]) w = i;
+    int w = -1;                     // a wave keeps its group table in one VGPR pair: <= 64 groups
+    for (int i = 0; i < nwaves; i++)
+      if (per_wave[i].size() < 64 && (w < 0 || load[i] < load[w])) w = i;
     per_wave[w].push_back(g);
     load[w] += gsl[g] + 1;        // +1: the per-group store/bookkeeping cost
   }

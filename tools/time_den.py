@@ -1,0 +1,23 @@
+"""Time the two denominator launches in isolation (events on the launch stream)."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO]
+import torch
+from pychain_amd import _lib, _plan, native, synthetic as syn
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+dev = torch.device("cuda:0")
+w = syn.make_workload(name, device=dev)
+plan = _plan.graph_plan(w["den_graph"], w["cfg"]["D"], dev)
+Ld = w["lengths"].to(dev)
+L = _lib.lib()
+call = lambda: native.den_forward_backward(plan, w["x"], Ld, 1e-5)
+call(); torch.cuda.synchronize()
+for mname, mask in (("recursion", 1), ("gamma", 2), ("both", 3)):
+    L.pychain_hip_set_den_phase_mask(mask)
+    call(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in ev:
+        a.record(); call(); b.record()
+    torch.cuda.synchronize()
+    print(name, mname, "ms", sorted(a.elapsed_time(b) for a, b in ev)[2])
+L.pychain_hip_set_den_phase_mask(3)
