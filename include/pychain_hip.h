@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 2
+#define PYCHAIN_HIP_ABI_VERSION 3
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -158,6 +158,40 @@ int pychain_hip_num_forward_backward(
     int grad_mode, float grad_scale,
     float* objf_per_seq, float* grad, int32_t* bad_count,
     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused ChainLoss (replaces the two ChainFunction calls + the autograd add of
+ * pychain/loss.py:97-105 with one pass):
+ *
+ *   grad[b,t,n] = grad_scale * (gamma_den(b,t,n) - gamma_num(b,t,n))      written ONCE
+ *   den_objf[b], num_objf[b] = per-sequence log-probabilities
+ *
+ * so that loss = -(sum num_objf - sum den_objf) [* grad_scale when the caller folds the
+ * 1/sum(lengths) of `avg=True` into grad_scale] and d loss / d nnet_output = grad.
+ * Numerically identical to calling the two entry points above and subtracting.
+ *
+ * Scheduling: the numerator recursion is independent of the denominator until the final
+ * subtraction, so it runs CONCURRENTLY on a library-owned non-blocking side stream
+ * (fork/join with events on `stream`; created once per device on first use, the only
+ * hidden state of this library); the join precedes the sparse subtraction.
+ * bad_count: dev int32[2] = {denominator, numerator}.
+ * Arguments as in pychain_hip_den_forward_backward / pychain_hip_num_forward_backward.
+ */
+int pychain_hip_chain_loss_forward_backward(
+    /* denominator */
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
+    float leaky_hmm_coefficient,
+    /* numerator */
+    const int32_t* forward_transitions, const int32_t* forward_transition_indices,
+    const float* forward_transition_probs, const int32_t* backward_transitions,
+    const int32_t* backward_transition_indices, const float* backward_transition_probs,
+    const float* initial_probs, const float* final_probs, int graph_batch_stride,
+    int num_num_states, int num_num_transitions,
+    /* shared */
+    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs, float grad_scale,
+    float* den_objf_per_seq, float* num_objf_per_seq, float* grad, int32_t* bad_count,
+    void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
+    void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,4 +6,4 @@
 repository root, so code written against the reference imports unchanged.)
 """
 from .graph import ChainGraph, ChainGraphBatch  # noqa: F401
-from .loss import ChainFunction, ChainLoss  # noqa: F401
+from .loss import ChainFunction, ChainLoss, ChainLossFunction  # noqa: F401

@@ -56,33 +56,29 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + 256;
 }
 
-extern "C" int pychain_hip_den_forward_backward(
-    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int H, int D,
-    const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
-    int B, int T, float leaky_hmm_coefficient, float grad_scale,
-    float* objf_per_seq, float* grad, int32_t* bad_count,
-    void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, int H, int D,
+                  const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+                  int B, int T, float leaky_hmm_coefficient, float grad_scale,
+                  float* objf_per_seq, float* grad, int32_t* bad_count,
+                  void* workspace, size_t workspace_bytes, const char* who) {
   if (!plans_dev || !nnet_output || !seq_lengths || !objf_per_seq || !grad || !bad_count || !workspace)
-    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: null pointer argument");
+    return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
   if (B <= 0 || T <= 0 || H <= 0 || D <= 0)
-    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: bad sizes B=%d T=%d H=%d D=%d", B, T, H, D);
+    return fail(PYCHAIN_HIP_EINVAL, "%s: bad sizes B=%d T=%d H=%d D=%d", who, B, T, H, D);
   if (H > 65535 || D > 65535)
-    return fail(PYCHAIN_HIP_EUNSUPPORTED, "den_forward_backward: num_states and num_pdfs must be <= 65535");
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: num_states and num_pdfs must be <= 65535", who);
   // chain-computation.cc:68 asserts 0 < coefficient < 1 (compiled out under NDEBUG); here it is an error
   if (!(leaky_hmm_coefficient > 0.f && leaky_hmm_coefficient < 1.f))
-    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: leaky_hmm_coefficient must be in (0,1), got %g",
+    return fail(PYCHAIN_HIP_EINVAL, "%s: leaky_hmm_coefficient must be in (0,1), got %g", who,
                 (double)leaky_hmm_coefficient);
   if (plan_stride_bytes < 0 || (plan_stride_bytes & 15))
-    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: plan stride must be a non-negative multiple of 16");
+    return fail(PYCHAIN_HIP_EINVAL, "%s: plan stride must be a non-negative multiple of 16", who);
   if (((uintptr_t)plans_dev | (uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)workspace) & 15)
-    return fail(PYCHAIN_HIP_EINVAL, "den_forward_backward: plan, nnet_output, grad and workspace must be 16-byte aligned");
+    return fail(PYCHAIN_HIP_EINVAL, "%s: plan, nnet_output, grad and workspace must be 16-byte aligned", who);
   if (workspace_bytes < pychain_hip_den_workspace_bytes(B, T, H, D))
-    return fail(PYCHAIN_HIP_EWORKSPACE, "den_forward_backward: workspace too small (%zu < %zu)", workspace_bytes,
+    return fail(PYCHAIN_HIP_EWORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
                 pychain_hip_den_workspace_bytes(B, T, H, D));
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
-    return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: hipMemsetAsync failed");
-  DenArgs a;
   memset(&a, 0, sizeof(a));
   a.plans = (const char*)plans_dev; a.plan_stride = plan_stride_bytes;
   a.x = nnet_output; a.lengths = seq_lengths; a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
@@ -94,6 +90,24 @@ extern "C" int pychain_hip_den_forward_backward(
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_store = (float*)ws;
   a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
+  return PYCHAIN_HIP_OK;
+}
+}  // namespace
+
+extern "C" int pychain_hip_den_forward_backward(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int H, int D,
+    const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+    int B, int T, float leaky_hmm_coefficient, float grad_scale,
+    float* objf_per_seq, float* grad, int32_t* bad_count,
+    void* workspace, size_t workspace_bytes, void* stream) {
+  DenArgs a;
+  int rc = fill_den_args(a, plans_dev, plan_stride_bytes, H, D, nnet_output, input_is_exp, seq_lengths, B, T,
+                         leaky_hmm_coefficient, grad_scale, objf_per_seq, grad, bad_count, workspace,
+                         workspace_bytes, "den_forward_backward");
+  if (rc != PYCHAIN_HIP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
+    return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: hipMemsetAsync failed");
   const char* why = nullptr;
   hipError_t e = launch_den(a, (D + 63) / 64, resident_slot_rows, st, &why);
   if (e != hipSuccess)
@@ -102,10 +116,55 @@ extern "C" int pychain_hip_den_forward_backward(
   return PYCHAIN_HIP_OK;
 }
 
+namespace {
+struct NumCarve { size_t alpha, occ, total; };
+NumCarve num_carve(int B, int T, int H, int K) {
+  NumCarve c;
+  c.alpha = 0;
+  c.occ = align256(8 * (size_t)B * (T + 1) * H);
+  c.total = c.occ + align256(4 * (size_t)B * T * K) + 256;
+  return c;
+}
+
+int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float* fp,
+                  const int32_t* bt, const int32_t* bi, const float* bp,
+                  const float* initial, const float* final_, int graph_batch_stride,
+                  const float* nnet_output, const int64_t* seq_lengths,
+                  int B, int T, int D, int H, int K, int grad_mode, float grad_scale,
+                  float* objf_per_seq, float* grad, int32_t* bad_count,
+                  void* workspace, size_t workspace_bytes, const char* who) {
+  if (!ft || !fi || !fp || !bt || !bi || !bp || !initial || !final_ || !nnet_output || !seq_lengths ||
+      !objf_per_seq || !grad || !bad_count || !workspace)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
+  if (B <= 0 || T <= 0 || H <= 0 || D <= 0 || K <= 0)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: bad sizes B=%d T=%d H=%d K=%d D=%d", who, B, T, H, K, D);
+  if (H > 65535 || D > 65535)
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: num_states and num_pdfs must be <= 65535", who);
+  if (graph_batch_stride != 0 && graph_batch_stride != 1)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: graph_batch_stride must be 0 or 1", who);
+  if (grad_mode < PYCHAIN_HIP_GRAD_LOG || grad_mode > PYCHAIN_HIP_GRAD_ACCUM)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: unknown grad_mode %d", who, grad_mode);
+  if (((uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)fi | (uintptr_t)bi) & 15)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: nnet_output, grad and index tensors must be 16-byte aligned", who);
+  const NumCarve c = num_carve(B, T, H, K);
+  if (workspace_bytes < c.total) return fail(PYCHAIN_HIP_EWORKSPACE, "%s: workspace too small", who);
+  memset(&a, 0, sizeof(a));
+  a.fwd_trans = ft; a.fwd_idx = fi; a.fwd_probs = fp; a.bwd_trans = bt; a.bwd_idx = bi; a.bwd_probs = bp;
+  a.initial = initial; a.final_ = final_; a.x = nnet_output; a.lengths = seq_lengths;
+  a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
+  a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
+  a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 16;
+  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  a.alpha_ws = (double*)(ws + c.alpha);
+  a.occ_ws = (float*)(ws + c.occ);
+  return PYCHAIN_HIP_OK;
+}
+}  // namespace
+
 extern "C" size_t pychain_hip_num_workspace_bytes(int B, int T, int H, int K, int D) {
-  (void)K; (void)D;
-  if (B <= 0 || T <= 0 || H <= 0) return 0;
-  return align256(4 * (size_t)B * (T + 1) * H) + align256(4 * (size_t)B * (T + 1)) + 256;
+  (void)D;
+  if (B <= 0 || T <= 0 || H <= 0 || K <= 0) return 0;
+  return num_carve(B, T, H, K).total;
 }
 
 extern "C" int pychain_hip_num_forward_backward(
@@ -116,38 +175,73 @@ extern "C" int pychain_hip_num_forward_backward(
     int B, int T, int D, int H, int K, int grad_mode, float grad_scale,
     float* objf_per_seq, float* grad, int32_t* bad_count,
     void* workspace, size_t workspace_bytes, void* stream) {
-  if (!ft || !fi || !fp || !bt || !bi || !bp || !initial || !final_ || !nnet_output || !seq_lengths ||
-      !objf_per_seq || !grad || !bad_count || !workspace)
-    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: null pointer argument");
-  if (B <= 0 || T <= 0 || H <= 0 || D <= 0 || K <= 0)
-    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: bad sizes B=%d T=%d H=%d K=%d D=%d", B, T, H, K, D);
-  if (H > 65535 || D > 65535)
-    return fail(PYCHAIN_HIP_EUNSUPPORTED, "num_forward_backward: num_states and num_pdfs must be <= 65535");
-  if (graph_batch_stride != 0 && graph_batch_stride != 1)
-    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: graph_batch_stride must be 0 or 1");
-  if (grad_mode < PYCHAIN_HIP_GRAD_LOG || grad_mode > PYCHAIN_HIP_GRAD_ACCUM)
-    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: unknown grad_mode %d", grad_mode);
-  if (((uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)fi | (uintptr_t)bi) & 15)
-    return fail(PYCHAIN_HIP_EINVAL, "num_forward_backward: nnet_output, grad and index tensors must be 16-byte aligned");
-  if (workspace_bytes < pychain_hip_num_workspace_bytes(B, T, H, K, D))
-    return fail(PYCHAIN_HIP_EWORKSPACE, "num_forward_backward: workspace too small");
+  NumArgs a;
+  int rc = fill_num_args(a, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, seq_lengths,
+                         B, T, D, H, K, grad_mode, grad_scale, objf_per_seq, grad, bad_count, workspace,
+                         workspace_bytes, "num_forward_backward");
+  if (rc != PYCHAIN_HIP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(PYCHAIN_HIP_ELAUNCH, "num_forward_backward: hipMemsetAsync failed");
-  NumArgs a;
-  memset(&a, 0, sizeof(a));
-  a.fwd_trans = ft; a.fwd_idx = fi; a.fwd_probs = fp; a.bwd_trans = bt; a.bwd_idx = bi; a.bwd_probs = bp;
-  a.initial = initial; a.final_ = final_; a.x = nnet_output; a.lengths = seq_lengths;
-  a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
-  a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
-  a.grad_mode = grad_mode; a.grad_scale = grad_scale;
-  char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  a.alpha_ws = (float*)ws;
-  a.logtot_ws = (float*)(ws + align256(4 * (size_t)B * (T + 1) * H));
   const char* why = nullptr;
-  hipError_t e = launch_num(a, st, &why);
+  hipError_t e = launch_num_fb(a, st, &why);
+  if (e == hipSuccess) e = launch_num_emit(a, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "num_forward_backward: %s",
+                why ? why : hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
+// ---- fused ChainLoss ------------------------------------------------------------------
+namespace {
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideStream* side_stream_for_current_device() {
+  static SideStream table[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = table[dev];
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &s;
+}
+}  // namespace
+
+extern "C" int pychain_hip_chain_loss_forward_backward(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
+    const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
+    const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
+    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D, float grad_scale,
+    float* den_objf, float* num_objf, float* grad, int32_t* bad_count,
+    void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
+  if (!bad_count) return fail(PYCHAIN_HIP_EINVAL, "chain_loss_forward_backward: null bad_count");
+  DenArgs da;
+  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, leaky,
+                         grad_scale, den_objf, grad, bad_count, den_ws, den_ws_bytes, "chain_loss_forward_backward");
+  if (rc != PYCHAIN_HIP_OK) return rc;
+  NumArgs na;
+  rc = fill_num_args(na, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, seq_lengths,
+                     B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM, -grad_scale, num_objf, grad, bad_count + 1,
+                     num_ws, num_ws_bytes, "chain_loss_forward_backward");
+  if (rc != PYCHAIN_HIP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  SideStream* side = side_stream_for_current_device();
+  if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "chain_loss_forward_backward: cannot create the side stream");
+  const char* why = nullptr;
+  hipError_t e = hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st);
+  // fork: numerator recursion on the side stream, denominator on the caller's stream
+  if (e == hipSuccess) e = hipEventRecord(side->fork, st);
+  if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+  if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
+  if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
+  if (e == hipSuccess) e = launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
+  // join, then subtract the numerator occupancies from the denominator gradient
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);
+  if (e == hipSuccess) e = launch_num_emit(na, st, &why);
+  if (e != hipSuccess)
+    return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "chain_loss_forward_backward: %s",
                 why ? why : hipGetErrorString(e));
   return PYCHAIN_HIP_OK;
 }

@@ -1,4 +1,4 @@
-// num_kernels.h - launch interface of the numerator kernel (num_kernels.hip).
+// num_kernels.h - launch interface of the numerator kernels (num_kernels.hip).
 #ifndef PYCHAIN_HIP_NUM_KERNELS_H_
 #define PYCHAIN_HIP_NUM_KERNELS_H_
 
@@ -16,16 +16,20 @@ struct NumArgs {
   float* objf;               // [B]
   float* grad;               // [B,T,D]
   int32_t* bad;              // [1]
-  float* alpha_ws;           // [B,T+1,H]  alpha(t,h) as the reference stores it (log, scaled)
-  float* logtot_ws;          // [B,T+1]    alpha-sum(t)
+  double* alpha_ws;          // [B,T+1,H]  alpha(t,h): unnormalised log-probabilities (fp64)
+  float* occ_ws;             // [B,T,K]    occupancy of every forward arc at every frame
   int graph_stride;          // 1 = per-sequence graphs, 0 = shared
   int B, T, D, H, K;
   int grad_mode;
+  int frames_per_block;      // emit kernel
   float grad_scale;
 };
 
-size_t num_lds_bytes(int H, int K, int D);
-hipError_t launch_num(const NumArgs& a, hipStream_t st, const char** why);
+size_t num_fb_lds_bytes(int H, int K, int D);
+// forward-backward recursion (launch 1): reads x + graphs, writes objf, alpha_ws, occ_ws
+hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why);
+// occupancies -> gradient rows (launch 2): reads occ_ws, writes/accumulates grad
+hipError_t launch_num_emit(const NumArgs& a, hipStream_t st, const char** why);
 
 }  // namespace pychain_hip
 #endif

@@ -3,12 +3,21 @@
 // reference; shares no structure with them (the reference launches one kernel per
 // frame with one thread per (sequence, state) and CAS-loop atomicLogAdd).
 //
-// One persistent workgroup per sequence.  The utterance's small graph is cached in LDS
-// once, the time loops run inside the kernel, the per-frame state vectors stay in LDS,
-// one state per thread; the frame's log-sum-exp is a wave64 shuffle reduction of
-// (max, sum) pairs + one LDS hop.  Occupancies are accumulated in LDS as 64-bit
-// fixed point (2^-56 resolution), which makes the per-pdf sums order-independent:
-// deterministic without sorting, no float atomics.
+//   launch 1  num_fb_kernel    one persistent workgroup per sequence walks alpha forward and
+//             beta backward in time inside the kernel: one state per thread, the utterance's
+//             small graph cached in LDS/registers, ONE barrier per frame.  Log-probabilities
+//             are carried in float64 WITHOUT per-frame renormalisation (the reference
+//             renormalises fp32 values each frame, chain-log-domain-computation.cc:150-158;
+//             in fp64 the raw log-probabilities - a few 1e4 in magnitude at T=1500 - keep
+//             ~1e-12 absolute accuracy, so no block reduction sits on the sequential path).
+//             exp/log act on small differences and run on the fp32 transcendental unit.
+//             Output: per-arc occupancies occ[b,t,k] (fp32, linear domain) and the
+//             sequence log-probability.  At T=1500 this is ~1e-5 from the fp64 evaluation of
+//             the reference's equations, where the reference's own fp32 recursion is ~2e-4.
+//   launch 2  num_emit_kernel  time-parallel: merges the per-arc occupancies of a frame by
+//             pdf-id (64-bit fixed point in LDS: order-independent, hence deterministic) and
+//             writes the gradient in the requested form: log (reference contract, -inf
+//             where zero), linear, or accumulated into an existing dense gradient.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -19,260 +28,333 @@
 namespace pychain_hip {
 namespace {
 
-constexpr int kNumNT = 256;
-constexpr int kNumNW = kNumNT / 64;
-constexpr float kMinLogDiff = -15.9423847198486328125f;   // log(FLT_EPSILON), base.h:12
+constexpr int kFbNT = 512;                 // num_fb_kernel: one state per thread up to 512 states
+constexpr int kFbNW = kFbNT / 64;
+constexpr int kEmNT = 256;                 // num_emit_kernel
 constexpr float kFixScale = 72057594037927936.0f;          // 2^56
 constexpr float kFixInv = 1.0f / 72057594037927936.0f;
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.693147182464599609375f;
 
-// base.h:14-32 (same cut-off: the smaller term is dropped below log(FLT_EPSILON))
-__device__ __forceinline__ float log_add(float x, float y) {
-  const float mx = fmaxf(x, y), mn = fminf(x, y);
-  const float d = mn - mx;                       // <= 0, or NaN for (-inf) - (-inf)
-  return (d >= kMinLogDiff) ? mx + log1pf(expf(d)) : mx;
-}
+__device__ __forceinline__ float fexp(float d) { return __builtin_amdgcn_exp2f(d * kLog2e); }   // d <= ~0
+__device__ __forceinline__ float flog(float s) { return __builtin_amdgcn_logf(s) * kLn2; }       // s >= 1
 
-struct MS { float m, s; };                        // running (max, sum exp(v - max))
-__device__ __forceinline__ MS ms_merge(MS a, MS b) {
-  const float M = fmaxf(a.m, b.m);
-  if (M == -INFINITY) return MS{-INFINITY, 0.f};
-  return MS{M, a.s * expf(a.m - M) + b.s * expf(b.m - M)};
-}
-__device__ __forceinline__ MS ms_push(MS a, float v) { return ms_merge(a, MS{v, v == -INFINITY ? 0.f : 1.f}); }
+struct ArcW { uint32_t pk; float lp; };    // pk = state | pdf << 16
 
-// block-wide log-sum-exp of per-thread (m,s) pairs; red = float[2*kNumNW] in LDS.
-// Contains two barriers; every thread returns the same value.
-__device__ __forceinline__ float block_lse(MS v, float* red, int lane, int wave) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    MS other{__shfl_xor(v.m, o, 64), __shfl_xor(v.s, o, 64)};
-    v = ms_merge(v, other);
+// log-sum-exp accumulator over float64 terms with fp32 transcendentals: m = running max,
+// s = sum exp(term - m).  value() = m + log s.
+struct Lse {
+  double m; float s;
+  __device__ __forceinline__ void init() { m = -INFINITY; s = 0.f; }
+  __device__ __forceinline__ void push(double e) {
+    if (e > m) { s = (m == -INFINITY) ? 1.f : s * fexp((float)(m - e)) + 1.f; m = e; }
+    else if (e != -INFINITY) { s += fexp((float)(e - m)); }
   }
-  __syncthreads();                                // red may still be read from the previous call
-  if (lane == 0) { red[wave] = v.m; red[kNumNW + wave] = v.s; }
-  __syncthreads();
-  MS t{-INFINITY, 0.f};
+  __device__ __forceinline__ double value() const { return m == -INFINITY ? -INFINITY : m + (double)flog(s); }
+};
+
+__device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
-  for (int w = 0; w < kNumNW; w++) t = ms_merge(t, MS{red[w], red[kNumNW + w]});
-  return t.m == -INFINITY ? -INFINITY : t.m + logf(t.s);
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
 }
 
 template <int VEC, int XCH>
-__global__ __launch_bounds__(kNumNT) void num_kernel(const NumArgs a) {
+__global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
-  const int L = (int)a.lengths[b];
+  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
   const int H = a.H, K = a.K, D = a.D, T = a.T, Dp = (D + 3) & ~3;
   const size_t g = (size_t)b * a.graph_stride;
 
-  // ---- carve LDS
+  // ---- LDS: state vectors (fp64, ping-pong), nnet-output rows (ping-pong), arcs, reductions
   char* p = smem_raw;
-  unsigned long long* gam = reinterpret_cast<unsigned long long*>(p); p += sizeof(unsigned long long) * (size_t)Dp;
+  const int Hq = (H + 1) & ~1;
+  double* va = reinterpret_cast<double*>(p); p += 8 * (size_t)Hq;
+  double* vb = reinterpret_cast<double*>(p); p += 8 * (size_t)Hq;
+  double* redd = reinterpret_cast<double*>(p); p += 8 * 16;
+  float* redf = reinterpret_cast<float*>(p); p += 4 * 16;
   float* xr0 = reinterpret_cast<float*>(p); p += 4 * (size_t)Dp;
   float* xr1 = reinterpret_cast<float*>(p); p += 4 * (size_t)Dp;
-  const int Hq = (H + 3) & ~3;
-  float* va = reinterpret_cast<float*>(p); p += 4 * (size_t)Hq;     // state vector ping
-  float* vb = reinterpret_cast<float*>(p); p += 4 * (size_t)Hq;     // state vector pong
-  float* arow = reinterpret_cast<float*>(p); p += 4 * (size_t)Hq;   // alpha(t,.) during the backward pass
-  float* red = reinterpret_cast<float*>(p); p += 4 * 2 * kNumNW;
-  const int2* in_be; const uint32_t* in_pk; const float* in_lp;
-  const int2* out_be; const uint32_t* out_pk; const float* out_lp;
+  ArcW* in_arc = reinterpret_cast<ArcW*>(p); p += 8 * (size_t)K;      // by destination: (src, pdf, lp)
+  ArcW* out_arc = reinterpret_cast<ArcW*>(p); p += 8 * (size_t)K;     // by source:      (dst, pdf, lp)
   {
     const int32_t* bt = a.bwd_trans + g * K * 3; const int32_t* ft = a.fwd_trans + g * K * 3;
-    const int2* bi = reinterpret_cast<const int2*>(a.bwd_idx + g * H * 2);
-    const int2* fi = reinterpret_cast<const int2*>(a.fwd_idx + g * H * 2);
     const float* bp = a.bwd_probs + g * K; const float* fp = a.fwd_probs + g * K;
-    // graph -> LDS, packed (state | pdf << 16)
-    int2* l_in_be = reinterpret_cast<int2*>(p); p += 8 * (size_t)H;
-    int2* l_out_be = reinterpret_cast<int2*>(p); p += 8 * (size_t)H;
-    uint32_t* l_in_pk = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)K;
-    uint32_t* l_out_pk = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)K;
-    float* l_in_lp = reinterpret_cast<float*>(p); p += 4 * (size_t)K;
-    float* l_out_lp = reinterpret_cast<float*>(p); p += 4 * (size_t)K;
-    for (int h = tid; h < H; h += kNumNT) { l_in_be[h] = bi[h]; l_out_be[h] = fi[h]; }
-    for (int k = tid; k < K; k += kNumNT) {
-      l_in_pk[k] = (uint32_t)bt[3 * k] | ((uint32_t)bt[3 * k + 2] << 16);      // (src, pdf)
-      l_out_pk[k] = (uint32_t)ft[3 * k + 1] | ((uint32_t)ft[3 * k + 2] << 16); // (dst, pdf)
-      l_in_lp[k] = bp[k]; l_out_lp[k] = fp[k];
+    for (int k = tid; k < K; k += kFbNT) {
+      in_arc[k] = ArcW{(uint32_t)bt[3 * k] | ((uint32_t)bt[3 * k + 2] << 16), bp[k]};
+      out_arc[k] = ArcW{(uint32_t)ft[3 * k + 1] | ((uint32_t)ft[3 * k + 2] << 16), fp[k]};
     }
-    in_be = l_in_be; out_be = l_out_be; in_pk = l_in_pk; out_pk = l_out_pk; in_lp = l_in_lp; out_lp = l_out_lp;
   }
-  const float* init = a.initial + g * H;
-  const float* fin = a.final_ + g * H;
   const float* xseq = a.x + (size_t)b * T * D;
-  float* gseq = a.grad + (size_t)b * T * D;
-  float* aws = a.alpha_ws + (size_t)b * (T + 1) * H;      // alpha(t,h), t = 0..L
-  float* lws = a.logtot_ws + (size_t)b * (T + 1);         // alpha-sum(t) (log), t = 0..L
+  double* aws = a.alpha_ws + (size_t)b * (T + 1) * H;     // alpha(t,h), t = 0..L  (fp64 log-prob)
+  float* occ = a.occ_ws + (size_t)b * T * K;              // occ(t,k) per forward arc
+  const int2* bi = reinterpret_cast<const int2*>(a.bwd_idx + g * H * 2);
+  const int2* fi = reinterpret_cast<const int2*>(a.fwd_idx + g * H * 2);
 
-  for (int n = tid; n < Dp; n += kNumNT) gam[n] = 0ull;
-  // AlphaFirstFrame, chain-log-domain-computation.cc:84-90 (alpha-sum(0) = 0 by fiat)
-  for (int h = tid; h < H; h += kNumNT) { const float v = init[h]; va[h] = v; aws[h] = v; }
-  if (tid == 0) lws[0] = 0.f;
-  XRow<kNumNT, VEC, XCH> xq;
+  // this thread's state(s): h = tid (+ kFbNT, ... for graphs with more than 512 states)
+  const int h0 = tid;
+  const bool own = h0 < H;
+  int2 ibe = make_int2(0, 0), obe = make_int2(0, 0);
+  float fin0 = -INFINITY;
+  if (own) { ibe = bi[h0]; obe = fi[h0]; fin0 = a.final_[g * H + h0]; }
+  XRow<kFbNT, VEC, XCH> xq;
   xq.load(xseq, D, tid);
+  // AlphaFirstFrame, chain-log-domain-computation.cc:84-90
+  for (int h = tid; h < H; h += kFbNT) { const double v = (double)a.initial[g * H + h]; va[h] = v; aws[h] = v; }
   xq.store(xr0, xseq, D, tid, kXClamp);
   __syncthreads();
+  // first two arcs of this thread's state in registers (the common left-to-right case needs no more)
+  ArcW i0{0u, -INFINITY}, i1{0u, -INFINITY}, o0{0u, -INFINITY}, o1{0u, -INFINITY};
+  if (own) {
+    if (ibe.y - ibe.x > 0) i0 = in_arc[ibe.x];
+    if (ibe.y - ibe.x > 1) i1 = in_arc[ibe.x + 1];
+    if (obe.y - obe.x > 0) o0 = out_arc[obe.x];
+    if (obe.y - obe.x > 1) o1 = out_arc[obe.x + 1];
+  }
 
-  // ---- forward: AlphaGeneralFrame :93-159
-  float logtot_prev = 0.f;
-  double logsum = 0.0;                    // sum_{t<L} alpha-sum(t), :179-189
+  // ---- forward: alpha(t,h) = LogSum_k alpha(t-1,src_k) + lp_k + x(t-1,pdf_k)   (:93-159, unnormalised)
   for (int t = 1; t <= L; t++) {
-    const float* vin = (t & 1) ? va : vb;
-    float* vout = (t & 1) ? vb : va;
+    const double* vin = (t & 1) ? va : vb;
+    double* vout = (t & 1) ? vb : va;
     const float* xcur = (t & 1) ? xr0 : xr1;        // row t-1
     float* xnext = (t & 1) ? xr1 : xr0;
     const bool have_next = t < L;
     const float* xrow_next = xseq + (size_t)(have_next ? t : 0) * D;
     if (have_next) xq.load(xrow_next, D, tid);
-    MS ms{-INFINITY, 0.f};
-    for (int h = tid; h < H; h += kNumNT) {
-      const int2 be = in_be[h];
-      float v = -INFINITY;
-      for (int k = be.x; k < be.y; k++) {
-        const uint32_t pk = in_pk[k];
-        v = log_add(v, vin[pk & 0xffffu] + in_lp[k] + xcur[pk >> 16]);
+    if (own) {
+      Lse acc; acc.init();
+      const double e0 = vin[i0.pk & 0xffffu] + ((double)i0.lp + (double)xcur[i0.pk >> 16]);
+      const double e1 = vin[i1.pk & 0xffffu] + ((double)i1.lp + (double)xcur[i1.pk >> 16]);
+      acc.push(e0); acc.push(e1);
+      for (int k = ibe.x + 2; k < ibe.y; k++) {
+        const ArcW w = in_arc[k];
+        acc.push(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]));
       }
-      v -= logtot_prev;
+      const double v = acc.value();
+      vout[h0] = v;
+      aws[(size_t)t * H + h0] = v;
+    }
+    for (int h = h0 + kFbNT; h < H; h += kFbNT) {             // graphs with more than 512 states
+      const int2 be = bi[h];
+      Lse acc; acc.init();
+      for (int k = be.x; k < be.y; k++) {
+        const ArcW w = in_arc[k];
+        acc.push(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]));
+      }
+      const double v = acc.value();
       vout[h] = v;
       aws[(size_t)t * H + h] = v;
-      ms = ms_push(ms, v);
     }
     if (have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
-    const float logtot = block_lse(ms, red, lane, wave);   // barriers inside publish vout / xnext
-    if (tid == 0) {
-      lws[t] = logtot;
-      if (t < L && logtot != -INFINITY) logsum += (double)logtot;
-    }
-    logtot_prev = logtot;
+    __syncthreads();
   }
 
-  // ---- ComputeTotLogLike :170-190 and BetaLastFrame :192-202
-  const float* vL = (L & 1) ? vb : va;
-  float* bnext = (L & 1) ? va : vb;        // beta(L) goes to the buffer alpha(L) does not occupy
-  MS ms{-INFINITY, 0.f};
-  for (int h = tid; h < H; h += kNumNT) ms = ms_push(ms, vL[h] + fin[h]);
-  const float last = block_lse(ms, red, lane, wave);
-  int bad = 0;
+  // ---- total log-probability: LogSum_i alpha(L,i) + final(i)   (ComputeTotLogLike :170-190)
+  const double* vL = (L & 1) ? vb : va;
+  double* bnext = (L & 1) ? va : vb;        // beta(L) goes to the buffer alpha(L) does not occupy
+  double mx = -INFINITY;
+  for (int h = tid; h < H; h += kFbNT) mx = fmax(mx, vL[h] + (double)a.final_[g * H + h]);
+  mx = wave_max(mx);
+  if (tid < 16) { redd[tid] = -INFINITY; redf[tid] = 0.f; }
+  __syncthreads();
+  if (lane == 0) redd[wave] = mx;
+  __syncthreads();
+  double gm = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < kFbNW; w++) gm = fmax(gm, redd[w]);
+  float se = 0.f;
+  if (gm != -INFINITY)
+    for (int h = tid; h < H; h += kFbNT) se += fexp((float)(vL[h] + (double)a.final_[g * H + h] - gm));
+  se = wave_sum(se);
+  if (lane == 0) redf[wave] = se;
+  __syncthreads();
+  const float stot = dpp_row_sum(redf[lane & 15]);
+  const double logp = gm == -INFINITY ? -INFINITY : gm + (double)flog(stot);
   if (tid == 0) {
-    const float objf = (float)(logsum + (double)last);
+    const float objf = (float)logp;
     a.objf[b] = objf;
-    if (!(objf - objf == 0.f)) bad = 1;
+    if (!(objf - objf == 0.f)) atomicAdd(a.bad, 1);
   }
-  for (int h = tid; h < H; h += kNumNT) bnext[h] = fin[h] - last;
-  // first backward frame needs x(L-1) and alpha(L-1)
+  // BetaLastFrame :192-202 (unnormalised: beta(L,i) = final(i); the 1/P factor enters the occupancy)
+  for (int h = tid; h < H; h += kFbNT) bnext[h] = (double)a.final_[g * H + h];
   {
     const float* xrow = xseq + (size_t)(L - 1) * D;
     xq.load(xrow, D, tid);
     xq.store(xr0, xrow, D, tid, kXClamp);
-    for (int h = tid; h < H; h += kNumNT) arow[h] = aws[(size_t)(L - 1) * H + h];
   }
+  double a_cur = own ? aws[(size_t)(L - 1) * H + h0] : 0.0;   // alpha(t,h0): written by this very thread
   __syncthreads();
 
-  // ---- backward: BetaGeneralFrame :204-271
-  const float scale = a.grad_scale;
-  float* bcur = (L & 1) ? vb : va;
+  // ---- backward: beta(t,h) = LogSum_k lp_k + beta(t+1,dst_k) + x(t,pdf_k);  occ = exp(alpha + term - logP)
+  double* bcur = (L & 1) ? vb : va;
   int step = 0;
-  float inv_scale = lws[L - 1];                       // alpha-sum(t), :246 (prefetched one frame ahead)
   for (int t = L - 1; t >= 0; t--, step++) {
     const float* xcur = (step & 1) ? xr1 : xr0;
     float* xnext = (step & 1) ? xr0 : xr1;
     const bool have_next = t > 0;
     const float* xrow_next = xseq + (size_t)(have_next ? t - 1 : 0) * D;
     if (have_next) xq.load(xrow_next, D, tid);
-    float anext[4];                                   // alpha(t-1,.) prefetch (H <= 4*NT fast path)
-    const bool areg = H <= 4 * kNumNT;
-    if (have_next && areg) {
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int h = c * kNumNT + tid;
-        anext[c] = h < H ? aws[(size_t)(t - 1) * H + h] : 0.f;
+    double a_next = 0.0;
+    if (have_next && own) a_next = aws[(size_t)(t - 1) * H + h0];
+    float* orow = occ + (size_t)t * K;
+    if (own) {
+      Lse acc; acc.init();
+      const double base = a_cur - logp;
+      const double e0 = bnext[o0.pk & 0xffffu] + ((double)o0.lp + (double)xcur[o0.pk >> 16]);
+      const double e1 = bnext[o1.pk & 0xffffu] + ((double)o1.lp + (double)xcur[o1.pk >> 16]);
+      acc.push(e0); acc.push(e1);
+      if (obe.y - obe.x > 0) orow[obe.x] = fexp((float)(base + e0));
+      if (obe.y - obe.x > 1) orow[obe.x + 1] = fexp((float)(base + e1));
+      for (int k = obe.x + 2; k < obe.y; k++) {
+        const ArcW w = out_arc[k];
+        const double e = bnext[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]);
+        acc.push(e);
+        orow[k] = fexp((float)(base + e));
       }
+      bcur[h0] = acc.value();
     }
-    float inv_scale_next = 0.f;
-    if (have_next) inv_scale_next = lws[t - 1];
-    for (int h = tid; h < H; h += kNumNT) {
-      const int2 be = out_be[h];
-      const float ah = arow[h];
-      float tot = -INFINITY;
+    for (int h = h0 + kFbNT; h < H; h += kFbNT) {
+      const int2 be = fi[h];
+      const double base = aws[(size_t)t * H + h] - logp;
+      Lse acc; acc.init();
       for (int k = be.x; k < be.y; k++) {
-        const uint32_t pk = out_pk[k];
-        const uint32_t pdf = pk >> 16;
-        const float vf = out_lp[k] + bnext[pk & 0xffffu] + xcur[pdf] - inv_scale;
-        tot = log_add(tot, vf);
-        const float occ = expf(vf + ah);             // posterior of this arc at frame t, in [0,1]
-        if (occ > 0.f) {
-          if (occ <= 2.f) atomicAdd(&gam[pdf], (unsigned long long)(occ * kFixScale));
+        const ArcW w = out_arc[k];
+        const double e = bnext[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]);
+        acc.push(e);
+        orow[k] = fexp((float)(base + e));
+      }
+      bcur[h] = acc.value();
+    }
+    if (have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
+    a_cur = a_next;
+    __syncthreads();
+    double* tmp = bnext; bnext = bcur; bcur = tmp;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// launch 2: per-arc occupancies -> gradient rows (time-parallel)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kEmNT) void num_emit_kernel(const NumArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int L = (int)a.lengths[b];
+  const int K = a.K, D = a.D, T = a.T, Dp = (D + 3) & ~3;
+  const int t_begin = blockIdx.x * a.frames_per_block;
+  const int t_end = min(t_begin + a.frames_per_block, T);
+  float* gseq = a.grad + (size_t)b * T * D;
+  const int mode = a.grad_mode;
+  const float fill = mode == PYCHAIN_HIP_GRAD_LOG ? -INFINITY : 0.f;
+  const int t_live_end = min(t_end, L);
+  if (t_begin < L) {
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);   // [Dp]
+    int* s_kmax_p = reinterpret_cast<int*>(acc + Dp);                              // [4] (all LDS dynamic: base stays 16-B aligned)
+    uint16_t* pdf = reinterpret_cast<uint16_t*>(s_kmax_p + 4);                     // [K]
+    const size_t g = (size_t)b * a.graph_stride;
+    const int32_t* ft = a.fwd_trans + g * K * 3;
+    const int2* fi = reinterpret_cast<const int2*>(a.fwd_idx + g * a.H * 2);
+    // arcs that no state indexes (batch padding, pychain/graph.py:132-139) carry no occupancy
+    int kmax = 0;
+    for (int h = tid; h < a.H; h += kEmNT) kmax = max(kmax, fi[h].y);
+    if (tid == 0) *s_kmax_p = 0;
+    __syncthreads();
+    atomicMax(s_kmax_p, kmax);
+    for (int n = tid; n < Dp; n += kEmNT) acc[n] = 0ull;
+    for (int k = tid; k < K; k += kEmNT) pdf[k] = (uint16_t)ft[3 * k + 2];
+    __syncthreads();
+    const int Kused = *s_kmax_p;
+    const float* occ = a.occ_ws + (size_t)b * T * K;
+    int bad = 0;
+    for (int t = t_begin; t < t_live_end; t++) {
+      const float* orow = occ + (size_t)t * K;
+      float* grow = gseq + (size_t)t * D;
+      for (int k = tid; k < Kused; k += kEmNT) {
+        const float v = orow[k];
+        if (v > 0.f) {
+          if (v <= 2.f) atomicAdd(&acc[pdf[k]], (unsigned long long)(v * kFixScale));
           else bad = 1;
-        } else if (occ != 0.f) {
-          bad = 1;                                    // NaN
+        } else if (v != 0.f) {
+          bad = 1;                                  // NaN
         }
       }
-      bcur[h] = tot;
-    }
-    __syncthreads();
-    // frame's occupancy row -> HBM, accumulators reset
-    float* grow = gseq + (size_t)t * D;
-    for (int n = tid; n < D; n += kNumNT) {
-      const unsigned long long u = gam[n];
-      if (u != 0ull) gam[n] = 0ull;
-      const float v = (float)u * kFixInv;
-      if (a.grad_mode == PYCHAIN_HIP_GRAD_LOG) grow[n] = u ? logf(v) : -INFINITY;
-      else if (a.grad_mode == PYCHAIN_HIP_GRAD_LINEAR) grow[n] = scale * v;
-      else if (u) grow[n] += scale * v;
-    }
-    if (have_next) {
-      xq.store(xnext, xrow_next, D, tid, kXClamp);
-      if (areg) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) { const int h = c * kNumNT + tid; if (h < H) arow[h] = anext[c]; }
+      __syncthreads();
+      if (mode == PYCHAIN_HIP_GRAD_ACCUM) {
+        for (int k = tid; k < Kused; k += kEmNT) {
+          const int n = pdf[k];
+          const unsigned long long u = atomicExch(&acc[n], 0ull);   // exactly one arc per pdf sees the merged sum
+          if (u) grow[n] += a.grad_scale * ((float)u * kFixInv);
+        }
       } else {
-        for (int h = tid; h < H; h += kNumNT) arow[h] = aws[(size_t)(t - 1) * H + h];
+        for (int n = tid; n < D; n += kEmNT) {
+          const unsigned long long u = acc[n];
+          if (u) acc[n] = 0ull;
+          const float v = (float)u * kFixInv;
+          grow[n] = mode == PYCHAIN_HIP_GRAD_LOG ? (u ? logf(v) : -INFINITY) : a.grad_scale * v;
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
-    inv_scale = inv_scale_next;
-    float* tmp = bnext; bnext = bcur; bcur = tmp;
+    if (bad) atomicAdd(a.bad, 1);
   }
   // padded frames: -inf (full_like(-inf), :57) / zero; ACCUM leaves them alone
-  if (a.grad_mode != PYCHAIN_HIP_GRAD_ACCUM) {
-    const float fill = a.grad_mode == PYCHAIN_HIP_GRAD_LOG ? -INFINITY : 0.f;
-    for (size_t i = (size_t)L * D + tid; i < (size_t)T * D; i += kNumNT) gseq[i] = fill;
+  if (mode != PYCHAIN_HIP_GRAD_ACCUM) {
+    const int t0 = max(t_begin, t_live_end);
+    for (size_t i = (size_t)t0 * D + tid; i < (size_t)t_end * D; i += kEmNT) gseq[i] = fill;
   }
-  if (bad) atomicAdd(a.bad, 1);
 }
 
 template <int VEC, int XCH>
-hipError_t launch_variant(const NumArgs& a, size_t lds, hipStream_t st) {
-  auto k = num_kernel<VEC, XCH>;
+hipError_t launch_fb(const NumArgs& a, size_t lds, hipStream_t st) {
+  auto k = num_fb_kernel<VEC, XCH>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(a.B), dim3(kNumNT), lds, st, a);
+  hipLaunchKernelGGL(k, dim3(a.B), dim3(kFbNT), lds, st, a);
   return hipGetLastError();
 }
 
 }  // namespace
 
-size_t num_lds_bytes(int H, int K, int D) {
-  const size_t Dp = (D + 3) & ~3, Hq = (H + 3) & ~3;
-  return 8 * Dp + 8 * Dp + 12 * Hq + 4 * 2 * kNumNW + 16 * (size_t)H + 16 * (size_t)K + 64;
+size_t num_fb_lds_bytes(int H, int K, int D) {
+  const size_t Dp = (D + 3) & ~3, Hq = (H + 1) & ~1;
+  return 16 * Hq + 8 * 16 + 4 * 16 + 8 * Dp + 16 * (size_t)K + 64;
+}
+size_t num_emit_lds_bytes(int K, int D) {
+  const size_t Dp = (D + 3) & ~3;
+  return 8 * Dp + 16 + 2 * (size_t)K + 64;
 }
 
-hipError_t launch_num(const NumArgs& a, hipStream_t st, const char** why) {
-  const size_t lds = num_lds_bytes(a.H, a.K, a.D);
+hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
+  const size_t lds = num_fb_lds_bytes(a.H, a.K, a.D);
   if (lds > 160 * 1024) {
-    *why = "numerator graph + nnet-output row do not fit the 160 KiB LDS of one CU";
+    *why = "numerator graph + nnet-output rows do not fit the 160 KiB LDS of one CU";
     return hipErrorInvalidValue;
   }
   const int D = a.D;
   if (D % 4 == 0) {
-    if (D <= 4 * 4 * kNumNT) return launch_variant<4, 4>(a, lds, st);
-    if (D <= 4 * 12 * kNumNT) return launch_variant<4, 12>(a, lds, st);
-  } else if (D <= 4 * kNumNT) {
-    return launch_variant<1, 4>(a, lds, st);
+    if (D <= 4 * 2 * kFbNT) return launch_fb<4, 2>(a, lds, st);
+    if (D <= 4 * 8 * kFbNT) return launch_fb<4, 8>(a, lds, st);
+  } else if (D <= 8 * kFbNT) {
+    return launch_fb<1, 8>(a, lds, st);
   }
-  return launch_variant<1, 0>(a, lds, st);
+  return launch_fb<1, 0>(a, lds, st);
+}
+
+hipError_t launch_num_emit(const NumArgs& a, hipStream_t st, const char** why) {
+  const size_t lds = num_emit_lds_bytes(a.K, a.D);
+  if (lds > 160 * 1024) {
+    *why = "pdf accumulators do not fit the 160 KiB LDS of one CU";
+    return hipErrorInvalidValue;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(num_emit_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  hipLaunchKernelGGL(num_emit_kernel, dim3(gx, a.B), dim3(kEmNT), lds, st, a);
+  return hipGetLastError();
 }
 
 }  // namespace pychain_hip

@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib, _plan, native
 from .graph import ChainGraphBatch
 
-__all__ = ["ChainFunction", "ChainLoss"]
+__all__ = ["ChainFunction", "ChainLossFunction", "ChainLoss"]
 
 
 class ChainFunction(torch.autograd.Function):
@@ -65,14 +65,60 @@ class ChainFunction(torch.autograd.Function):
         return torch.mul(input_grad, objf_grad), None, None, None
 
 
+class ChainLossFunction(torch.autograd.Function):
+    """Denominator + numerator in one pass: the gradient
+    (gamma_den - gamma_num) * scale is written once by the kernels instead of two dense
+    gradients, two scalar multiplies and an autograd add (loss.py:85,100-104); the numerator
+    recursion overlaps the denominator on a side stream.  Same numbers as the two-call path."""
+
+    @staticmethod
+    def forward(ctx, input, input_lengths, den_graph, num_graphs, leaky_coefficient, avg):
+        x = input.detach()
+        B, D = x.size(0), x.size(2)
+        if B != num_graphs.batch_size:
+            raise ValueError(
+                "input batch size ({}) does not equal to graph batch size ({})"
+                .format(B, num_graphs.batch_size))
+        lengths = torch.as_tensor(input_lengths)
+        plan = _plan.graph_plan(den_graph, D, x.device)
+        gt = num_graphs.device_tensors(x.device)
+        gstride = 0 if num_graphs.shared_graph is not None else 1
+        # avg=True divides by the frame count (loss.py:103-104); with host-side lengths that
+        # factor is folded into the kernels' gradient scale, otherwise it is applied afterwards
+        fold = avg and not lengths.is_cuda
+        norm = float(lengths.sum()) if fold else 1.0
+        den_objf, num_objf, grad, bad = native.chain_loss_forward_backward(
+            plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient, 1.0 / norm)
+        objf = -(num_objf.sum() - den_objf.sum())
+        if avg:
+            if fold:
+                objf = objf / norm
+            else:
+                n = lengths.sum().to(objf.dtype)
+                objf = objf / n
+                grad = grad / n
+        ctx.save_for_backward(grad)
+        ChainFunction.last_bad_count = bad.sum()
+        return objf
+
+    @staticmethod
+    def backward(ctx, objf_grad):
+        grad, = ctx.saved_tensors
+        return torch.mul(grad, objf_grad), None, None, None, None, None
+
+
 class ChainLoss(nn.Module):
     def __init__(self, den_graph, leaky_coefficient=1e-5, avg=True):
         super(ChainLoss, self).__init__()
         self.den_graph = den_graph
         self.avg = avg
         self.leaky_coefficient = leaky_coefficient
+        self.fused = True   # one-pass kernel path; False = two ChainFunction calls as in the reference
 
     def forward(self, x, x_lengths, num_graphs):
+        if (self.fused and x.is_cuda and not self.den_graph.log_domain and num_graphs.log_domain):
+            return ChainLossFunction.apply(x, x_lengths, self.den_graph, num_graphs,
+                                           self.leaky_coefficient, self.avg)
         batch_size = x.size(0)
         den_graphs = ChainGraphBatch(self.den_graph, batch_size)
         den_objf = ChainFunction.apply(x, x_lengths, den_graphs, self.leaky_coefficient)

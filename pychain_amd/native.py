@@ -20,8 +20,8 @@ def _require_device(t, what):
             "fallback by design." % (what, t.device))
 
 
-def _workspace(nbytes, device):
-    key = str(device)
+def _workspace(nbytes, device, tag="a"):
+    key = (str(device), tag)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -64,7 +64,7 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
         grad = torch.empty_like(x)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
         nws = L.pychain_hip_den_workspace_bytes(B, T, int(num_states), D)
-        ws = _workspace(nws, dev)
+        ws = _workspace(nws, dev, "den")
         _lib.check(L.pychain_hip_den_forward_backward(
             plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(),
             int(bool(input_is_exp)),
@@ -98,7 +98,7 @@ def num_forward_backward(gt, graph_stride, num_states, x, lengths, grad_mode=_li
             grad = torch.empty_like(x)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
         nws = L.pychain_hip_num_workspace_bytes(B, T, int(num_states), K, D)
-        ws = _workspace(nws, dev)
+        ws = _workspace(nws, dev, "num")
         _lib.check(L.pychain_hip_num_forward_backward(
             gt["forward_transitions"].data_ptr(), gt["forward_transition_indices"].data_ptr(),
             gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
@@ -108,6 +108,41 @@ def num_forward_backward(gt, graph_stride, num_states, x, lengths, grad_mode=_li
             objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
             "pychain_hip_num_forward_backward")
     return objf, grad, bad
+
+
+def chain_loss_forward_backward(plan, gt, graph_stride, num_states_num, x, lengths,
+                                leaky_coefficient=1e-5, grad_scale=1.0):
+    """Fused ChainLoss: returns (den_objf[B], num_objf[B], grad[B,T,D] = grad_scale*(gamma_den - gamma_num),
+    bad_count[2]).  The numerator recursion overlaps the denominator on a side stream."""
+    _require_device(x, "nnet_output")
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, T, D = x.shape
+    _check_lengths(lengths, B, T)
+    K = gt["forward_transitions"].shape[1]
+    L = _lib.lib()
+    dev = x.device
+    with torch.cuda.device(dev):
+        ld = _lengths_dev(lengths, dev)
+        den_objf = torch.empty(B, dtype=torch.float32, device=dev)
+        num_objf = torch.empty(B, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(x)
+        bad = torch.empty(2, dtype=torch.int32, device=dev)
+        dws = _workspace(L.pychain_hip_den_workspace_bytes(B, T, plan.num_states, D), dev, "den")
+        nws = _workspace(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dev, "num")
+        _lib.check(L.pychain_hip_chain_loss_forward_backward(
+            plan.blob.data_ptr(), plan.stride, plan.slot_rows, plan.num_states, float(leaky_coefficient),
+            gt["forward_transitions"].data_ptr(), gt["forward_transition_indices"].data_ptr(),
+            gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
+            gt["backward_transition_indices"].data_ptr(), gt["backward_transition_probs"].data_ptr(),
+            gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
+            int(num_states_num), K,
+            x.data_ptr(), ld.data_ptr(), B, T, D, float(grad_scale),
+            den_objf.data_ptr(), num_objf.data_ptr(), grad.data_ptr(), bad.data_ptr(),
+            dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
+            "pychain_hip_chain_loss_forward_backward")
+    return den_objf, num_objf, grad, bad
 
 
 # ---------------------------------------------------------------------------
