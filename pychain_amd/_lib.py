@@ -2,7 +2,7 @@
 
 There is NO fallback: if the shared library is missing, or a call is made with
 tensors that are not on a HIP device, this raises.  The product path never
-touches oracle/.
+touches the CPU checker.
 """
 import ctypes
 import os

@@ -1,0 +1,130 @@
+"""Host-side API mirror: containers, errors, alias package,
+C-ABI exports.  CPU only."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GRAPH_FIELDS, graph_from_npz
+from pychain_amd import ChainGraph, ChainGraphBatch, _lib, synthetic as syn
+from pychain_amd.simplefst import StdVectorFst
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cmp_batch(gb, z, prefix):
+    for f in GRAPH_FIELDS + ["start_state"]:
+        if prefix + f in z.files:
+            got = getattr(gb, f)
+            assert got is not None, f
+            ref = z[prefix + f]
+            assert tuple(got.shape) == ref.shape and str(got.dtype).replace("torch.", "") == str(ref.dtype), f
+            assert np.array_equal(got.numpy(), ref, equal_nan=True), f
+        else:
+            assert getattr(gb, f) is None, f
+    assert gb.num_states == int(z[prefix + "num_states"])
+    assert gb.batch_size == int(z[prefix + "batch_size"])
+    assert gb.log_domain == bool(z[prefix + "log_domain"])
+
+
+def test_containers_match_reference_snapshots(golden):
+    """ChainGraphBatch by-one / by-list / reorder / prob-domain list == the reference classes."""
+    z = golden("a5_containers")
+    den = graph_from_npz(z, "den_")
+    _cmp_batch(ChainGraphBatch(den, 3), z, "byone_")
+    graphs = [graph_from_npz(z, "g%d_" % i) for i in range(3)]
+    mk = max(g.num_transitions for g in graphs) + 2
+    mh = max(g.num_states for g in graphs) + 1
+    gl = ChainGraphBatch(graphs, max_num_transitions=mk, max_num_states=mh)
+    _cmp_batch(gl, z, "bylist_")
+    assert gl.num_transitions == int(z["bylist_num_transitions"])
+    gl.reorder(torch.tensor([2, 0, 1]))
+    _cmp_batch(gl, z, "reordered_")
+    pg = [graph_from_npz(z, "pg%d_" % i) for i in range(2)]
+    _cmp_batch(ChainGraphBatch(pg, max_num_transitions=9, max_num_states=5), z, "problist_")
+
+
+def test_container_errors():
+    g = syn.make_den_graph(6, 14, 9, seed=11)
+    with pytest.raises(ValueError, match="batch size should be specified"):
+        ChainGraphBatch(g)
+    with pytest.raises(ValueError, match="max_num_transitions"):
+        ChainGraphBatch([g])
+    with pytest.raises(ValueError, match="max_num_states"):
+        ChainGraphBatch([g], max_num_transitions=20)
+    with pytest.raises(ValueError, match="should be either initialized"):
+        ChainGraphBatch("nope", 2)
+    with pytest.raises(Exception, match="empty graph"):
+        f = StdVectorFst(); f.add_state(); f.set_start(0)
+        ChainGraph(f)
+    with pytest.raises(AssertionError):
+        ChainGraph(syn.make_num_fst(4, 9, 1), initial_mode="leaky", log_domain=True)
+
+
+def test_chain_graph_modes():
+    fst = syn.make_den_fst(6, 14, 9, seed=11)
+    a = ChainGraph(fst, initial_mode="leaky", final_mode="ones")
+    assert torch.equal(a.initial_probs, a.leaky_probs) and bool((a.final_probs == 1).all())
+    assert abs(float(a.leaky_probs.sum()) - 1.0) < 1e-6 and bool((a.leaky_probs >= 0).all())
+    b = ChainGraph(fst)   # fst / fst
+    assert float(b.initial_probs[b.start_state]) == 1.0 and float(b.initial_probs.sum()) == 1.0
+    c = ChainGraph(syn.make_num_fst(5, 9, 3), log_domain=True, final_mode="ones")
+    assert c.leaky_probs is None and float(c.initial_probs[0]) == 0.0 and bool((c.final_probs == 0).all())
+    assert bool(torch.isinf(c.initial_probs[1:]).all())
+    # layout rules of fstext.cc:36-76: out-arcs by source, in-arcs by destination then ascending source
+    assert bool((a.forward_transitions[:-1, 0] <= a.forward_transitions[1:, 0]).all())
+    assert bool((a.backward_transitions[:-1, 1] <= a.backward_transitions[1:, 1]).all())
+    for h in range(a.num_states):
+        lo, hi = a.backward_transition_indices[h].tolist()
+        src = a.backward_transitions[lo:hi, 0]
+        assert bool((src[:-1] <= src[1:]).all()) and bool((a.backward_transitions[lo:hi, 1] == h).all())
+
+
+def test_fst_binary_roundtrip(tmp_path):
+    fst = syn.make_den_fst(7, 20, 11, seed=5)
+    p = str(tmp_path / "g.fst")
+    assert fst.write(p)
+    back = StdVectorFst.read(p)
+    for x, y in zip(StdVectorFst.fst_to_tensor(fst), StdVectorFst.fst_to_tensor(back)):
+        assert torch.equal(x, y)
+    with open(str(tmp_path / "ark"), "wb") as f:   # Kaldi-ark style: FST at a byte offset
+        f.write(b"utt1 " + fst._to_bytes())
+    assert StdVectorFst.read_ark(str(tmp_path / "ark"), 5).num_states() == 7
+
+
+def test_alias_package_and_exports():
+    import pychain
+    import pychain.graph
+    import pychain.loss
+    assert pychain.ChainLoss is pychain.loss.ChainLoss and pychain.ChainGraph is pychain.graph.ChainGraph
+    import pychain_C
+    for name in ("forward_backward", "forward_backward_log_domain", "set_verbose_level"):
+        assert callable(getattr(pychain_C, name))
+    # every symbol the header declares is exported by the library (no compute calls here)
+    hdr = open(os.path.join(REPO, "include", "pychain_hip.h")).read()
+    declared = set(re.findall(r"\b(pychain_hip_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pychain_hip_abi_version() == _lib.ABI_VERSION
+    _lib.lib().pychain_hip_set_verbose_level(2)
+    assert _lib.lib().pychain_hip_get_verbose_level() == 2
+    _lib.lib().pychain_hip_set_verbose_level(0)
+
+
+def test_no_cpu_fallback():
+    from pychain_amd import ChainFunction
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ChainFunction.apply(torch.zeros(2, 5, 9), torch.tensor([5, 5]),
+                            ChainGraphBatch(syn.make_den_graph(6, 14, 9, seed=11), 2))
+    # the product package never imports, links or opens anything under oracle/
+    pat = re.compile(r"^\s*(import|from)\s+(oracle|ref_loader|build_ref)\b|oracle[/\\]|chain_oracle|libchain_oracle|_ref/",
+                     re.M)
+    for root, _d, files in os.walk(os.path.join(REPO, "pychain_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                assert not pat.search(open(os.path.join(root, fn)).read()), fn
