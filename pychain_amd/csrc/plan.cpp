@@ -23,6 +23,74 @@ struct BuiltTile {
   std::vector<int> row_order;       // sorted position -> original row id
 };
 
+// ---- LDS bank-conflict-aware slot assignment -------------------------------------------
+// A wave64 ds_read_b32 is serviced as two 32-lane halves over 32 banks (bank = word address
+// mod 32; both operand arrays start on a multiple of 32 words); a half costs as many LDS
+// cycles as its most-loaded bank.  Within a group, row r (lane r) may issue its arcs in any
+// slot order, so for every 32-row half the arcs are permuted inside their rows to minimise
+// the number of same-bank pairs per slot-row, over both gathered operands.  Greedy
+// placement followed by a deterministic local search (fixed-seed LCG: plans are reproducible).
+// Measured on the C3 graph: 7.0 -> ~3.9 LDS cycles per half slot-row (2.0 = conflict-free).
+struct HalfOpt {
+  int nrows, nslots;
+  std::vector<int> cell;                 // [row*nslots + slot] -> arc index in the row's list, -1 = padding
+  std::vector<std::vector<Arc>> const* rows;
+  std::vector<int> const* order;
+  int pos0;
+  std::vector<int> cnt;                  // [slot][operand][bank]
+  const Arc* arc(int r, int j) const {
+    const int a = cell[r * nslots + j];
+    return a < 0 ? nullptr : &(*rows)[(*order)[pos0 + r]][a];
+  }
+  int& c(int slot, int op, int bank) { return cnt[(slot * 2 + op) * 32 + bank]; }
+  void add(int slot, const Arc* a, int d) { if (a) { c(slot, 0, a->i0 & 31) += d; c(slot, 1, a->i1 & 31) += d; } }
+  // colliding pairs an arc would have in `slot` (arc itself not counted)
+  int cost_in(int slot, const Arc* a) { return a ? c(slot, 0, a->i0 & 31) + c(slot, 1, a->i1 & 31) : 0; }
+};
+
+void optimise_half(HalfOpt& h) {
+  const int R = h.nrows, A = h.nslots;
+  h.cell.assign((size_t)R * A, -1);
+  h.cnt.assign((size_t)A * 64, 0);
+  // greedy: rows with most arcs first; each arc goes to the free slot of its row with fewest collisions
+  std::vector<int> rorder(R);
+  std::iota(rorder.begin(), rorder.end(), 0);
+  std::stable_sort(rorder.begin(), rorder.end(), [&](int a, int b) {
+    return (*h.rows)[(*h.order)[h.pos0 + a]].size() > (*h.rows)[(*h.order)[h.pos0 + b]].size(); });
+  for (int r : rorder) {
+    const auto& arcs = (*h.rows)[(*h.order)[h.pos0 + r]];
+    for (int a = 0; a < (int)arcs.size(); a++) {
+      int best = -1, bc = 0;
+      for (int j = 0; j < A; j++) {
+        if (h.cell[r * A + j] >= 0) continue;
+        const int cst = h.cost_in(j, &arcs[a]);
+        if (best < 0 || cst < bc) { best = j; bc = cst; }
+      }
+      h.cell[r * A + best] = a;
+      h.add(best, &arcs[a], +1);
+    }
+  }
+  // local search: swap two slots of one row when that does not increase the collision count
+  uint32_t rng = 0x9E3779B9u;
+  auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+  const long iters = (long)R * A * 160;
+  for (long it = 0; it < iters; it++) {
+    const int r = next() % R, j1 = next() % A, j2 = next() % A;
+    if (j1 == j2) continue;
+    const Arc* a1 = h.arc(r, j1); const Arc* a2 = h.arc(r, j2);
+    if (!a1 && !a2) continue;
+    h.add(j1, a1, -1); h.add(j2, a2, -1);
+    const int before = h.cost_in(j1, a1) + h.cost_in(j2, a2);
+    const int after = h.cost_in(j2, a1) + h.cost_in(j1, a2);
+    if (after <= before) {
+      std::swap(h.cell[r * A + j1], h.cell[r * A + j2]);
+      h.add(j2, a1, +1); h.add(j1, a2, +1);
+    } else {
+      h.add(j1, a1, +1); h.add(j2, a2, +1);
+    }
+  }
+}
+
 // rows[r] = arcs of original row r.  `order` = row ids sorted by descending degree
 // (stable), rows beyond order.size() do not exist.  npos = number of row positions
 // (multiple of 64) the output vector has.
@@ -58,17 +126,29 @@ BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vecto
     int n = 0;
     for (int g : per_wave[w]) {
       t.groups.push_back(GroupEntry{g * 64, gsl[g]});
-      for (int j = 0; j < gsl[g]; j++)
+      const int A = gsl[g];
+      HalfOpt half[2];
+      for (int hh = 0; hh < 2 && A > 0; hh++) {
+        const int p0 = g * 64 + hh * 32;
+        half[hh].nrows = std::max(0, std::min(32, (int)order.size() - p0));
+        half[hh].nslots = A; half[hh].rows = &rows; half[hh].order = &order; half[hh].pos0 = p0;
+        if (half[hh].nrows > 0) optimise_half(half[hh]);
+      }
+      for (int j = 0; j < A; j++) {
+        // padding lanes re-read the operands of a real arc of their half (an LDS broadcast: no conflict)
+        uint32_t fill[2] = {0u, 0u};
+        for (int hh = 0; hh < 2; hh++)
+          for (int r = 0; r < half[hh].nrows; r++)
+            if (const Arc* a = half[hh].arc(r, j)) { fill[hh] = a->i0 | (a->i1 << 16); break; }
         for (int l = 0; l < 64; l++) {
-          const int pos = g * 64 + l;
-          uint32_t idx = 0; float p = 0.f;
-          if (pos < (int)order.size() && j < (int)rows[order[pos]].size()) {
-            const Arc& a = rows[order[pos]][j];
-            idx = a.i0 | (a.i1 << 16); p = a.p;
-          }
+          const int hh = l >> 5, r = l & 31;
+          uint32_t idx = fill[hh]; float p = 0.f;
+          if (r < half[hh].nrows)
+            if (const Arc* a = half[hh].arc(r, j)) { idx = a->i0 | (a->i1 << 16); p = a->p; }
           uint32_t pb; memcpy(&pb, &p, 4);
           t.slots.push_back(idx); t.slots.push_back(pb);
         }
+      }
       n += gsl[g];
     }
     we.nslot_rows = n;
