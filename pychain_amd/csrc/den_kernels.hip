@@ -44,7 +44,7 @@ constexpr int kNW = PLAN_REC_WAVES;        // waves per workgroup (both kernels)
 constexpr int kNT = kNW * 64;              // threads per workgroup
 static_assert(PLAN_REC_WAVES == PLAN_GAM_WAVES, "one workgroup shape for both kernels");
 static_assert(kNW <= 16, "block totals are reduced inside one 16-lane DPP row");
-constexpr int kMaxResident = 64;           // slot-rows per wave kept in VGPRs (3 VGPRs each; 2 waves/SIMD => 256 VGPRs)
+constexpr int kMaxResident = 40;           // slot-rows per wave kept in VGPRs (2 VGPRs each; 4 waves/SIMD => 128 VGPRs)
 
 // ---- one frame of a tile plan: out[row] = sum_k p_k * U[i0_k] * V[i1_k] ------------------
 // The first R slot-rows of a wave are held in registers as ABSOLUTE LDS byte addresses of
@@ -53,8 +53,11 @@ constexpr int kMaxResident = 64;           // slot-rows per wave kept in VGPRs (
 // ONCE per workgroup and the per-frame inner loop touches only LDS.
 template <int R>
 struct ArcRegs {
-  uint32_t o0[R > 0 ? R : 1];
-  uint32_t o1[R > 0 ? R : 1];
+  // 2 VGPRs per slot-row: both absolute LDS byte addresses packed 16:16, and the probability.
+  // (A wave issues ~1 instruction per 4-5 cycles whatever its ILP - tools/ubench - so the CU
+  // needs 4 waves per SIMD to fill its issue slots; that leaves 128 VGPRs per lane, and the
+  // two unpack VALU ops per arc are cheaper than halving the number of waves.)
+  uint32_t pk[R > 0 ? R : 1];
   float p[R > 0 ? R : 1];
   __device__ __forceinline__ void load(const int nslot_rows, const uint2* __restrict__ wave_slots,
                                        uint32_t lds_u, uint32_t lds_v) {
@@ -62,19 +65,11 @@ struct ArcRegs {
     for (int s = 0; s < R; s++) {
       uint2 a = make_uint2(0u, 0u);                    // rows past the plan: p = 0, harmless addresses
       if (s < nslot_rows) a = wave_slots[s * 64];
-      o0[s] = lds_u + ((a.x & 0xffffu) << 2);
-      o1[s] = lds_v + ((a.x >> 16) << 2);
+      pk[s] = (lds_u + ((a.x & 0xffffu) << 2)) | ((lds_v + ((a.x >> 16) << 2)) << 16);
 #ifdef PYCHAIN_EXP_NOCONFLICT      // timing experiment: lane-linear gathers (wrong results)
-      o0[s] = lds_u + (((threadIdx.x & 63) + 64 * (s & 7)) << 2);
-      o1[s] = lds_v + (((threadIdx.x & 63) + 64 * (s & 7)) << 2);
-#endif
-#ifdef PYCHAIN_EXP_BROADCAST       // timing experiment: every lane reads the same word
-      o0[s] = lds_u + 4 * s; o1[s] = lds_v + 4 * s;
+      pk[s] = (lds_u + (((threadIdx.x & 63) + 64 * (s & 7)) << 2)) | ((lds_v + (((threadIdx.x & 63) + 64 * (s & 7)) << 2)) << 16);
 #endif
       p[s] = __uint_as_float(a.y);
-      // Opaque: otherwise the optimiser keeps the packed word and re-derives both addresses
-      // (and / shift / add x2) in every frame to save a register.
-      asm volatile("" : "+v"(o0[s]), "+v"(o1[s]));
     }
   }
 };
@@ -129,7 +124,7 @@ struct GroupRegs {
   } while (0)
 
 template <int R, int MODE>
-__device__ __forceinline__ void tile_rows(const ArcRegs<R>& ar, const GroupRegs& gr,
+__device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
                                           const uint2* __restrict__ tail_slots, int lane,
                                           const float* __restrict__ U, const float* __restrict__ V,
                                           float* __restrict__ out, const int* __restrict__ row_map,
@@ -156,11 +151,16 @@ __device__ __forceinline__ void tile_rows(const ArcRegs<R>& ar, const GroupRegs&
 #pragma unroll
       for (int k = 0; k < kChunk; k++) {
         pr[k] = 0.f;
+        if (c + k < R) {
+          // opaque per frame: otherwise the optimiser hoists both unpacked addresses of every
+          // slot-row out of the frame loop (3 VGPRs per arc instead of 2)
+          asm volatile("" : "+v"(ar.pk[c + k]));
 #ifndef PYCHAIN_EXP_NOLDS
-        if (c + k < R) pr[k] = (ar.p[c + k] * lds_abs(ar.o0[c + k])) * lds_abs(ar.o1[c + k]);
+          pr[k] = (ar.p[c + k] * lds_abs(ar.pk[c + k] & 0xffffu)) * lds_abs(ar.pk[c + k] >> 16);
 #else
-        if (c + k < R) pr[k] = (ar.p[c + k] * __uint_as_float(ar.o0[c + k])) * __uint_as_float(ar.o1[c + k]);
+          pr[k] = (ar.p[c + k] * __uint_as_float(ar.pk[c + k] & 0xffffu)) * __uint_as_float(ar.pk[c + k] >> 16);
 #endif
+        }
       }
       const uint32_t ends = ((c < 32 ? m_lo : m_hi) >> (c & 31)) & ((1u << kChunk) - 1u);
       if (__builtin_expect(ends == 0u, 1)) {
@@ -475,11 +475,10 @@ hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream
 
 // rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
 // than kMaxResident keep the first kMaxResident rows in registers and stream their tail.
-inline int pick_r(int rows) {
-  if (rows <= 0) return 0;
+inline int pick_r(const DenArgs& a, int rows, int lds_words) {
+  if (rows <= 0 || lds_words * 4 > 65535) return 0;   // packed 16-bit LDS addresses
   if (rows <= 16) return 16;
   if (rows <= 32) return 32;
-  if (rows <= 48) return 48;
   return kMaxResident;
 }
 
@@ -488,22 +487,20 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
   hipError_t e = hipSuccess;
   if (a.phase_mask & 1) {
     const dim3 grid(2 * a.B);
-    switch (pick_r(hint & 0xffff)) {
+    switch (pick_r(a, hint & 0xffff, a.Hp + ((a.D + 3) & ~3))) {
       case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0>, a, grid, lds_rec, st); break;
       case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16>, a, grid, lds_rec, st); break;
       case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32>, a, grid, lds_rec, st); break;
-      case 48: e = launch_one(den_recursion_kernel<VEC, XCH, 48>, a, grid, lds_rec, st); break;
       default: e = launch_one(den_recursion_kernel<VEC, XCH, kMaxResident>, a, grid, lds_rec, st); break;
     }
     if (e != hipSuccess) return e;
   }
   if (a.phase_mask & 2) {
     const dim3 grid(gx, a.B);
-    switch (pick_r((hint >> 16) & 0x7fff)) {
+    switch (pick_r(a, (hint >> 16) & 0x7fff, 2 * a.Hp)) {
       case 0: e = launch_one(den_gamma_kernel<VEC, XCH, 0>, a, grid, lds_gam, st); break;
       case 16: e = launch_one(den_gamma_kernel<VEC, XCH, 16>, a, grid, lds_gam, st); break;
       case 32: e = launch_one(den_gamma_kernel<VEC, XCH, 32>, a, grid, lds_gam, st); break;
-      case 48: e = launch_one(den_gamma_kernel<VEC, XCH, 48>, a, grid, lds_gam, st); break;
       default: e = launch_one(den_gamma_kernel<VEC, XCH, kMaxResident>, a, grid, lds_gam, st); break;
     }
   }
@@ -524,11 +521,11 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
   const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   const int D = a.D, r = resident_slot_rows;
   if (D % 4 == 0) {
+    if (D <= 4 * 1 * kNT) return launch_r<4, 1>(a, r, lds_rec, lds_gam, gx, st);
     if (D <= 4 * 2 * kNT) return launch_r<4, 2>(a, r, lds_rec, lds_gam, gx, st);
     if (D <= 4 * 4 * kNT) return launch_r<4, 4>(a, r, lds_rec, lds_gam, gx, st);
-    if (D <= 4 * 8 * kNT) return launch_r<4, 8>(a, r, lds_rec, lds_gam, gx, st);
-  } else if (D <= 8 * kNT) {
-    return launch_r<1, 8>(a, r, lds_rec, lds_gam, gx, st);
+  } else if (D <= 4 * kNT) {
+    return launch_r<1, 4>(a, r, lds_rec, lds_gam, gx, st);
   }
   return launch_r<1, 0>(a, r, lds_rec, lds_gam, gx, st);
 }
