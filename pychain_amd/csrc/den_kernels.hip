@@ -406,18 +406,52 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   for (int i = tid; i < tp.ngroups * 64; i += kNT) rmap[i] = row_pdf[i];
   int bad = 0;
   const int t_live_end = min(t_end, L);
+  // Software pipeline over frames: the global loads of frame t+1 (alpha', beta, nnet-output
+  // rows) are issued into registers before frame t is evaluated and committed to LDS after
+  // the last LDS read of frame t, so HBM latency is off the per-frame critical path.
+  XRow<kNT, VEC, XCH> xq;
+  constexpr int kUV = 1;                             // float4 chunks of U and of V per thread (Hp <= 4*kNT fast path)
+  float4 ureg[kUV], vreg[kUV];
+  const bool uv_in_regs = Hp <= kUV * 4 * kNT;
+  // (macros, not lambdas: by-reference captures would put the staging registers on the stack)
+#define GAMMA_PREFETCH(t)                                                                     \
+  do {                                                                                        \
+    xq.load(xseq + (size_t)(t) * D, D, tid);                                                  \
+    if (uv_in_regs) {                                                                         \
+      const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
+      const float* br_ = bseq + (size_t)((t) + 1) * Hp;                                       \
+      _Pragma("unroll") for (int c = 0; c < kUV; c++) {                                       \
+        const int i = (c * kNT + tid) * 4;                                                    \
+        if (i < Hp) { ureg[c] = *reinterpret_cast<const float4*>(ar_ + i);                    \
+                      vreg[c] = *reinterpret_cast<const float4*>(br_ + i); }                  \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
+#define GAMMA_COMMIT(t)                                                                       \
+  do {                                                                                        \
+    xq.store(xr, xseq + (size_t)(t) * D, D, tid, a.input_is_exp);                             \
+    if (uv_in_regs) {                                                                         \
+      _Pragma("unroll") for (int c = 0; c < kUV; c++) {                                       \
+        const int i = (c * kNT + tid) * 4;                                                    \
+        if (i < Hp) { *reinterpret_cast<float4*>(U + i) = ureg[c];                            \
+                      *reinterpret_cast<float4*>(V + i) = vreg[c]; }                          \
+      }                                                                                       \
+    } else {                                                                                  \
+      const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
+      const float* br_ = bseq + (size_t)((t) + 1) * Hp;                                       \
+      for (int i = tid * 4; i < Hp; i += kNT * 4) {                                           \
+        *reinterpret_cast<float4*>(U + i) = *reinterpret_cast<const float4*>(ar_ + i);        \
+        *reinterpret_cast<float4*>(V + i) = *reinterpret_cast<const float4*>(br_ + i);        \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
+  GAMMA_PREFETCH(t_begin);
+  GAMMA_COMMIT(t_begin);
+  __syncthreads();
   for (int t = t_begin; t < t_live_end; t++) {
     float* grow = gseq + (size_t)t * D;
-    XRow<kNT, VEC, XCH> xq;
-    xq.load(xseq + (size_t)t * D, D, tid);
-    const float* ar = aseq + (size_t)t * Hp;
-    const float* br = bseq + (size_t)(t + 1) * Hp;
-    for (int i = tid * 4; i < Hp; i += kNT * 4) {
-      *reinterpret_cast<float4*>(U + i) = *reinterpret_cast<const float4*>(ar + i);
-      *reinterpret_cast<float4*>(V + i) = *reinterpret_cast<const float4*>(br + i);
-    }
-    xq.store(xr, xseq + (size_t)t * D, D, tid, a.input_is_exp);
-    __syncthreads();
+    const bool have_next = t + 1 < t_live_end;
+    if (have_next) GAMMA_PREFETCH(t + 1);
     float s0 = 0.f, s1 = 0.f;
     tile_rows<R, 1>(arcs, groups, tail_slots, lane, U, V, q, rmap, nullptr, s0, s1);
     __syncthreads();
@@ -437,7 +471,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     }
     part = wave_sum(part);
     if (lane == 0) red[wave] = part;
-    __syncthreads();
+    __syncthreads();                                   // also: every read of U/V/xr of this frame is done
     const float tot = block_total(red, lane);
     const float sc = a.grad_scale / tot;
     if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
@@ -454,10 +488,13 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
           }
         }
       }
+      if (have_next) GAMMA_COMMIT(t + 1);
     } else {
       for (int e = tid; e < D; e += kNT) grow[e] = xr[e] * q[e] * sc;
+      __syncthreads();                                 // generic-D path re-reads xr/q above
+      if (have_next) GAMMA_COMMIT(t + 1);
     }
-    __syncthreads();   // U/V/xr/q are rewritten by the next frame
+    __syncthreads();   // next frame's operands are in place; q is rewritten by the next frame
   }
   // padded tail of a chunk that straddles the sequence end
   if (t_live_end < t_end)

@@ -116,6 +116,37 @@ BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vecto
     per_wave[w].push_back(g);
     load[w] += gsl[g] + 1;        // +1: the per-group store/bookkeeping cost
   }
+  // refine the LPT deal: move or swap single groups while that lowers the heavier of the two
+  // waves involved (the frame time of a workgroup is set by its most loaded wave)
+  auto cost = [&](int g) { return gsl[g] + 1; };
+  for (int pass = 0; pass < 64; pass++) {
+    int wmax = 0;
+    for (int i = 1; i < nwaves; i++) if (load[i] > load[wmax]) wmax = i;
+    bool improved = false;
+    for (size_t ia = 0; ia < per_wave[wmax].size() && !improved; ia++) {
+      const int ga = per_wave[wmax][ia];
+      for (int w2 = 0; w2 < nwaves && !improved; w2++) {
+        if (w2 == wmax) continue;
+        // move
+        if (per_wave[w2].size() < 64 && load[w2] + cost(ga) < load[wmax]) {
+          per_wave[w2].push_back(ga); per_wave[wmax].erase(per_wave[wmax].begin() + ia);
+          load[w2] += cost(ga); load[wmax] -= cost(ga); improved = true; break;
+        }
+        // swap
+        for (size_t ib = 0; ib < per_wave[w2].size(); ib++) {
+          const int gb = per_wave[w2][ib];
+          const int d = cost(ga) - cost(gb);
+          if (d > 0 && load[w2] + d < load[wmax]) {
+            per_wave[wmax][ia] = gb; per_wave[w2][ib] = ga;
+            load[wmax] -= d; load[w2] += d; improved = true; break;
+          }
+        }
+      }
+    }
+    if (!improved) break;
+  }
+  for (auto& v : per_wave)   // descending slot counts inside a wave: groups without arcs come last
+    std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
   t.waves.resize(nwaves);
   int row_cursor = 0;
   for (int w = 0; w < nwaves; w++) {
