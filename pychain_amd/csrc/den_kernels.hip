@@ -44,20 +44,26 @@ constexpr int kNW = PLAN_REC_WAVES;        // waves per workgroup (both kernels)
 constexpr int kNT = kNW * 64;              // threads per workgroup
 static_assert(PLAN_REC_WAVES == PLAN_GAM_WAVES, "one workgroup shape for both kernels");
 static_assert(kNW <= 16, "block totals are reduced inside one 16-lane DPP row");
-constexpr int kMaxResident = 40;           // slot-rows per wave kept in VGPRs (2 VGPRs each; 4 waves/SIMD => 128 VGPRs)
+constexpr int kMaxResident = PLAN_REC_WAVES > 12 ? 40 : 44;   // slot-rows per wave kept in VGPRs
 
 // ---- one frame of a tile plan: out[row] = sum_k p_k * U[i0_k] * V[i1_k] ------------------
 // The first R slot-rows of a wave are held in registers as ABSOLUTE LDS byte addresses of
 // the two operands plus the arc probability (R = 0: everything is streamed from the
 // L2-resident plan).  The plan of a wave is loop-invariant over frames, so this is loaded
 // ONCE per workgroup and the per-frame inner loop touches only LDS.
+#ifndef PYCHAIN_ARC_PACKED
+#define PYCHAIN_ARC_PACKED (PLAN_REC_WAVES > 12)   // 16 waves: 128 VGPRs/lane -> 2 registers per slot-row
+#endif
 template <int R>
 struct ArcRegs {
+#if PYCHAIN_ARC_PACKED
   // 2 VGPRs per slot-row: both absolute LDS byte addresses packed 16:16, and the probability.
-  // (A wave issues ~1 instruction per 4-5 cycles whatever its ILP - tools/ubench - so the CU
-  // needs 4 waves per SIMD to fill its issue slots; that leaves 128 VGPRs per lane, and the
-  // two unpack VALU ops per arc are cheaper than halving the number of waves.)
   uint32_t pk[R > 0 ? R : 1];
+#else
+  // 3 VGPRs per slot-row: the two absolute LDS byte addresses and the probability.
+  uint32_t o0[R > 0 ? R : 1];
+  uint32_t o1[R > 0 ? R : 1];
+#endif
   float p[R > 0 ? R : 1];
   __device__ __forceinline__ void load(const int nslot_rows, const uint2* __restrict__ wave_slots,
                                        uint32_t lds_u, uint32_t lds_v) {
@@ -65,12 +71,34 @@ struct ArcRegs {
     for (int s = 0; s < R; s++) {
       uint2 a = make_uint2(0u, 0u);                    // rows past the plan: p = 0, harmless addresses
       if (s < nslot_rows) a = wave_slots[s * 64];
-      pk[s] = (lds_u + ((a.x & 0xffffu) << 2)) | ((lds_v + ((a.x >> 16) << 2)) << 16);
+      uint32_t a0 = lds_u + ((a.x & 0xffffu) << 2), a1 = lds_v + ((a.x >> 16) << 2);
 #ifdef PYCHAIN_EXP_NOCONFLICT      // timing experiment: lane-linear gathers (wrong results)
-      pk[s] = (lds_u + (((threadIdx.x & 63) + 64 * (s & 7)) << 2)) | ((lds_v + (((threadIdx.x & 63) + 64 * (s & 7)) << 2)) << 16);
+      a0 = lds_u + (((threadIdx.x & 63) + 64 * (s & 7)) << 2); a1 = lds_v + (((threadIdx.x & 63) + 64 * (s & 7)) << 2);
+#endif
+#if PYCHAIN_ARC_PACKED
+      pk[s] = a0 | (a1 << 16);
+#else
+      o0[s] = a0; o1[s] = a1;
+      asm volatile("" : "+v"(o0[s]), "+v"(o1[s]));    // opaque: no re-derivation from the packed word per frame
 #endif
       p[s] = __uint_as_float(a.y);
     }
+  }
+  // the two gathered operands of slot-row s
+  __device__ __forceinline__ void gather(int s, float& u, float& v) {
+#if PYCHAIN_ARC_PACKED
+    // opaque per frame: otherwise the optimiser hoists both unpacked addresses of every
+    // slot-row out of the frame loop (3 VGPRs per arc instead of 2)
+    asm volatile("" : "+v"(pk[s]));
+    const uint32_t a0 = pk[s] & 0xffffu, a1 = pk[s] >> 16;
+#else
+    const uint32_t a0 = o0[s], a1 = o1[s];
+#endif
+#ifndef PYCHAIN_EXP_NOLDS
+    u = lds_abs(a0); v = lds_abs(a1);
+#else
+    u = __uint_as_float(a0); v = __uint_as_float(a1);
+#endif
   }
 };
 
@@ -138,39 +166,42 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
   uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32);
   asm volatile("" : "+s"(m_lo), "+s"(m_hi));
   // Per chunk of kChunk slot-rows: all gathers first (2*kChunk independent ds_reads in flight),
-  // then all products (independent VALU, no branch in between so they pipeline), then the
-  // running row sums.  A chunk without a group end is one adder tree; group ends (a few per
-  // frame) take the per-slot path.  Products are rounded before they are added - the
-  // reference's CPU loop does the same (chain-computation.cc:161).
+  // then the arithmetic (no branch in between so it pipelines).  A chunk without a group end
+  // runs two fma chains; group ends (a few per frame) take the per-slot path.
   static_assert(32 % 8 == 0, "a chunk never straddles the two mask words");
-  constexpr int kChunk = 8;
+  // Software pipeline: the gathers of chunk c+1 are issued BEFORE chunk c is consumed, so a
+  // wave always has 8 ds_reads in flight while it does arithmetic (a wave issues only ~1
+  // instruction per 5 cycles - tools/ubench - so un-overlapped LDS latency is pure loss).
+  // Rows past the wave's plan carry p = 0 and valid addresses: no per-chunk bound check.
+  constexpr int kChunk = 4;
+  static_assert(R % kChunk == 0, "resident slot-rows come in whole chunks");
+  constexpr int NC = R / kChunk;
+  float ub[2][kChunk], vb[2][kChunk];
+  if (R > 0) {
 #pragma unroll
-  for (int c = 0; c < R; c += kChunk) {
-    if (c < gr.nslots) {
-      float pr[kChunk];
+    for (int k = 0; k < kChunk; k++) ar.gather(k, ub[0][k], vb[0][k]);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int cb = c & 1;
+    if (c + 1 < NC) {
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) ar.gather((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
+    }
+    float pu[kChunk];
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) pu[k] = ar.p[c * kChunk + k] * ub[cb][k];   // (p * alpha) rounded, then fused with x
+    const uint32_t ends = ((c * kChunk < 32 ? m_lo : m_hi) >> ((c * kChunk) & 31)) & ((1u << kChunk) - 1u);
+    if (__builtin_expect(ends == 0u, 1)) {
+      float a0 = acc, a1 = 0.f;                      // two chains: half the dependent-fma latency
+#pragma unroll
+      for (int k = 0; k < kChunk; k += 2) { a0 = fmaf(pu[k], vb[cb][k], a0); a1 = fmaf(pu[k + 1], vb[cb][k + 1], a1); }
+      acc = a0 + a1;
+    } else {
 #pragma unroll
       for (int k = 0; k < kChunk; k++) {
-        pr[k] = 0.f;
-        if (c + k < R) {
-          // opaque per frame: otherwise the optimiser hoists both unpacked addresses of every
-          // slot-row out of the frame loop (3 VGPRs per arc instead of 2)
-          asm volatile("" : "+v"(ar.pk[c + k]));
-#ifndef PYCHAIN_EXP_NOLDS
-          pr[k] = (ar.p[c + k] * lds_abs(ar.pk[c + k] & 0xffffu)) * lds_abs(ar.pk[c + k] >> 16);
-#else
-          pr[k] = (ar.p[c + k] * __uint_as_float(ar.pk[c + k] & 0xffffu)) * __uint_as_float(ar.pk[c + k] >> 16);
-#endif
-        }
-      }
-      const uint32_t ends = ((c < 32 ? m_lo : m_hi) >> (c & 31)) & ((1u << kChunk) - 1u);
-      if (__builtin_expect(ends == 0u, 1)) {
-        acc += ((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7]));
-      } else {
-#pragma unroll
-        for (int k = 0; k < kChunk; k++) {
-          acc += pr[k];
-          if ((ends >> k) & 1u) PYCHAIN_TILE_FLUSH();
-        }
+        acc = fmaf(pu[k], vb[cb][k], acc);
+        if ((ends >> k) & 1u) PYCHAIN_TILE_FLUSH();
       }
     }
   }
@@ -182,7 +213,7 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
     for (int s = R; s < gr.nslots; s++) {
       const uint2 a = *sp;
       sp += 64;
-      acc += (__uint_as_float(a.y) * U[a.x & 0xffffu]) * V[a.x >> 16];
+      acc = fmaf(__uint_as_float(a.y) * U[a.x & 0xffffu], V[a.x >> 16], acc);
       if (--remaining == 0) {
         PYCHAIN_TILE_FLUSH();
         remaining = __builtin_amdgcn_readlane(gr.n, g & 63);
@@ -513,7 +544,7 @@ hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream
 // rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
 // than kMaxResident keep the first kMaxResident rows in registers and stream their tail.
 inline int pick_r(const DenArgs& a, int rows, int lds_words) {
-  if (rows <= 0 || lds_words * 4 > 65535) return 0;   // packed 16-bit LDS addresses
+  if (rows <= 0 || (PYCHAIN_ARC_PACKED && lds_words * 4 > 65535)) return 0;   // packed 16-bit LDS addresses
   if (rows <= 16) return 16;
   if (rows <= 32) return 32;
   return kMaxResident;
@@ -560,6 +591,7 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
   if (D % 4 == 0) {
     if (D <= 4 * 1 * kNT) return launch_r<4, 1>(a, r, lds_rec, lds_gam, gx, st);
     if (D <= 4 * 2 * kNT) return launch_r<4, 2>(a, r, lds_rec, lds_gam, gx, st);
+    if (D <= 4 * 3 * kNT) return launch_r<4, 3>(a, r, lds_rec, lds_gam, gx, st);
     if (D <= 4 * 4 * kNT) return launch_r<4, 4>(a, r, lds_rec, lds_gam, gx, st);
   } else if (D <= 4 * kNT) {
     return launch_r<1, 4>(a, r, lds_rec, lds_gam, gx, st);

@@ -39,14 +39,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
-// exp(c) for |c| <= 30 in 6 VALU ops: v_exp_f32 on a split product c*log2(e) = t + r,
-// exp(c) = 2^t * (1 + r ln2).  Relative error ~1e-7 (one v_exp ulp); the generic expf
-// spends ~25 instructions on range handling this input range never needs.
+// exp(c) for |c| <= 30 in 5 VALU ops: v_exp_f32 on c*log2(e) with the rounding error of
+// that product fed back, exp(c) = 2^t * (1 + r ln2).  Relative error ~2e-7 (v_exp ulp + the
+// dropped low part of log2 e, |c|*1.9e-8*ln2 <= 4e-7); the generic expf spends ~25
+// instructions on range handling this input range never needs.
 __device__ __forceinline__ float exp_bounded(float c) {
   const float kL2E = 1.44269502162933349609375f;       // fp32(log2 e)
-  const float kL2E_lo = 1.925963033500011e-8f;          // log2 e - fp32(log2 e)
   const float t = c * kL2E;
-  const float r = fmaf(c, kL2E, -t) + c * kL2E_lo;
+  const float r = fmaf(c, kL2E, -t);
   const float e = __builtin_amdgcn_exp2f(t);
   return fmaf(e, r * 0.693147182464599609375f, e);
 }

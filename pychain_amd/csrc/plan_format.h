@@ -30,8 +30,10 @@
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
 #define PLAN_VERSION 4
+#ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
-#define PLAN_GAM_WAVES 16      // same for the gamma plan
+#define PLAN_GAM_WAVES 16
+#endif      // same for the gamma plan
 
 struct TilePlan {              // all offsets are bytes from the start of the blob
   int32_t ngroups;
