@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=12, help="utterances in the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="utterances in the CPU baseline sample")
     return ap.parse_args()
 
 
@@ -79,11 +79,21 @@ def kernel_rooflines(w, dev, iters):
     bytes_rec = (8 * D + 4 * (H + 1)) * frames
     bytes_gam = (4 * D + 4 * (H + 1)) * frames
     ms_rec, ms_gam = out["den_recursion_kernel"], out["den_gamma_kernel"]
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, summary committed
+    # under profiles/): only quoted when it was measured on this very workload
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_hbm_traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("workload") == cfg.get("name") and tj.get("frames") == frames:
+            traffic = tj["den_recursion_kernel"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roof = {
         "bound": "hbm", "kernel": "den_recursion_kernel",
         "achieved": round(bytes_rec / (ms_rec * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(bytes_rec / (ms_rec * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-        "traffic": None, "ms_per_launch": round(ms_rec, 4), "algorithmic_bytes_per_launch": bytes_rec,
+        "traffic": traffic, "ms_per_launch": round(ms_rec, 4), "algorithmic_bytes_per_launch": bytes_rec,
         "other_kernels": {"den_gamma_kernel": {"ms_per_launch": round(ms_gam, 4),
                                                "achieved": round(bytes_gam / (ms_gam * 1e-3) / 1e9, 2),
                                                "algorithmic_bytes_per_launch": bytes_gam}},
