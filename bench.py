@@ -175,7 +175,7 @@ def main():
     from pychain_amd.parallel import allreduce_stats
 
     # every rank draws its own utterances (seed offset by rank): weak scaling, global B = world * B
-    w = syn.make_workload(args.workload, device=dev, seed=1000 * rank)
+    w = syn.make_workload(args.workload, device=dev, seed=0, data_seed=1000 * rank)
     w["cfg"]["name"] = args.workload
     cfg = w["cfg"]
     w["lengths_dev"] = w["lengths"].to(dev)

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -73,7 +74,8 @@ void optimise_half(HalfOpt& h) {
   // local search: swap two slots of one row when that does not increase the collision count
   uint32_t rng = 0x9E3779B9u;
   auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
-  const long iters = (long)R * A * 160;
+  static const long iter_mult = getenv("PYCHAIN_PLAN_ITERS") ? atol(getenv("PYCHAIN_PLAN_ITERS")) : 160;   // tuning knob
+  const long iters = (long)R * A * iter_mult;
   for (long it = 0; it < iters; it++) {
     const int r = next() % R, j1 = next() % A, j2 = next() % A;
     if (j1 == j2) continue;
@@ -106,6 +108,8 @@ BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vecto
       const int pos = g * 64 + l;
       if (pos < (int)order.size()) gsl[g] = std::max(gsl[g], (int)rows[order[pos]].size());
     }
+  static const int pad_rows = getenv("PYCHAIN_PLAN_PAD") ? atoi(getenv("PYCHAIN_PLAN_PAD")) : 0;   // tuning knob
+  for (int g = 0; g < ngroups; g++) if (gsl[g] >= 4) gsl[g] += pad_rows;
   // longest-processing-time-first: groups are already in descending slot order
   std::vector<std::vector<int>> per_wave(nwaves);
   std::vector<int> load(nwaves, 0);

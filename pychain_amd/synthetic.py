@@ -130,12 +130,15 @@ def make_input(B, T, D, seed=1, scale=2.0, device="cpu"):
     return torch.from_numpy(x.reshape(B, T, D))
 
 
-def make_workload(name, device="cpu", seed=0):
-    """Returns dict(x, lengths, den_graph, num_graphs or None, cfg)."""
+def make_workload(name, device="cpu", seed=0, data_seed=None):
+    """Returns dict(x, lengths, den_graph, num_graphs or None, cfg).  `seed` fixes the
+    denominator graph (the model), `data_seed` (default = seed) the utterances: ranks of a
+    data-parallel job share the graph and draw different utterances."""
     cfg = dict(CONFIGS[name])
     B, T, H, K, D = cfg["B"], cfg["T"], cfg["H"], cfg["K"], cfg["D"]
-    lengths = make_lengths(B, T, cfg["lengths"], seed=seed + 2)
+    ds = seed if data_seed is None else data_seed
+    lengths = make_lengths(B, T, cfg["lengths"], seed=ds + 2)
     den = make_den_graph(H, K, D, seed=seed)
-    num = make_num_graphs(lengths.tolist(), D, seed=seed + 100) if cfg["num"] else None
-    x = make_input(B, T, D, seed=seed + 1, device=device)
+    num = make_num_graphs(lengths.tolist(), D, seed=ds + 100) if cfg["num"] else None
+    x = make_input(B, T, D, seed=ds + 1, device=device)
     return dict(x=x, lengths=lengths, den_graph=den, num_graphs=num, cfg=cfg)
