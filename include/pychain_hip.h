@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 3
+#define PYCHAIN_HIP_ABI_VERSION 4
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -190,6 +190,42 @@ int pychain_hip_chain_loss_forward_backward(
     /* shared */
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs, float grad_scale,
     float* den_objf_per_seq, float* num_objf_per_seq, float* grad, int32_t* bad_count,
+    void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
+    void* stream);
+
+/* The same fused loss split at the autograd boundary (pychain/loss.py:27-87: forward returns
+ * objf, backward returns input_grad * objf_grad):
+ *
+ *   _forward   runs the recursions (denominator alpha/beta + numerator alpha/beta, the latter on
+ *              the side stream) and yields the per-sequence log-probabilities; the stored
+ *              trajectories stay in the two workspaces, which the caller must keep untouched
+ *              until _backward;
+ *   _backward  runs the time-parallel occupancy passes and writes
+ *              grad = grad_scale * (*grad_scale_dev) * (gamma_den - gamma_num) ONCE.
+ *              grad_scale_dev (device float*, may be NULL = 1) is the upstream scalar gradient,
+ *              read on the device: no host sync and no extra pass over [B,T,D] to apply it
+ *              (the reference multiplies the stored gradient again, loss.py:85).
+ * bad_count: dev int32[2] for _forward, dev int32[2] for _backward (may be the same words).
+ */
+int pychain_hip_chain_loss_forward(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
+    float leaky_hmm_coefficient,
+    const int32_t* forward_transitions, const int32_t* forward_transition_indices,
+    const float* forward_transition_probs, const int32_t* backward_transitions,
+    const int32_t* backward_transition_indices, const float* backward_transition_probs,
+    const float* initial_probs, const float* final_probs, int graph_batch_stride,
+    int num_num_states, int num_num_transitions,
+    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs,
+    float* den_objf_per_seq, float* num_objf_per_seq, int32_t* bad_count,
+    void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
+    void* stream);
+int pychain_hip_chain_loss_backward(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
+    const int32_t* forward_transitions, const int32_t* forward_transition_indices,
+    int graph_batch_stride, int num_num_states, int num_num_transitions,
+    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs,
+    float grad_scale, const float* grad_scale_dev,
+    float* grad, int32_t* bad_count,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
 

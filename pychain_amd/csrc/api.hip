@@ -209,6 +209,89 @@ SideStream* side_stream_for_current_device() {
 }
 }  // namespace
 
+extern "C" int pychain_hip_chain_loss_forward(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
+    const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
+    const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
+    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
+    float* den_objf, float* num_objf, int32_t* bad_count,
+    void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
+  const char* who = "chain_loss_forward";
+  if (!bad_count) return fail(PYCHAIN_HIP_EINVAL, "%s: null bad_count", who);
+  DenArgs da;
+  // `grad` is not touched by the recursion launch; any non-null aligned pointer passes the checks
+  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, leaky,
+                         1.f, den_objf, (float*)den_ws, bad_count, den_ws, den_ws_bytes, who);
+  if (rc != PYCHAIN_HIP_OK) return rc;
+  NumArgs na;
+  rc = fill_num_args(na, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, seq_lengths,
+                     B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM, 1.f, num_objf, (float*)num_ws, bad_count + 1,
+                     num_ws, num_ws_bytes, who);
+  if (rc != PYCHAIN_HIP_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  SideStream* side = side_stream_for_current_device();
+  if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "%s: cannot create the side stream", who);
+  const char* why = nullptr;
+  hipError_t e = hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st);
+  // fork: numerator recursion on the side stream, denominator recursion on the caller's stream
+  if (e == hipSuccess) e = hipEventRecord(side->fork, st);
+  if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+  if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
+  if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
+  da.phase_mask = 1;
+  if (e == hipSuccess) e = launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
+  if (e != hipSuccess)
+    return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
+namespace {
+int chain_loss_backward_impl(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H,
+    const int32_t* ft, const int32_t* fi, int graph_batch_stride, int num_H, int num_K,
+    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
+    float grad_scale, const float* grad_scale_dev, float* grad, int32_t* bad_count,
+    void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream, bool zero_bad) {
+  const char* who = "chain_loss_backward";
+  if (!bad_count || !ft || !fi) return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
+  DenArgs da;
+  float dummy_coef = 0.5f;       // the occupancy launch does not use the leaky coefficient
+  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, dummy_coef,
+                         grad_scale, (float*)den_ws, grad, bad_count, den_ws, den_ws_bytes, who);
+  if (rc != PYCHAIN_HIP_OK) return rc;
+  da.grad_scale_dev = grad_scale_dev;
+  NumArgs na;
+  // the emit launch reads only forward_transitions / indices (pdf-ids, used arc range) of the graphs
+  rc = fill_num_args(na, ft, fi, (const float*)ft, ft, fi, (const float*)ft, (const float*)ft, (const float*)ft,
+                     graph_batch_stride, nnet_output, seq_lengths, B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM,
+                     -grad_scale, (float*)num_ws, grad, bad_count + 1, num_ws, num_ws_bytes, who);
+  if (rc != PYCHAIN_HIP_OK) return rc;
+  na.grad_scale_dev = grad_scale_dev;
+  hipStream_t st = (hipStream_t)stream;
+  const char* why = nullptr;
+  hipError_t e = zero_bad ? hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st) : hipSuccess;
+  da.phase_mask = 2;
+  if (e == hipSuccess) e = launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
+  if (e == hipSuccess) e = launch_num_emit(na, st, &why);
+  if (e != hipSuccess)
+    return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int pychain_hip_chain_loss_backward(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H,
+    const int32_t* ft, const int32_t* fi, int graph_batch_stride, int num_H, int num_K,
+    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
+    float grad_scale, const float* grad_scale_dev, float* grad, int32_t* bad_count,
+    void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
+  return chain_loss_backward_impl(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, ft, fi, graph_batch_stride,
+                                  num_H, num_K, nnet_output, seq_lengths, B, T, D, grad_scale, grad_scale_dev, grad,
+                                  bad_count, den_ws, den_ws_bytes, num_ws, num_ws_bytes, stream, true);
+}
+
 extern "C" int pychain_hip_chain_loss_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
     const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
@@ -216,32 +299,13 @@ extern "C" int pychain_hip_chain_loss_forward_backward(
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D, float grad_scale,
     float* den_objf, float* num_objf, float* grad, int32_t* bad_count,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
-  if (!bad_count) return fail(PYCHAIN_HIP_EINVAL, "chain_loss_forward_backward: null bad_count");
-  DenArgs da;
-  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, leaky,
-                         grad_scale, den_objf, grad, bad_count, den_ws, den_ws_bytes, "chain_loss_forward_backward");
+  if (!grad) return fail(PYCHAIN_HIP_EINVAL, "chain_loss_forward_backward: null grad");
+  int rc = pychain_hip_chain_loss_forward(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky, ft, fi, fp, bt,
+                                          bi, bp, initial, final_, graph_batch_stride, num_H, num_K, nnet_output,
+                                          seq_lengths, B, T, D, den_objf, num_objf, bad_count, den_ws, den_ws_bytes,
+                                          num_ws, num_ws_bytes, stream);
   if (rc != PYCHAIN_HIP_OK) return rc;
-  NumArgs na;
-  rc = fill_num_args(na, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, seq_lengths,
-                     B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM, -grad_scale, num_objf, grad, bad_count + 1,
-                     num_ws, num_ws_bytes, "chain_loss_forward_backward");
-  if (rc != PYCHAIN_HIP_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  SideStream* side = side_stream_for_current_device();
-  if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "chain_loss_forward_backward: cannot create the side stream");
-  const char* why = nullptr;
-  hipError_t e = hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st);
-  // fork: numerator recursion on the side stream, denominator on the caller's stream
-  if (e == hipSuccess) e = hipEventRecord(side->fork, st);
-  if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-  if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
-  if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
-  if (e == hipSuccess) e = launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
-  // join, then subtract the numerator occupancies from the denominator gradient
-  if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);
-  if (e == hipSuccess) e = launch_num_emit(na, st, &why);
-  if (e != hipSuccess)
-    return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "chain_loss_forward_backward: %s",
-                why ? why : hipGetErrorString(e));
-  return PYCHAIN_HIP_OK;
+  return chain_loss_backward_impl(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, ft, fi, graph_batch_stride,
+                                  num_H, num_K, nnet_output, seq_lengths, B, T, D, grad_scale, nullptr, grad,
+                                  bad_count, den_ws, den_ws_bytes, num_ws, num_ws_bytes, stream, false);
 }

@@ -22,6 +22,7 @@ struct DenArgs {
   int frames_per_block;      // gamma kernel: frames one workgroup handles
   int phase_mask;            // bit0 recursion launch, bit1 gamma launch (bench aid)
   float coef, grad_scale;
+  const float* grad_scale_dev;   // optional device scalar multiplied into grad_scale (upstream autograd gradient)
 };
 
 // Enqueues the two launches on `st`.  On failure returns the HIP error and, when the

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   for (int i = tid; i < Dp; i += kNT) q[i] = 0.f;   // pdfs without arcs stay zero forever
   for (int i = tid; i < tp.ngroups * 64; i += kNT) rmap[i] = row_pdf[i];
   int bad = 0;
+  const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
   const int t_live_end = min(t_end, L);
   // Software pipeline over frames: the global loads of frame t+1 (alpha', beta, nnet-output
   // rows) are issued into registers before frame t is evaluated and committed to LDS after
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     if (lane == 0) red[wave] = part;
     __syncthreads();                                   // also: every read of U/V/xr of this frame is done
     const float tot = block_total(red, lane);
-    const float sc = a.grad_scale / tot;
+    const float sc = gscale / tot;
     if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
     if constexpr (XCH > 0) {
 #pragma unroll

@@ -23,6 +23,7 @@ struct NumArgs {
   int grad_mode;
   int frames_per_block;      // emit kernel
   float grad_scale;
+  const float* grad_scale_dev;   // optional device scalar multiplied into grad_scale
 };
 
 size_t num_fb_lds_bytes(int H, int K, int D);

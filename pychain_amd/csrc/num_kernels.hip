@@ -248,6 +248,7 @@ __global__ __launch_bounds__(kEmNT) void num_emit_kernel(const NumArgs a) {
   const int t_end = min(t_begin + a.frames_per_block, T);
   float* gseq = a.grad + (size_t)b * T * D;
   const int mode = a.grad_mode;
+  const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
   const float fill = mode == PYCHAIN_HIP_GRAD_LOG ? -INFINITY : 0.f;
   const int t_live_end = min(t_end, L);
   if (t_begin < L) {
@@ -286,14 +287,14 @@ __global__ __launch_bounds__(kEmNT) void num_emit_kernel(const NumArgs a) {
         for (int k = tid; k < Kused; k += kEmNT) {
           const int n = pdf[k];
           const unsigned long long u = atomicExch(&acc[n], 0ull);   // exactly one arc per pdf sees the merged sum
-          if (u) grow[n] += a.grad_scale * ((float)u * kFixInv);
+          if (u) grow[n] += gscale * ((float)u * kFixInv);
         }
       } else {
         for (int n = tid; n < D; n += kEmNT) {
           const unsigned long long u = acc[n];
           if (u) acc[n] = 0ull;
           const float v = (float)u * kFixInv;
-          grow[n] = mode == PYCHAIN_HIP_GRAD_LOG ? (u ? logf(v) : -INFINITY) : a.grad_scale * v;
+          grow[n] = mode == PYCHAIN_HIP_GRAD_LOG ? (u ? logf(v) : -INFINITY) : gscale * v;
         }
       }
       __syncthreads();

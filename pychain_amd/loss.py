@@ -66,10 +66,12 @@ class ChainFunction(torch.autograd.Function):
 
 
 class ChainLossFunction(torch.autograd.Function):
-    """Denominator + numerator in one pass: the gradient
-    (gamma_den - gamma_num) * scale is written once by the kernels instead of two dense
-    gradients, two scalar multiplies and an autograd add (loss.py:85,100-104); the numerator
-    recursion overlaps the denominator on a side stream.  Same numbers as the two-call path."""
+    """Denominator + numerator in one pass, split at the autograd
+    boundary: forward runs the four recursions (numerator on a side stream) and returns the
+    loss; backward runs the time-parallel occupancy passes and writes
+    (gamma_den - gamma_num) * objf_grad [/ frames] ONCE, with the upstream gradient read on
+    the device - instead of two dense gradients, two scalar multiplies and an autograd add
+    (loss.py:85,100-104).  Same numbers as the two-call path."""
 
     @staticmethod
     def forward(ctx, input, input_lengths, den_graph, num_graphs, leaky_coefficient, avg):
@@ -83,28 +85,30 @@ class ChainLossFunction(torch.autograd.Function):
         plan = _plan.graph_plan(den_graph, D, x.device)
         gt = num_graphs.device_tensors(x.device)
         gstride = 0 if num_graphs.shared_graph is not None else 1
-        # avg=True divides by the frame count (loss.py:103-104); with host-side lengths that
-        # factor is folded into the kernels' gradient scale, otherwise it is applied afterwards
-        fold = avg and not lengths.is_cuda
-        norm = float(lengths.sum()) if fold else 1.0
-        den_objf, num_objf, grad, bad = native.chain_loss_forward_backward(
-            plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient, 1.0 / norm)
+        den_objf, num_objf, bad, state = native.chain_loss_forward(
+            plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient)
         objf = -(num_objf.sum() - den_objf.sum())
+        # avg=True divides by the frame count (loss.py:103-104): a host scalar when the lengths
+        # live on the host, else a device scalar - never a sync
+        ctx.host_scale, ctx.dev_norm = 1.0, None
         if avg:
-            if fold:
-                objf = objf / norm
+            if lengths.is_cuda:
+                ctx.dev_norm = lengths.sum().to(objf.dtype)
+                objf = objf / ctx.dev_norm
             else:
-                n = lengths.sum().to(objf.dtype)
-                objf = objf / n
-                grad = grad / n
-        ctx.save_for_backward(grad)
+                ctx.host_scale = 1.0 / float(lengths.sum())
+                objf = objf * ctx.host_scale
+        ctx.state = state
         ChainFunction.last_bad_count = bad.sum()
         return objf
 
     @staticmethod
     def backward(ctx, objf_grad):
-        grad, = ctx.saved_tensors
-        return torch.mul(grad, objf_grad), None, None, None, None, None
+        g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
+        grad, bad = native.chain_loss_backward(ctx.state, ctx.host_scale, g)
+        ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad.sum()
+        ctx.state = None          # release the stored trajectories
+        return grad, None, None, None, None, None
 
 
 class ChainLoss(nn.Module):

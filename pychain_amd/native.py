@@ -145,6 +145,71 @@ def chain_loss_forward_backward(plan, gt, graph_stride, num_states_num, x, lengt
     return den_objf, num_objf, grad, bad
 
 
+class ChainLossState(object):
+    """What `chain_loss_forward` leaves behind for `chain_loss_backward`: the stored
+    trajectories (workspaces) and the handles of everything the occupancy passes read."""
+    __slots__ = ("plan", "gt", "graph_stride", "num_states_num", "x", "lengths_dev", "den_ws", "num_ws", "shape")
+
+
+def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky_coefficient=1e-5):
+    """Recursions only: returns (den_objf[B], num_objf[B], bad_count[2], state)."""
+    _require_device(x, "nnet_output")
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    B, T, D = x.shape
+    _check_lengths(lengths, B, T)
+    K = gt["forward_transitions"].shape[1]
+    L = _lib.lib()
+    dev = x.device
+    st = ChainLossState()
+    with torch.cuda.device(dev):
+        ld = _lengths_dev(lengths, dev)
+        den_objf = torch.empty(B, dtype=torch.float32, device=dev)
+        num_objf = torch.empty(B, dtype=torch.float32, device=dev)
+        bad = torch.empty(2, dtype=torch.int32, device=dev)
+        # per-call workspaces (they must survive until backward); the caching allocator makes this cheap
+        dws = torch.empty(L.pychain_hip_den_workspace_bytes(B, T, plan.num_states, D), dtype=torch.uint8, device=dev)
+        nws = torch.empty(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dtype=torch.uint8,
+                          device=dev)
+        _lib.check(L.pychain_hip_chain_loss_forward(
+            plan.blob.data_ptr(), plan.stride, plan.slot_rows, plan.num_states, float(leaky_coefficient),
+            gt["forward_transitions"].data_ptr(), gt["forward_transition_indices"].data_ptr(),
+            gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
+            gt["backward_transition_indices"].data_ptr(), gt["backward_transition_probs"].data_ptr(),
+            gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
+            int(num_states_num), K, x.data_ptr(), ld.data_ptr(), B, T, D,
+            den_objf.data_ptr(), num_objf.data_ptr(), bad.data_ptr(),
+            dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
+            "pychain_hip_chain_loss_forward")
+    st.plan, st.gt, st.graph_stride, st.num_states_num = plan, gt, int(graph_stride), int(num_states_num)
+    st.x, st.lengths_dev, st.den_ws, st.num_ws, st.shape = x, ld, dws, nws, (B, T, D, K)
+    return den_objf, num_objf, bad, st
+
+
+def chain_loss_backward(st, grad_scale=1.0, grad_scale_dev=None):
+    """Occupancy passes: grad[B,T,D] = grad_scale * grad_scale_dev * (gamma_den - gamma_num), written once.
+    `grad_scale_dev`: optional 0-dim float32 device tensor (the upstream autograd gradient)."""
+    B, T, D, K = st.shape
+    L = _lib.lib()
+    dev = st.x.device
+    with torch.cuda.device(dev):
+        grad = torch.empty_like(st.x)
+        bad = torch.empty(2, dtype=torch.int32, device=dev)
+        sptr = 0
+        if grad_scale_dev is not None:
+            grad_scale_dev = grad_scale_dev.detach().to(device=dev, dtype=torch.float32).contiguous()
+            sptr = grad_scale_dev.data_ptr()
+        _lib.check(L.pychain_hip_chain_loss_backward(
+            st.plan.blob.data_ptr(), st.plan.stride, st.plan.slot_rows, st.plan.num_states,
+            st.gt["forward_transitions"].data_ptr(), st.gt["forward_transition_indices"].data_ptr(),
+            st.graph_stride, st.num_states_num, K, st.x.data_ptr(), st.lengths_dev.data_ptr(), B, T, D,
+            float(grad_scale), sptr, grad.data_ptr(), bad.data_ptr(),
+            st.den_ws.data_ptr(), st.den_ws.numel(), st.num_ws.data_ptr(), st.num_ws.numel(), _stream(dev)),
+            "pychain_hip_chain_loss_backward")
+    return grad, bad
+
+
 # ---------------------------------------------------------------------------
 # pychain_C-compatible surface (positional signatures of pychain.cc:26-41, :81-94)
 # ---------------------------------------------------------------------------
