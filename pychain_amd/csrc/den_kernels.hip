@@ -336,10 +336,16 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     const int tn = fwd ? j + 1 : L - 2 - j;          // nnet-output row of the NEXT step
     const bool have_next = fwd ? (tn < L) : (tn >= 1);
     const float* xrow_next = xseq + (size_t)(have_next ? tn : 0) * D;
+#ifndef PYCHAIN_EXP_NO_X
     if (have_next) xq.load(xrow_next, D, tid);       // in flight during the arc work
+#endif
 
     float s0 = 0.f, s1 = 0.f;
+#ifndef PYCHAIN_EXP_NO_ARCS     // (PYCHAIN_EXP_*: ablation builds for timing only - results are wrong)
     tile_rows<R, 0>(arcs, groups, tail_slots, lane, cur, xr, raw, nullptr, fwd ? nullptr : lk, s0, s1);
+#else
+    s0 = 1.f; s1 = 1.f;
+#endif
     PH_ADD(0, pt); pt = PH_T();
     s0 = wave_sum(s0);
     if (!fwd) s1 = wave_sum(s1);
@@ -354,10 +360,14 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     logsum += (double)fast_log(tot);
     const int tstore = fwd ? j + 1 : L - 1 - j;
     const bool do_store = fwd ? (tstore < L) : true;
+#ifndef PYCHAIN_EXP_NO_NORM
     normalise_row(fwd, raw, lk, cur, do_store ? store + (size_t)tstore * Hp : nullptr, inv, coef, coef * wtot,
                   H, Hp, tid);
+#endif
     PH_ADD(3, pt); pt = PH_T();
+#ifndef PYCHAIN_EXP_NO_X
     if (have_next) xq.store(xr, xrow_next, D, tid, a.input_is_exp);
+#endif
     PH_ADD(4, pt); pt = PH_T();
     __syncthreads();
     PH_ADD(5, pt);
