@@ -173,7 +173,10 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
   // wave always has 8 ds_reads in flight while it does arithmetic (a wave issues only ~1
   // instruction per 5 cycles - tools/ubench - so un-overlapped LDS latency is pure loss).
   // Rows past the wave's plan carry p = 0 and valid addresses: no per-chunk bound check.
-  constexpr int kChunk = 4;
+#ifndef PYCHAIN_CHUNK
+#define PYCHAIN_CHUNK 4
+#endif
+  constexpr int kChunk = PYCHAIN_CHUNK;
   static_assert(R % kChunk == 0, "resident slot-rows come in whole chunks");
   constexpr int NC = R / kChunk;
   float ub[2][kChunk], vb[2][kChunk];
