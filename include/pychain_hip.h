@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 4
+#define PYCHAIN_HIP_ABI_VERSION 5
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -228,6 +228,35 @@ int pychain_hip_chain_loss_backward(
     float* grad, int32_t* bad_count,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
+
+/* ------------------------------------------------------------------------
+ * Graph ingestion without OpenFST (host only, one-time per graph): what the reference's
+ * `simplefst` module provides on top of OpenFST (openfst_binding/src/fstext.cc:174-184).
+ * Handles are opaque host objects; *_read / *_from_arcs return NULL on error.
+ *   pychain_hip_fst_read(file, 0)        StdVectorFst.read       (fstext.cc:178)
+ *   pychain_hip_fst_read(file, offset)   StdVectorFst.read_ark   (ReadFstFromArk, fstext.cc:7-16)
+ *   pychain_hip_fst_write                StdVectorFst.write      (fstext.cc:177)
+ *   pychain_hip_fst_num_states / _start  num_states / start_state (fstext.cc:182-183)
+ *   pychain_hip_fst_to_tensors           fst_to_tensor           (FstToTensor, fstext.cc:19-117)
+ *   pychain_hip_fst_leaky_probs          set_leaky_probs         (SetLeakyProbs, fstext.cc:120-171)
+ * fst_to_tensors outputs are caller-allocated: forward/backward transitions [K,3] int32, probs [K],
+ * indices [H,2] int32, final [H]; K = pychain_hip_fst_num_arcs.
+ */
+void*   pychain_hip_fst_read(const char* filename, int64_t byte_offset);
+void*   pychain_hip_fst_from_arcs(int32_t num_states, int32_t start, int64_t num_arcs,
+                                  const int32_t* src, const int32_t* dst, const int32_t* ilabel,
+                                  const float* weight, const float* final_weight);
+void    pychain_hip_fst_free(void* fst);
+int     pychain_hip_fst_write(const void* fst, const char* filename);
+int32_t pychain_hip_fst_num_states(const void* fst);
+int32_t pychain_hip_fst_start(const void* fst);
+int64_t pychain_hip_fst_num_arcs(const void* fst);
+int     pychain_hip_fst_to_tensors(const void* fst, int log_domain,
+                                   int32_t* forward_transitions, float* forward_transition_probs,
+                                   int32_t* forward_transition_indices,
+                                   int32_t* backward_transitions, float* backward_transition_probs,
+                                   int32_t* backward_transition_indices, float* final_probs);
+int     pychain_hip_fst_leaky_probs(const void* fst, float* leaky_probs);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -38,6 +38,15 @@ _SIGNATURES = {
                                        + [_vp, _vp, _i, _i, _i] + [_vp] * 3 + [_vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i,
                                              _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "pychain_hip_fst_read": (_vp, [ctypes.c_char_p, _i64]),
+    "pychain_hip_fst_from_arcs": (_vp, [ctypes.c_int32, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "pychain_hip_fst_free": (None, [_vp]),
+    "pychain_hip_fst_write": (_i, [_vp, ctypes.c_char_p]),
+    "pychain_hip_fst_num_states": (ctypes.c_int32, [_vp]),
+    "pychain_hip_fst_start": (ctypes.c_int32, [_vp]),
+    "pychain_hip_fst_num_arcs": (_i64, [_vp]),
+    "pychain_hip_fst_to_tensors": (_i, [_vp, _i] + [_vp] * 7),
+    "pychain_hip_fst_leaky_probs": (_i, [_vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

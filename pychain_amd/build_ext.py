@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(_HERE, "libpychain_hip.so")
-SOURCES = ["plan.cpp", "den_kernels.hip", "num_kernels.hip", "api.hip"]
+SOURCES = ["plan.cpp", "fst.cpp", "den_kernels.hip", "num_kernels.hip", "api.hip"]
 HEADERS = ["common.h", "plan_format.h", "den_kernels.h", "num_kernels.h", "device_utils.h"]
 
 

@@ -4,8 +4,11 @@ The reference's `simplefst` is a pybind11 wrapper over OpenFST 1.7.5
 (openfst_binding/src/fstext.cc:174-184).  OpenFST is not on this image and is
 not on the hot path; what IS on the path is the tensor layout `FstToTensor`
 defines (fstext.cc:19-117) and the `SetLeakyProbs` recipe (fstext.cc:120-171).
-This module restates both over a plain arc list so `ChainGraph(fst, ...)` keeps
-its reference signature.
+This module restates both so `ChainGraph(fst, ...)` keeps its reference signature.
+The heavy lifting (binary FST I/O, FstToTensor, SetLeakyProbs) is native C++ behind the
+C ABI (pychain_amd/csrc/fst.cpp - the reference's is C++ too); the pure-Python
+restatements below (`_py_*`) are kept as an independent second implementation that the
+tests hold the native one against.
 
 Layout rules reproduced (file:line in the reference):
   * pdf_id   = ilabel - 1                       fstext.cc:41
@@ -20,8 +23,12 @@ Layout rules reproduced (file:line in the reference):
 import math
 import struct
 
+import ctypes
+
 import numpy as np
 import torch
+
+from . import _lib
 
 __all__ = ["StdVectorFst"]
 
@@ -35,20 +42,55 @@ class StdVectorFst(object):
         self._start = -1
         self._final = []   # weight per state; +inf = not final
         self._arcs = []    # per state: list of (ilabel, olabel, weight, nextstate)
+        self._handle = None
+
+    def __del__(self):
+        self._drop_native()
+
+    def _drop_native(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.lib().pychain_hip_fst_free(h)
+            except Exception:
+                pass
+        self._handle = None
+
+    def _native(self):
+        """Opaque handle of the C++ twin of this FST (rebuilt after mutation)."""
+        if self._handle is None:
+            src, dst, il, w = [], [], [], []
+            for s, arcs in enumerate(self._arcs):
+                for (i, _o, wt, ns) in arcs:
+                    src.append(s); dst.append(ns); il.append(i); w.append(wt)
+            a = lambda v, t: np.ascontiguousarray(np.asarray(v, dtype=t))
+            src, dst, il, w = a(src, np.int32), a(dst, np.int32), a(il, np.int32), a(w, np.float32)
+            fin = a(self._final, np.float32)
+            p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+            h = _lib.lib().pychain_hip_fst_from_arcs(len(self._final), int(self._start), len(src),
+                                                     p(src), p(dst), p(il), p(w), p(fin))
+            if not h:
+                raise _lib.PychainHipError(_lib.lib().pychain_hip_last_error().decode())
+            self._handle = h
+        return self._handle
 
     # ---- construction -------------------------------------------------
     def add_state(self):
+        self._drop_native()
         self._final.append(_INF)
         self._arcs.append([])
         return len(self._final) - 1
 
     def set_start(self, s):
+        self._drop_native()
         self._start = int(s)
 
     def set_final(self, s, weight=0.0):
+        self._drop_native()
         self._final[int(s)] = float(weight)
 
     def add_arc(self, s, ilabel, olabel, weight, nextstate):
+        self._drop_native()
         self._arcs[int(s)].append((int(ilabel), int(olabel), float(weight), int(nextstate)))
 
     @classmethod
@@ -90,7 +132,31 @@ class StdVectorFst(object):
 
     @staticmethod
     def fst_to_tensor(fst, log_domain=False):
-        """Returns the 7 tensors in the order of fstext.cc:109-116."""
+        """Returns the 7 tensors in the order of fstext.cc:109-116 (native C++)."""
+        L = _lib.lib()
+        h = fst._native()
+        H, K = int(L.pychain_hip_fst_num_states(h)), int(L.pychain_hip_fst_num_arcs(h))
+        ft, bt = torch.empty((K, 3), dtype=torch.int32), torch.empty((K, 3), dtype=torch.int32)
+        fp, bp = torch.empty(K, dtype=torch.float32), torch.empty(K, dtype=torch.float32)
+        fi, bi = torch.empty((H, 2), dtype=torch.int32), torch.empty((H, 2), dtype=torch.int32)
+        fin = torch.empty(H, dtype=torch.float32)
+        _lib.check(L.pychain_hip_fst_to_tensors(h, int(bool(log_domain)), ft.data_ptr(), fp.data_ptr(), fi.data_ptr(),
+                                                bt.data_ptr(), bp.data_ptr(), bi.data_ptr(), fin.data_ptr()),
+                   "pychain_hip_fst_to_tensors")
+        return [ft, fp, fi, bt, bp, bi, fin]
+
+    @staticmethod
+    def set_leaky_probs(fst):
+        """Averaged 100-step occupancy started from the start state (fstext.cc:120-171, native C++)."""
+        L = _lib.lib()
+        h = fst._native()
+        out = torch.empty(int(L.pychain_hip_fst_num_states(h)), dtype=torch.float32)
+        _lib.check(L.pychain_hip_fst_leaky_probs(h, out.data_ptr()), "pychain_hip_fst_leaky_probs")
+        return out
+
+    @staticmethod
+    def _py_fst_to_tensor(fst, log_domain=False):
+        """Pure-Python restatement of FstToTensor (second opinion for the tests)."""
         H = fst.num_states()
         out_src, out_dst, out_pdf, out_lp = [], [], [], []
         in_lists = [[] for _ in range(H)]
@@ -129,9 +195,8 @@ class StdVectorFst(object):
                 torch.from_numpy(bwd), bwd_p, torch.from_numpy(bwd_idx), fin]
 
     @staticmethod
-    def set_leaky_probs(fst):
-        """Averaged 100-step occupancy started from the start state
-        (fstext.cc:120-171).  float64 internally, float32 result."""
+    def _py_set_leaky_probs(fst):
+        """Pure-Python restatement of SetLeakyProbs (second opinion for the tests)."""
         num_iters = 100
         H = fst.num_states()
         src, dst, p = [], [], []
@@ -159,9 +224,23 @@ class StdVectorFst(object):
     _MAGIC = 2125659606
 
     def write(self, filename):
-        with open(filename, "wb") as f:
-            f.write(self._to_bytes())
+        _lib.check(_lib.lib().pychain_hip_fst_write(self._native(), str(filename).encode()), "pychain_hip_fst_write")
         return True
+
+    @classmethod
+    def _from_native(cls, h):
+        """Python twin of a native FST (so it stays inspectable/mutable)."""
+        L = _lib.lib()
+        f = cls()
+        f._handle = h
+        ts = cls.fst_to_tensor(f, log_domain=True)
+        ft, fp, fin = ts[0].numpy(), ts[1].numpy(), ts[6].numpy()
+        f._final = [(-float(v) if v != -_INF else _INF) for v in fin]
+        f._arcs = [[] for _ in range(len(f._final))]
+        for (s, d, n), lp in zip(ft.tolist(), fp.tolist()):
+            f._arcs[s].append((n + 1, n + 1, -lp, d))
+        f._start = int(L.pychain_hip_fst_start(h))
+        return f
 
     def _to_bytes(self):
         def s(b):
@@ -212,11 +291,17 @@ class StdVectorFst(object):
 
     @classmethod
     def read(cls, filename):
-        with open(filename, "rb") as f:
-            return cls._from_stream(f, filename)
+        return cls.read_ark(filename, 0)
 
     @classmethod
     def read_ark(cls, filename, offset):
+        h = _lib.lib().pychain_hip_fst_read(str(filename).encode(), int(offset))
+        if not h:
+            raise IOError(_lib.lib().pychain_hip_last_error().decode())
+        return cls._from_native(h)
+
+    @classmethod
+    def _py_read(cls, filename, offset=0):
         with open(filename, "rb") as f:
             f.seek(offset)
             return cls._from_stream(f, filename)

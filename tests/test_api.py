@@ -83,6 +83,16 @@ def test_chain_graph_modes():
         assert bool((src[:-1] <= src[1:]).all()) and bool((a.backward_transitions[lo:hi, 1] == h).all())
 
 
+def test_native_ingestion_matches_python_restatement():
+    """C++ FstToTensor / SetLeakyProbs (csrc/fst.cpp) == the independent pure-Python restatement."""
+    for fst, logd in ((syn.make_den_fst(50, 400, 30, seed=2), False), (syn.make_num_fst(9, 30, 4), True)):
+        for a, b in zip(StdVectorFst.fst_to_tensor(fst, logd), StdVectorFst._py_fst_to_tensor(fst, logd)):
+            assert a.dtype == b.dtype and a.shape == b.shape
+            assert torch.equal(a, b) if a.dtype == torch.int32 else torch.allclose(a, b, rtol=1e-6, atol=0)
+    fst = syn.make_den_fst(50, 400, 30, seed=2)
+    assert torch.allclose(StdVectorFst.set_leaky_probs(fst), StdVectorFst._py_set_leaky_probs(fst), rtol=1e-5, atol=1e-9)
+
+
 def test_fst_binary_roundtrip(tmp_path):
     fst = syn.make_den_fst(7, 20, 11, seed=5)
     p = str(tmp_path / "g.fst")
@@ -93,6 +103,12 @@ def test_fst_binary_roundtrip(tmp_path):
     with open(str(tmp_path / "ark"), "wb") as f:   # Kaldi-ark style: FST at a byte offset
         f.write(b"utt1 " + fst._to_bytes())
     assert StdVectorFst.read_ark(str(tmp_path / "ark"), 5).num_states() == 7
+    # the native reader and the pure-Python reader agree on the bytes the native writer produced
+    py = StdVectorFst._py_read(p)
+    for x, y in zip(StdVectorFst.fst_to_tensor(back), StdVectorFst._py_fst_to_tensor(py)):
+        assert torch.allclose(x.float(), y.float())
+    with pytest.raises(IOError):
+        StdVectorFst.read(str(tmp_path / "missing.fst"))
 
 
 def test_alias_package_and_exports():
