@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 5
+#define PYCHAIN_HIP_ABI_VERSION 6
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -197,9 +197,13 @@ int pychain_hip_chain_loss_forward_backward(
  * objf, backward returns input_grad * objf_grad):
  *
  *   _forward   runs the recursions (denominator alpha/beta + numerator alpha/beta, the latter on
- *              the side stream) and yields the per-sequence log-probabilities; the stored
+ *              a side stream) and yields the per-sequence log-probabilities; the stored
  *              trajectories stay in the two workspaces, which the caller must keep untouched
- *              until _backward;
+ *              until _backward.  If `grad` is non-NULL the occupancy passes run as well,
+ *              OVERLAPPED with the recursions (the frames whose alpha'/beta rows already exist
+ *              are evaluated on the CUs the 2B persistent recursion workgroups leave idle), and
+ *              grad = grad_scale * (gamma_den - gamma_num) is written; a caller that later
+ *              learns an upstream gradient != 1 applies it with pychain_hip_rescale;
  *   _backward  runs the time-parallel occupancy passes and writes
  *              grad = grad_scale * (*grad_scale_dev) * (gamma_den - gamma_num) ONCE.
  *              grad_scale_dev (device float*, may be NULL = 1) is the upstream scalar gradient,
@@ -216,9 +220,12 @@ int pychain_hip_chain_loss_forward(
     const float* initial_probs, const float* final_probs, int graph_batch_stride,
     int num_num_states, int num_num_transitions,
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs,
-    float* den_objf_per_seq, float* num_objf_per_seq, int32_t* bad_count,
+    float* den_objf_per_seq, float* num_objf_per_seq,
+    float* grad /* may be NULL */, float grad_scale, int32_t* bad_count,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
+/* data[0..n) *= *scale_dev, skipped on the device when the scalar is exactly 1. */
+int pychain_hip_rescale(float* data, size_t n, const float* scale_dev, void* stream);
 int pychain_hip_chain_loss_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
     const int32_t* forward_transitions, const int32_t* forward_transition_indices,

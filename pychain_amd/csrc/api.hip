@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/pychain_hip.h"
@@ -53,7 +54,7 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   (void)D;
   if (B <= 0 || T <= 0 || H <= 0) return 0;
   const size_t Hp = roundup64(H);
-  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + 256;
+  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256;
 }
 
 namespace {
@@ -90,7 +91,80 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_store = (float*)ws;
   a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
+  a.logsum_ws = (double*)(ws + align256(4 * (size_t)B * T * a.Hp) + align256(4 * (size_t)B * (T + 1) * a.Hp));
+  a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_seg = 0; a.gam_nseg = 0;
   return PYCHAIN_HIP_OK;
+}
+}  // namespace
+
+// ---- library-owned side streams (the only hidden state): one for the numerator recursion,
+// one for the occupancy launches that overlap the denominator recursion ------------------
+namespace {
+constexpr int kMaxSegments = 16;
+struct SideStream {
+  hipStream_t stream = nullptr, stream2 = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, seg[kMaxSegments] = {}, join2 = nullptr;
+};
+SideStream* side_stream_for_current_device() {
+  static SideStream table[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = table[dev];
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < kMaxSegments; i++)
+      if (hipEventCreateWithFlags(&s.seg[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &s;
+}
+
+// Number of time segments the denominator is cut into so that the occupancy pass of the frames
+// whose alpha'/beta rows already exist runs on idle CUs WHILE the recursions continue
+// (2B persistent workgroups leave the other CUs free).  1 = no overlap.
+int den_segments(int T) {
+  if (const char* e = getenv("PYCHAIN_DEN_SEGMENTS")) { int n = atoi(e); if (n >= 1 && n <= kMaxSegments) return n; }
+  if (T >= 1024) return 3;     // measured at C3 (T=1500): 1 -> 6.02 ms, 2 -> 5.79, 3 -> 5.18, 4 -> 5.33 per call
+  if (T >= 256) return 2;      // (every extra recursion launch costs ~0.1 ms: arcs are reloaded into registers)
+  return 1;
+}
+
+// recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
+hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why) {
+  const int gmax = (a.D + 63) / 64;
+  const int user_mask = a.phase_mask;
+  const int nseg = (occupancy && user_mask == 3) ? den_segments(a.T) : 1;
+  hipError_t e = hipSuccess;
+  if (nseg <= 1) {
+    a.phase_mask = occupancy ? user_mask : (user_mask & 1);
+    e = launch_den(a, gmax, resident_slot_rows, st, why);
+    a.phase_mask = user_mask;
+    return e;
+  }
+  SideStream* side = side_stream_for_current_device();
+  if (!side) { *why = "cannot create the side streams"; return hipErrorInvalidValue; }
+  // Frame t becomes computable after max(t, L-1-t) recursion steps, i.e. nothing before T/2 and
+  // then ever faster: segment ends at T/2, 3T/4, 7T/8, ... so every occupancy launch but the
+  // last overlaps the next recursion segment and the last one holds ~2^-(nseg-1) of the frames.
+  for (int s = 0; s < nseg; s++) {
+    const double frac = s == nseg - 1 ? 1.0 : 1.0 - 1.0 / (double)(2 << s);
+    a.seg_bound[s] = s == nseg - 1 ? a.T : ((int)(frac * a.T) + 31) / 32 * 32;
+  }
+  for (int s = 0; s < nseg && e == hipSuccess; s++) {
+    a.phase_mask = 1; a.seg_begin = s ? a.seg_bound[s - 1] : 0; a.seg_end = s == nseg - 1 ? 0x7fffffff : a.seg_bound[s];
+    e = launch_den(a, gmax, resident_slot_rows, st, why);
+    if (e == hipSuccess) e = hipEventRecord(side->seg[s], st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[s], 0);
+    a.phase_mask = 2; a.gam_seg = s; a.gam_nseg = nseg;
+    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
+  }
+  if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
+  a.phase_mask = user_mask; a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_nseg = 0;
+  return e;
 }
 }  // namespace
 
@@ -109,7 +183,7 @@ extern "C" int pychain_hip_den_forward_backward(
   if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: hipMemsetAsync failed");
   const char* why = nullptr;
-  hipError_t e = launch_den(a, (D + 63) / 64, resident_slot_rows, st, &why);
+  hipError_t e = run_den(a, resident_slot_rows, true, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "den_forward_backward: %s",
                 why ? why : hipGetErrorString(e));
@@ -193,40 +267,25 @@ extern "C" int pychain_hip_num_forward_backward(
 }
 
 // ---- fused ChainLoss ------------------------------------------------------------------
-namespace {
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-SideStream* side_stream_for_current_device() {
-  static SideStream table[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream& s = table[dev];
-  if (!s.stream) {
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-  }
-  return &s;
-}
-}  // namespace
 
 extern "C" int pychain_hip_chain_loss_forward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
     const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
     const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
-    float* den_objf, float* num_objf, int32_t* bad_count,
+    float* den_objf, float* num_objf, float* grad, float grad_scale, int32_t* bad_count,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
   const char* who = "chain_loss_forward";
   if (!bad_count) return fail(PYCHAIN_HIP_EINVAL, "%s: null bad_count", who);
   DenArgs da;
-  // `grad` is not touched by the recursion launch; any non-null aligned pointer passes the checks
+  // without `grad` only the recursions run; any non-null aligned pointer then passes the checks
   int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, leaky,
-                         1.f, den_objf, (float*)den_ws, bad_count, den_ws, den_ws_bytes, who);
+                         grad_scale, den_objf, grad ? grad : (float*)den_ws, bad_count, den_ws, den_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   NumArgs na;
   rc = fill_num_args(na, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, seq_lengths,
-                     B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM, 1.f, num_objf, (float*)num_ws, bad_count + 1,
-                     num_ws, num_ws_bytes, who);
+                     B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM, -grad_scale, num_objf,
+                     grad ? grad : (float*)num_ws, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   SideStream* side = side_stream_for_current_device();
@@ -238,11 +297,38 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
   if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
-  da.phase_mask = 1;
-  if (e == hipSuccess) e = launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
+  da.phase_mask = 3;
+  if (e == hipSuccess) e = run_den(da, resident_slot_rows, grad != nullptr, st, &why);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
+  if (e == hipSuccess && grad) e = launch_num_emit(na, st, &why);   // grad -= grad_scale * gamma_num
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
+// grad *= *scale_dev unless the scalar is exactly 1 (the common `loss.backward()` case costs one
+// tiny launch; any other upstream gradient costs one pass over the buffer).
+namespace {
+__global__ void rescale_kernel(float4* data, size_t n4, float* tail, int ntail, const float* scale_dev) {
+  const float g = *scale_dev;
+  if (g == 1.0f) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 v = data[i];
+    v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+    data[i] = v;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] *= g;
+}
+}  // namespace
+
+extern "C" int pychain_hip_rescale(float* data, size_t n, const float* scale_dev, void* stream) {
+  if (!data || !scale_dev || ((uintptr_t)data & 15))
+    return fail(PYCHAIN_HIP_EINVAL, "rescale: null or unaligned argument");
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(rescale_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (float4*)data, n4,
+                     data + 4 * n4, (int)(n - 4 * n4), scale_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PYCHAIN_HIP_ELAUNCH, "rescale: %s", hipGetErrorString(e));
   return PYCHAIN_HIP_OK;
 }
 
@@ -300,12 +386,8 @@ extern "C" int pychain_hip_chain_loss_forward_backward(
     float* den_objf, float* num_objf, float* grad, int32_t* bad_count,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
   if (!grad) return fail(PYCHAIN_HIP_EINVAL, "chain_loss_forward_backward: null grad");
-  int rc = pychain_hip_chain_loss_forward(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky, ft, fi, fp, bt,
-                                          bi, bp, initial, final_, graph_batch_stride, num_H, num_K, nnet_output,
-                                          seq_lengths, B, T, D, den_objf, num_objf, bad_count, den_ws, den_ws_bytes,
-                                          num_ws, num_ws_bytes, stream);
-  if (rc != PYCHAIN_HIP_OK) return rc;
-  return chain_loss_backward_impl(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, ft, fi, graph_batch_stride,
-                                  num_H, num_K, nnet_output, seq_lengths, B, T, D, grad_scale, nullptr, grad,
-                                  bad_count, den_ws, den_ws_bytes, num_ws, num_ws_bytes, stream, false);
+  return pychain_hip_chain_loss_forward(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky, ft, fi, fp, bt,
+                                        bi, bp, initial, final_, graph_batch_stride, num_H, num_K, nnet_output,
+                                        seq_lengths, B, T, D, den_objf, num_objf, grad, grad_scale, bad_count, den_ws,
+                                        den_ws_bytes, num_ws, num_ws_bytes, stream);
 }

@@ -21,6 +21,14 @@ struct DenArgs {
   int input_is_exp;
   int frames_per_block;      // gamma kernel: frames one workgroup handles
   int phase_mask;            // bit0 recursion launch, bit1 gamma launch (bench aid)
+  // Time segmentation (overlap of the occupancy pass with the recursions):
+  // the recursion launch executes steps [seg_begin, seg_end) of every sequence; the occupancy
+  // launch number gam_seg (of gam_nseg) handles exactly the frames whose
+  // alpha' and beta rows became available with recursion segment gam_seg.  gam_nseg = 0: all.
+  int seg_begin, seg_end;
+  int gam_seg, gam_nseg;
+  int seg_bound[16];         // recursion segment s covers steps [seg_bound[s-1], seg_bound[s]) (seg_bound[-1] = 0)
+  double* logsum_ws;         // [B] running sum of log tot-alpha carried across recursion segments
   float coef, grad_scale;
   const float* grad_scale_dev;   // optional device scalar multiplied into grad_scale (upstream autograd gradient)
 };

@@ -264,6 +264,9 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const bool fwd = blockIdx.x < (unsigned)a.B;
   const int b = fwd ? blockIdx.x : blockIdx.x - a.B;
   const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int nsteps = fwd ? L : L - 1;
+  const int j_begin = a.seg_begin, j_end = min(a.seg_end, nsteps);
+  if (j_begin > 0 && j_begin >= nsteps) return;      // this sequence finished in an earlier segment
   const int Hp = a.Hp, H = a.H, D = a.D, Dp = (D + 3) & ~3;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
@@ -294,38 +297,49 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
   const float coef = a.coef;
 
-  // ---- frame 0 (alpha) / frame L (beta): chain-computation.cc:92-95,97-110,178-194 / :232-245,313-330
-  if (tid < 32) red[tid] = 0.f;
-  float p0 = 0.f, p1 = 0.f;
-  for (int i = tid; i < Hp; i += kNT) {
-    const float l = leaky_g[i], s = start_g[i];
-    lk[i] = l; raw[i] = s;
-    p0 += s; p1 += s * l;
-  }
-  p0 = wave_sum(p0); p1 = wave_sum(p1);
-  XRow<kNT, VEC, XCH> xq;
-  {
-    const int t0 = fwd ? 0 : L - 1;                 // first nnet-output row this side consumes
-    xq.load(xseq + (size_t)t0 * D, D, tid);
-    xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
-  }
-  __syncthreads();                                   // red zeroed
-  if (lane == 0) { red[wave] = p0; red[16 + wave] = p1; }
-  __syncthreads();
-  float tot = block_total(red, lane), wtot = block_total(red + 16, lane);
   double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229
   int bad = 0;
-  {
+  float tot, wtot;
+  XRow<kNT, VEC, XCH> xq;
+  if (tid < 32) red[tid] = 0.f;
+  if (j_begin == 0) {
+    // ---- frame 0 (alpha) / frame L (beta): chain-computation.cc:92-95,97-110,178-194 / :232-245,313-330
+    float p0 = 0.f, p1 = 0.f;
+    for (int i = tid; i < Hp; i += kNT) {
+      const float l = leaky_g[i], s = start_g[i];
+      lk[i] = l; raw[i] = s;
+      p0 += s; p1 += s * l;
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1);
+    {
+      const int t0 = fwd ? 0 : L - 1;                 // first nnet-output row this side consumes
+      xq.load(xseq + (size_t)t0 * D, D, tid);
+      xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    }
+    __syncthreads();                                   // red zeroed
+    if (lane == 0) { red[wave] = p0; red[16 + wave] = p1; }
+    __syncthreads();
+    tot = block_total(red, lane); wtot = block_total(red + 16, lane);
     const float inv = __builtin_amdgcn_rcpf(tot);
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
     logsum += (double)fast_log(tot);
     normalise_row(fwd, raw, lk, cur, store + (size_t)(fwd ? 0 : L) * Hp, inv, coef, coef * wtot, H, Hp, tid);
+  } else {
+    // ---- resume a later time segment: the state vector is the row the previous segment stored last
+    const float* row = store + (size_t)(fwd ? j_begin : L - j_begin) * Hp;
+    for (int i = tid * 4; i < Hp; i += kNT * 4) {
+      *reinterpret_cast<float4*>(cur + i) = *reinterpret_cast<const float4*>(row + i);
+      *reinterpret_cast<float4*>(lk + i) = *reinterpret_cast<const float4*>(leaky_g + i);
+    }
+    const int t0 = fwd ? j_begin : L - 1 - j_begin;
+    xq.load(xseq + (size_t)t0 * D, D, tid);
+    xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    if (fwd) logsum = a.logsum_ws[b];
   }
   __syncthreads();
 
   // ---- general frames.  alpha: step j produces alpha'(j+1) from alpha'(j) and x(j), j = 0..L-1
   //                        beta:  step j produces beta(t) from beta(t+1) and x(t), t = L-1-j, j = 0..L-2
-  const int nsteps = fwd ? L : L - 1;
 #ifdef PYCHAIN_PROFILE_PHASES
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
 #define PH_T() __builtin_readcyclecounter()
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 #define PH_T() 0ull
 #define PH_ADD(i, t0) (void)(t0)
 #endif
-  for (int j = 0; j < nsteps; j++) {
+  for (int j = j_begin; j < j_end; j++) {
     unsigned long long pt = PH_T();
     const int tn = fwd ? j + 1 : L - 2 - j;          // nnet-output row of the NEXT step
     const bool have_next = fwd ? (tn < L) : (tn >= 1);
@@ -378,10 +392,13 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 #ifdef PYCHAIN_PROFILE_PHASES
   if (lane == 0 && (b == 0) && (wave == 0 || wave == kNW - 1))
     printf("dir %d wave %d steps %d cycles/step: arcs %llu wsum %llu bar1 %llu update %llu xstore %llu bar2 %llu\n", (int)fwd, wave,
-           nsteps, ph[0] / nsteps, ph[1] / nsteps, ph[2] / nsteps, ph[3] / nsteps, ph[4] / nsteps, ph[5] / nsteps);
+           nsteps, ph[0] / max(1, j_end - j_begin), ph[1] / max(1, j_end - j_begin), ph[2] / max(1, j_end - j_begin),
+           ph[3] / max(1, j_end - j_begin), ph[4] / max(1, j_end - j_begin), ph[5] / max(1, j_end - j_begin));
 #endif
 
-  if (fwd) {
+  if (j_end < nsteps) {                              // more segments follow: park the running log-sum
+    if (fwd && tid == 0) a.logsum_ws[b] = logsum;
+  } else if (fwd) {
     // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i alpha'(L,i) final(i) + sum_t log tot(t)
     const float* fin = reinterpret_cast<const float*>(plan + hd->off_final_a);
     float f = 0.f;
@@ -399,6 +416,21 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
+// Which recursion segment makes frame t of a length-L sequence computable: its alpha'(t) row
+// exists once the forward recursion has run t steps, its beta(t+1) row once the backward
+// recursion has run L-1-t steps; segment s covers steps [seg_bound[s-1], seg_bound[s]).
+__device__ __forceinline__ int den_segment_of_frame(int t, int L, const DenArgs& a) {
+  const int need = max(t, L - 1 - t);               // recursion steps both directions must have run
+  int s = 0;
+  while (s < a.gam_nseg - 1 && a.seg_bound[s] < need) s++;
+  return s;
+}
+__device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const DenArgs& a) {
+  if (a.gam_nseg > 0)
+    while (t < t_end && den_segment_of_frame(t, L, a) != a.gam_seg) t++;
+  return t;
+}
+
 // ------------------------------------------------------------------------------------
 // launch 2: occupancies (time-parallel)
 // ------------------------------------------------------------------------------------
@@ -414,8 +446,17 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const int t_begin = blockIdx.x * a.frames_per_block;
   const int t_end = min(t_begin + a.frames_per_block, a.T);
   float* gseq = a.grad + (size_t)b * a.T * D;
+  const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
   if (t_begin >= L) {                               // whole chunk is padding: exact zeros (zeros_like, :58)
-    for (size_t i = (size_t)t_begin * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
+    if (first_launch)
+      for (size_t i = (size_t)t_begin * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
+    return;
+  }
+  const int t_live_end = min(t_end, L);
+  const int t_first = den_next_frame(t_begin, t_live_end, L, a);
+  if (t_first >= t_live_end) {                      // none of this chunk's frames belongs to this launch
+    if (first_launch && t_live_end < t_end)
+      for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
     return;
   }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
@@ -450,7 +491,6 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   for (int i = tid; i < tp.ngroups * 64; i += kNT) rmap[i] = row_pdf[i];
   int bad = 0;
   const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
-  const int t_live_end = min(t_end, L);
   // Software pipeline over frames: the global loads of frame t+1 (alpha', beta, nnet-output
   // rows) are issued into registers before frame t is evaluated and committed to LDS after
   // the last LDS read of frame t, so HBM latency is off the per-frame critical path.
@@ -490,13 +530,14 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
       }                                                                                       \
     }                                                                                         \
   } while (0)
-  GAMMA_PREFETCH(t_begin);
-  GAMMA_COMMIT(t_begin);
+  GAMMA_PREFETCH(t_first);
+  GAMMA_COMMIT(t_first);
   __syncthreads();
-  for (int t = t_begin; t < t_live_end; t++) {
+  for (int t = t_first; t < t_live_end;) {
     float* grow = gseq + (size_t)t * D;
-    const bool have_next = t + 1 < t_live_end;
-    if (have_next) GAMMA_PREFETCH(t + 1);
+    const int t_next = den_next_frame(t + 1, t_live_end, L, a);
+    const bool have_next = t_next < t_live_end;
+    if (have_next) GAMMA_PREFETCH(t_next);
     float s0 = 0.f, s1 = 0.f;
     tile_rows<R, 1>(arcs, groups, tail_slots, lane, U, V, q, rmap, nullptr, s0, s1);
     __syncthreads();
@@ -533,16 +574,17 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
           }
         }
       }
-      if (have_next) GAMMA_COMMIT(t + 1);
+      if (have_next) GAMMA_COMMIT(t_next);
     } else {
       for (int e = tid; e < D; e += kNT) grow[e] = xr[e] * q[e] * sc;
       __syncthreads();                                 // generic-D path re-reads xr/q above
-      if (have_next) GAMMA_COMMIT(t + 1);
+      if (have_next) GAMMA_COMMIT(t_next);
     }
     __syncthreads();   // next frame's operands are in place; q is rewritten by the next frame
+    t = t_next;
   }
   // padded tail of a chunk that straddles the sequence end
-  if (t_live_end < t_end)
+  if (first_launch && t_live_end < t_end)
     for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }

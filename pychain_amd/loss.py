@@ -85,28 +85,38 @@ class ChainLossFunction(torch.autograd.Function):
         plan = _plan.graph_plan(den_graph, D, x.device)
         gt = num_graphs.device_tensors(x.device)
         gstride = 0 if num_graphs.shared_graph is not None else 1
-        den_objf, num_objf, bad, state = native.chain_loss_forward(
-            plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient)
-        objf = -(num_objf.sum() - den_objf.sum())
         # avg=True divides by the frame count (loss.py:103-104): a host scalar when the lengths
         # live on the host, else a device scalar - never a sync
         ctx.host_scale, ctx.dev_norm = 1.0, None
         if avg:
             if lengths.is_cuda:
-                ctx.dev_norm = lengths.sum().to(objf.dtype)
-                objf = objf / ctx.dev_norm
+                ctx.dev_norm = lengths.sum().to(torch.float32)
             else:
                 ctx.host_scale = 1.0 / float(lengths.sum())
-                objf = objf * ctx.host_scale
+        # When a gradient will be asked for, the occupancy passes run inside forward, overlapped
+        # with the recursions, for an upstream gradient of 1 (what `loss.backward()` sends);
+        # backward then only rescales if the upstream gradient turns out to differ.
+        ctx.speculative = bool(ctx.needs_input_grad[0]) and ChainLossFunction.overlap
+        den_objf, num_objf, bad, state = native.chain_loss_forward(
+            plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
+            with_grad=ctx.speculative, grad_scale=ctx.host_scale)
+        objf = -(num_objf.sum() - den_objf.sum()) * ctx.host_scale
+        if ctx.dev_norm is not None:
+            objf = objf / ctx.dev_norm
         ctx.state = state
         ChainFunction.last_bad_count = bad.sum()
         return objf
 
+    overlap = True     # class-level switch: False = occupancy passes run in backward (no speculation)
+
     @staticmethod
     def backward(ctx, objf_grad):
         g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
-        grad, bad = native.chain_loss_backward(ctx.state, ctx.host_scale, g)
-        ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad.sum()
+        if ctx.speculative:
+            grad = native.rescale_(ctx.state.grad, g)
+        else:
+            grad, bad = native.chain_loss_backward(ctx.state, ctx.host_scale, g)
+            ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad.sum()
         ctx.state = None          # release the stored trajectories
         return grad, None, None, None, None, None
 

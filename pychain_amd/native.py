@@ -148,11 +148,14 @@ def chain_loss_forward_backward(plan, gt, graph_stride, num_states_num, x, lengt
 class ChainLossState(object):
     """What `chain_loss_forward` leaves behind for `chain_loss_backward`: the stored
     trajectories (workspaces) and the handles of everything the occupancy passes read."""
-    __slots__ = ("plan", "gt", "graph_stride", "num_states_num", "x", "lengths_dev", "den_ws", "num_ws", "shape")
+    __slots__ = ("plan", "gt", "graph_stride", "num_states_num", "x", "lengths_dev", "den_ws", "num_ws", "shape",
+                 "grad")
 
 
-def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky_coefficient=1e-5):
-    """Recursions only: returns (den_objf[B], num_objf[B], bad_count[2], state)."""
+def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky_coefficient=1e-5,
+                       with_grad=False, grad_scale=1.0):
+    """Recursions (and, `with_grad`, the occupancy passes overlapped with them: state.grad =
+    grad_scale * (gamma_den - gamma_num)).  Returns (den_objf[B], num_objf[B], bad_count[2], state)."""
     _require_device(x, "nnet_output")
     x = x.contiguous()
     if x.dtype != torch.float32:
@@ -172,6 +175,7 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
         dws = torch.empty(L.pychain_hip_den_workspace_bytes(B, T, plan.num_states, D), dtype=torch.uint8, device=dev)
         nws = torch.empty(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dtype=torch.uint8,
                           device=dev)
+        grad = torch.empty_like(x) if with_grad else None
         _lib.check(L.pychain_hip_chain_loss_forward(
             plan.blob.data_ptr(), plan.stride, plan.slot_rows, plan.num_states, float(leaky_coefficient),
             gt["forward_transitions"].data_ptr(), gt["forward_transition_indices"].data_ptr(),
@@ -179,9 +183,10 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
             gt["backward_transition_indices"].data_ptr(), gt["backward_transition_probs"].data_ptr(),
             gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
             int(num_states_num), K, x.data_ptr(), ld.data_ptr(), B, T, D,
-            den_objf.data_ptr(), num_objf.data_ptr(), bad.data_ptr(),
-            dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
+            den_objf.data_ptr(), num_objf.data_ptr(), grad.data_ptr() if with_grad else 0, float(grad_scale),
+            bad.data_ptr(), dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_forward")
+    st.grad = grad
     st.plan, st.gt, st.graph_stride, st.num_states_num = plan, gt, int(graph_stride), int(num_states_num)
     st.x, st.lengths_dev, st.den_ws, st.num_ws, st.shape = x, ld, dws, nws, (B, T, D, K)
     return den_objf, num_objf, bad, st
@@ -208,6 +213,15 @@ def chain_loss_backward(st, grad_scale=1.0, grad_scale_dev=None):
             st.den_ws.data_ptr(), st.den_ws.numel(), st.num_ws.data_ptr(), st.num_ws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_backward")
     return grad, bad
+
+
+def rescale_(t, scale_dev):
+    """t *= scale_dev (0-dim device tensor), skipped on the device when the scalar is exactly 1."""
+    scale_dev = scale_dev.detach().to(device=t.device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.lib().pychain_hip_rescale(t.data_ptr(), t.numel(), scale_dev.data_ptr(), _stream(t.device)),
+                   "pychain_hip_rescale")
+    return t
 
 
 # ---------------------------------------------------------------------------
