@@ -112,7 +112,11 @@ SideStream* side_stream_for_current_device() {
   SideStream& s = table[dev];
   if (!s.stream) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    // the occupancy launches only fill idle CUs: lowest priority, so that the persistent recursion
+    // workgroups of the next segment (caller's stream) are dispatched first
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
