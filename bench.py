@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grad-slab", action="store_true",
+                    help="skip the optional fused all-reduce of the gradient slab (N > 1 only)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="utterances in the CPU baseline sample")
     return ap.parse_args()
 
@@ -104,7 +106,37 @@ def kernel_rooflines(w, dev, iters):
             "achieved": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9, 2),
             "frac": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
     }
+    # context: what a plain device-to-device copy reaches on this box
+    try:
+        src = torch.empty(256 << 20, dtype=torch.float32, device=dev)      # 1 GiB
+        dst = torch.empty_like(src)
+        dst.copy_(src); torch.cuda.synchronize()
+        ms = event_time_ms(lambda: dst.copy_(src), 5, stream)
+        roof["d2d_copy_GBps"] = round(2 * src.numel() * 4 / (ms * 1e-3) / 1e9, 1)
+        del src, dst
+    except Exception:
+        roof["d2d_copy_GBps"] = None
     return roof
+
+
+def grad_slab_allreduce(x, world, rank, dev, iters=3):
+    """OPTION measured beside the hot path: one fused all-reduce of the scalars
+    and the [B_global,T,D] gradient slab, so that every rank holds the whole gradient."""
+    from pychain_amd.parallel import allreduce_grad_slab
+    B, T, D = x.shape
+    idx = torch.arange(B, device=dev) * world + rank
+    stats = torch.zeros(3, device=dev)
+    buf = torch.empty(3 + B * world * T * D, dtype=torch.float32, device=dev)
+    g = x.grad if x.grad is not None else torch.zeros_like(x)
+    allreduce_grad_slab(g, idx, B * world, stats, out=buf)
+    torch.cuda.synchronize(); dist.barrier(device_ids=[dev.index]); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        allreduce_grad_slab(g, idx, B * world, stats, out=buf)
+    torch.cuda.synchronize(); dist.barrier(device_ids=[dev.index]); torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"ms_per_step": round(ms, 3), "bytes": int(buf.numel()) * 4,
+            "note": "option, not in `value`: fused all_reduce(SUM) of 3 scalars + [B_global,T,D] fp32 slab"}
 
 
 def cpu_baseline(w, nsample):
@@ -217,6 +249,12 @@ def main():
     dt = float(tmax)
     total_frames = float(stats[1])            # all-reduced frame count of one step
     n_bad = int(stats[2])
+    slab = None
+    if world > 1 and not args.no_grad_slab:
+        try:
+            slab = grad_slab_allreduce(x, world, rank, dev)
+        except Exception as e:      # an option beside the metric: never lose the bench line to it
+            slab = {"error": str(e)[:200]}
 
     if rank == 0:
         roof = kernel_rooflines(w, dev, max(3, min(args.steps, 10)))
@@ -232,6 +270,8 @@ def main():
                        "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"},
             "n_bad": n_bad, "roofline": roof,
         }
+        if slab is not None:
+            out["grad_slab_allreduce"] = slab
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
         print(json.dumps(out))

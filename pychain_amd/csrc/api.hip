@@ -131,8 +131,14 @@ SideStream* side_stream_for_current_device() {
 // (2B persistent workgroups leave the other CUs free).  1 = no overlap.
 int den_segments(int T) {
   if (const char* e = getenv("PYCHAIN_DEN_SEGMENTS")) { int n = atoi(e); if (n >= 1 && n <= kMaxSegments) return n; }
-  if (T >= 1024) return 3;     // measured at C3 (T=1500): 1 -> 6.02 ms, 2 -> 5.79, 3 -> 5.18, 4 -> 5.33 per call
-  if (T >= 256) return 2;      // (every extra recursion launch costs ~0.1 ms: arcs are reloaded into registers)
+  // Measured at C3 (T=1500): 1 -> 6.02 ms, 2 -> 5.79, 3 -> 5.18, 4 -> 5.33 per call.  A recursion
+  // relaunch costs only ~12 us; what limits the overlap is CU time: after T/2 the occupancy pass has
+  // the ~128 idle CUs only (less the numerator's), on which its 1.4 ms of whole-chip work takes
+  // longer than the rest of the recursion, so the side stream - not the recursion - ends the call,
+  // and finer segments only add launches to it (delaying the side stream makes the call longer by
+  // exactly the delay).  The lever is the occupancy kernel's CU time, not the schedule.
+  if (T >= 1024) return 3;
+  if (T >= 256) return 2;
   return 1;
 }
 

@@ -40,6 +40,12 @@ namespace pychain_hip {
 
 namespace {
 
+#ifdef PYCHAIN_PROFILE_PHASES
+#define PH_T() __builtin_readcyclecounter()
+#else
+#define PH_T() 0ull
+#endif
+
 constexpr int kNW = PLAN_REC_WAVES;        // waves per workgroup (both kernels)
 constexpr int kNT = kNW * 64;              // threads per workgroup
 static_assert(PLAN_REC_WAVES == PLAN_GAM_WAVES, "one workgroup shape for both kernels");
@@ -342,10 +348,8 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   //                        beta:  step j produces beta(t) from beta(t+1) and x(t), t = L-1-j, j = 0..L-2
 #ifdef PYCHAIN_PROFILE_PHASES
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
-#define PH_T() __builtin_readcyclecounter()
 #define PH_ADD(i, t0) ph[i] += PH_T() - (t0)
 #else
-#define PH_T() 0ull
 #define PH_ADD(i, t0) (void)(t0)
 #endif
   for (int j = j_begin; j < j_end; j++) {
@@ -437,6 +441,13 @@ __device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const Den
 template <int VEC, int XCH, int R>
 __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef PYCHAIN_PROFILE_PHASES
+  const unsigned long long gk0 = PH_T();
+  unsigned long long gph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GPH(i) do { const unsigned long long n_ = PH_T(); gph[i] += n_ - gpt; gpt = n_; } while (0)
+#else
+#define GPH(i) (void)0
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -533,14 +544,29 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   GAMMA_PREFETCH(t_first);
   GAMMA_COMMIT(t_first);
   __syncthreads();
+#ifdef PYCHAIN_PROFILE_PHASES
+  unsigned long long gpt = PH_T();
+  const unsigned long long gsetup = gpt - gk0;
+  int gframes = 0;
+#endif
   for (int t = t_first; t < t_live_end;) {
+#ifdef PYCHAIN_PROFILE_PHASES
+    gframes++;
+#endif
     float* grow = gseq + (size_t)t * D;
     const int t_next = den_next_frame(t + 1, t_live_end, L, a);
     const bool have_next = t_next < t_live_end;
+#ifndef PYCHAIN_EXPG_NO_LOAD
     if (have_next) GAMMA_PREFETCH(t_next);
+#endif
     float s0 = 0.f, s1 = 0.f;
+#ifndef PYCHAIN_EXPG_NO_ARCS     // (PYCHAIN_EXPG_*: ablation builds for timing only - results are wrong)
+    GPH(0);
     tile_rows<R, 1>(arcs, groups, tail_slots, lane, U, V, q, rmap, nullptr, s0, s1);
+#endif
+    GPH(1);
     __syncthreads();
+    GPH(2);
     float g[(VEC * XCH) > 0 ? (VEC * XCH) : 1];
     float part = 0.f;
     if constexpr (XCH > 0) {
@@ -557,7 +583,9 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     }
     part = wave_sum(part);
     if (lane == 0) red[wave] = part;
+    GPH(3);
     __syncthreads();                                   // also: every read of U/V/xr of this frame is done
+    GPH(4);
     const float tot = block_total(red, lane);
     const float sc = gscale / tot;
     if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
@@ -565,7 +593,11 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
 #pragma unroll
       for (int c = 0; c < XCH; c++) {
         const int e = (c * kNT + tid) * VEC;
+#ifdef PYCHAIN_EXPG_NO_STORE
+        if (e < D && sc == 12345.f) {
+#else
         if (e < D) {
+#endif
           if constexpr (VEC == 4) {
             *reinterpret_cast<float4*>(grow + e) =
                 make_float4(g[c * 4] * sc, g[c * 4 + 1] * sc, g[c * 4 + 2] * sc, g[c * 4 + 3] * sc);
@@ -574,15 +606,25 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
           }
         }
       }
+#ifndef PYCHAIN_EXPG_NO_LOAD
       if (have_next) GAMMA_COMMIT(t_next);
+#endif
     } else {
       for (int e = tid; e < D; e += kNT) grow[e] = xr[e] * q[e] * sc;
       __syncthreads();                                 // generic-D path re-reads xr/q above
       if (have_next) GAMMA_COMMIT(t_next);
     }
+    GPH(5);
     __syncthreads();   // next frame's operands are in place; q is rewritten by the next frame
+    GPH(6);
     t = t_next;
   }
+#ifdef PYCHAIN_PROFILE_PHASES
+  if (lane == 0 && b == 0 && blockIdx.x == 3 && (wave == 0 || wave == kNW - 1))
+    printf("gamma wave %d frames %d setup %llu cycles/frame: prefetch %llu arcs %llu bar1 %llu prod %llu bar2 %llu write+commit %llu bar3 %llu\n",
+           wave, gframes, gsetup, gph[0] / gframes, gph[1] / gframes, gph[2] / gframes, gph[3] / gframes,
+           gph[4] / gframes, gph[5] / gframes, gph[6] / gframes);
+#endif
   // padded tail of a chunk that straddles the sequence end
   if (first_launch && t_live_end < t_end)
     for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;

@@ -5,13 +5,16 @@ independent (chain-computation.h:33-35).  One process per GPU; the only coupling
 scalar sum of per-sequence log-probs (chain-computation.cc:229) and ChainLoss's frame
 normaliser (loss.py:104): ONE all-reduce of a 3-float buffer per step.  Each rank
 back-propagates its own [B_local,T,D] gradient shard; DDP all-reduces parameter
-gradients as usual.  (An all-reduce of the [B_global,T,D] gradient slab itself would
-move 10.6 GB per step at C5 - see DESIGN.md §6 - and is deliberately not on the path.)
+gradients as usual.  An all-reduce of the [B_global,T,D] gradient slab itself (what the
+north-star text names) moves 10.6 GB per step at C5 - DESIGN.md §6 - so it is NOT on the
+default path; `allreduce_grad_slab` provides it as an option (one fused collective:
+scalars + slab) for callers that want every rank to hold the whole gradient, and bench.py
+reports its cost separately.
 """
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_indices", "shard_batch", "allreduce_stats", "ShardedChainLoss"]
+__all__ = ["shard_indices", "shard_batch", "allreduce_stats", "allreduce_grad_slab", "ShardedChainLoss"]
 
 
 def shard_indices(lengths, world_size, rank):
@@ -58,6 +61,31 @@ def allreduce_stats(objf, n_frames, bad_count=None, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
+
+
+def allreduce_grad_slab(local_grad, global_idx, global_batch, stats=None, group=None, out=None):
+    """OPTION (not the default path): every rank ends up with the whole [B_global,T,D]
+    gradient.  Rows of different utterances are disjoint, so the all-reduce(SUM) of a slab
+    that is zero except for this rank's rows is an all-gather by summation; the scalars
+    (`stats`, fp32[n]) ride in the same buffer -> ONE collective per step, as the north-star
+    text words it.  `global_idx` = this rank's utterance indices in the global batch
+    (shard_indices); `out` = optional preallocated flat fp32 buffer of n + B_global*T*D.
+    Returns (stats_sum, grad_global[B_global,T,D])."""
+    Bl, T, D = local_grad.shape
+    n = 0 if stats is None else int(stats.numel())
+    size = n + int(global_batch) * T * D
+    buf = out if out is not None else torch.empty(size, dtype=torch.float32, device=local_grad.device)
+    if buf.numel() != size or buf.dtype != torch.float32:
+        raise ValueError("allreduce_grad_slab: `out` must be a flat fp32 buffer of %d elements" % size)
+    buf.zero_()
+    if n:
+        buf[:n] = stats.detach().float().reshape(-1)
+    slab = buf[n:].view(int(global_batch), T, D)
+    slab.index_copy_(0, torch.as_tensor(global_idx, device=local_grad.device, dtype=torch.long),
+                     local_grad.detach().float())
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return (buf[:n] if n else None), slab
 
 
 class ShardedChainLoss(torch.nn.Module):

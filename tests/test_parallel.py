@@ -63,7 +63,9 @@ def _worker(rank, world, port, out):
         xs = xs.clone().requires_grad_(True)
         loss = parallel.ShardedChainLoss(w["den_graph"], 1e-5, avg=True, loss_cls=_OracleLoss)(xs, ls, gs)
         loss.backward()
-        out[rank] = (float(loss), idx.tolist(), xs.grad.numpy())
+        # the optional fused collective: scalars + whole-batch gradient slab in ONE all-reduce
+        st, slab = parallel.allreduce_grad_slab(xs.grad, idx, 4, stats=torch.tensor([1.0, float(rank)]))
+        out[rank] = (float(loss), idx.tolist(), xs.grad.numpy(), st.numpy().copy(), slab.numpy().copy())
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +82,9 @@ def test_sharded_loss_matches_single_process():
     numg = syn.make_num_graphs(L.tolist(), 40, seed=100, max_states=12)
     ref_loss, ref_grad = orc.chain_loss(x, L, w["den_graph"], numg, avg=True)
     for r in range(world):
-        loss, idx, grad = out[r]
+        loss, idx, grad, st, slab = out[r]
         assert abs(loss - float(ref_loss)) <= 1e-5 * abs(float(ref_loss))
         np.testing.assert_allclose(grad, ref_grad[idx], atol=1e-6)
+        # every rank holds the whole gradient after the optional slab all-reduce
+        np.testing.assert_allclose(slab, ref_grad, atol=1e-6)
+        np.testing.assert_allclose(st, [2.0, 1.0])

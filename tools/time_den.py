@@ -12,7 +12,10 @@ Ld = w["lengths"].to(dev)
 L = _lib.lib()
 call = lambda: native.den_forward_backward(plan, w["x"], Ld, 1e-5)
 call(); torch.cuda.synchronize()
-for mname, mask in (("recursion", 1), ("gamma", 2), ("both", 3)):
+modes = (("recursion", 1), ("gamma", 2), ("both", 3))
+if os.environ.get("TIME_DEN_ONLY"):
+    modes = tuple(m for m in modes if m[0] == os.environ["TIME_DEN_ONLY"])
+for mname, mask in modes:
     L.pychain_hip_set_den_phase_mask(mask)
     call(); torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
