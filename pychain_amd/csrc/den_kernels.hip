@@ -91,11 +91,18 @@ struct ArcRegs {
     }
   }
   // the two gathered operands of slot-row s
+  // Opaque per frame and chunk: otherwise the optimiser hoists both unpacked addresses of every
+  // slot-row out of the frame loop (3 VGPRs per arc instead of 2).  One statement per chunk:
+  // every inline asm costs a hazard s_nop.
+  template <int N>
+  __device__ __forceinline__ void opaque(int s) {
+#if PYCHAIN_ARC_PACKED
+    if constexpr (N == 4) asm volatile("" : "+v"(pk[s]), "+v"(pk[s + 1]), "+v"(pk[s + 2]), "+v"(pk[s + 3]));
+    else for (int k = 0; k < N; k++) asm volatile("" : "+v"(pk[s + k]));
+#endif
+  }
   __device__ __forceinline__ void gather(int s, float& u, float& v) {
 #if PYCHAIN_ARC_PACKED
-    // opaque per frame: otherwise the optimiser hoists both unpacked addresses of every
-    // slot-row out of the frame loop (3 VGPRs per arc instead of 2)
-    asm volatile("" : "+v"(pk[s]));
     const uint32_t a0 = pk[s] & 0xffffu, a1 = pk[s] >> 16;
 #else
     const uint32_t a0 = o0[s], a1 = o1[s];
@@ -108,6 +115,10 @@ struct ArcRegs {
   }
 };
 
+#ifndef PYCHAIN_CHUNK
+#define PYCHAIN_CHUNK 4      // slot-rows gathered ahead per step of the software pipeline
+#endif
+
 // The wave's group table lives in registers: lane i of `base` / `n` = output base and
 // slot-row count of the wave's i-th group (read back with v_readlane), `endmask` bit s =
 // resident slot-row s closes a group.  The frame loop issues NO memory instruction for
@@ -116,6 +127,7 @@ struct ArcRegs {
 struct GroupRegs {
   int base, n;
   unsigned long long endmask;
+  uint32_t chunkmask;       // bit c = chunk c of the resident slot-rows contains a group end
   int ngroups, nslots;      // of this wave
   int tail_g, tail_rem;     // group / slot-rows left in it when the streamed tail (slot-row R) starts
   template <int R>
@@ -136,57 +148,56 @@ struct GroupRegs {
         if (cum - 1 < R && cum - 1 < 64) endmask |= 1ull << (cum - 1);
       }
     }
+    chunkmask = 0u;
+    for (int c = 0; c * PYCHAIN_CHUNK < 64; c++)
+      if ((endmask >> (c * PYCHAIN_CHUNK)) & ((1ull << PYCHAIN_CHUNK) - 1ull)) chunkmask |= 1u << c;
   }
 };
 
 // MODE 0: out[out_base+lane] = acc (recursions).  MODE 1: out[row_map[out_base+lane]] = acc
 // (occupancy pass: plan order -> natural pdf order, row_map in LDS, -1 = padding row).
-#define PYCHAIN_TILE_FLUSH()                                                   \
-  do {                                                                         \
-    const int pos = cur_base + lane;                                           \
-    if constexpr (MODE == 0) {                                                 \
-      out[pos] = acc;                                                          \
-      s0 += acc;                                                               \
-      if (wvec) s1 += acc * wvec[pos];                                         \
-    } else {                                                                   \
-      const int nat = row_map[pos];                                            \
-      if (nat >= 0) out[nat] = acc;                                            \
-    }                                                                          \
-    acc = 0.f;                                                                 \
-    g++;                                                                       \
-    cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);                     \
-  } while (0)
+template <int MODE>
+__device__ __forceinline__ void tile_store(float acc, int pos, float* __restrict__ out, const int* __restrict__ row_map) {
+  if constexpr (MODE == 0) {
+    out[pos] = acc;
+  } else {
+    const int nat = row_map[pos];
+    if (nat >= 0) out[nat] = acc;
+  }
+}
 
+// s_waitcnt on lgkmcnt only (gfx9 encoding: vmcnt[3:0] expcnt[6:4] lgkmcnt[11:8] vmcnt_hi[15:14])
+#define PYCHAIN_WAIT_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
+
+// One frame of a tile plan.  The resident loop is written for instruction count (the arc phase
+// is bound by LDS gather cycles, then by instructions issued - DESIGN.md §4):
+// per chunk of kChunk slot-rows 2 unpack + 2 ds_read + mul + fma per slot-row, ONE s_waitcnt and
+// ONE s_bitcmp/s_cbranch pair.  Nothing but `acc` is carried through the chunks: a group end
+// (a few per frame, out of line) finds its group by a popcount of the end mask and adds to the
+// row sums in place.
 template <int R, int MODE>
 __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
                                           const uint2* __restrict__ tail_slots, int lane,
                                           const float* __restrict__ U, const float* __restrict__ V,
                                           float* __restrict__ out, const int* __restrict__ row_map,
                                           const float* __restrict__ wvec, float& s0, float& s1) {
-  int g = 0;
-  int cur_base = __builtin_amdgcn_readlane(gr.base, 0);
   float acc = 0.f;
-  // Group ends are tested with s_bitcmp1 on two 32-bit SGPRs.  The asm makes them opaque per
-  // call: otherwise the optimiser precomputes one 64-bit lane mask PER SLOT-ROW outside the
-  // frame loop, spills them, and every slot-row pays two v_readlane reloads.
-  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32);
-  asm volatile("" : "+s"(m_lo), "+s"(m_hi));
-  // Per chunk of kChunk slot-rows: all gathers first (2*kChunk independent ds_reads in flight),
-  // then the arithmetic (no branch in between so it pipelines).  A chunk without a group end
-  // runs two fma chains; group ends (a few per frame) take the per-slot path.
-  static_assert(32 % 8 == 0, "a chunk never straddles the two mask words");
-  // Software pipeline: the gathers of chunk c+1 are issued BEFORE chunk c is consumed, so a
-  // wave always has 8 ds_reads in flight while it does arithmetic (a wave issues only ~1
-  // instruction per 5 cycles - tools/ubench - so un-overlapped LDS latency is pure loss).
-  // Rows past the wave's plan carry p = 0 and valid addresses: no per-chunk bound check.
 #ifndef PYCHAIN_CHUNK
 #define PYCHAIN_CHUNK 4
 #endif
   constexpr int kChunk = PYCHAIN_CHUNK;
-  static_assert(R % kChunk == 0, "resident slot-rows come in whole chunks");
+  static_assert(R % kChunk == 0 && 32 % kChunk == 0 && R <= 64, "whole chunks; a chunk never straddles the mask words");
   constexpr int NC = R / kChunk;
+  // Opaque per call: otherwise the optimiser precomputes per-slot-row lane masks outside the
+  // frame loop and spills them.
+  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), cm = gr.chunkmask;
+  asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
+  // Software pipeline: the gathers of chunk c+1 are issued BEFORE chunk c is consumed; LDS
+  // returns in order, so one wait for "all but the newest 2*kChunk" covers the whole chunk.
+  // Rows past the wave's plan carry p = 0 and valid addresses: no bound check.
   float ub[2][kChunk], vb[2][kChunk];
   if (R > 0) {
+    ar.template opaque<kChunk>(0);
 #pragma unroll
     for (int k = 0; k < kChunk; k++) ar.gather(k, ub[0][k], vb[0][k]);
   }
@@ -194,42 +205,66 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
   for (int c = 0; c < NC; c++) {
     const int cb = c & 1;
     if (c + 1 < NC) {
+      ar.template opaque<kChunk>((c + 1) * kChunk);
 #pragma unroll
       for (int k = 0; k < kChunk; k++) ar.gather((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
     }
-    float pu[kChunk];
+#if !defined(PYCHAIN_EXP_NOLDS) && !defined(PYCHAIN_EXP_NOWAIT)
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    // the common case unconditionally; a chunk with a group end (a few per frame) redoes it
+    float nacc = acc;
 #pragma unroll
-    for (int k = 0; k < kChunk; k++) pu[k] = ar.p[c * kChunk + k] * ub[cb][k];   // (p * alpha) rounded, then fused with x
-    const uint32_t ends = ((c * kChunk < 32 ? m_lo : m_hi) >> ((c * kChunk) & 31)) & ((1u << kChunk) - 1u);
-    if (__builtin_expect(ends == 0u, 1)) {
-      float a0 = acc, a1 = 0.f;                      // two chains: half the dependent-fma latency
-#pragma unroll
-      for (int k = 0; k < kChunk; k += 2) { a0 = fmaf(pu[k], vb[cb][k], a0); a1 = fmaf(pu[k + 1], vb[cb][k + 1], a1); }
-      acc = a0 + a1;
-    } else {
+    for (int k = 0; k < kChunk; k++) nacc = fmaf(ar.p[c * kChunk + k] * ub[cb][k], vb[cb][k], nacc);   // (p*u) rounded, then fused with v
+    if (__builtin_expect(((cm >> c) & 1u) != 0u, 0)) {
+      nacc = acc;
 #pragma unroll
       for (int k = 0; k < kChunk; k++) {
-        acc = fmaf(pu[k], vb[cb][k], acc);
-        if ((ends >> k) & 1u) PYCHAIN_TILE_FLUSH();
+        const int sidx = c * kChunk + k;
+        nacc = fmaf(ar.p[sidx] * ub[cb][k], vb[cb][k], nacc);
+        if (((sidx < 32 ? m_lo : m_hi) >> (sidx & 31)) & 1u) {
+          // group index = number of group ends before this slot-row
+          const uint32_t lo_before = sidx < 32 ? (m_lo & ((1u << (sidx & 31)) - 1u)) : m_lo;
+          const uint32_t hi_before = sidx < 32 ? 0u : (m_hi & ((1u << (sidx & 31)) - 1u));
+          const int g = __builtin_popcount(lo_before) + __builtin_popcount(hi_before);
+          const int pos = __builtin_amdgcn_readlane(gr.base, g) + lane;
+          tile_store<MODE>(nacc, pos, out, row_map);
+          if constexpr (MODE == 0) {
+            // row sums, updated IN PLACE (tied asm operands): a plain `s0 += nacc` makes s0/s1 loop-carried
+            // values of the chunk chain and costs register copies on the common path of every chunk
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(s0) : "v"(nacc));
+            if (wvec) { const float wv = wvec[pos]; asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s1) : "v"(nacc), "v"(wv)); }
+          }
+          nacc = 0.f;
+        }
       }
     }
+    acc = nacc;
   }
+  int g = __builtin_popcount(m_lo) + __builtin_popcount(m_hi);     // groups closed by the resident rows
   if (gr.nslots > R) {                           // plan larger than the register budget: stream the tail
     const uint2* sp = tail_slots;
     g = gr.tail_g;
-    cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
+    int cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
     int remaining = gr.tail_rem;
     for (int s = R; s < gr.nslots; s++) {
       const uint2 a = *sp;
       sp += 64;
       acc = fmaf(__uint_as_float(a.y) * U[a.x & 0xffffu], V[a.x >> 16], acc);
       if (--remaining == 0) {
-        PYCHAIN_TILE_FLUSH();
+        tile_store<MODE>(acc, cur_base + lane, out, row_map);
+        if constexpr (MODE == 0) { s0 += acc; if (wvec) s1 += acc * wvec[cur_base + lane]; }
+        acc = 0.f;
+        g++;
+        cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
         remaining = __builtin_amdgcn_readlane(gr.n, g & 63);
       }
     }
   }
-  while (g < gr.ngroups) PYCHAIN_TILE_FLUSH();   // trailing groups whose rows have no arcs: zeros
+  for (; g < gr.ngroups; g++)                    // trailing groups whose rows have no arcs: zeros
+    tile_store<MODE>(0.f, __builtin_amdgcn_readlane(gr.base, g & 63) + lane, out, row_map);
 }
 
 // Normalise the frame's raw sums into the gather operand and stream the row to HBM, 16 bytes
@@ -367,6 +402,11 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 #else
     s0 = 1.f; s1 = 1.f;
 #endif
+#ifdef PYCHAIN_EXP_ARCS_ONLY    // timing experiment: the arc phase alone (ARCS_ONLY=2: plus one barrier per frame)
+    if (s0 == 12345.f) raw[tid] = s0;
+    if (PYCHAIN_EXP_ARCS_ONLY == 2) __syncthreads();
+    continue;
+#endif
     PH_ADD(0, pt); pt = PH_T();
     s0 = wave_sum(s0);
     if (!fwd) s1 = wave_sum(s1);
@@ -394,7 +434,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     PH_ADD(5, pt);
   }
 #ifdef PYCHAIN_PROFILE_PHASES
-  if (lane == 0 && (b == 0) && (wave == 0 || wave == kNW - 1))
+  if (lane == 0 && (b == 0))
     printf("dir %d wave %d steps %d cycles/step: arcs %llu wsum %llu bar1 %llu update %llu xstore %llu bar2 %llu\n", (int)fwd, wave,
            nsteps, ph[0] / max(1, j_end - j_begin), ph[1] / max(1, j_end - j_begin), ph[2] / max(1, j_end - j_begin),
            ph[3] / max(1, j_end - j_begin), ph[4] / max(1, j_end - j_begin), ph[5] / max(1, j_end - j_begin));
