@@ -84,9 +84,9 @@ int64_t pychain_hip_den_plan_build(
 /* Facts about a filled HOST blob that the launcher needs (the blob itself lives on the
  * device at call time and is never read back):
  *   info[0] num_states  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes
- *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers) of the
- *           recursion plans in bits 0-15 and of the occupancy plan in bits 16-30; combine
- *           several plans by taking the max of each half
+ *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers), three
+ *           10-bit fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
+ *           and for 8 waves (20-29); combine several plans by taking the max of each field
  *   info[5..7] reserved (0)
  */
 int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]);
@@ -98,7 +98,7 @@ int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t 
  * plans_dev/plan_stride_bytes: device address of the first plan and the byte
  *   distance between the plans of consecutive sequences; 0 = every sequence
  *   shares one graph (the ChainLoss denominator, pychain/loss.py:99).
- * resident_slot_rows: the launch hint info[4] of pychain_hip_den_plan_info (per-half max
+ * resident_slot_rows: the launch hint info[4] of pychain_hip_den_plan_info (per-field max
  *   over the passed plans); selects the kernel variant that keeps every wave's arcs
  *   in registers for the whole launch.  0 = unknown (arcs are re-read from L2 each frame;
  *   same results, slower).

@@ -80,7 +80,7 @@ def batch_plans(tensors, num_pdfs, device):
     rows = [0] if same else range(B)
     blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
     hints = [plan_info(b)["slot_rows"] for b in blobs]
-    slot_rows = max(h & 0xffff for h in hints) | (max(h >> 16 for h in hints) << 16)
+    slot_rows = sum(max((h >> sh) & 1023 for h in hints) << sh for sh in (0, 10, 20))
     if same:
         return DevicePlan(torch.from_numpy(blobs[0]).to(device), 0, slot_rows, H)
     stride = (max(b.nbytes for b in blobs) + 255) // 256 * 256

@@ -43,10 +43,12 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   info[0] = hd->H; info[1] = hd->K; info[2] = hd->D; info[3] = hd->total_bytes;
   int m = hd->alpha.max_wave_slot_rows;
   if (hd->beta.max_wave_slot_rows > m) m = hd->beta.max_wave_slot_rows;
-  int gmm = hd->gamma.max_wave_slot_rows;
-  if (m > 0x7fff) m = 0x7fff;
-  if (gmm > 0x7fff) gmm = 0x7fff;
-  info[4] = m | (gmm << 16);     // launch hint: recursion rows | occupancy rows << 16
+  int gmm = hd->gamma.max_wave_slot_rows, gm2 = hd->gamma2.max_wave_slot_rows;
+  if (m > 1023) m = 1023;
+  if (gmm > 1023) gmm = 1023;
+  if (gm2 > 1023) gm2 = 1023;
+  // launch hint, 10 bits each: recursion rows | occupancy rows (16 waves) << 10 | occupancy rows (8 waves) << 20
+  info[4] = m | (gmm << 10) | (gm2 << 20);
   return PYCHAIN_HIP_OK;
 }
 

@@ -671,12 +671,295 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
+// ------------------------------------------------------------------------------------
+// launch 2, two-frame form: frames t and t+1 of a sequence are evaluated TOGETHER.
+// The occupancy pass is time-parallel, so its cost is CU time, not latency, and what it
+// spends per frame is LDS gather cycles (2 ds_read_b32 per arc), VALU/issue slots and three
+// workgroup barriers.  Here alpha'(t,.)/alpha'(t+1,.) and beta(t+1,.)/beta(t+2,.) are
+// interleaved in LDS as float2, so ONE ds_read_b64 per operand serves both frames at the
+// LDS cost of one ds_read_b32, the arithmetic is packed fp32 (v_pk_mul/v_pk_fma), address
+// unpacking and the group bookkeeping are shared, and a pair costs two barriers.  8 waves
+// of up to 256 VGPRs: every wave keeps twice the arcs of the 16-wave form in registers.
+// The nnet-output rows never enter LDS (each thread multiplies the elements it loaded).
+// ------------------------------------------------------------------------------------
+constexpr int kNW2 = PLAN_GAM2_WAVES;
+constexpr int kNT2 = kNW2 * 64;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const v2f lds_cv2f;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+__device__ __forceinline__ v2f lds_abs2(uint32_t byte_addr) { return *(lds_cv2f*)(byte_addr); }
+#pragma clang diagnostic pop
+
+template <int R>
+struct ArcRegs2 {
+  uint32_t pk[R > 0 ? R : 1];       // absolute LDS byte addresses of the two float2 operands, packed 16:16
+  float p[R > 0 ? R : 1];
+  __device__ __forceinline__ void load(const int nslot_rows, const uint2* __restrict__ wave_slots,
+                                       uint32_t lds_u, uint32_t lds_v) {
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      uint2 a = make_uint2(0u, 0u);
+      if (s < nslot_rows) a = wave_slots[s * 64];
+      pk[s] = (lds_u + ((a.x & 0xffffu) << 3)) | ((lds_v + ((a.x >> 16) << 3)) << 16);
+      p[s] = __uint_as_float(a.y);
+    }
+  }
+  __device__ __forceinline__ void opaque4(int s) {
+    asm volatile("" : "+v"(pk[s]), "+v"(pk[s + 1]), "+v"(pk[s + 2]), "+v"(pk[s + 3]));
+  }
+  __device__ __forceinline__ void gather(int s, v2f& u, v2f& v) {
+    u = lds_abs2(pk[s] & 0xffffu); v = lds_abs2(pk[s] >> 16);
+  }
+};
+
+// (u.x * p, u.y * p) as two scalar multiplies: a packed multiply by the splat {p, p} makes the
+// optimiser keep a 64-bit copy of every arc probability in registers (3 VGPRs per arc instead of 2)
+__device__ __forceinline__ v2f scale2(v2f u, float p) { return v2f{u.x * p, u.y * p}; }
+
+__device__ __forceinline__ void tile_store2(v2f acc, int pos, float* __restrict__ q2, const int* __restrict__ row_map) {
+  const int nat = row_map[pos];
+  if (nat >= 0) *reinterpret_cast<v2f*>(q2 + 2 * nat) = acc;
+}
+
+// q2[2*pdf + f] = sum_k p_k * U2[2*i0_k + f] * V2[2*i1_k + f]   (f = 0, 1: the two frames)
+template <int R>
+__device__ __forceinline__ void tile_rows2(ArcRegs2<R>& ar, const GroupRegs& gr, const uint2* __restrict__ tail_slots,
+                                           int lane, const float* __restrict__ U2, const float* __restrict__ V2,
+                                           float* __restrict__ q2, const int* __restrict__ row_map) {
+  constexpr int kChunk = 4;
+  static_assert(R % kChunk == 0 && R <= 64 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
+  constexpr int NC = R / kChunk;
+  v2f acc = {0.f, 0.f};
+  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), cm = gr.chunkmask;
+  asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
+  v2f ub[2][kChunk], vb[2][kChunk];
+  if (R > 0) {
+    ar.opaque4(0);
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) ar.gather(k, ub[0][k], vb[0][k]);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int cb = c & 1;
+    if (c + 1 < NC) {
+      ar.opaque4((c + 1) * kChunk);
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) ar.gather((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    v2f nacc = acc;
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) nacc = __builtin_elementwise_fma(scale2(ub[cb][k], ar.p[c * kChunk + k]), vb[cb][k], nacc);
+    if (__builtin_expect(((cm >> c) & 1u) != 0u, 0)) {
+      nacc = acc;
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) {
+        const int sidx = c * kChunk + k;
+        nacc = __builtin_elementwise_fma(scale2(ub[cb][k], ar.p[sidx]), vb[cb][k], nacc);
+        if (((sidx < 32 ? m_lo : m_hi) >> (sidx & 31)) & 1u) {
+          const uint32_t lo_before = sidx < 32 ? (m_lo & ((1u << (sidx & 31)) - 1u)) : m_lo;
+          const uint32_t hi_before = sidx < 32 ? 0u : (m_hi & ((1u << (sidx & 31)) - 1u));
+          const int g = __builtin_popcount(lo_before) + __builtin_popcount(hi_before);
+          tile_store2(nacc, __builtin_amdgcn_readlane(gr.base, g) + lane, q2, row_map);
+          nacc = v2f{0.f, 0.f};
+        }
+      }
+    }
+    acc = nacc;
+  }
+  int g = __builtin_popcount(m_lo) + __builtin_popcount(m_hi);
+  if (gr.nslots > R) {                           // plan larger than the register budget: stream the tail
+    const uint2* sp = tail_slots;
+    g = gr.tail_g;
+    int cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
+    int remaining = gr.tail_rem;
+    for (int s = R; s < gr.nslots; s++) {
+      const uint2 a = *sp;
+      sp += 64;
+      const v2f u = *reinterpret_cast<const v2f*>(U2 + 2 * (a.x & 0xffffu));
+      const v2f v = *reinterpret_cast<const v2f*>(V2 + 2 * (a.x >> 16));
+      acc = __builtin_elementwise_fma(scale2(u, __uint_as_float(a.y)), v, acc);
+      if (--remaining == 0) {
+        tile_store2(acc, cur_base + lane, q2, row_map);
+        acc = v2f{0.f, 0.f};
+        g++;
+        cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
+        remaining = __builtin_amdgcn_readlane(gr.n, g & 63);
+      }
+    }
+  }
+  for (; g < gr.ngroups; g++)
+    tile_store2(v2f{0.f, 0.f}, __builtin_amdgcn_readlane(gr.base, g & 63) + lane, q2, row_map);
+}
+
+__device__ __forceinline__ bool den_frame_in_launch(int t, int t_live_end, int L, const DenArgs& a) {
+  return t < t_live_end && (a.gam_nseg == 0 || den_segment_of_frame(t, L, a) == a.gam_seg);
+}
+
+template <int XCH, int R>
+__global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int UVC = 2;                              // float4 chunks of a state row per thread: Hp <= 4 * UVC * kNT2
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int Hp = a.Hp, D = a.D, T = a.T, Dp = (D + 3) & ~3;
+  const int t_begin = blockIdx.x * a.frames_per_block;          // frames_per_block is even
+  const int t_end = min(t_begin + a.frames_per_block, T);
+  float* gseq = a.grad + (size_t)b * T * D;
+  const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
+  const int t_live_end = min(t_end, L);
+  // pairs (t0, t0+1), t0 even, with at least one frame of this launch
+  int t0 = t_begin;
+  while (t0 < t_live_end && !den_frame_in_launch(t0, t_live_end, L, a) && !den_frame_in_launch(t0 + 1, t_live_end, L, a)) t0 += 2;
+  if (t0 >= t_live_end) {                             // nothing to evaluate: padding of the first launch is exact zeros
+    if (first_launch)
+      for (size_t i = (size_t)max(t_begin, min(t_live_end, t_end)) * D + tid; i < (size_t)t_end * D; i += kNT2) gseq[i] = 0.f;
+    return;
+  }
+  const char* plan = a.plans + (size_t)b * a.plan_stride;
+  const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
+  const TilePlan tp = hd->gamma2;
+  const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
+  const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
+  const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
+  const int32_t* row_pdf = reinterpret_cast<const int32_t*>(plan + hd->off_row_pdf);
+
+  float* U2 = reinterpret_cast<float*>(smem_raw);    // [Hp] x {alpha'(t0,.), alpha'(t0+1,.)}
+  float* V2 = U2 + 2 * Hp;                            // [Hp] x {beta(t0+1,.), beta(t0+2,.)}
+  float* q2 = V2 + 2 * Hp;                            // [Dp] x {frame 0, frame 1} per-pdf arc sums, natural pdf order
+  int* rmap = reinterpret_cast<int*>(q2 + 2 * Dp);   // plan row -> pdf-id [ngroups*64]
+  float* red = reinterpret_cast<float*>(rmap + tp.ngroups * 64);   // [2][16]
+  const uint32_t lds0 = lds_addr(smem_raw);
+
+  GroupRegs groups;
+  groups.load<R>(we, gtab, lane);
+  const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
+  ArcRegs2<R> arcs;
+  arcs.load(groups.nslots, wave_slots, lds0, lds0 + 8u * (uint32_t)Hp);
+  const uint2* tail_slots = wave_slots + (size_t)R * 64;
+
+  const float* xseq = a.x + (size_t)b * T * D;
+  const float* aseq = a.alpha_store + (size_t)b * T * Hp;
+  const float* bseq = a.beta_store + (size_t)b * (T + 1) * Hp;
+
+  if (tid < 32) red[tid] = 0.f;
+  for (int i = tid; i < 2 * Dp; i += kNT2) q2[i] = 0.f;          // pdfs without arcs stay zero forever
+  for (int i = tid; i < tp.ngroups * 64; i += kNT2) rmap[i] = row_pdf[i];
+  int bad = 0;
+  const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
+
+  // state rows of a pair: global -> registers (one pair ahead) -> LDS, interleaved
+  float4 ua[UVC], ub[UVC], va[UVC], vb[UVC];
+#define GAMMA2_PREFETCH(t)                                                                       \
+  do {                                                                                           \
+    const float* a0_ = aseq + (size_t)(t) * Hp;                                                  \
+    const float* a1_ = aseq + (size_t)min((t) + 1, T - 1) * Hp;                                  \
+    const float* b0_ = bseq + (size_t)((t) + 1) * Hp;                                            \
+    const float* b1_ = bseq + (size_t)min((t) + 2, T) * Hp;                                      \
+    _Pragma("unroll") for (int c = 0; c < UVC; c++) {                                            \
+      const int i = (c * kNT2 + tid) * 4;                                                        \
+      if (i < Hp) {                                                                              \
+        ua[c] = *reinterpret_cast<const float4*>(a0_ + i); ub[c] = *reinterpret_cast<const float4*>(a1_ + i); \
+        va[c] = *reinterpret_cast<const float4*>(b0_ + i); vb[c] = *reinterpret_cast<const float4*>(b1_ + i); \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+#define GAMMA2_COMMIT()                                                                          \
+  do {                                                                                           \
+    _Pragma("unroll") for (int c = 0; c < UVC; c++) {                                            \
+      const int i = (c * kNT2 + tid) * 4;                                                        \
+      if (i < Hp) {                                                                              \
+        *reinterpret_cast<float4*>(U2 + 2 * i) = make_float4(ua[c].x, ub[c].x, ua[c].y, ub[c].y); \
+        *reinterpret_cast<float4*>(U2 + 2 * i + 4) = make_float4(ua[c].z, ub[c].z, ua[c].w, ub[c].w); \
+        *reinterpret_cast<float4*>(V2 + 2 * i) = make_float4(va[c].x, vb[c].x, va[c].y, vb[c].y); \
+        *reinterpret_cast<float4*>(V2 + 2 * i + 4) = make_float4(va[c].z, vb[c].z, va[c].w, vb[c].w); \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
+  GAMMA2_PREFETCH(t0);
+  GAMMA2_COMMIT();
+  __syncthreads();
+  XRow<kNT2, 4, XCH> x0, x1;
+  while (t0 < t_live_end) {
+    const bool valid0 = den_frame_in_launch(t0, t_live_end, L, a), valid1 = den_frame_in_launch(t0 + 1, t_live_end, L, a);
+    int tn = t0 + 2;
+    while (tn < t_live_end && !den_frame_in_launch(tn, t_live_end, L, a) && !den_frame_in_launch(tn + 1, t_live_end, L, a)) tn += 2;
+    const bool have_next = tn < t_live_end;
+    // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
+    x0.load(xseq + (size_t)t0 * D, D, tid);
+    x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
+    if (have_next) GAMMA2_PREFETCH(tn);
+    tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap);
+    __syncthreads();                                   // q2 complete; every gather of this pair is done
+    float g0[4 * XCH], g1[4 * XCH];
+    float part0 = 0.f, part1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < XCH; c++) {
+      const int e = (c * kNT2 + tid) * 4;
+      float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+      if (e < D) { qa = *reinterpret_cast<const float4*>(q2 + 2 * e); qb = *reinterpret_cast<const float4*>(q2 + 2 * e + 4); }
+      const float qf0[4] = {qa.x, qa.z, qb.x, qb.z}, qf1[4] = {qa.y, qa.w, qb.y, qb.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        g0[c * 4 + k] = e < D ? clamp_exp(x0.v[c * 4 + k], a.input_is_exp) * qf0[k] : 0.f;
+        g1[c * 4 + k] = e < D ? clamp_exp(x1.v[c * 4 + k], a.input_is_exp) * qf1[k] : 0.f;
+        part0 += g0[c * 4 + k]; part1 += g1[c * 4 + k];
+      }
+    }
+    part0 = wave_sum(part0); part1 = wave_sum(part1);
+    if (lane == 0) { red[wave] = part0; red[16 + wave] = part1; }
+    if (have_next) GAMMA2_COMMIT();                    // U2/V2 are free since the barrier above
+    __syncthreads();                                   // totals visible; next operands in place; q2 read
+    const float tot0 = block_total(red, lane), tot1 = block_total(red + 16, lane);
+    const float sc0 = gscale / tot0, sc1 = gscale / tot1;
+    if (valid0 && (!(tot0 > 0.f) || !(sc0 - sc0 == 0.f))) bad = 1;
+    if (valid1 && (!(tot1 > 0.f) || !(sc1 - sc1 == 0.f))) bad = 1;
+    float* grow0 = gseq + (size_t)t0 * D;
+    float* grow1 = grow0 + D;
+#pragma unroll
+    for (int c = 0; c < XCH; c++) {
+      const int e = (c * kNT2 + tid) * 4;
+      if (e < D) {
+        if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(g0[c * 4] * sc0, g0[c * 4 + 1] * sc0, g0[c * 4 + 2] * sc0, g0[c * 4 + 3] * sc0);
+        if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(g1[c * 4] * sc1, g1[c * 4 + 1] * sc1, g1[c * 4 + 2] * sc1, g1[c * 4 + 3] * sc1);
+      }
+    }
+    t0 = tn;
+  }
+  // padded tail of a chunk that straddles the sequence end
+  if (first_launch && t_live_end < t_end)
+    for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT2) gseq[i] = 0.f;
+  if (bad && lane == 0) atomicAdd(a.bad, 1);
+}
+
 template <typename K>
-hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream_t st, int nthreads = kNT) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(kNT), lds, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(nthreads), lds, st, a);
   return hipGetLastError();
+}
+
+// the two-frame occupancy kernel: what it supports, and its launch
+inline size_t gamma2_lds_bytes(const DenArgs& a, int gamma_max_groups) {
+  return sizeof(float) * (4 * (size_t)a.Hp + 2 * (size_t)((a.D + 3) & ~3) + (size_t)gamma_max_groups * 64 + 32);
+}
+inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
+  static const bool off = getenv("PYCHAIN_GAMMA16") != nullptr;        // tuning / test knob: force the one-frame kernel
+  return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
+         a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) <= 160 * 1024;
+}
+template <int XCH>
+hipError_t launch_gamma2(const DenArgs& a, int rows2, size_t lds, dim3 grid, hipStream_t st) {
+  if (rows2 <= 16) return launch_one(den_gamma2_kernel<XCH, 16>, a, grid, lds, st, kNT2);
+  if (rows2 <= 32) return launch_one(den_gamma2_kernel<XCH, 32>, a, grid, lds, st, kNT2);
+  return launch_one(den_gamma2_kernel<XCH, 64>, a, grid, lds, st, kNT2);
 }
 
 // rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
@@ -689,11 +972,11 @@ inline int pick_r(const DenArgs& a, int rows, int lds_words) {
 }
 
 template <int VEC, int XCH>
-hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, int gx, hipStream_t st) {
+hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, int gx, hipStream_t st, int gamma_max_groups) {
   hipError_t e = hipSuccess;
   if (a.phase_mask & 1) {
     const dim3 grid(2 * a.B);
-    switch (pick_r(a, hint & 0xffff, a.Hp + ((a.D + 3) & ~3))) {
+    switch (pick_r(a, hint & 1023, a.Hp + ((a.D + 3) & ~3))) {
       case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0>, a, grid, lds_rec, st); break;
       case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16>, a, grid, lds_rec, st); break;
       case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32>, a, grid, lds_rec, st); break;
@@ -703,7 +986,12 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
   }
   if (a.phase_mask & 2) {
     const dim3 grid(gx, a.B);
-    switch (pick_r(a, (hint >> 16) & 0x7fff, 2 * a.Hp)) {
+    if (gamma2_eligible(a, (hint >> 20) & 1023, gamma_max_groups)) {
+      const size_t lds2 = gamma2_lds_bytes(a, gamma_max_groups);
+      return a.D <= 4 * kNT2 ? launch_gamma2<1>(a, (hint >> 20) & 1023, lds2, grid, st)
+                             : launch_gamma2<2>(a, (hint >> 20) & 1023, lds2, grid, st);
+    }
+    switch (pick_r(a, (hint >> 10) & 1023, 2 * a.Hp)) {
       case 0: e = launch_one(den_gamma_kernel<VEC, XCH, 0>, a, grid, lds_gam, st); break;
       case 16: e = launch_one(den_gamma_kernel<VEC, XCH, 16>, a, grid, lds_gam, st); break;
       case 32: e = launch_one(den_gamma_kernel<VEC, XCH, 32>, a, grid, lds_gam, st); break;
@@ -727,14 +1015,14 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
   const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
   const int D = a.D, r = resident_slot_rows;
   if (D % 4 == 0) {
-    if (D <= 4 * 1 * kNT) return launch_r<4, 1>(a, r, lds_rec, lds_gam, gx, st);
-    if (D <= 4 * 2 * kNT) return launch_r<4, 2>(a, r, lds_rec, lds_gam, gx, st);
-    if (D <= 4 * 3 * kNT) return launch_r<4, 3>(a, r, lds_rec, lds_gam, gx, st);
-    if (D <= 4 * 4 * kNT) return launch_r<4, 4>(a, r, lds_rec, lds_gam, gx, st);
+    if (D <= 4 * 1 * kNT) return launch_r<4, 1>(a, r, lds_rec, lds_gam, gx, st, gamma_max_groups);
+    if (D <= 4 * 2 * kNT) return launch_r<4, 2>(a, r, lds_rec, lds_gam, gx, st, gamma_max_groups);
+    if (D <= 4 * 3 * kNT) return launch_r<4, 3>(a, r, lds_rec, lds_gam, gx, st, gamma_max_groups);
+    if (D <= 4 * 4 * kNT) return launch_r<4, 4>(a, r, lds_rec, lds_gam, gx, st, gamma_max_groups);
   } else if (D <= 4 * kNT) {
-    return launch_r<1, 4>(a, r, lds_rec, lds_gam, gx, st);
+    return launch_r<1, 4>(a, r, lds_rec, lds_gam, gx, st, gamma_max_groups);
   }
-  return launch_r<1, 0>(a, r, lds_rec, lds_gam, gx, st);
+  return launch_r<1, 0>(a, r, lds_rec, lds_gam, gx, st, gamma_max_groups);
 }
 
 }  // namespace pychain_hip

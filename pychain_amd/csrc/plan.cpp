@@ -260,6 +260,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   BuiltTile ta = build_tile(rows_a, order_a, Hp, PLAN_REC_WAVES);
   BuiltTile tb = build_tile(rows_b, order_b, Hp, PLAN_REC_WAVES);
   BuiltTile tg = build_tile(rows_g, order_g, gpos, PLAN_GAM_WAVES);
+  BuiltTile tg2 = build_tile(rows_g, order_g, gpos, PLAN_GAM2_WAVES);
 
   // ---- lay the blob out
   size_t off = align16(sizeof(PlanHeader));
@@ -274,7 +275,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
     tp.off_group_tab = (int32_t)off; off = align16(off + std::max<size_t>(1, t.groups.size()) * sizeof(GroupEntry));
     tp.off_slots = (int32_t)off; off = align16(off + std::max<size_t>(1, t.slots.size()) * 4);
   };
-  place_tile(hd.alpha, ta); place_tile(hd.beta, tb); place_tile(hd.gamma, tg);
+  place_tile(hd.alpha, ta); place_tile(hd.beta, tb); place_tile(hd.gamma, tg); place_tile(hd.gamma2, tg2);
   auto place_vec = [&](int32_t& o, size_t n) { o = (int32_t)off; off = align16(off + n * 4); };
   place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
@@ -292,7 +293,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
     memcpy(base + tp.off_group_tab, t.groups.data(), t.groups.size() * sizeof(GroupEntry));
     memcpy(base + tp.off_slots, t.slots.data(), t.slots.size() * 4);
   };
-  write_tile(hd.alpha, ta); write_tile(hd.beta, tb); write_tile(hd.gamma, tg);
+  write_tile(hd.alpha, ta); write_tile(hd.beta, tb); write_tile(hd.gamma, tg); write_tile(hd.gamma2, tg2);
   float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);

@@ -29,11 +29,12 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 4
+#define PLAN_VERSION 5
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
-#define PLAN_GAM_WAVES 16
-#endif      // same for the gamma plan
+#define PLAN_GAM_WAVES 16      // same for the gamma plan
+#endif
+#define PLAN_GAM2_WAVES 8      // the gamma plan again, scheduled for the two-frame occupancy kernel (8 waves x 256 VGPRs)
 
 struct TilePlan {              // all offsets are bytes from the start of the blob
   int32_t ngroups;
@@ -71,6 +72,7 @@ struct PlanHeader {
   int32_t off_final_b;         // float[Hp]  final_probs,   beta numbering
   int32_t off_row_pdf;         // int32[gamma.ngroups*64] natural pdf-id of each gamma row, -1 = padding
   int32_t reserved1[2];
+  TilePlan gamma2;             // same rows as `gamma` (row_pdf applies), dealt to PLAN_GAM2_WAVES waves
 };
 
 #endif
