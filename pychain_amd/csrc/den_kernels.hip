@@ -101,6 +101,7 @@ struct ArcRegs {
     else for (int k = 0; k < N; k++) asm volatile("" : "+v"(pk[s + k]));
 #endif
   }
+  template <int VOFF = 0>         // VOFF: compile-time byte offset of operand V (folds into the ds_read offset field)
   __device__ __forceinline__ void gather(int s, float& u, float& v) {
 #if PYCHAIN_ARC_PACKED
     const uint32_t a0 = pk[s] & 0xffffu, a1 = pk[s] >> 16;
@@ -108,7 +109,7 @@ struct ArcRegs {
     const uint32_t a0 = o0[s], a1 = o1[s];
 #endif
 #ifndef PYCHAIN_EXP_NOLDS
-    u = lds_abs(a0); v = lds_abs(a1);
+    u = lds_abs(a0); v = lds_abs(a1 + VOFF);
 #else
     u = __uint_as_float(a0); v = __uint_as_float(a1);
 #endif
@@ -175,7 +176,7 @@ __device__ __forceinline__ void tile_store(float acc, int pos, float* __restrict
 // ONE s_bitcmp/s_cbranch pair.  Nothing but `acc` is carried through the chunks: a group end
 // (a few per frame, out of line) finds its group by a popcount of the end mask and adds to the
 // row sums in place.
-template <int R, int MODE>
+template <int R, int MODE, int VOFF = 0>
 __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
                                           const uint2* __restrict__ tail_slots, int lane,
                                           const float* __restrict__ U, const float* __restrict__ V,
@@ -199,7 +200,7 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
   if (R > 0) {
     ar.template opaque<kChunk>(0);
 #pragma unroll
-    for (int k = 0; k < kChunk; k++) ar.gather(k, ub[0][k], vb[0][k]);
+    for (int k = 0; k < kChunk; k++) ar.template gather<VOFF>(k, ub[0][k], vb[0][k]);
   }
 #pragma unroll
   for (int c = 0; c < NC; c++) {
@@ -207,7 +208,7 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
     if (c + 1 < NC) {
       ar.template opaque<kChunk>((c + 1) * kChunk);
 #pragma unroll
-      for (int k = 0; k < kChunk; k++) ar.gather((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
+      for (int k = 0; k < kChunk; k++) ar.template gather<VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
     }
 #if !defined(PYCHAIN_EXP_NOLDS) && !defined(PYCHAIN_EXP_NOWAIT)
     __builtin_amdgcn_sched_barrier(0);
@@ -296,7 +297,11 @@ __device__ __forceinline__ float block_total(const float* red, int lane) { retur
 // ------------------------------------------------------------------------------------
 // launch 1: alpha and beta recursions
 // ------------------------------------------------------------------------------------
-template <int VEC, int XCH, int R>
+// DB: the nnet-output row is double-buffered in LDS (two 16 KiB regions, D <= 4096), so the row of
+// the next frame is exp'd and stored by each wave right after ITS arc work - while slower waves
+// still gather - instead of by all waves at once between the two barriers.
+constexpr int kXOff = 16384;
+template <int VEC, int XCH, int R, bool DB>
 __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
@@ -318,18 +323,17 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 
   // LDS: cur = normalised state vector of the previous frame (gather operand U), xr = exp'd
   // nnet-output row (operand V), raw = this frame's un-normalised sums, lk = leaky probs.
-  float* cur = reinterpret_cast<float*>(smem_raw);
-  float* xr = cur + Hp;
-  float* raw = xr + Dp;
+  float* xr = reinterpret_cast<float*>(smem_raw);                      // DB: xr = buffer 0, xr + kXOff/4 = buffer 1
+  float* cur = xr + (DB ? 2 * (kXOff / 4) : Dp);
+  float* raw = cur + Hp;
   float* lk = raw + Hp;
   float* red = lk + Hp;              // [2][16]
-  const uint32_t lds0 = lds_addr(smem_raw);
 
   GroupRegs groups;
   groups.load<R>(we, gtab, lane);
   const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
   ArcRegs<R> arcs;
-  arcs.load(groups.nslots, wave_slots, lds0, lds0 + 4u * (uint32_t)Hp);
+  arcs.load(groups.nslots, wave_slots, lds_addr(cur), lds_addr(xr));
   const uint2* tail_slots = wave_slots + (size_t)R * 64;
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     }
     const int t0 = fwd ? j_begin : L - 1 - j_begin;
     xq.load(xseq + (size_t)t0 * D, D, tid);
-    xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);   // j_begin is even: buffer 0
     if (fwd) logsum = a.logsum_ws[b];
   }
   __syncthreads();
@@ -387,52 +391,78 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 #else
 #define PH_ADD(i, t0) (void)(t0)
 #endif
-  for (int j = j_begin; j < j_end; j++) {
-    unsigned long long pt = PH_T();
-    const int tn = fwd ? j + 1 : L - 2 - j;          // nnet-output row of the NEXT step
-    const bool have_next = fwd ? (tn < L) : (tn >= 1);
-    const float* xrow_next = xseq + (size_t)(have_next ? tn : 0) * D;
-#ifndef PYCHAIN_EXP_NO_X
-    if (have_next) xq.load(xrow_next, D, tid);       // in flight during the arc work
-#endif
-
-    float s0 = 0.f, s1 = 0.f;
-#ifndef PYCHAIN_EXP_NO_ARCS     // (PYCHAIN_EXP_*: ablation builds for timing only - results are wrong)
-    tile_rows<R, 0>(arcs, groups, tail_slots, lane, cur, xr, raw, nullptr, fwd ? nullptr : lk, s0, s1);
+  // One frame step.  VOFF = byte offset of the nnet-output buffer this step gathers from (double-
+  // buffered form: even steps read buffer 0 and fill buffer 1, odd steps the reverse; the frame
+  // loop is unrolled by two IN SOURCE ORDER - a branch between two inlined copies of the arc loop
+  // makes the optimiser hoist their common address arithmetic above the branch and spill it).
+#define PYCHAIN_REC_STEP(J, VOFF)                                                                          \
+  do {                                                                                                      \
+    const int j = (J);                                                                                      \
+    unsigned long long pt = PH_T();                                                                         \
+    const int tn = fwd ? j + 1 : L - 2 - j;          /* nnet-output row of the NEXT step */                \
+    const bool have_next = fwd ? (tn < L) : (tn >= 1);                                                      \
+    const float* xrow_next = xseq + (size_t)(have_next ? tn : 0) * D;                                       \
+    if (kWithX && have_next) xq.load(xrow_next, D, tid);       /* in flight during the arc work */          \
+    float s0 = 0.f, s1 = 0.f;                                                                               \
+    if (kWithArcs)                                                                                          \
+      tile_rows<R, 0, VOFF>(arcs, groups, tail_slots, lane, cur, xr + (VOFF) / 4, raw, nullptr, fwd ? nullptr : lk, s0, s1); \
+    else { s0 = 1.f; s1 = 1.f; }                                                                            \
+    /* double-buffered: the other buffer was last read in the previous step, which every wave has left */   \
+    if (DB && kWithX && have_next) xq.store(xr + (kXOff - (VOFF)) / 4, xrow_next, D, tid, a.input_is_exp);  \
+    if (kArcsOnly) { if (s0 == 12345.f) raw[tid] = s0; if (kArcsOnly == 2) __syncthreads(); break; }        \
+    PH_ADD(0, pt); pt = PH_T();                                                                             \
+    s0 = wave_sum(s0);                                                                                      \
+    if (!fwd) s1 = wave_sum(s1);                                                                            \
+    if (lane == 0) { red[wave] = s0; red[16 + wave] = s1; }                                                 \
+    PH_ADD(1, pt); pt = PH_T();                                                                             \
+    __syncthreads();                                 /* every gather of this frame is done */               \
+    PH_ADD(2, pt); pt = PH_T();                                                                             \
+    tot = block_total(red, lane);                                                                           \
+    wtot = fwd ? 0.f : block_total(red + 16, lane);                                                         \
+    const float inv = __builtin_amdgcn_rcpf(tot);                                                           \
+    if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;                                                              \
+    logsum += (double)fast_log(tot);                                                                        \
+    const int tstore = fwd ? j + 1 : L - 1 - j;                                                             \
+    const bool do_store = fwd ? (tstore < L) : true;                                                        \
+    if (kWithNorm)                                                                                          \
+      normalise_row(fwd, raw, lk, cur, do_store ? store + (size_t)tstore * Hp : nullptr, inv, coef, coef * wtot, H, Hp, tid); \
+    PH_ADD(3, pt); pt = PH_T();                                                                             \
+    if (!DB && kWithX && have_next) xq.store(xr, xrow_next, D, tid, a.input_is_exp);                        \
+    PH_ADD(4, pt); pt = PH_T();                                                                             \
+    __syncthreads();                                                                                        \
+    PH_ADD(5, pt);                                                                                          \
+  } while (0)
+  // (PYCHAIN_EXP_*: ablation builds for timing only - results are wrong)
+#ifdef PYCHAIN_EXP_NO_X
+  constexpr bool kWithX = false;
 #else
-    s0 = 1.f; s1 = 1.f;
+  constexpr bool kWithX = true;
 #endif
-#ifdef PYCHAIN_EXP_ARCS_ONLY    // timing experiment: the arc phase alone (ARCS_ONLY=2: plus one barrier per frame)
-    if (s0 == 12345.f) raw[tid] = s0;
-    if (PYCHAIN_EXP_ARCS_ONLY == 2) __syncthreads();
-    continue;
+#ifdef PYCHAIN_EXP_NO_ARCS
+  constexpr bool kWithArcs = false;
+#else
+  constexpr bool kWithArcs = true;
 #endif
-    PH_ADD(0, pt); pt = PH_T();
-    s0 = wave_sum(s0);
-    if (!fwd) s1 = wave_sum(s1);
-    if (lane == 0) { red[wave] = s0; red[16 + wave] = s1; }
-    PH_ADD(1, pt); pt = PH_T();
-    __syncthreads();                                 // every gather of this frame is done
-    PH_ADD(2, pt); pt = PH_T();
-    tot = block_total(red, lane);
-    wtot = fwd ? 0.f : block_total(red + 16, lane);
-    const float inv = __builtin_amdgcn_rcpf(tot);
-    if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
-    logsum += (double)fast_log(tot);
-    const int tstore = fwd ? j + 1 : L - 1 - j;
-    const bool do_store = fwd ? (tstore < L) : true;
-#ifndef PYCHAIN_EXP_NO_NORM
-    normalise_row(fwd, raw, lk, cur, do_store ? store + (size_t)tstore * Hp : nullptr, inv, coef, coef * wtot,
-                  H, Hp, tid);
+#ifdef PYCHAIN_EXP_NO_NORM
+  constexpr bool kWithNorm = false;
+#else
+  constexpr bool kWithNorm = true;
 #endif
-    PH_ADD(3, pt); pt = PH_T();
-#ifndef PYCHAIN_EXP_NO_X
-    if (have_next) xq.store(xr, xrow_next, D, tid, a.input_is_exp);
+#ifdef PYCHAIN_EXP_ARCS_ONLY
+  constexpr int kArcsOnly = PYCHAIN_EXP_ARCS_ONLY;
+#else
+  constexpr int kArcsOnly = 0;
 #endif
-    PH_ADD(4, pt); pt = PH_T();
-    __syncthreads();
-    PH_ADD(5, pt);
+  if constexpr (DB) {
+    // segments start at even steps (seg bounds are multiples of 32), so step parity = buffer parity
+    for (int jj = j_begin; jj < j_end; jj += 2) {      // (the macro declares `j`)
+      PYCHAIN_REC_STEP(jj, 0);
+      if (jj + 1 < j_end) PYCHAIN_REC_STEP(jj + 1, kXOff);
+    }
+  } else {
+    for (int jj = j_begin; jj < j_end; jj++) PYCHAIN_REC_STEP(jj, 0);
   }
+#undef PYCHAIN_REC_STEP
 #ifdef PYCHAIN_PROFILE_PHASES
   if (lane == 0 && (b == 0))
     printf("dir %d wave %d steps %d cycles/step: arcs %llu wsum %llu bar1 %llu update %llu xstore %llu bar2 %llu\n", (int)fwd, wave,
@@ -894,8 +924,12 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
     x0.load(xseq + (size_t)t0 * D, D, tid);
     x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
+#ifndef PYCHAIN_EXPG_NO_LOAD
     if (have_next) GAMMA2_PREFETCH(tn);
+#endif
+#ifndef PYCHAIN_EXPG_NO_ARCS
     tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap);
+#endif
     __syncthreads();                                   // q2 complete; every gather of this pair is done
     float g0[4 * XCH], g1[4 * XCH];
     float part0 = 0.f, part1 = 0.f;
@@ -914,7 +948,9 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     }
     part0 = wave_sum(part0); part1 = wave_sum(part1);
     if (lane == 0) { red[wave] = part0; red[16 + wave] = part1; }
+#ifndef PYCHAIN_EXPG_NO_LOAD
     if (have_next) GAMMA2_COMMIT();                    // U2/V2 are free since the barrier above
+#endif
     __syncthreads();                                   // totals visible; next operands in place; q2 read
     const float tot0 = block_total(red, lane), tot1 = block_total(red + 16, lane);
     const float sc0 = gscale / tot0, sc1 = gscale / tot1;
@@ -925,7 +961,11 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
 #pragma unroll
     for (int c = 0; c < XCH; c++) {
       const int e = (c * kNT2 + tid) * 4;
+#ifdef PYCHAIN_EXPG_NO_STORE
+      if (e < D && sc0 == 12345.f) {
+#else
       if (e < D) {
+#endif
         if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(g0[c * 4] * sc0, g0[c * 4 + 1] * sc0, g0[c * 4 + 2] * sc0, g0[c * 4 + 3] * sc0);
         if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(g1[c * 4] * sc1, g1[c * 4 + 1] * sc1, g1[c * 4 + 2] * sc1, g1[c * 4 + 3] * sc1);
       }
@@ -976,11 +1016,13 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
   hipError_t e = hipSuccess;
   if (a.phase_mask & 1) {
     const dim3 grid(2 * a.B);
-    switch (pick_r(a, hint & 1023, a.Hp + ((a.D + 3) & ~3))) {
-      case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0>, a, grid, lds_rec, st); break;
-      case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16>, a, grid, lds_rec, st); break;
-      case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32>, a, grid, lds_rec, st); break;
-      default: e = launch_one(den_recursion_kernel<VEC, XCH, kMaxResident>, a, grid, lds_rec, st); break;
+    // <4, 1> (D <= 4096, D % 4 == 0) double-buffers the nnet-output row: gathered operands end at 32 KiB + 4 Hp
+    constexpr bool DB = VEC == 4 && XCH == 1;
+    switch (pick_r(a, hint & 1023, DB ? 2 * (kXOff / 4) + a.Hp : a.Hp + ((a.D + 3) & ~3))) {
+      case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0, DB>, a, grid, lds_rec, st); break;
+      case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16, DB>, a, grid, lds_rec, st); break;
+      case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32, DB>, a, grid, lds_rec, st); break;
+      default: e = launch_one(den_recursion_kernel<VEC, XCH, kMaxResident, DB>, a, grid, lds_rec, st); break;
     }
     if (e != hipSuccess) return e;
   }
@@ -1006,7 +1048,8 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,
                       const char** why) {
   const int Dp = (a.D + 3) & ~3;
-  const size_t lds_rec = sizeof(float) * (3 * (size_t)a.Hp + (size_t)Dp + 32);
+  const bool db = a.D % 4 == 0 && a.D <= 4 * kNT;        // the <4, 1> instantiation: two 16 KiB nnet-output buffers
+  const size_t lds_rec = sizeof(float) * (3 * (size_t)a.Hp + (db ? 2 * (size_t)(kXOff / 4) : (size_t)Dp) + 32);
   const size_t lds_gam = sizeof(float) * (2 * (size_t)a.Hp + 2 * (size_t)Dp + (size_t)gamma_max_groups * 64 + 16);
   if (lds_rec > 160 * 1024 || lds_gam > 160 * 1024) {
     *why = "state vector + nnet-output row do not fit the 160 KiB LDS of one CU";
