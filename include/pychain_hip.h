@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 6
+#define PYCHAIN_HIP_ABI_VERSION 7
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -229,6 +229,7 @@ int pychain_hip_rescale(float* data, size_t n, const float* scale_dev, void* str
 int pychain_hip_chain_loss_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
     const int32_t* forward_transitions, const int32_t* forward_transition_indices,
+    const float* forward_transition_probs,
     int graph_batch_stride, int num_num_states, int num_num_transitions,
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs,
     float grad_scale, const float* grad_scale_dev,

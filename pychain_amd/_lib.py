@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -38,7 +38,7 @@ _SIGNATURES = {
                                        + [_vp, _vp, _i, _i, _i] + [_vp, _vp, _vp, _f, _vp]
                                        + [_vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_rescale": (_i, [_vp, _sz, _vp, _vp]),
-    "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i,
+    "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i,
                                              _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_fst_read": (_vp, [ctypes.c_char_p, _i64]),
     "pychain_hip_fst_from_arcs": (_vp, [ctypes.c_int32, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),

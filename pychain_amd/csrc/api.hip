@@ -145,14 +145,25 @@ int den_segments(int T) {
 }
 
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
-hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why) {
+// `gamma_wait`: event every occupancy launch has to wait for (the numerator rows it folds in), or null
+hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
+                   hipEvent_t gamma_wait = nullptr) {
   const int gmax = (a.D + 63) / 64;
   const int user_mask = a.phase_mask;
   const int nseg = (occupancy && user_mask == 3) ? den_segments(a.T) : 1;
   hipError_t e = hipSuccess;
   if (nseg <= 1) {
-    a.phase_mask = occupancy ? user_mask : (user_mask & 1);
-    e = launch_den(a, gmax, resident_slot_rows, st, why);
+    const int mask = occupancy ? user_mask : (user_mask & 1);
+    if (gamma_wait && (mask & 2)) {
+      a.phase_mask = mask & 1;
+      if (a.phase_mask) e = launch_den(a, gmax, resident_slot_rows, st, why);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st, gamma_wait, 0);
+      a.phase_mask = 2;
+      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
+    } else {
+      a.phase_mask = mask;
+      e = launch_den(a, gmax, resident_slot_rows, st, why);
+    }
     a.phase_mask = user_mask;
     return e;
   }
@@ -170,6 +181,7 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
     e = launch_den(a, gmax, resident_slot_rows, st, why);
     if (e == hipSuccess) e = hipEventRecord(side->seg[s], st);
     if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[s], 0);
+    if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
     a.phase_mask = 2; a.gam_seg = s; a.gam_nseg = nseg;
     if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
   }
@@ -203,12 +215,16 @@ extern "C" int pychain_hip_den_forward_backward(
 }
 
 namespace {
-struct NumCarve { size_t alpha, occ, total; };
+struct NumCarve { size_t alpha, beta, logp, rows, upd, ucount, total; };
 NumCarve num_carve(int B, int T, int H, int K) {
   NumCarve c;
   c.alpha = 0;
-  c.occ = align256(8 * (size_t)B * (T + 1) * H);
-  c.total = c.occ + align256(4 * (size_t)B * T * K) + 256;
+  c.beta = c.alpha + align256(8 * (size_t)B * (T + 1) * H);
+  c.logp = c.beta + align256(8 * (size_t)B * (T + 1) * H);
+  c.rows = c.logp + align256(8 * (size_t)B);
+  c.upd = c.rows + align256(4 * (size_t)B * T * K);
+  c.ucount = c.upd + align256(4 * (size_t)B * K);
+  c.total = c.ucount + align256(4 * (size_t)B) + 256;
   return c;
 }
 
@@ -241,8 +257,8 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
   a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 16;
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  a.alpha_ws = (double*)(ws + c.alpha);
-  a.occ_ws = (float*)(ws + c.occ);
+  a.alpha_ws = (double*)(ws + c.alpha); a.beta_ws = (double*)(ws + c.beta); a.logp_ws = (double*)(ws + c.logp);
+  a.rows_ws = (float*)(ws + c.rows); a.upd_ws = (int32_t*)(ws + c.upd); a.ucount_ws = (int32_t*)(ws + c.ucount);
   return PYCHAIN_HIP_OK;
 }
 }  // namespace
@@ -271,7 +287,7 @@ extern "C" int pychain_hip_num_forward_backward(
     return fail(PYCHAIN_HIP_ELAUNCH, "num_forward_backward: hipMemsetAsync failed");
   const char* why = nullptr;
   hipError_t e = launch_num_fb(a, st, &why);
-  if (e == hipSuccess) e = launch_num_emit(a, st, &why);
+  if (e == hipSuccess) e = launch_num_occ(a, false, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "num_forward_backward: %s",
                 why ? why : hipGetErrorString(e));
@@ -304,15 +320,26 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "%s: cannot create the side stream", who);
   const char* why = nullptr;
   hipError_t e = hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st);
-  // fork: numerator recursion on the side stream, denominator recursion on the caller's stream
+  // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
+  // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
+  // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
+  static const bool no_fold = getenv("PYCHAIN_NO_FOLD") != nullptr;        // test / tuning knob
+  const bool fold = grad && !no_fold && den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
+  if (fold) {
+    da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
+    da.fold_scale = -grad_scale;
+  }
+  // fork: numerator on the side stream, denominator recursion on the caller's stream
   if (e == hipSuccess) e = hipEventRecord(side->fork, st);
   if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+  if (e == hipSuccess && fold) e = launch_num_prep(na, side->stream, &why);
   if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
+  if (e == hipSuccess && fold) e = launch_num_occ(na, true, side->stream, &why);
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
   da.phase_mask = 3;
-  if (e == hipSuccess) e = run_den(da, resident_slot_rows, grad != nullptr, st, &why);
+  if (e == hipSuccess) e = run_den(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
-  if (e == hipSuccess && grad) e = launch_num_emit(na, st, &why);   // grad -= grad_scale * gamma_num
+  if (e == hipSuccess && grad && !fold) e = launch_num_occ(na, false, st, &why);   // grad -= grad_scale * gamma_num
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
   return PYCHAIN_HIP_OK;
@@ -347,12 +374,12 @@ extern "C" int pychain_hip_rescale(float* data, size_t n, const float* scale_dev
 namespace {
 int chain_loss_backward_impl(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H,
-    const int32_t* ft, const int32_t* fi, int graph_batch_stride, int num_H, int num_K,
+    const int32_t* ft, const int32_t* fi, const float* fp, int graph_batch_stride, int num_H, int num_K,
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
     float grad_scale, const float* grad_scale_dev, float* grad, int32_t* bad_count,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream, bool zero_bad) {
   const char* who = "chain_loss_backward";
-  if (!bad_count || !ft || !fi) return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
+  if (!bad_count || !ft || !fi || !fp) return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
   DenArgs da;
   float dummy_coef = 0.5f;       // the occupancy launch does not use the leaky coefficient
   int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, dummy_coef,
@@ -360,8 +387,8 @@ int chain_loss_backward_impl(
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
   NumArgs na;
-  // the emit launch reads only forward_transitions / indices (pdf-ids, used arc range) of the graphs
-  rc = fill_num_args(na, ft, fi, (const float*)ft, ft, fi, (const float*)ft, (const float*)ft, (const float*)ft,
+  // the occupancy launch reads only the forward transitions / indices / log-probs of the graphs
+  rc = fill_num_args(na, ft, fi, fp, ft, fi, fp, fp, fp,
                      graph_batch_stride, nnet_output, seq_lengths, B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM,
                      -grad_scale, (float*)num_ws, grad, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
@@ -371,7 +398,7 @@ int chain_loss_backward_impl(
   hipError_t e = zero_bad ? hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st) : hipSuccess;
   da.phase_mask = 2;
   if (e == hipSuccess) e = launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
-  if (e == hipSuccess) e = launch_num_emit(na, st, &why);
+  if (e == hipSuccess) e = launch_num_occ(na, false, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
   return PYCHAIN_HIP_OK;
@@ -381,11 +408,11 @@ int chain_loss_backward_impl(
 
 extern "C" int pychain_hip_chain_loss_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H,
-    const int32_t* ft, const int32_t* fi, int graph_batch_stride, int num_H, int num_K,
+    const int32_t* ft, const int32_t* fi, const float* fp, int graph_batch_stride, int num_H, int num_K,
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
     float grad_scale, const float* grad_scale_dev, float* grad, int32_t* bad_count,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
-  return chain_loss_backward_impl(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, ft, fi, graph_batch_stride,
+  return chain_loss_backward_impl(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, ft, fi, fp, graph_batch_stride,
                                   num_H, num_K, nnet_output, seq_lengths, B, T, D, grad_scale, grad_scale_dev, grad,
                                   bad_count, den_ws, den_ws_bytes, num_ws, num_ws_bytes, stream, true);
 }

@@ -31,7 +31,17 @@ struct DenArgs {
   double* logsum_ws;         // [B] running sum of log tot-alpha carried across recursion segments
   float coef, grad_scale;
   const float* grad_scale_dev;   // optional device scalar multiplied into grad_scale (upstream autograd gradient)
+  // Numerator fold (fused ChainLoss, two-frame occupancy kernel only): grad += fold_scale * occupancy of the
+  // numerator, read from compact rows over the sequence's distinct pdf-ids (num_kernels.h).  Null = no fold.
+  const float* fold_rows;        // [B,T,fold_K]
+  const int32_t* fold_upd;       // [B,fold_K]
+  const int32_t* fold_ucount;    // [B]
+  int fold_K;
+  float fold_scale;
 };
+
+// true if launch_den would run the two-frame occupancy kernel (the only one that can fold the numerator in)
+bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
 
 // Enqueues the two launches on `st`.  On failure returns the HIP error and, when the
 // shape is unsupported, a reason in *why.

@@ -865,6 +865,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   float* q2 = V2 + 2 * Hp;                            // [Dp] x {frame 0, frame 1} per-pdf arc sums, natural pdf order
   int* rmap = reinterpret_cast<int*>(q2 + 2 * Dp);   // plan row -> pdf-id [ngroups*64]
   float* red = reinterpret_cast<float*>(rmap + tp.ngroups * 64);   // [2][16]
+  float* n2 = red + 32;                               // [2][Dp] x {frame 0, frame 1} numerator occupancies (fold only; one buffer per pair parity)
   const uint32_t lds0 = lds_addr(smem_raw);
 
   GroupRegs groups;
@@ -883,6 +884,19 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   for (int i = tid; i < tp.ngroups * 64; i += kNT2) rmap[i] = row_pdf[i];
   int bad = 0;
   const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
+  // numerator fold: thread u (and u + kNT2) owns the u-th distinct pdf of the sequence; the set of
+  // touched pdfs is the same in every frame, so n2 needs no clearing between pairs
+  const bool fold = a.fold_rows != nullptr;
+  const float nscale = a.grad_scale_dev ? a.fold_scale * *a.grad_scale_dev : a.fold_scale;
+  const int U = fold ? a.fold_ucount[b] : 0;
+  const int32_t* upd = a.fold_upd + (size_t)b * a.fold_K;
+  const float* frows = a.fold_rows + (size_t)b * T * a.fold_K;
+  int pd0 = -1, pd1 = -1;
+  if (fold) {
+    for (int i = tid; i < 4 * Dp; i += kNT2) n2[i] = 0.f;
+    if (tid < U) pd0 = upd[tid];
+    if (tid + kNT2 < U) pd1 = upd[tid + kNT2];
+  }
 
   // state rows of a pair: global -> registers (one pair ahead) -> LDS, interleaved
   float4 ua[UVC], ub[UVC], va[UVC], vb[UVC];
@@ -916,6 +930,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   GAMMA2_COMMIT();
   __syncthreads();
   XRow<kNT2, 4, XCH> x0, x1;
+  int npar = 0;
   while (t0 < t_live_end) {
     const bool valid0 = den_frame_in_launch(t0, t_live_end, L, a), valid1 = den_frame_in_launch(t0 + 1, t_live_end, L, a);
     int tn = t0 + 2;
@@ -927,10 +942,22 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
 #ifndef PYCHAIN_EXPG_NO_LOAD
     if (have_next) GAMMA2_PREFETCH(tn);
 #endif
+    float r00 = 0.f, r01 = 0.f, r10 = 0.f, r11 = 0.f;  // numerator rows of this pair (in flight during the arc work)
+    const float* fr0 = frows + (size_t)t0 * a.fold_K;
+    const float* fr1 = frows + (size_t)min(t0 + 1, T - 1) * a.fold_K;
+    if (pd0 >= 0) { r00 = fr0[tid]; r10 = fr1[tid]; }
+    if (pd1 >= 0) { r01 = fr0[tid + kNT2]; r11 = fr1[tid + kNT2]; }
 #ifndef PYCHAIN_EXPG_NO_ARCS
     tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap);
 #endif
-    __syncthreads();                                   // q2 complete; every gather of this pair is done
+    float* n2p = n2 + (npar ? 2 * Dp : 0);             // this buffer was last read two pairs ago
+    if (fold) {
+      if (pd0 >= 0) *reinterpret_cast<v2f*>(n2p + 2 * pd0) = v2f{r00, r10};
+      if (pd1 >= 0) *reinterpret_cast<v2f*>(n2p + 2 * pd1) = v2f{r01, r11};
+      for (int u = tid + 2 * kNT2; u < U; u += kNT2) *reinterpret_cast<v2f*>(n2p + 2 * upd[u]) = v2f{fr0[u], fr1[u]};
+    }
+    npar ^= 1;
+    __syncthreads();                                   // q2 (and n2) complete; every gather of this pair is done
     float g0[4 * XCH], g1[4 * XCH];
     float part0 = 0.f, part1 = 0.f;
 #pragma unroll
@@ -939,6 +966,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
       if (e < D) { qa = *reinterpret_cast<const float4*>(q2 + 2 * e); qb = *reinterpret_cast<const float4*>(q2 + 2 * e + 4); }
       const float qf0[4] = {qa.x, qa.z, qb.x, qb.z}, qf1[4] = {qa.y, qa.w, qb.y, qb.w};
+
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         g0[c * 4 + k] = e < D ? clamp_exp(x0.v[c * 4 + k], a.input_is_exp) * qf0[k] : 0.f;
@@ -966,8 +994,16 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
 #else
       if (e < D) {
 #endif
-        if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(g0[c * 4] * sc0, g0[c * 4 + 1] * sc0, g0[c * 4 + 2] * sc0, g0[c * 4 + 3] * sc0);
-        if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(g1[c * 4] * sc1, g1[c * 4 + 1] * sc1, g1[c * 4 + 2] * sc1, g1[c * 4 + 3] * sc1);
+        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;     // numerator occupancies {f0,f1} x 4 pdfs
+        if (fold) { na = *reinterpret_cast<const float4*>(n2p + 2 * e); nb = *reinterpret_cast<const float4*>(n2p + 2 * e + 4); }
+        // (g * sc) rounded, then + numerator: bit-identical to the unfused order (occupancy pass, then
+        // the numerator accumulated into the stored gradient)
+#define G2(gv, scv, nv) __fadd_rn(__fmul_rn((gv), (scv)), __fmul_rn((nv), nscale))
+        if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(G2(g0[c * 4], sc0, na.x), G2(g0[c * 4 + 1], sc0, na.z),
+                                                                           G2(g0[c * 4 + 2], sc0, nb.x), G2(g0[c * 4 + 3], sc0, nb.z));
+        if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(G2(g1[c * 4], sc1, na.y), G2(g1[c * 4 + 1], sc1, na.w),
+                                                                           G2(g1[c * 4 + 2], sc1, nb.y), G2(g1[c * 4 + 3], sc1, nb.w));
+#undef G2
       }
     }
     t0 = tn;
@@ -988,7 +1024,7 @@ hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream
 
 // the two-frame occupancy kernel: what it supports, and its launch
 inline size_t gamma2_lds_bytes(const DenArgs& a, int gamma_max_groups) {
-  return sizeof(float) * (4 * (size_t)a.Hp + 2 * (size_t)((a.D + 3) & ~3) + (size_t)gamma_max_groups * 64 + 32);
+  return sizeof(float) * (4 * (size_t)a.Hp + (a.fold_rows ? 6 : 2) * (size_t)((a.D + 3) & ~3) + (size_t)gamma_max_groups * 64 + 32);
 }
 inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
   static const bool off = getenv("PYCHAIN_GAMMA16") != nullptr;        // tuning / test knob: force the one-frame kernel
@@ -1044,6 +1080,10 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
 }
 
 }  // namespace
+
+bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 1023, gamma_max_groups);
+}
 
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,
                       const char** why) {

@@ -17,20 +17,27 @@ struct NumArgs {
   float* grad;               // [B,T,D]
   int32_t* bad;              // [1]
   double* alpha_ws;          // [B,T+1,H]  alpha(t,h): unnormalised log-probabilities (fp64)
-  float* occ_ws;             // [B,T,K]    occupancy of every forward arc at every frame
+  double* beta_ws;           // [B,T+1,H]  beta(t,h)
+  double* logp_ws;           // [B]        sequence log-probability (fp64)
+  float* rows_ws;            // [B,T,K]    compact rows: occupancy of the u-th distinct pdf of the sequence
+  int32_t* upd_ws;           // [B,K]      the distinct pdf-ids of a sequence's arcs, ascending
+  int32_t* ucount_ws;        // [B]        how many
   int graph_stride;          // 1 = per-sequence graphs, 0 = shared
   int B, T, D, H, K;
   int grad_mode;
-  int frames_per_block;      // emit kernel
+  int frames_per_block;      // occupancy kernel
   float grad_scale;
   const float* grad_scale_dev;   // optional device scalar multiplied into grad_scale
 };
 
 size_t num_fb_lds_bytes(int H, int K, int D);
-// forward-backward recursion (launch 1): reads x + graphs, writes objf, alpha_ws, occ_ws
+// forward and backward recursions (launch 1, 2B workgroups): reads x + graphs, writes objf, logp_ws, alpha_ws, beta_ws
 hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why);
-// occupancies -> gradient rows (launch 2): reads occ_ws, writes/accumulates grad
-hipError_t launch_num_emit(const NumArgs& a, hipStream_t st, const char** why);
+// distinct pdf-ids per sequence (upd_ws, ucount_ws): needed before a compact occupancy launch
+hipError_t launch_num_prep(const NumArgs& a, hipStream_t st, const char** why);
+// occupancies -> gradient rows (launch 2): reads alpha_ws, beta_ws, logp_ws, x; writes/accumulates grad
+// (grad_mode) or, with `compact`, rows_ws
+hipError_t launch_num_occ(const NumArgs& a, bool compact, hipStream_t st, const char** why);
 
 }  // namespace pychain_hip
 #endif

@@ -3,21 +3,24 @@
 // reference; shares no structure with them (the reference launches one kernel per
 // frame with one thread per (sequence, state) and CAS-loop atomicLogAdd).
 //
-//   launch 1  num_fb_kernel    one persistent workgroup per sequence walks alpha forward and
-//             beta backward in time inside the kernel: one state per thread, the utterance's
-//             small graph cached in LDS/registers, ONE barrier per frame.  Log-probabilities
-//             are carried in float64 WITHOUT per-frame renormalisation (the reference
-//             renormalises fp32 values each frame, chain-log-domain-computation.cc:150-158;
-//             in fp64 the raw log-probabilities - a few 1e4 in magnitude at T=1500 - keep
-//             ~1e-12 absolute accuracy, so no block reduction sits on the sequential path).
-//             exp/log act on small differences and run on the fp32 transcendental unit.
-//             Output: per-arc occupancies occ[b,t,k] (fp32, linear domain) and the
-//             sequence log-probability.  At T=1500 this is ~1e-5 from the fp64 evaluation of
-//             the reference's equations, where the reference's own fp32 recursion is ~2e-4.
-//   launch 2  num_emit_kernel  time-parallel: merges the per-arc occupancies of a frame by
-//             pdf-id (64-bit fixed point in LDS: order-independent, hence deterministic) and
-//             writes the gradient in the requested form: log (reference contract, -inf
-//             where zero), linear, or accumulated into an existing dense gradient.
+//   launch 1  num_fb_kernel    2B persistent workgroups, one per (sequence, direction): block b
+//             walks alpha forward in time, block B+b walks beta backward, CONCURRENTLY - the
+//             log-probabilities are carried in float64 WITHOUT per-frame renormalisation (the
+//             reference renormalises fp32 values each frame, chain-log-domain-computation.cc:
+//             150-158; in fp64 the raw log-probabilities - a few 1e4 in magnitude at T=1500 -
+//             keep ~1e-12 absolute accuracy), so neither direction needs the other's
+//             normaliser and no block reduction sits on the sequential path.  One state per
+//             thread, the utterance's small graph cached in LDS/registers, ONE barrier per
+//             frame; exp/log act on small differences and run on the fp32 transcendental unit.
+//             Output: every alpha(t,.) and beta(t,.) row (fp64) and the sequence log-probability.
+//   launch 2  num_occ_kernel   time-parallel over (sequence, frame chunk): occupancy of every
+//             arc  exp(alpha(t,src) + lp + x(t,pdf) + beta(t+1,dst) - logP), merged by pdf-id
+//             in 64-bit fixed point in LDS (order-independent, hence deterministic), written
+//             in the requested form: log (reference contract, -inf where zero), linear,
+//             accumulated into an existing dense gradient, or as compact rows over the
+//             sequence's distinct pdf-ids (what the fused ChainLoss folds into the
+//             denominator's occupancy pass).  At T=1500 the result is ~1e-5 from the fp64
+//             evaluation of the reference's equations; the reference's own fp32 recursion ~2e-4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,7 +33,7 @@ namespace {
 
 constexpr int kFbNT = 512;                 // num_fb_kernel: one state per thread up to 512 states
 constexpr int kFbNW = kFbNT / 64;
-constexpr int kEmNT = 256;                 // num_emit_kernel
+constexpr int kOcNT = 256;                 // num_occ_kernel, num_prep_kernel
 constexpr float kFixScale = 72057594037927936.0f;          // 2^56
 constexpr float kFixInv = 1.0f / 72057594037927936.0f;
 constexpr float kLog2e = 1.44269504088896340736f;
@@ -64,12 +67,13 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
+  const bool fwd = blockIdx.x < (unsigned)a.B;
+  const int b = fwd ? blockIdx.x : blockIdx.x - a.B;
   const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
   const int H = a.H, K = a.K, D = a.D, T = a.T, Dp = (D + 3) & ~3;
   const size_t g = (size_t)b * a.graph_stride;
 
-  // ---- LDS: state vectors (fp64, ping-pong), nnet-output rows (ping-pong), arcs, reductions
+  // ---- LDS: state vectors (fp64, ping-pong), nnet-output rows (ping-pong), this direction's arcs
   char* p = smem_raw;
   const int Hq = (H + 1) & ~1;
   double* va = reinterpret_cast<double*>(p); p += 8 * (size_t)Hq;
@@ -78,83 +82,82 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
   float* redf = reinterpret_cast<float*>(p); p += 4 * 16;
   float* xr0 = reinterpret_cast<float*>(p); p += 4 * (size_t)Dp;
   float* xr1 = reinterpret_cast<float*>(p); p += 4 * (size_t)Dp;
-  ArcW* in_arc = reinterpret_cast<ArcW*>(p); p += 8 * (size_t)K;      // by destination: (src, pdf, lp)
-  ArcW* out_arc = reinterpret_cast<ArcW*>(p); p += 8 * (size_t)K;     // by source:      (dst, pdf, lp)
+  ArcW* arc = reinterpret_cast<ArcW*>(p); p += 8 * (size_t)K;   // fwd: by destination (src, pdf, lp); bwd: by source (dst, pdf, lp)
   {
-    const int32_t* bt = a.bwd_trans + g * K * 3; const int32_t* ft = a.fwd_trans + g * K * 3;
-    const float* bp = a.bwd_probs + g * K; const float* fp = a.fwd_probs + g * K;
-    for (int k = tid; k < K; k += kFbNT) {
-      in_arc[k] = ArcW{(uint32_t)bt[3 * k] | ((uint32_t)bt[3 * k + 2] << 16), bp[k]};
-      out_arc[k] = ArcW{(uint32_t)ft[3 * k + 1] | ((uint32_t)ft[3 * k + 2] << 16), fp[k]};
-    }
+    const int32_t* tr = (fwd ? a.bwd_trans : a.fwd_trans) + g * K * 3;
+    const float* pr = (fwd ? a.bwd_probs : a.fwd_probs) + g * K;
+    for (int k = tid; k < K; k += kFbNT)
+      arc[k] = ArcW{(uint32_t)tr[3 * k + (fwd ? 0 : 1)] | ((uint32_t)tr[3 * k + 2] << 16), pr[k]};
   }
   const float* xseq = a.x + (size_t)b * T * D;
-  double* aws = a.alpha_ws + (size_t)b * (T + 1) * H;     // alpha(t,h), t = 0..L  (fp64 log-prob)
-  float* occ = a.occ_ws + (size_t)b * T * K;              // occ(t,k) per forward arc
-  const int2* bi = reinterpret_cast<const int2*>(a.bwd_idx + g * H * 2);
-  const int2* fi = reinterpret_cast<const int2*>(a.fwd_idx + g * H * 2);
+  double* rows = (fwd ? a.alpha_ws : a.beta_ws) + (size_t)b * (T + 1) * H;     // row t = alpha(t,.) / beta(t,.), fp64 log-prob
+  const int2* idx = reinterpret_cast<const int2*>((fwd ? a.bwd_idx : a.fwd_idx) + g * H * 2);
 
   // this thread's state(s): h = tid (+ kFbNT, ... for graphs with more than 512 states)
   const int h0 = tid;
   const bool own = h0 < H;
-  int2 ibe = make_int2(0, 0), obe = make_int2(0, 0);
-  float fin0 = -INFINITY;
-  if (own) { ibe = bi[h0]; obe = fi[h0]; fin0 = a.final_[g * H + h0]; }
+  int2 be = make_int2(0, 0);
+  if (own) be = idx[h0];
   XRow<kFbNT, VEC, XCH> xq;
-  xq.load(xseq, D, tid);
-  // AlphaFirstFrame, chain-log-domain-computation.cc:84-90
-  for (int h = tid; h < H; h += kFbNT) { const double v = (double)a.initial[g * H + h]; va[h] = v; aws[h] = v; }
-  xq.store(xr0, xseq, D, tid, kXClamp);
+  {
+    const float* xrow = xseq + (size_t)(fwd ? 0 : L - 1) * D;
+    xq.load(xrow, D, tid);
+    // AlphaFirstFrame :84-90 / BetaLastFrame :192-202 (unnormalised: beta(L,i) = final(i); 1/P enters the occupancy)
+    for (int h = tid; h < H; h += kFbNT) {
+      const double v = (double)(fwd ? a.initial : a.final_)[g * H + h];
+      va[h] = v; rows[(size_t)(fwd ? 0 : L) * H + h] = v;
+    }
+    xq.store(xr0, xrow, D, tid, kXClamp);
+  }
   __syncthreads();
   // first two arcs of this thread's state in registers (the common left-to-right case needs no more)
-  ArcW i0{0u, -INFINITY}, i1{0u, -INFINITY}, o0{0u, -INFINITY}, o1{0u, -INFINITY};
+  ArcW w0{0u, -INFINITY}, w1{0u, -INFINITY};
   if (own) {
-    if (ibe.y - ibe.x > 0) i0 = in_arc[ibe.x];
-    if (ibe.y - ibe.x > 1) i1 = in_arc[ibe.x + 1];
-    if (obe.y - obe.x > 0) o0 = out_arc[obe.x];
-    if (obe.y - obe.x > 1) o1 = out_arc[obe.x + 1];
+    if (be.y - be.x > 0) w0 = arc[be.x];
+    if (be.y - be.x > 1) w1 = arc[be.x + 1];
   }
 
-  // ---- forward: alpha(t,h) = LogSum_k alpha(t-1,src_k) + lp_k + x(t-1,pdf_k)   (:93-159, unnormalised)
-  for (int t = 1; t <= L; t++) {
-    const double* vin = (t & 1) ? va : vb;
-    double* vout = (t & 1) ? vb : va;
-    const float* xcur = (t & 1) ? xr0 : xr1;        // row t-1
-    float* xnext = (t & 1) ? xr1 : xr0;
-    const bool have_next = t < L;
-    const float* xrow_next = xseq + (size_t)(have_next ? t : 0) * D;
+  // fwd: alpha(t,h) = LogSum_k alpha(t-1,src_k) + lp_k + x(t-1,pdf_k), t = 1..L     (:93-159, unnormalised)
+  // bwd: beta(t,h)  = LogSum_k lp_k + beta(t+1,dst_k) + x(t,pdf_k),    t = L-1..0   (:204-271, unnormalised)
+  for (int s = 1; s <= L; s++) {
+    const double* vin = (s & 1) ? va : vb;
+    double* vout = (s & 1) ? vb : va;
+    const float* xcur = (s & 1) ? xr0 : xr1;
+    float* xnext = (s & 1) ? xr1 : xr0;
+    const bool have_next = s < L;
+    const float* xrow_next = xseq + (size_t)(have_next ? (fwd ? s : L - 1 - s) : 0) * D;
+    const size_t trow = (size_t)(fwd ? s : L - s) * H;
     if (have_next) xq.load(xrow_next, D, tid);
     if (own) {
       Lse acc; acc.init();
-      const double e0 = vin[i0.pk & 0xffffu] + ((double)i0.lp + (double)xcur[i0.pk >> 16]);
-      const double e1 = vin[i1.pk & 0xffffu] + ((double)i1.lp + (double)xcur[i1.pk >> 16]);
-      acc.push(e0); acc.push(e1);
-      for (int k = ibe.x + 2; k < ibe.y; k++) {
-        const ArcW w = in_arc[k];
+      acc.push(vin[w0.pk & 0xffffu] + ((double)w0.lp + (double)xcur[w0.pk >> 16]));
+      acc.push(vin[w1.pk & 0xffffu] + ((double)w1.lp + (double)xcur[w1.pk >> 16]));
+      for (int k = be.x + 2; k < be.y; k++) {
+        const ArcW w = arc[k];
         acc.push(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]));
       }
       const double v = acc.value();
       vout[h0] = v;
-      aws[(size_t)t * H + h0] = v;
+      rows[trow + h0] = v;
     }
     for (int h = h0 + kFbNT; h < H; h += kFbNT) {             // graphs with more than 512 states
-      const int2 be = bi[h];
+      const int2 e2 = idx[h];
       Lse acc; acc.init();
-      for (int k = be.x; k < be.y; k++) {
-        const ArcW w = in_arc[k];
+      for (int k = e2.x; k < e2.y; k++) {
+        const ArcW w = arc[k];
         acc.push(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]));
       }
       const double v = acc.value();
       vout[h] = v;
-      aws[(size_t)t * H + h] = v;
+      rows[trow + h] = v;
     }
     if (have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
     __syncthreads();
   }
+  if (!fwd) return;
 
   // ---- total log-probability: LogSum_i alpha(L,i) + final(i)   (ComputeTotLogLike :170-190)
   const double* vL = (L & 1) ? vb : va;
-  double* bnext = (L & 1) ? va : vb;        // beta(L) goes to the buffer alpha(L) does not occupy
   double mx = -INFINITY;
   for (int h = tid; h < H; h += kFbNT) mx = fmax(mx, vL[h] + (double)a.final_[g * H + h]);
   mx = wave_max(mx);
@@ -176,74 +179,58 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
   if (tid == 0) {
     const float objf = (float)logp;
     a.objf[b] = objf;
+    a.logp_ws[b] = logp;
     if (!(objf - objf == 0.f)) atomicAdd(a.bad, 1);
-  }
-  // BetaLastFrame :192-202 (unnormalised: beta(L,i) = final(i); the 1/P factor enters the occupancy)
-  for (int h = tid; h < H; h += kFbNT) bnext[h] = (double)a.final_[g * H + h];
-  {
-    const float* xrow = xseq + (size_t)(L - 1) * D;
-    xq.load(xrow, D, tid);
-    xq.store(xr0, xrow, D, tid, kXClamp);
-  }
-  double a_cur = own ? aws[(size_t)(L - 1) * H + h0] : 0.0;   // alpha(t,h0): written by this very thread
-  __syncthreads();
-
-  // ---- backward: beta(t,h) = LogSum_k lp_k + beta(t+1,dst_k) + x(t,pdf_k);  occ = exp(alpha + term - logP)
-  double* bcur = (L & 1) ? vb : va;
-  int step = 0;
-  for (int t = L - 1; t >= 0; t--, step++) {
-    const float* xcur = (step & 1) ? xr1 : xr0;
-    float* xnext = (step & 1) ? xr0 : xr1;
-    const bool have_next = t > 0;
-    const float* xrow_next = xseq + (size_t)(have_next ? t - 1 : 0) * D;
-    if (have_next) xq.load(xrow_next, D, tid);
-    double a_next = 0.0;
-    if (have_next && own) a_next = aws[(size_t)(t - 1) * H + h0];
-    float* orow = occ + (size_t)t * K;
-    if (own) {
-      Lse acc; acc.init();
-      const double base = a_cur - logp;
-      const double e0 = bnext[o0.pk & 0xffffu] + ((double)o0.lp + (double)xcur[o0.pk >> 16]);
-      const double e1 = bnext[o1.pk & 0xffffu] + ((double)o1.lp + (double)xcur[o1.pk >> 16]);
-      acc.push(e0); acc.push(e1);
-      if (obe.y - obe.x > 0) orow[obe.x] = fexp((float)(base + e0));
-      if (obe.y - obe.x > 1) orow[obe.x + 1] = fexp((float)(base + e1));
-      for (int k = obe.x + 2; k < obe.y; k++) {
-        const ArcW w = out_arc[k];
-        const double e = bnext[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]);
-        acc.push(e);
-        orow[k] = fexp((float)(base + e));
-      }
-      bcur[h0] = acc.value();
-    }
-    for (int h = h0 + kFbNT; h < H; h += kFbNT) {
-      const int2 be = fi[h];
-      const double base = aws[(size_t)t * H + h] - logp;
-      Lse acc; acc.init();
-      for (int k = be.x; k < be.y; k++) {
-        const ArcW w = out_arc[k];
-        const double e = bnext[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]);
-        acc.push(e);
-        orow[k] = fexp((float)(base + e));
-      }
-      bcur[h] = acc.value();
-    }
-    if (have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
-    a_cur = a_next;
-    __syncthreads();
-    double* tmp = bnext; bnext = bcur; bcur = tmp;
   }
 }
 
 // ------------------------------------------------------------------------------------
-// launch 2: per-arc occupancies -> gradient rows (time-parallel)
+// the distinct pdf-ids of every sequence's numerator graph, ascending: upd[b][u], ucount[b]
+// (compact rows are indexed by u).  One workgroup per sequence, once per call.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kEmNT) void num_emit_kernel(const NumArgs a) {
+__global__ __launch_bounds__(kOcNT) void num_prep_kernel(const NumArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int K = a.K, D = a.D;
+  int* used = reinterpret_cast<int*>(smem_raw);          // [D]  1 = some arc emits this pdf
+  int* s_misc = used + D;                                // [0] = used arcs, [1..] scan scratch
+  const size_t g = (size_t)b * a.graph_stride;
+  const int32_t* ft = a.fwd_trans + g * K * 3;
+  const int2* fi = reinterpret_cast<const int2*>(a.fwd_idx + g * a.H * 2);
+  int kmax = 0;
+  for (int h = tid; h < a.H; h += kOcNT) kmax = max(kmax, fi[h].y);
+  if (tid == 0) s_misc[0] = 0;
+  for (int n = tid; n < D; n += kOcNT) used[n] = 0;
+  __syncthreads();
+  atomicMax(&s_misc[0], kmax);
+  __syncthreads();
+  const int Kused = s_misc[0];
+  for (int k = tid; k < Kused; k += kOcNT) used[ft[3 * k + 2]] = 1;
+  __syncthreads();
+  // exclusive scan of `used` in chunks of kOcNT consecutive pdfs per thread
+  const int per = (D + kOcNT - 1) / kOcNT;
+  int cnt = 0;
+  for (int n = tid * per; n < min(D, (tid + 1) * per); n++) cnt += used[n];
+  int* scan = s_misc + 4;
+  scan[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) { int run = 0; for (int i = 0; i < kOcNT; i++) { const int c = scan[i]; scan[i] = run; run += c; } a.ucount_ws[b] = run; }
+  __syncthreads();
+  int u = scan[tid];
+  int32_t* upd = a.upd_ws + (size_t)b * K;
+  for (int n = tid * per; n < min(D, (tid + 1) * per); n++) if (used[n]) upd[u++] = n;
+}
+
+// ------------------------------------------------------------------------------------
+// launch 2: occupancies from the stored alpha / beta rows -> gradient rows (time-parallel)
+// ------------------------------------------------------------------------------------
+constexpr int kGradCompact = 3;            // internal mode: rows_ws[b,t,u] = occupancy of the u-th distinct pdf
+__global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int L = (int)a.lengths[b];
-  const int K = a.K, D = a.D, T = a.T, Dp = (D + 3) & ~3;
+  const int K = a.K, D = a.D, T = a.T, H = a.H, Dp = (D + 3) & ~3;
   const int t_begin = blockIdx.x * a.frames_per_block;
   const int t_end = min(t_begin + a.frames_per_block, T);
   float* gseq = a.grad + (size_t)b * T * D;
@@ -252,31 +239,52 @@ __global__ __launch_bounds__(kEmNT) void num_emit_kernel(const NumArgs a) {
   const float fill = mode == PYCHAIN_HIP_GRAD_LOG ? -INFINITY : 0.f;
   const int t_live_end = min(t_end, L);
   if (t_begin < L) {
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);   // [Dp]
-    int* s_kmax_p = reinterpret_cast<int*>(acc + Dp);                              // [4] (all LDS dynamic: base stays 16-B aligned)
-    uint16_t* pdf = reinterpret_cast<uint16_t*>(s_kmax_p + 4);                     // [K]
+    char* p = smem_raw;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(p); p += 8 * (size_t)Dp;     // [Dp]
+    double* arow = reinterpret_cast<double*>(p); p += 8 * (size_t)((H + 1) & ~1);                  // alpha(t,.)
+    double* brow = reinterpret_cast<double*>(p); p += 8 * (size_t)((H + 1) & ~1);                  // beta(t+1,.)
+    int* s_kmax_p = reinterpret_cast<int*>(p); p += 16;
+    uint32_t* sd = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)K;                             // src | dst << 16
+    float* lp = reinterpret_cast<float*>(p); p += 4 * (size_t)K;
+    uint16_t* pdf = reinterpret_cast<uint16_t*>(p);                                                // [K]
     const size_t g = (size_t)b * a.graph_stride;
     const int32_t* ft = a.fwd_trans + g * K * 3;
-    const int2* fi = reinterpret_cast<const int2*>(a.fwd_idx + g * a.H * 2);
+    const float* fp = a.fwd_probs + g * K;
+    const int2* fi = reinterpret_cast<const int2*>(a.fwd_idx + g * H * 2);
     // arcs that no state indexes (batch padding, pychain/graph.py:132-139) carry no occupancy
     int kmax = 0;
-    for (int h = tid; h < a.H; h += kEmNT) kmax = max(kmax, fi[h].y);
+    for (int h = tid; h < H; h += kOcNT) kmax = max(kmax, fi[h].y);
     if (tid == 0) *s_kmax_p = 0;
     __syncthreads();
     atomicMax(s_kmax_p, kmax);
-    for (int n = tid; n < Dp; n += kEmNT) acc[n] = 0ull;
-    for (int k = tid; k < K; k += kEmNT) pdf[k] = (uint16_t)ft[3 * k + 2];
+    for (int n = tid; n < Dp; n += kOcNT) acc[n] = 0ull;
+    for (int k = tid; k < K; k += kOcNT) {
+      sd[k] = (uint32_t)ft[3 * k] | ((uint32_t)ft[3 * k + 1] << 16);
+      pdf[k] = (uint16_t)ft[3 * k + 2];
+      lp[k] = fp[k];
+    }
     __syncthreads();
     const int Kused = *s_kmax_p;
-    const float* occ = a.occ_ws + (size_t)b * T * K;
+    const double logp = a.logp_ws[b];
+    const double* aws = a.alpha_ws + (size_t)b * (T + 1) * H;
+    const double* bws = a.beta_ws + (size_t)b * (T + 1) * H;
+    const float* xseq = a.x + (size_t)b * T * D;
+    const int U = mode == kGradCompact ? a.ucount_ws[b] : 0;
+    const int32_t* upd = a.upd_ws + (size_t)b * K;
     int bad = 0;
     for (int t = t_begin; t < t_live_end; t++) {
-      const float* orow = occ + (size_t)t * K;
+      for (int h = tid; h < H; h += kOcNT) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)(t + 1) * H + h]; }
+      __syncthreads();
+      const float* xrow = xseq + (size_t)t * D;
       float* grow = gseq + (size_t)t * D;
-      for (int k = tid; k < Kused; k += kEmNT) {
-        const float v = orow[k];
+      for (int k = tid; k < Kused; k += kOcNT) {
+        const uint32_t w = sd[k];
+        const int n = pdf[k];
+        const float xv = __builtin_amdgcn_fmed3f(xrow[n], -30.f, 30.f);
+        // BetaGeneralFrame :204-271: occupancy = exp(alpha(t,src) + lp + x(t,pdf) + beta(t+1,dst) - logP)
+        const float v = fexp((float)((arow[w & 0xffffu] + brow[w >> 16] - logp) + ((double)lp[k] + (double)xv)));
         if (v > 0.f) {
-          if (v <= 2.f) atomicAdd(&acc[pdf[k]], (unsigned long long)(v * kFixScale));
+          if (v <= 2.f) atomicAdd(&acc[n], (unsigned long long)(v * kFixScale));
           else bad = 1;
         } else if (v != 0.f) {
           bad = 1;                                  // NaN
@@ -284,13 +292,21 @@ __global__ __launch_bounds__(kEmNT) void num_emit_kernel(const NumArgs a) {
       }
       __syncthreads();
       if (mode == PYCHAIN_HIP_GRAD_ACCUM) {
-        for (int k = tid; k < Kused; k += kEmNT) {
+        for (int k = tid; k < Kused; k += kOcNT) {
           const int n = pdf[k];
           const unsigned long long u = atomicExch(&acc[n], 0ull);   // exactly one arc per pdf sees the merged sum
-          if (u) grow[n] += gscale * ((float)u * kFixInv);
+          if (u) grow[n] = __fadd_rn(grow[n], __fmul_rn(gscale, __fmul_rn((float)u, kFixInv)));   // (no fma: same bits as the folded form)
+        }
+      } else if (mode == kGradCompact) {
+        float* crow = a.rows_ws + ((size_t)b * T + t) * K;
+        for (int u = tid; u < U; u += kOcNT) {
+          const int n = upd[u];
+          const unsigned long long v = acc[n];
+          if (v) acc[n] = 0ull;
+          crow[u] = __fmul_rn((float)v, kFixInv);
         }
       } else {
-        for (int n = tid; n < D; n += kEmNT) {
+        for (int n = tid; n < D; n += kOcNT) {
           const unsigned long long u = acc[n];
           if (u) acc[n] = 0ull;
           const float v = (float)u * kFixInv;
@@ -301,10 +317,10 @@ __global__ __launch_bounds__(kEmNT) void num_emit_kernel(const NumArgs a) {
     }
     if (bad) atomicAdd(a.bad, 1);
   }
-  // padded frames: -inf (full_like(-inf), :57) / zero; ACCUM leaves them alone
-  if (mode != PYCHAIN_HIP_GRAD_ACCUM) {
+  // padded frames: -inf (full_like(-inf), :57) / zero; ACCUM and the compact rows leave them alone
+  if (mode == PYCHAIN_HIP_GRAD_LOG || mode == PYCHAIN_HIP_GRAD_LINEAR) {
     const int t0 = max(t_begin, t_live_end);
-    for (size_t i = (size_t)t0 * D + tid; i < (size_t)t_end * D; i += kEmNT) gseq[i] = fill;
+    for (size_t i = (size_t)t0 * D + tid; i < (size_t)t_end * D; i += kOcNT) gseq[i] = fill;
   }
 }
 
@@ -313,7 +329,7 @@ hipError_t launch_fb(const NumArgs& a, size_t lds, hipStream_t st) {
   auto k = num_fb_kernel<VEC, XCH>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(a.B), dim3(kFbNT), lds, st, a);
+  hipLaunchKernelGGL(k, dim3(2 * a.B), dim3(kFbNT), lds, st, a);
   return hipGetLastError();
 }
 
@@ -321,11 +337,11 @@ hipError_t launch_fb(const NumArgs& a, size_t lds, hipStream_t st) {
 
 size_t num_fb_lds_bytes(int H, int K, int D) {
   const size_t Dp = (D + 3) & ~3, Hq = (H + 1) & ~1;
-  return 16 * Hq + 8 * 16 + 4 * 16 + 8 * Dp + 16 * (size_t)K + 64;
+  return 16 * Hq + 8 * 16 + 4 * 16 + 8 * Dp + 8 * (size_t)K + 64;
 }
-size_t num_emit_lds_bytes(int K, int D) {
-  const size_t Dp = (D + 3) & ~3;
-  return 8 * Dp + 16 + 2 * (size_t)K + 64;
+size_t num_occ_lds_bytes(int H, int K, int D) {
+  const size_t Dp = (D + 3) & ~3, Hq = (H + 1) & ~1;
+  return 8 * Dp + 16 * Hq + 16 + 10 * (size_t)K + 64;
 }
 
 hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
@@ -344,17 +360,29 @@ hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
   return launch_fb<1, 0>(a, lds, st);
 }
 
-hipError_t launch_num_emit(const NumArgs& a, hipStream_t st, const char** why) {
-  const size_t lds = num_emit_lds_bytes(a.K, a.D);
-  if (lds > 160 * 1024) {
-    *why = "pdf accumulators do not fit the 160 KiB LDS of one CU";
-    return hipErrorInvalidValue;
-  }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(num_emit_kernel),
+hipError_t launch_num_prep(const NumArgs& a, hipStream_t st, const char** why) {
+  const size_t lds = 4 * (size_t)a.D + 16 + 4 * kOcNT + 64;
+  if (lds > 160 * 1024) { *why = "pdf table does not fit the 160 KiB LDS of one CU"; return hipErrorInvalidValue; }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(num_prep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(num_prep_kernel, dim3(a.B), dim3(kOcNT), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_num_occ(const NumArgs& a, bool compact, hipStream_t st, const char** why) {
+  const size_t lds = num_occ_lds_bytes(a.H, a.K, a.D);
+  if (lds > 160 * 1024) {
+    *why = "pdf accumulators + numerator graph do not fit the 160 KiB LDS of one CU";
+    return hipErrorInvalidValue;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(num_occ_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  NumArgs b = a;
+  if (compact) b.grad_mode = kGradCompact;
   const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
-  hipLaunchKernelGGL(num_emit_kernel, dim3(gx, a.B), dim3(kEmNT), lds, st, a);
+  hipLaunchKernelGGL(num_occ_kernel, dim3(gx, a.B), dim3(kOcNT), lds, st, b);
   return hipGetLastError();
 }
 

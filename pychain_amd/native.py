@@ -208,6 +208,7 @@ def chain_loss_backward(st, grad_scale=1.0, grad_scale_dev=None):
         _lib.check(L.pychain_hip_chain_loss_backward(
             st.plan.blob.data_ptr(), st.plan.stride, st.plan.slot_rows, st.plan.num_states,
             st.gt["forward_transitions"].data_ptr(), st.gt["forward_transition_indices"].data_ptr(),
+            st.gt["forward_transition_probs"].data_ptr(),
             st.graph_stride, st.num_states_num, K, st.x.data_ptr(), st.lengths_dev.data_ptr(), B, T, D,
             float(grad_scale), sptr, grad.data_ptr(), bad.data_ptr(),
             st.den_ws.data_ptr(), st.den_ws.numel(), st.num_ws.data_ptr(), st.num_ws.numel(), _stream(dev)),
