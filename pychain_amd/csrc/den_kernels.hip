@@ -998,7 +998,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
         if (fold) { na = *reinterpret_cast<const float4*>(n2p + 2 * e); nb = *reinterpret_cast<const float4*>(n2p + 2 * e + 4); }
         // (g * sc) rounded, then + numerator: bit-identical to the unfused order (occupancy pass, then
         // the numerator accumulated into the stored gradient)
-#define G2(gv, scv, nv) __fadd_rn(__fmul_rn((gv), (scv)), __fmul_rn((nv), nscale))
+#define G2(gv, scv, nv) mul_add_mul_rn((gv), (scv), (nv), nscale)
         if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(G2(g0[c * 4], sc0, na.x), G2(g0[c * 4 + 1], sc0, na.z),
                                                                            G2(g0[c * 4 + 2], sc0, nb.x), G2(g0[c * 4 + 3], sc0, nb.z));
         if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(G2(g1[c * 4], sc1, na.y), G2(g1[c * 4 + 1], sc1, na.w),

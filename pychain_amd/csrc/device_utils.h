@@ -62,6 +62,21 @@ __device__ __forceinline__ float clamp_exp(float v, int mode) {
   return mode == kXClamp ? c : exp_bounded(c);
 }
 
+// a*b + c*d and a*b + c with every product ROUNDED before the sum (no fma contraction: HIP compiles
+// with -ffp-contract=fast and __fmul_rn/__fadd_rn are plain operators there).  Used where two code
+// paths must produce the same bits (gradient written once vs. written, then accumulated into).
+__device__ __forceinline__ float mul_add_mul_rn(float a, float b, float c, float d) {
+#pragma clang fp contract(off)
+  const float p = a * b;
+  const float q = c * d;
+  return p + q;
+}
+__device__ __forceinline__ float mul_add_rn(float a, float b, float c) {
+#pragma clang fp contract(off)
+  const float p = a * b;
+  return p + c;
+}
+
 // ---- nnet-output row: global -> registers (early) -> LDS (late) ------------------
 template <int NT, int VEC, int XCH>
 struct XRow {

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
         for (int k = tid; k < Kused; k += kOcNT) {
           const int n = pdf[k];
           const unsigned long long u = atomicExch(&acc[n], 0ull);   // exactly one arc per pdf sees the merged sum
-          if (u) grow[n] = __fadd_rn(grow[n], __fmul_rn(gscale, __fmul_rn((float)u, kFixInv)));   // (no fma: same bits as the folded form)
+          if (u) grow[n] = mul_add_rn((float)u * kFixInv, gscale, grow[n]);   // (no fma: same bits as the folded form)
         }
       } else if (mode == kGradCompact) {
         float* crow = a.rows_ws + ((size_t)b * T + t) * K;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
           const int n = upd[u];
           const unsigned long long v = acc[n];
           if (v) acc[n] = 0ull;
-          crow[u] = __fmul_rn((float)v, kFixInv);
+          crow[u] = (float)v * kFixInv;
         }
       } else {
         for (int n = tid; n < D; n += kOcNT) {
