@@ -334,14 +334,14 @@ extern "C" int pychain_hip_chain_loss_forward(
   // fork: numerator on the side stream, denominator recursion on the caller's stream
   if (e == hipSuccess) e = hipEventRecord(side->fork, st);
   if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-  if (e == hipSuccess && fold) e = launch_num_prep(na, side->stream, &why);
+  if (e == hipSuccess && grad) e = launch_num_prep(na, side->stream, &why);
   if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
-  if (e == hipSuccess && fold) e = launch_num_occ(na, true, side->stream, &why);
+  if (e == hipSuccess && grad) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
   da.phase_mask = 3;
   if (e == hipSuccess) e = run_den(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
-  if (e == hipSuccess && grad && !fold) e = launch_num_occ(na, false, st, &why);   // grad -= grad_scale * gamma_num
+  if (e == hipSuccess && grad && !fold) e = launch_num_scatter(na, st, &why);      // grad -= grad_scale * gamma_num
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
   return PYCHAIN_HIP_OK;

@@ -38,6 +38,8 @@ hipError_t launch_num_prep(const NumArgs& a, hipStream_t st, const char** why);
 // occupancies -> gradient rows (launch 2): reads alpha_ws, beta_ws, logp_ws, x; writes/accumulates grad
 // (grad_mode) or, with `compact`, rows_ws
 hipError_t launch_num_occ(const NumArgs& a, bool compact, hipStream_t st, const char** why);
+// compact rows (rows_ws, upd_ws, ucount_ws) accumulated into grad, scaled by grad_scale
+hipError_t launch_num_scatter(const NumArgs& a, hipStream_t st, const char** why);
 
 }  // namespace pychain_hip
 #endif

@@ -324,6 +324,28 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// compact rows -> an existing dense gradient: grad[b,t,pdf_u] += grad_scale * rows[b,t,u]
+// (time-parallel; the fused ChainLoss uses it when the occupancy pass cannot fold the numerator in)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kOcNT) void num_scatter_kernel(const NumArgs a) {
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int L = (int)a.lengths[b], K = a.K, T = a.T, D = a.D;
+  const int t_begin = blockIdx.x * a.frames_per_block;
+  const int t_end = min(min(t_begin + a.frames_per_block, T), L);
+  const int U = a.ucount_ws[b];
+  const int32_t* upd = a.upd_ws + (size_t)b * K;
+  const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
+  for (int u = tid; u < U; u += kOcNT) {
+    const int n = upd[u];
+    for (int t = t_begin; t < t_end; t++) {
+      const float v = a.rows_ws[((size_t)b * T + t) * K + u];
+      float* gp = a.grad + ((size_t)b * T + t) * D + n;
+      if (v != 0.f) *gp = mul_add_rn(v, gscale, *gp);      // same bits as the ACCUM mode of num_occ_kernel
+    }
+  }
+}
+
 template <int VEC, int XCH>
 hipError_t launch_fb(const NumArgs& a, size_t lds, hipStream_t st) {
   auto k = num_fb_kernel<VEC, XCH>;
@@ -367,6 +389,13 @@ hipError_t launch_num_prep(const NumArgs& a, hipStream_t st, const char** why) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(num_prep_kernel, dim3(a.B), dim3(kOcNT), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_num_scatter(const NumArgs& a, hipStream_t st, const char** why) {
+  (void)why;
+  const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  hipLaunchKernelGGL(num_scatter_kernel, dim3(gx, a.B), dim3(kOcNT), 0, st, a);
   return hipGetLastError();
 }
 
