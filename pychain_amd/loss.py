@@ -10,7 +10,9 @@ error behaviour).  What differs is underneath:
     sequences share (no B-fold replication, no per-call H2D; graph.py:99-120,
     chain-computation.cc:77-89);
   * lengths may be given in any order and on any device (the reference needs
-    them sorted descending on the CPU for pack_padded_sequence, loss.py:37-40).
+    them sorted descending on the CPU for pack_padded_sequence, loss.py:37-40);
+  * fp16 / bf16 network outputs are accepted (evaluated in fp32, gradient returned in the
+    input's dtype); the reference's C++ accessors take float32 only.
 
 There is no CPU implementation here: CPU tensors raise.
 """
@@ -54,6 +56,7 @@ class ChainFunction(torch.autograd.Function):
             objf, input_grad, bad = native.num_forward_backward(
                 gt, gstride, graphs.num_states, x, input_lengths, grad_mode=_lib.GRAD_LINEAR)
         ctx.save_for_backward(input_grad)
+        ctx.in_dtype = input.dtype   # fp16 / bf16 inputs are evaluated in fp32; the gradient goes back in their dtype
         ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
         ChainFunction.last_bad_count = bad
         return objf.sum()
@@ -62,7 +65,7 @@ class ChainFunction(torch.autograd.Function):
     def backward(ctx, objf_grad):
         input_grad, = ctx.saved_tensors
         # clamp is inside the Function and therefore not differentiated (loss.py:30,82-87)
-        return torch.mul(input_grad, objf_grad), None, None, None
+        return torch.mul(input_grad, objf_grad).to(ctx.in_dtype), None, None, None
 
 
 class ChainLossFunction(torch.autograd.Function):
@@ -104,6 +107,7 @@ class ChainLossFunction(torch.autograd.Function):
         if ctx.dev_norm is not None:
             objf = objf / ctx.dev_norm
         ctx.state = state
+        ctx.in_dtype = input.dtype
         ChainFunction.last_bad_count = bad.sum()
         return objf
 
@@ -118,7 +122,7 @@ class ChainLossFunction(torch.autograd.Function):
             grad, bad = native.chain_loss_backward(ctx.state, ctx.host_scale, g)
             ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad.sum()
         ctx.state = None          # release the stored trajectories
-        return grad, None, None, None, None, None
+        return grad.to(ctx.in_dtype), None, None, None, None, None
 
 
 class ChainLoss(nn.Module):
