@@ -1,5 +1,20 @@
 // plan.cpp - host-side compiler from the reference graph layout to the device plan.
 // See plan_format.h for the format and include/pychain_hip.h for the contract.
+//
+// Most of this file decides WHICH arcs meet in one LDS gather instruction.  A wave64
+// ds_read_b32 is serviced as two 32-lane halves over 32 banks (bank = dword address mod 32);
+// a half costs as many LDS cycles as its most-loaded bank, and the recursion kernels are
+// bound by exactly these cycles.  Three freedoms are used, none of which the
+// kernels can see (the plan format does not change):
+//   1. rows of equal arc count may trade places: which 32 rows form a half-group, and - the
+//      position of a state in the LDS vector being its row position - in which bank every
+//      state lives                                                    (Balancer, annealing);
+//   2. every group gets a little slack (kSlack extra slot-rows): a half-group that is 97 % full
+//      cannot avoid a bank holding more than its share of the arcs;
+//   3. a row may issue its arcs in any slot order                     (SlotOrder, annealing).
+// Modelled LDS cycles per half slot-row for the two gathers of an arc on the C3 graph
+// (2.0 = conflict-free): natural order 7.0, slot order alone 3.8, all three 2.3 at 19 % more
+// slot-rows.  Deterministic (fixed-seed LCG): the same graph always gives the same plan.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -14,115 +29,260 @@
 
 namespace {
 
-struct Arc { uint32_t i0, i1; float p; };
+long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+
+// An arc of a tile: the entities (state ids / pdf ids) of its two gathered operands and its probability.
+struct Arc { int e0, e1; float p; };
+
+// Where the entities of an operand vector live: dword position in LDS (bank = position mod 32).
+enum { kLayA = 0, kLayB = 1, kLayX = 2 };   // alpha' states, beta states, nnet-output row (identity)
+
+struct Tile {
+  const std::vector<std::vector<Arc>>* rows = nullptr;   // arcs of every row, by row id
+  std::vector<int> order;            // row position -> row id; positions are cut into groups of 64
+  int npos = 0;                      // row positions (multiple of 64)
+  int lay[2] = {0, 0};               // layout of operand 0 / 1
+  int own_layout = -1;               // the layout whose positions ARE this tile's row positions (-1: none)
+  int weight = 1;                    // weight of this tile's LDS cycles in the objective
+  std::vector<int> gsl;              // slot-rows per group
+};
+
+struct Layouts {
+  std::vector<int> pos[3];           // entity -> position
+  int bank(int l, int e) const { return pos[l][e] & 31; }
+};
+
+struct Lcg {
+  uint32_t s;
+  uint32_t next() { s = s * 1664525u + 1013904223u; return s >> 8; }
+  double unit() { return (double)(next() & 0xffffff) * (1.0 / 16777216.0); }
+};
+
+// ---- freedom 1: row placement -------------------------------------------------------------------
+// Objective: in every half-group (32 rows x A slot-rows) no bank holds more than A arcs, for either
+// operand - the necessary condition for a conflict-free slot order (energy: overload, then squares).
+// Move: two rows of equal arc count trade places; in the alpha / beta tiles that also swaps the two
+// states' positions in the alpha' / beta vector, i.e. the banks of every arc that gathers them.
+struct Balancer {
+  std::vector<Tile>& tiles;
+  Layouts& lay;
+  std::vector<int> hg0;                              // first half-group id of a tile
+  std::vector<int> hist, cap, wgt;                   // [hg][op][32]; capacity and weight of a half-group
+  std::vector<std::vector<int>> pos_of_row;          // [tile][row id] -> row position
+  struct Occ { int tile, row, op; };
+  std::vector<std::vector<Occ>> occ[2];              // [layout A / B][state]: arcs that gather this state
+  Lcg rng{0x2545F491u};
+
+  Balancer(std::vector<Tile>& t, Layouts& l) : tiles(t), lay(l) {
+    int n = 0;
+    for (auto& tl : tiles) {
+      hg0.push_back(n);
+      for (int g : tl.gsl) for (int hh = 0; hh < 2; hh++) { cap.push_back(g); wgt.push_back(tl.weight); }
+      n += 2 * (int)tl.gsl.size();
+    }
+    hist.assign((size_t)n * 64, 0);
+    occ[0].resize(lay.pos[kLayA].size()); occ[1].resize(lay.pos[kLayB].size());
+    pos_of_row.resize(tiles.size());
+    for (size_t ti = 0; ti < tiles.size(); ti++) {
+      const Tile& tl = tiles[ti];
+      pos_of_row[ti].assign(tl.rows->size(), -1);
+      for (size_t i = 0; i < tl.order.size(); i++) pos_of_row[ti][tl.order[i]] = (int)i;
+      for (int row : tl.order)
+        for (const Arc& a : (*tl.rows)[row]) {
+          const int e[2] = {a.e0, a.e1};
+          for (int op = 0; op < 2; op++) {
+            if (tl.lay[op] != kLayX) occ[tl.lay[op]][e[op]].push_back(Occ{(int)ti, row, op});
+            h(hg_of((int)ti, row), op)[lay.bank(tl.lay[op], e[op])]++;
+          }
+        }
+    }
+  }
+  int* h(int hg, int op) { return &hist[((size_t)hg * 2 + op) * 32]; }
+  int hg_of(int ti, int row) const { return hg0[ti] + pos_of_row[ti][row] / 32; }
+  static long phi(int x, int c, int w) { return (long)w * ((x > c ? 64L * (x - c) : 0L) + (long)x * x); }
+  long overload() const {
+    long o = 0;
+    for (size_t hg = 0; hg < cap.size(); hg++) for (int k = 0; k < 64; k++) o += std::max(0, hist[hg * 64 + k] - cap[hg]);
+    return o;
+  }
+  long shift(int hg, int op, int ob, int nb) {       // one arc of (hg, op) from bank ob to bank nb
+    int* q = h(hg, op);
+    const long d = phi(q[ob] - 1, cap[hg], wgt[hg]) - phi(q[ob], cap[hg], wgt[hg]) +
+                   phi(q[nb] + 1, cap[hg], wgt[hg]) - phi(q[nb], cap[hg], wgt[hg]);
+    q[ob]--; q[nb]++;
+    return d;
+  }
+  long rebank(int l, int e, int ob, int nb) {        // every arc that gathers state e of layout l changes bank
+    long d = 0;
+    if (ob != nb) for (const Occ& o : occ[l][e]) d += shift(hg_of(o.tile, o.row), o.op, ob, nb);
+    return d;
+  }
+  long move_row(int ti, int row, int from, int to) {  // the arcs OF row change half-group
+    long d = 0;
+    const Tile& tl = tiles[ti];
+    for (const Arc& a : (*tl.rows)[row]) {
+      const int e[2] = {a.e0, a.e1};
+      for (int op = 0; op < 2; op++) {
+        const int b = lay.bank(tl.lay[op], e[op]);
+        int* qf = h(from, op); int* qt = h(to, op);
+        d += phi(qf[b] - 1, cap[from], wgt[from]) - phi(qf[b], cap[from], wgt[from]); qf[b]--;
+        d += phi(qt[b] + 1, cap[to], wgt[to]) - phi(qt[b], cap[to], wgt[to]); qt[b]++;
+      }
+    }
+    return d;
+  }
+  void run(long iters, double t0, double t1) {
+    if (iters <= 0) return;
+    const double cool = pow(t1 / t0, 1.0 / (double)iters);
+    double T = t0;
+    for (long it = 0; it < iters; it++, T *= cool) {
+      const int ti = rng.next() % tiles.size();
+      Tile& tl = tiles[ti];
+      const int n = (int)tl.order.size();
+      if (n <= 32) continue;
+      const int p1 = rng.next() % n;
+      const int span = 1 + rng.next() % 512;           // rows are sorted by arc count: equal counts are neighbours
+      const int p2 = p1 + ((rng.next() & 1) ? span : -span);
+      if (p2 < 0 || p2 >= n || p2 / 32 == p1 / 32) continue;
+      const int r1 = tl.order[p1], r2 = tl.order[p2];
+      if ((*tl.rows)[r1].size() != (*tl.rows)[r2].size()) continue;
+      const int h1 = hg0[ti] + p1 / 32, h2 = hg0[ti] + p2 / 32;
+      const int L = tl.own_layout;
+      // apply, evaluate, undo on rejection (all updates are exact inverses of each other)
+      long d = move_row(ti, r1, h1, h2) + move_row(ti, r2, h2, h1);
+      pos_of_row[ti][r1] = p2; pos_of_row[ti][r2] = p1;
+      if (L >= 0) {
+        d += rebank(L, r1, p1 & 31, p2 & 31); lay.pos[L][r1] = p2;
+        d += rebank(L, r2, p2 & 31, p1 & 31); lay.pos[L][r2] = p1;
+      }
+      if (d <= 0 || rng.unit() < exp(-(double)d / T)) {
+        tl.order[p1] = r2; tl.order[p2] = r1;
+      } else {
+        if (L >= 0) {
+          rebank(L, r2, p1 & 31, p2 & 31); lay.pos[L][r2] = p2;
+          rebank(L, r1, p2 & 31, p1 & 31); lay.pos[L][r1] = p1;
+        }
+        pos_of_row[ti][r1] = p1; pos_of_row[ti][r2] = p2;
+        move_row(ti, r2, h1, h2); move_row(ti, r1, h2, h1);
+      }
+    }
+  }
+};
+
+// ---- freedom 3: slot order ------------------------------------------------------------------------
+// cell[g][lane][slot] = index of the arc in its row's list, -1 = padding.  Per half-group: greedy
+// placement, then simulated annealing on  sum over columns and operands of
+// kLambda * (max bank load) + sum of squared bank loads;  a move swaps two slots of one row.
+struct SlotOrder {
+  const Tile& t;
+  const Layouts& lay;
+  std::vector<int> cell_off, cell;
+  Lcg rng{0x9E3779B9u};
+  long cycles = 0, columns = 0;                      // modelled LDS cycles / half slot-rows (statistics)
+
+  SlotOrder(const Tile& tile, const Layouts& l) : t(tile), lay(l) {
+    int off = 0;
+    for (int g : t.gsl) { cell_off.push_back(off); off += 64 * g; }
+    cell.assign(off, -1);
+  }
+  struct Col { int cnt[2][32]; int nm[2][34]; int mx[2]; };
+  static constexpr int kLambda = 12;
+  static int col_add(Col& c, int op, int b, int d) {   // returns the energy change
+    int& x = c.cnt[op][b];
+    const int before = kLambda * c.mx[op] + x * x;
+    c.nm[op][x]--; x += d; c.nm[op][x]++;
+    if (d > 0) { if (x > c.mx[op]) c.mx[op] = x; }
+    else { while (c.mx[op] > 0 && c.nm[op][c.mx[op]] == 0) c.mx[op]--; }
+    return kLambda * c.mx[op] + x * x - before;
+  }
+  void half(int g, int hh, long moves_per_cell) {
+    const int A = t.gsl[g];
+    int nr = 0;
+    for (int r = 0; r < 32; r++) if (g * 64 + hh * 32 + r < (int)t.order.size()) nr = r + 1;
+    if (A == 0 || nr == 0) return;
+    int* cl = &cell[cell_off[g] + hh * 32 * A];      // [row][slot]
+    std::vector<Col> cs(A);
+    for (auto& c : cs) { memset(&c, 0, sizeof(c)); c.nm[0][0] = c.nm[1][0] = 32; }
+    std::vector<int> b0(nr * A, -1), b1(nr * A, -1);
+    // greedy: rows with most arcs first; each arc goes to the free slot of its row with fewest collisions
+    std::vector<int> rorder(nr);
+    std::iota(rorder.begin(), rorder.end(), 0);
+    auto arcs_of = [&](int r) -> const std::vector<Arc>& { return (*t.rows)[t.order[g * 64 + hh * 32 + r]]; };
+    std::stable_sort(rorder.begin(), rorder.end(), [&](int x, int y) { return arcs_of(x).size() > arcs_of(y).size(); });
+    for (int r : rorder) {
+      const auto& arcs = arcs_of(r);
+      for (int a = 0; a < (int)arcs.size(); a++) {
+        const int x0 = lay.bank(t.lay[0], arcs[a].e0), x1 = lay.bank(t.lay[1], arcs[a].e1);
+        int best = -1, bc = 0;
+        for (int j = 0; j < A; j++) {
+          if (cl[r * A + j] >= 0) continue;
+          const int cst = cs[j].cnt[0][x0] + cs[j].cnt[1][x1];
+          if (best < 0 || cst < bc) { best = j; bc = cst; }
+        }
+        cl[r * A + best] = a; b0[r * A + best] = x0; b1[r * A + best] = x1;
+        col_add(cs[best], 0, x0, +1); col_add(cs[best], 1, x1, +1);
+      }
+    }
+    if (A >= 2) {
+      const long iters = moves_per_cell * nr * A;
+      const double t0 = 8.0, t1 = 0.2, cool = iters > 1 ? pow(t1 / t0, 1.0 / (double)iters) : 1.0;
+      double T = t0;
+      for (long it = 0; it < iters; it++, T *= cool) {
+        const int r = rng.next() % nr, j1 = rng.next() % A;
+        int j2 = rng.next() % (A - 1); if (j2 >= j1) j2++;
+        const int i1 = r * A + j1, i2 = r * A + j2;
+        if (b0[i1] < 0 && b0[i2] < 0) continue;
+        int dE = 0;
+        if (b0[i1] >= 0) dE += col_add(cs[j1], 0, b0[i1], -1) + col_add(cs[j1], 1, b1[i1], -1);
+        if (b0[i2] >= 0) dE += col_add(cs[j2], 0, b0[i2], -1) + col_add(cs[j2], 1, b1[i2], -1);
+        if (b0[i1] >= 0) dE += col_add(cs[j2], 0, b0[i1], +1) + col_add(cs[j2], 1, b1[i1], +1);
+        if (b0[i2] >= 0) dE += col_add(cs[j1], 0, b0[i2], +1) + col_add(cs[j1], 1, b1[i2], +1);
+        if (dE <= 0 || rng.unit() < exp(-(double)dE / T)) {
+          std::swap(cl[i1], cl[i2]); std::swap(b0[i1], b0[i2]); std::swap(b1[i1], b1[i2]);
+        } else {
+          if (b0[i2] >= 0) { col_add(cs[j1], 0, b0[i2], -1); col_add(cs[j1], 1, b1[i2], -1); }
+          if (b0[i1] >= 0) { col_add(cs[j2], 0, b0[i1], -1); col_add(cs[j2], 1, b1[i1], -1); }
+          if (b0[i2] >= 0) { col_add(cs[j2], 0, b0[i2], +1); col_add(cs[j2], 1, b1[i2], +1); }
+          if (b0[i1] >= 0) { col_add(cs[j1], 0, b0[i1], +1); col_add(cs[j1], 1, b1[i1], +1); }
+        }
+      }
+    }
+    for (int j = 0; j < A; j++) { cycles += std::max(cs[j].mx[0], 1) + std::max(cs[j].mx[1], 1); columns++; }
+  }
+  void run(long moves_per_cell) {
+    for (int g = 0; g < (int)t.gsl.size(); g++) for (int hh = 0; hh < 2; hh++) half(g, hh, moves_per_cell);
+  }
+};
 
 struct BuiltTile {
   std::vector<WaveEntry> waves;
   std::vector<GroupEntry> groups;   // wave order
   std::vector<uint32_t> slots;      // 2 words per lane per slot-row
   int total_slot_rows = 0, max_wave = 0, nrows = 0;
-  std::vector<int> row_order;       // sorted position -> original row id
 };
 
-// ---- LDS bank-conflict-aware slot assignment -------------------------------------------
-// A wave64 ds_read_b32 is serviced as two 32-lane halves over 32 banks (bank = word address
-// mod 32; both operand arrays start on a multiple of 32 words); a half costs as many LDS
-// cycles as its most-loaded bank.  Within a group, row r (lane r) may issue its arcs in any
-// slot order, so for every 32-row half the arcs are permuted inside their rows to minimise
-// the number of same-bank pairs per slot-row, over both gathered operands.  Greedy
-// placement followed by a deterministic local search (fixed-seed LCG: plans are reproducible).
-// Measured on the C3 graph: 7.0 -> ~3.9 LDS cycles per half slot-row (2.0 = conflict-free).
-struct HalfOpt {
-  int nrows, nslots;
-  std::vector<int> cell;                 // [row*nslots + slot] -> arc index in the row's list, -1 = padding
-  std::vector<std::vector<Arc>> const* rows;
-  std::vector<int> const* order;
-  int pos0;
-  std::vector<int> cnt;                  // [slot][operand][bank]
-  const Arc* arc(int r, int j) const {
-    const int a = cell[r * nslots + j];
-    return a < 0 ? nullptr : &(*rows)[(*order)[pos0 + r]][a];
-  }
-  int& c(int slot, int op, int bank) { return cnt[(slot * 2 + op) * 32 + bank]; }
-  void add(int slot, const Arc* a, int d) { if (a) { c(slot, 0, a->i0 & 31) += d; c(slot, 1, a->i1 & 31) += d; } }
-  // colliding pairs an arc would have in `slot` (arc itself not counted)
-  int cost_in(int slot, const Arc* a) { return a ? c(slot, 0, a->i0 & 31) + c(slot, 1, a->i1 & 31) : 0; }
-};
-
-void optimise_half(HalfOpt& h) {
-  const int R = h.nrows, A = h.nslots;
-  h.cell.assign((size_t)R * A, -1);
-  h.cnt.assign((size_t)A * 64, 0);
-  // greedy: rows with most arcs first; each arc goes to the free slot of its row with fewest collisions
-  std::vector<int> rorder(R);
-  std::iota(rorder.begin(), rorder.end(), 0);
-  std::stable_sort(rorder.begin(), rorder.end(), [&](int a, int b) {
-    return (*h.rows)[(*h.order)[h.pos0 + a]].size() > (*h.rows)[(*h.order)[h.pos0 + b]].size(); });
-  for (int r : rorder) {
-    const auto& arcs = (*h.rows)[(*h.order)[h.pos0 + r]];
-    for (int a = 0; a < (int)arcs.size(); a++) {
-      int best = -1, bc = 0;
-      for (int j = 0; j < A; j++) {
-        if (h.cell[r * A + j] >= 0) continue;
-        const int cst = h.cost_in(j, &arcs[a]);
-        if (best < 0 || cst < bc) { best = j; bc = cst; }
-      }
-      h.cell[r * A + best] = a;
-      h.add(best, &arcs[a], +1);
-    }
-  }
-  // local search: swap two slots of one row when that does not increase the collision count
-  uint32_t rng = 0x9E3779B9u;
-  auto next = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
-  static const long iter_mult = getenv("PYCHAIN_PLAN_ITERS") ? atol(getenv("PYCHAIN_PLAN_ITERS")) : 160;   // tuning knob
-  const long iters = (long)R * A * iter_mult;
-  for (long it = 0; it < iters; it++) {
-    const int r = next() % R, j1 = next() % A, j2 = next() % A;
-    if (j1 == j2) continue;
-    const Arc* a1 = h.arc(r, j1); const Arc* a2 = h.arc(r, j2);
-    if (!a1 && !a2) continue;
-    h.add(j1, a1, -1); h.add(j2, a2, -1);
-    const int before = h.cost_in(j1, a1) + h.cost_in(j2, a2);
-    const int after = h.cost_in(j2, a1) + h.cost_in(j1, a2);
-    if (after <= before) {
-      std::swap(h.cell[r * A + j1], h.cell[r * A + j2]);
-      h.add(j2, a1, +1); h.add(j1, a2, +1);
-    } else {
-      h.add(j1, a1, +1); h.add(j2, a2, +1);
-    }
-  }
-}
-
-// rows[r] = arcs of original row r.  `order` = row ids sorted by descending degree
-// (stable), rows beyond order.size() do not exist.  npos = number of row positions
-// (multiple of 64) the output vector has.
-BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vector<int>& order,
-                     int npos, int nwaves) {
-  BuiltTile t;
-  t.row_order = order;
-  t.nrows = (int)order.size();
-  const int ngroups = npos / 64;
-  std::vector<int> gsl(ngroups, 0);
-  for (int g = 0; g < ngroups; g++)
-    for (int l = 0; l < 64; l++) {
-      const int pos = g * 64 + l;
-      if (pos < (int)order.size()) gsl[g] = std::max(gsl[g], (int)rows[order[pos]].size());
-    }
-  static const int pad_rows = getenv("PYCHAIN_PLAN_PAD") ? atoi(getenv("PYCHAIN_PLAN_PAD")) : 0;   // tuning knob
-  for (int g = 0; g < ngroups; g++) if (gsl[g] >= 4) gsl[g] += pad_rows;
-  // longest-processing-time-first: groups are already in descending slot order
+// Deal the groups of a tile to `nwaves` waves and lay the slot stream out in wave order.
+BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, int nwaves) {
+  BuiltTile o;
+  o.nrows = (int)t.order.size();
+  const int ngroups = t.npos / 64;
+  const std::vector<int>& gsl = t.gsl;
+  // longest-processing-time-first over groups in descending slot order
+  std::vector<int> by_size(ngroups);
+  std::iota(by_size.begin(), by_size.end(), 0);
+  std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
   std::vector<std::vector<int>> per_wave(nwaves);
   std::vector<int> load(nwaves, 0);
-  for (int g = 0; g < ngroups; g++) {
+  auto cost = [&](int g) { return gsl[g] + 1; };     // +1: the per-group store/bookkeeping cost
+  for (int g : by_size) {
     int w = -1;                     // a wave keeps its group table in one VGPR pair: <= 64 groups
     for (int i = 0; i < nwaves; i++)
       if (per_wave[i].size() < 64 && (w < 0 || load[i] < load[w])) w = i;
     per_wave[w].push_back(g);
-    load[w] += gsl[g] + 1;        // +1: the per-group store/bookkeeping cost
+    load[w] += cost(g);
   }
-  // refine the LPT deal: move or swap single groups while that lowers the heavier of the two
-  // waves involved (the frame time of a workgroup is set by its most loaded wave)
-  auto cost = [&](int g) { return gsl[g] + 1; };
+  // refine the deal: move or swap single groups while that lowers the heavier of the two waves
+  // involved (the frame time of a workgroup is set by its most loaded wave)
   for (int pass = 0; pass < 64; pass++) {
     int wmax = 0;
     for (int i = 1; i < nwaves; i++) if (load[i] > load[wmax]) wmax = i;
@@ -131,13 +291,11 @@ BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vecto
       const int ga = per_wave[wmax][ia];
       for (int w2 = 0; w2 < nwaves && !improved; w2++) {
         if (w2 == wmax) continue;
-        // move
-        if (per_wave[w2].size() < 64 && load[w2] + cost(ga) < load[wmax]) {
+        if (per_wave[w2].size() < 64 && load[w2] + cost(ga) < load[wmax]) {          // move
           per_wave[w2].push_back(ga); per_wave[wmax].erase(per_wave[wmax].begin() + ia);
           load[w2] += cost(ga); load[wmax] -= cost(ga); improved = true; break;
         }
-        // swap
-        for (size_t ib = 0; ib < per_wave[w2].size(); ib++) {
+        for (size_t ib = 0; ib < per_wave[w2].size(); ib++) {                          // swap
           const int gb = per_wave[w2][ib];
           const int d = cost(ga) - cost(gb);
           if (d > 0 && load[w2] + d < load[wmax]) {
@@ -151,53 +309,65 @@ BuiltTile build_tile(const std::vector<std::vector<Arc>>& rows, const std::vecto
   }
   for (auto& v : per_wave)   // descending slot counts inside a wave: groups without arcs come last
     std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
-  t.waves.resize(nwaves);
+  o.waves.resize(nwaves);
   int row_cursor = 0;
   for (int w = 0; w < nwaves; w++) {
-    WaveEntry& we = t.waves[w];
-    we.first_group = (int)t.groups.size();
+    WaveEntry& we = o.waves[w];
+    we.first_group = (int)o.groups.size();
     we.ngroups = (int)per_wave[w].size();
     we.slot_row_begin = row_cursor;
     int n = 0;
     for (int g : per_wave[w]) {
-      t.groups.push_back(GroupEntry{g * 64, gsl[g]});
+      o.groups.push_back(GroupEntry{g * 64, gsl[g]});
       const int A = gsl[g];
-      HalfOpt half[2];
-      for (int hh = 0; hh < 2 && A > 0; hh++) {
-        const int p0 = g * 64 + hh * 32;
-        half[hh].nrows = std::max(0, std::min(32, (int)order.size() - p0));
-        half[hh].nslots = A; half[hh].rows = &rows; half[hh].order = &order; half[hh].pos0 = p0;
-        if (half[hh].nrows > 0) optimise_half(half[hh]);
-      }
       for (int j = 0; j < A; j++) {
         // padding lanes re-read the operands of a real arc of their half (an LDS broadcast: no conflict)
+        uint32_t words[64]; float probs[64]; bool real[64];
         uint32_t fill[2] = {0u, 0u};
-        for (int hh = 0; hh < 2; hh++)
-          for (int r = 0; r < half[hh].nrows; r++)
-            if (const Arc* a = half[hh].arc(r, j)) { fill[hh] = a->i0 | (a->i1 << 16); break; }
         for (int l = 0; l < 64; l++) {
-          const int hh = l >> 5, r = l & 31;
-          uint32_t idx = fill[hh]; float p = 0.f;
-          if (r < half[hh].nrows)
-            if (const Arc* a = half[hh].arc(r, j)) { idx = a->i0 | (a->i1 << 16); p = a->p; }
-          uint32_t pb; memcpy(&pb, &p, 4);
-          t.slots.push_back(idx); t.slots.push_back(pb);
+          real[l] = false; probs[l] = 0.f; words[l] = 0u;
+          const int pos = g * 64 + l;
+          if (pos >= (int)t.order.size()) continue;
+          const int a = so.cell[so.cell_off[g] + l * A + j];
+          if (a < 0) continue;
+          const Arc& arc = (*t.rows)[t.order[pos]][a];
+          words[l] = (uint32_t)lay.pos[t.lay[0]][arc.e0] | ((uint32_t)lay.pos[t.lay[1]][arc.e1] << 16);
+          probs[l] = arc.p; real[l] = true;
+          if (!fill[l >> 5]) fill[l >> 5] = words[l];
+        }
+        for (int l = 0; l < 64; l++) {
+          uint32_t pb; memcpy(&pb, &probs[l], 4);
+          o.slots.push_back(real[l] ? words[l] : fill[l >> 5]); o.slots.push_back(pb);
         }
       }
       n += gsl[g];
     }
     we.nslot_rows = n;
     row_cursor += n;
-    t.max_wave = std::max(t.max_wave, n);
+    o.max_wave = std::max(o.max_wave, n);
   }
-  t.total_slot_rows = row_cursor;
-  return t;
+  o.total_slot_rows = row_cursor;
+  return o;
 }
 
 std::vector<int> sort_by_degree(const std::vector<int>& deg, const std::vector<int>& ids) {
   std::vector<int> o = ids;
   std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return deg[a] > deg[b]; });
   return o;
+}
+
+void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::vector<int>& order, int npos,
+               int lay0, int lay1, int own_layout, int weight, int slack) {
+  t.rows = &rows; t.order = order; t.npos = npos; t.lay[0] = lay0; t.lay[1] = lay1; t.own_layout = own_layout; t.weight = weight;
+  const int ng = npos / 64;
+  t.gsl.assign(ng, 0);
+  for (int g = 0; g < ng; g++)
+    for (int l = 0; l < 64; l++) {
+      const int pos = g * 64 + l;
+      if (pos < (int)order.size()) t.gsl[g] = std::max(t.gsl[g], (int)rows[order[pos]].size());
+    }
+  // freedom 2: a few spare slot-rows per group (only where they are a small fraction of the group)
+  for (int g = 0; g < ng; g++) if (t.gsl[g] >= 6) t.gsl[g] += slack;
 }
 
 size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
@@ -232,35 +402,62 @@ extern "C" int64_t pychain_hip_den_plan_build(
   std::vector<int> indeg(H), outdeg(H), ids(H);
   std::iota(ids.begin(), ids.end(), 0);
   for (int h = 0; h < H; h++) { indeg[h] = bi[2 * h + 1] - bi[2 * h]; outdeg[h] = fi[2 * h + 1] - fi[2 * h]; }
-  const std::vector<int> order_a = sort_by_degree(indeg, ids), order_b = sort_by_degree(outdeg, ids);
-  std::vector<int> pa(H), pb(H);
-  for (int i = 0; i < H; i++) { pa[order_a[i]] = i; pb[order_b[i]] = i; }
 
-  // alpha rows: arcs entering h, in the reference's order (fstext.cc:63-76)
+  // rows by entity ids.  alpha rows: arcs entering h, in the reference's order (fstext.cc:63-76)
   std::vector<std::vector<Arc>> rows_a(H), rows_b(H), rows_g(D);
   for (int h = 0; h < H; h++) {
     for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++) {
       if (bt[3 * k + 1] != h)
         return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: backward transition %d is not grouped under its destination", k);
-      rows_a[h].push_back(Arc{(uint32_t)pa[bt[3 * k]], (uint32_t)bt[3 * k + 2], bp[k]});
+      rows_a[h].push_back(Arc{bt[3 * k], bt[3 * k + 2], bp[k]});
     }
     for (int k = fi[2 * h]; k < fi[2 * h + 1]; k++) {
       if (ft[3 * k] != h)
         return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: forward transition %d is not grouped under its source", k);
-      rows_b[h].push_back(Arc{(uint32_t)pb[ft[3 * k + 1]], (uint32_t)ft[3 * k + 2], fp[k]});
+      rows_b[h].push_back(Arc{ft[3 * k + 1], ft[3 * k + 2], fp[k]});
       // gamma rows keep the (state, arc) order the reference accumulates in (chain-computation.cc:293-305)
-      rows_g[ft[3 * k + 2]].push_back(Arc{(uint32_t)pa[h], (uint32_t)pb[ft[3 * k + 1]], fp[k]});
+      rows_g[ft[3 * k + 2]].push_back(Arc{h, ft[3 * k + 1], fp[k]});
     }
   }
   std::vector<int> gdeg(D), gids;
   for (int n = 0; n < D; n++) { gdeg[n] = (int)rows_g[n].size(); if (gdeg[n] > 0) gids.push_back(n); }
-  const std::vector<int> order_g = sort_by_degree(gdeg, gids);
-  const int gpos = ((int)order_g.size() + 63) / 64 * 64;
+  const int gpos = std::max(((int)gids.size() + 63) / 64 * 64, 64);
 
-  BuiltTile ta = build_tile(rows_a, order_a, Hp, PLAN_REC_WAVES);
-  BuiltTile tb = build_tile(rows_b, order_b, Hp, PLAN_REC_WAVES);
-  BuiltTile tg = build_tile(rows_g, order_g, gpos, PLAN_GAM_WAVES);
-  BuiltTile tg2 = build_tile(rows_g, order_g, gpos, PLAN_GAM2_WAVES);
+  // tuning knobs (environment): PYCHAIN_PLAN_SLACK spare slot-rows per recursion group, PYCHAIN_PLAN_BALANCE
+  // row-placement moves per transition (0 = rows stay in degree order), PYCHAIN_PLAN_ANNEAL slot moves per cell
+  const int slack = (int)env_long("PYCHAIN_PLAN_SLACK", 2);
+  const long balance_moves = env_long("PYCHAIN_PLAN_BALANCE", 170);
+  const long anneal_moves = env_long("PYCHAIN_PLAN_ANNEAL", 200);
+  const bool stats = env_long("PYCHAIN_PLAN_STATS", 0) != 0;
+
+  // The occupancy tiles take no slack: their kernels are not bound by gather cycles and the two-frame
+  // kernel keeps exactly 64 slot-rows per wave in registers.
+  std::vector<Tile> tiles(3);
+  init_tile(tiles[0], rows_a, sort_by_degree(indeg, ids), Hp, kLayA, kLayX, kLayA, 2, slack);   // the recursions are the critical path
+  init_tile(tiles[1], rows_b, sort_by_degree(outdeg, ids), Hp, kLayB, kLayX, kLayB, 2, slack);
+  init_tile(tiles[2], rows_g, sort_by_degree(gdeg, gids), gpos, kLayA, kLayB, -1, 1, 0);
+  Layouts lay;
+  lay.pos[kLayA].assign(H, 0); lay.pos[kLayB].assign(H, 0); lay.pos[kLayX].resize(D);
+  for (int i = 0; i < H; i++) { lay.pos[kLayA][tiles[0].order[i]] = i; lay.pos[kLayB][tiles[1].order[i]] = i; }
+  std::iota(lay.pos[kLayX].begin(), lay.pos[kLayX].end(), 0);
+  {
+    Balancer bal(tiles, lay);
+    const long before = stats ? bal.overload() : 0;
+    bal.run(balance_moves * K, 40.0, 0.5);
+    if (stats) fprintf(stderr, "[plan] row placement: bank overload %ld -> %ld (of %ld arc operands)\n", before, bal.overload(), 6L * K);
+  }
+  SlotOrder so_a(tiles[0], lay), so_b(tiles[1], lay), so_g(tiles[2], lay);
+  so_a.run(anneal_moves); so_b.run(anneal_moves); so_g.run(anneal_moves);
+  if (stats)
+    fprintf(stderr, "[plan] modelled LDS cycles per half slot-row (2.0 = conflict-free): alpha %.3f beta %.3f gamma %.3f; "
+                    "half slot-rows %ld %ld %ld\n", (double)so_a.cycles / std::max(1L, so_a.columns),
+            (double)so_b.cycles / std::max(1L, so_b.columns), (double)so_g.cycles / std::max(1L, so_g.columns),
+            so_a.columns, so_b.columns, so_g.columns);
+
+  BuiltTile ta = emit_tile(tiles[0], so_a, lay, PLAN_REC_WAVES);
+  BuiltTile tb = emit_tile(tiles[1], so_b, lay, PLAN_REC_WAVES);
+  BuiltTile tg = emit_tile(tiles[2], so_g, lay, PLAN_GAM_WAVES);
+  BuiltTile tg2 = emit_tile(tiles[2], so_g, lay, PLAN_GAM2_WAVES);
 
   // ---- lay the blob out
   size_t off = align16(sizeof(PlanHeader));
@@ -279,7 +476,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   auto place_vec = [&](int32_t& o, size_t n) { o = (int32_t)off; off = align16(off + n * 4); };
   place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
-  place_vec(hd.off_row_pdf, std::max(gpos, 64));
+  place_vec(hd.off_row_pdf, gpos);
   if (off > (size_t)INT32_MAX)
     return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED, "den_plan_build: plan larger than 2 GiB");
   hd.total_bytes = (int32_t)off;
@@ -298,9 +495,10 @@ extern "C" int64_t pychain_hip_den_plan_build(
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);
   for (int h = 0; h < H; h++) {
-    init_a[pa[h]] = initial[h]; leaky_a[pa[h]] = leaky[h]; final_a[pa[h]] = final_[h];
-    leaky_b[pb[h]] = leaky[h]; final_b[pb[h]] = final_[h];
+    const int pa = lay.pos[kLayA][h], pb = lay.pos[kLayB][h];
+    init_a[pa] = initial[h]; leaky_a[pa] = leaky[h]; final_a[pa] = final_[h];
+    leaky_b[pb] = leaky[h]; final_b[pb] = final_[h];
   }
-  for (int i = 0; i < std::max(gpos, 64); i++) row_pdf[i] = i < (int)order_g.size() ? order_g[i] : -1;
+  for (int i = 0; i < gpos; i++) row_pdf[i] = i < (int)tiles[2].order.size() ? tiles[2].order[i] : -1;
   return (int64_t)off;
 }
