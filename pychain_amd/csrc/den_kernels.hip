@@ -50,7 +50,8 @@ constexpr int kNW = PLAN_REC_WAVES;        // waves per workgroup (both kernels)
 constexpr int kNT = kNW * 64;              // threads per workgroup
 static_assert(PLAN_REC_WAVES == PLAN_GAM_WAVES, "one workgroup shape for both kernels");
 static_assert(kNW <= 16, "block totals are reduced inside one 16-lane DPP row");
-constexpr int kMaxResident = PLAN_REC_WAVES > 12 ? 40 : 44;   // slot-rows per wave kept in VGPRs
+constexpr int kMaxResident = PLAN_REC_WAVES > 12 ? PLAN_RESIDENT_2 : 44;   // slot-rows per wave kept in VGPRs
+static_assert(PLAN_REC_WAVES <= 12 || (PLAN_RESIDENT_0 == 16 && PLAN_RESIDENT_1 == 32), "the plan compiler sizes its slack for these loop lengths");
 
 // ---- one frame of a tile plan: out[row] = sum_k p_k * U[i0_k] * V[i1_k] ------------------
 // The first R slot-rows of a wave are held in registers as ABSOLUTE LDS byte addresses of

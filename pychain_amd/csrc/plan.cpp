@@ -9,8 +9,9 @@
 //   1. rows of equal arc count may trade places: which 32 rows form a half-group, and - the
 //      position of a state in the LDS vector being its row position - in which bank every
 //      state lives                                                    (Balancer, annealing);
-//   2. every group gets a little slack (kSlack extra slot-rows): a half-group that is 97 % full
-//      cannot avoid a bank holding more than its share of the arcs;
+//   2. every recursion group gets spare slot-rows, as many as the register-resident loop of the
+//      kernel walks anyway: a half-group that is 97 % full cannot avoid a bank holding more
+//      than its share of the arcs;
 //   3. a row may issue its arcs in any slot order                     (SlotOrder, annealing).
 // Modelled LDS cycles per half slot-row for the two gathers of an arc on the C3 graph
 // (2.0 = conflict-free): natural order 7.0, slot order alone 3.8, all three 2.3 at 19 % more
@@ -261,13 +262,11 @@ struct BuiltTile {
   int total_slot_rows = 0, max_wave = 0, nrows = 0;
 };
 
-// Deal the groups of a tile to `nwaves` waves and lay the slot stream out in wave order.
-BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, int nwaves) {
-  BuiltTile o;
-  o.nrows = (int)t.order.size();
-  const int ngroups = t.npos / 64;
-  const std::vector<int>& gsl = t.gsl;
-  // longest-processing-time-first over groups in descending slot order
+// Deal groups (slot-row counts `gsl`) to `nwaves` waves: longest-processing-time-first, then single
+// moves / swaps while they lower the heavier wave (the frame time of a workgroup is set by its most
+// loaded wave).  Returns the groups of every wave, in descending slot count.
+std::vector<std::vector<int>> deal_groups(const std::vector<int>& gsl, int nwaves) {
+  const int ngroups = (int)gsl.size();
   std::vector<int> by_size(ngroups);
   std::iota(by_size.begin(), by_size.end(), 0);
   std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
@@ -281,8 +280,6 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, int 
     per_wave[w].push_back(g);
     load[w] += cost(g);
   }
-  // refine the deal: move or swap single groups while that lowers the heavier of the two waves
-  // involved (the frame time of a workgroup is set by its most loaded wave)
   for (int pass = 0; pass < 64; pass++) {
     int wmax = 0;
     for (int i = 1; i < nwaves; i++) if (load[i] > load[wmax]) wmax = i;
@@ -309,6 +306,21 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, int 
   }
   for (auto& v : per_wave)   // descending slot counts inside a wave: groups without arcs come last
     std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
+  return per_wave;
+}
+int max_wave_rows(const std::vector<int>& gsl, int nwaves) {
+  int mx = 0;
+  for (const auto& w : deal_groups(gsl, nwaves)) { int n = 0; for (int g : w) n += gsl[g]; mx = std::max(mx, n); }
+  return mx;
+}
+
+// Deal the groups of a tile to `nwaves` waves and lay the slot stream out in wave order.
+BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, int nwaves) {
+  BuiltTile o;
+  o.nrows = (int)t.order.size();
+  const int ngroups = t.npos / 64;
+  const std::vector<int>& gsl = t.gsl;
+  std::vector<std::vector<int>> per_wave = deal_groups(gsl, nwaves);
   o.waves.resize(nwaves);
   int row_cursor = 0;
   for (int w = 0; w < nwaves; w++) {
@@ -357,7 +369,7 @@ std::vector<int> sort_by_degree(const std::vector<int>& deg, const std::vector<i
 }
 
 void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::vector<int>& order, int npos,
-               int lay0, int lay1, int own_layout, int weight, int slack) {
+               int lay0, int lay1, int own_layout, int weight, int slack, int nwaves) {
   t.rows = &rows; t.order = order; t.npos = npos; t.lay[0] = lay0; t.lay[1] = lay1; t.own_layout = own_layout; t.weight = weight;
   const int ng = npos / 64;
   t.gsl.assign(ng, 0);
@@ -366,8 +378,22 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
       const int pos = g * 64 + l;
       if (pos < (int)order.size()) t.gsl[g] = std::max(t.gsl[g], (int)rows[order[pos]].size());
     }
-  // freedom 2: a few spare slot-rows per group (only where they are a small fraction of the group)
-  for (int g = 0; g < ng; g++) if (t.gsl[g] >= 6) t.gsl[g] += slack;
+  // freedom 2: spare slot-rows per group.  The kernels keep 16, 32 or 40 slot-rows of a wave in
+  // registers and walk all of them every frame, so slack is free up to the next of those sizes:
+  // take the smallest size that leaves room for >= 2 spare rows per group, then as many (<= slack)
+  // as fit.  slack < 0: choose automatically (<= 4).
+  auto with_slack = [&](int k) { std::vector<int> v = t.gsl; for (int& x : v) if (x >= 4) x += k; return v; };
+  if (slack >= 0) { t.gsl = with_slack(slack); return; }
+  static const int kResident[3] = {PLAN_RESIDENT_0, PLAN_RESIDENT_1, PLAN_RESIDENT_2};
+  const int base = max_wave_rows(t.gsl, nwaves);
+  if (base > kResident[2]) return;                                  // the tail is streamed anyway
+  int chosen = 0;
+  for (int ri = 0; ri < 3 && chosen == 0; ri++) {
+    if (base > kResident[ri]) continue;
+    for (int k = 4; k >= (ri < 2 ? 2 : 1); k--)
+      if (max_wave_rows(with_slack(k), nwaves) <= kResident[ri]) { chosen = k; break; }
+  }
+  t.gsl = with_slack(chosen);
 }
 
 size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
@@ -423,9 +449,9 @@ extern "C" int64_t pychain_hip_den_plan_build(
   for (int n = 0; n < D; n++) { gdeg[n] = (int)rows_g[n].size(); if (gdeg[n] > 0) gids.push_back(n); }
   const int gpos = std::max(((int)gids.size() + 63) / 64 * 64, 64);
 
-  // tuning knobs (environment): PYCHAIN_PLAN_SLACK spare slot-rows per recursion group, PYCHAIN_PLAN_BALANCE
+  // tuning knobs (environment): PYCHAIN_PLAN_SLACK spare slot-rows per recursion group (default: automatic), PYCHAIN_PLAN_BALANCE
   // row-placement moves per transition (0 = rows stay in degree order), PYCHAIN_PLAN_ANNEAL slot moves per cell
-  const int slack = (int)env_long("PYCHAIN_PLAN_SLACK", 2);
+  const int slack = (int)env_long("PYCHAIN_PLAN_SLACK", -1);
   const long balance_moves = env_long("PYCHAIN_PLAN_BALANCE", 170);
   const long anneal_moves = env_long("PYCHAIN_PLAN_ANNEAL", 200);
   const bool stats = env_long("PYCHAIN_PLAN_STATS", 0) != 0;
@@ -433,9 +459,9 @@ extern "C" int64_t pychain_hip_den_plan_build(
   // The occupancy tiles take no slack: their kernels are not bound by gather cycles and the two-frame
   // kernel keeps exactly 64 slot-rows per wave in registers.
   std::vector<Tile> tiles(3);
-  init_tile(tiles[0], rows_a, sort_by_degree(indeg, ids), Hp, kLayA, kLayX, kLayA, 2, slack);   // the recursions are the critical path
-  init_tile(tiles[1], rows_b, sort_by_degree(outdeg, ids), Hp, kLayB, kLayX, kLayB, 2, slack);
-  init_tile(tiles[2], rows_g, sort_by_degree(gdeg, gids), gpos, kLayA, kLayB, -1, 1, 0);
+  init_tile(tiles[0], rows_a, sort_by_degree(indeg, ids), Hp, kLayA, kLayX, kLayA, 2, slack, PLAN_REC_WAVES);   // the recursions are the critical path
+  init_tile(tiles[1], rows_b, sort_by_degree(outdeg, ids), Hp, kLayB, kLayX, kLayB, 2, slack, PLAN_REC_WAVES);
+  init_tile(tiles[2], rows_g, sort_by_degree(gdeg, gids), gpos, kLayA, kLayB, -1, 1, 0, PLAN_GAM_WAVES);
   Layouts lay;
   lay.pos[kLayA].assign(H, 0); lay.pos[kLayB].assign(H, 0); lay.pos[kLayX].resize(D);
   for (int i = 0; i < H; i++) { lay.pos[kLayA][tiles[0].order[i]] = i; lay.pos[kLayB][tiles[1].order[i]] = i; }

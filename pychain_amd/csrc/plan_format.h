@@ -34,6 +34,10 @@
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
 #endif
+// slot-rows per wave the recursion kernels keep in registers (den_kernels.hip picks the smallest that fits)
+#define PLAN_RESIDENT_0 16
+#define PLAN_RESIDENT_1 32
+#define PLAN_RESIDENT_2 40
 #define PLAN_GAM2_WAVES 8      // the gamma plan again, scheduled for the two-frame occupancy kernel (8 waves x 256 VGPRs)
 
 struct TilePlan {              // all offsets are bytes from the start of the blob
