@@ -272,24 +272,53 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
     const int U = mode == kGradCompact ? a.ucount_ws[b] : 0;
     const int32_t* upd = a.upd_ws + (size_t)b * K;
     int bad = 0;
+    // Software pipeline over frames: the rows and nnet-output values of frame t+1 are loaded into
+    // registers while frame t is evaluated (kNR row elements and kNX arcs per thread are staged;
+    // larger graphs read the rest directly).
+    constexpr int kNR = 2, kNX = 4;
+    double pa[kNR], pb[kNR];
+    float px[kNX];
+#define NUM_OCC_PREFETCH(t)                                                                        \
+    do {                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < kNR; i++) {                                            \
+        const int h = tid + i * kOcNT;                                                             \
+        if (h < H) { pa[i] = aws[(size_t)(t) * H + h]; pb[i] = bws[(size_t)((t) + 1) * H + h]; }   \
+      }                                                                                            \
+      _Pragma("unroll") for (int i = 0; i < kNX; i++) {                                            \
+        const int k = tid + i * kOcNT;                                                             \
+        if (k < Kused) px[i] = xseq[(size_t)(t) * D + pdf[k]];                                     \
+      }                                                                                            \
+    } while (0)
+    NUM_OCC_PREFETCH(t_begin);
     for (int t = t_begin; t < t_live_end; t++) {
-      for (int h = tid; h < H; h += kOcNT) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)(t + 1) * H + h]; }
+#pragma unroll
+      for (int i = 0; i < kNR; i++) { const int h = tid + i * kOcNT; if (h < H) { arow[h] = pa[i]; brow[h] = pb[i]; } }
+      for (int h = tid + kNR * kOcNT; h < H; h += kOcNT) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)(t + 1) * H + h]; }
+      float xcur[kNX];
+#pragma unroll
+      for (int i = 0; i < kNX; i++) xcur[i] = px[i];
+      if (t + 1 < t_live_end) NUM_OCC_PREFETCH(t + 1);
       __syncthreads();
       const float* xrow = xseq + (size_t)t * D;
       float* grow = gseq + (size_t)t * D;
-      for (int k = tid; k < Kused; k += kOcNT) {
-        const uint32_t w = sd[k];
-        const int n = pdf[k];
-        const float xv = __builtin_amdgcn_fmed3f(xrow[n], -30.f, 30.f);
-        // BetaGeneralFrame :204-271: occupancy = exp(alpha(t,src) + lp + x(t,pdf) + beta(t+1,dst) - logP)
-        const float v = fexp((float)((arow[w & 0xffffu] + brow[w >> 16] - logp) + ((double)lp[k] + (double)xv)));
-        if (v > 0.f) {
-          if (v <= 2.f) atomicAdd(&acc[n], (unsigned long long)(v * kFixScale));
-          else bad = 1;
-        } else if (v != 0.f) {
-          bad = 1;                                  // NaN
-        }
-      }
+      // BetaGeneralFrame :204-271: occupancy = exp(alpha(t,src) + lp + x(t,pdf) + beta(t+1,dst) - logP)
+#define NUM_OCC_ARC(k, xraw)                                                                       \
+      do {                                                                                         \
+        const uint32_t w = sd[k];                                                                  \
+        const int n = pdf[k];                                                                      \
+        const float xv = __builtin_amdgcn_fmed3f((xraw), -30.f, 30.f);                             \
+        const float v = fexp((float)((arow[w & 0xffffu] + brow[w >> 16] - logp) + ((double)lp[k] + (double)xv))); \
+        if (v > 0.f) {                                                                             \
+          if (v <= 2.f) atomicAdd(&acc[n], (unsigned long long)(v * kFixScale));                   \
+          else bad = 1;                                                                            \
+        } else if (v != 0.f) {                                                                     \
+          bad = 1;                                  /* NaN */                                      \
+        }                                                                                          \
+      } while (0)
+#pragma unroll
+      for (int i = 0; i < kNX; i++) { const int k = tid + i * kOcNT; if (k < Kused) NUM_OCC_ARC(k, xcur[i]); }
+      for (int k = tid + kNX * kOcNT; k < Kused; k += kOcNT) NUM_OCC_ARC(k, xrow[pdf[k]]);
+#undef NUM_OCC_ARC
       __syncthreads();
       if (mode == PYCHAIN_HIP_GRAD_ACCUM) {
         for (int k = tid; k < Kused; k += kOcNT) {
@@ -315,6 +344,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
       }
       __syncthreads();
     }
+#undef NUM_OCC_PREFETCH
     if (bad) atomicAdd(a.bad, 1);
   }
   // padded frames: -inf (full_like(-inf), :57) / zero; ACCUM and the compact rows leave them alone
