@@ -140,8 +140,9 @@ int den_segments(int T) {
   // longer than the rest of the recursion, so the side stream - not the recursion - ends the call,
   // and finer segments only add launches to it (delaying the side stream makes the call longer by
   // exactly the delay).  The lever is the occupancy kernel's CU time, not the schedule.
-  // (with the two-frame occupancy kernel and the numerator folded in: 3 -> 4.86 ms, 4 -> 4.81, 5 -> 4.9)
-  if (T >= 1024) return 4;
+  // (whole step with the two-frame occupancy kernel, the numerator folded in and the recursion at 3.97 ms:
+  // 3 -> 4.43 ms, 4 -> 4.52, 5 -> 4.63)
+  if (T >= 1024) return 3;
   if (T >= 256) return 2;
   return 1;
 }
