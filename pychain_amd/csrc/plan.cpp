@@ -17,11 +17,13 @@
 // (2.0 = conflict-free): natural order 7.0, slot order alone 3.8, all three 2.3 at 19 % more
 // slot-rows.  Deterministic (fixed-seed LCG): the same graph always gives the same plan.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "../../include/pychain_hip.h"
@@ -178,8 +180,7 @@ struct SlotOrder {
   const Tile& t;
   const Layouts& lay;
   std::vector<int> cell_off, cell;
-  Lcg rng{0x9E3779B9u};
-  long cycles = 0, columns = 0;                      // modelled LDS cycles / half slot-rows (statistics)
+  std::atomic<long> cycles{0}, columns{0};           // modelled LDS cycles / half slot-rows (statistics)
 
   SlotOrder(const Tile& tile, const Layouts& l) : t(tile), lay(l) {
     int off = 0;
@@ -197,6 +198,7 @@ struct SlotOrder {
     return kLambda * c.mx[op] + x * x - before;
   }
   void half(int g, int hh, long moves_per_cell) {
+    Lcg rng{0x9E3779B9u ^ (uint32_t)((g * 2 + hh) * 2654435761u)};   // per half-group: results do not depend on the thread count
     const int A = t.gsl[g];
     int nr = 0;
     for (int r = 0; r < 32; r++) if (g * 64 + hh * 32 + r < (int)t.order.size()) nr = r + 1;
@@ -248,10 +250,20 @@ struct SlotOrder {
         }
       }
     }
-    for (int j = 0; j < A; j++) { cycles += std::max(cs[j].mx[0], 1) + std::max(cs[j].mx[1], 1); columns++; }
+    long cyc = 0;
+    for (int j = 0; j < A; j++) cyc += std::max(cs[j].mx[0], 1) + std::max(cs[j].mx[1], 1);
+    cycles += cyc; columns += A;
   }
+  // half-groups are independent: annealed on up to 8 host threads
   void run(long moves_per_cell) {
-    for (int g = 0; g < (int)t.gsl.size(); g++) for (int hh = 0; hh < 2; hh++) half(g, hh, moves_per_cell);
+    const int n = 2 * (int)t.gsl.size();
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int i; (i = next++) < n;) half(i >> 1, i & 1, moves_per_cell); };
+    const int nthreads = (int)std::min<long>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (long)n);
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nthreads; i++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
   }
 };
 
@@ -476,9 +488,9 @@ extern "C" int64_t pychain_hip_den_plan_build(
   so_a.run(anneal_moves); so_b.run(anneal_moves); so_g.run(anneal_moves);
   if (stats)
     fprintf(stderr, "[plan] modelled LDS cycles per half slot-row (2.0 = conflict-free): alpha %.3f beta %.3f gamma %.3f; "
-                    "half slot-rows %ld %ld %ld\n", (double)so_a.cycles / std::max(1L, so_a.columns),
-            (double)so_b.cycles / std::max(1L, so_b.columns), (double)so_g.cycles / std::max(1L, so_g.columns),
-            so_a.columns, so_b.columns, so_g.columns);
+                    "half slot-rows %ld %ld %ld\n", (double)so_a.cycles / std::max(1L, so_a.columns.load()),
+            (double)so_b.cycles / std::max(1L, so_b.columns.load()), (double)so_g.cycles / std::max(1L, so_g.columns.load()),
+            so_a.columns.load(), so_b.columns.load(), so_g.columns.load());
 
   BuiltTile ta = emit_tile(tiles[0], so_a, lay, PLAN_REC_WAVES);
   BuiltTile tb = emit_tile(tiles[1], so_b, lay, PLAN_REC_WAVES);
