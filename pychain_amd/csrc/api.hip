@@ -258,7 +258,7 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.initial = initial; a.final_ = final_; a.x = nnet_output; a.lengths = seq_lengths;
   a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
   a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
-  a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 16;
+  a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 32;
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_ws = (double*)(ws + c.alpha); a.beta_ws = (double*)(ws + c.beta); a.logp_ws = (double*)(ws + c.logp);
   a.rows_ws = (float*)(ws + c.rows); a.upd_ws = (int32_t*)(ws + c.upd); a.ucount_ws = (int32_t*)(ws + c.ucount);
