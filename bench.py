@@ -119,7 +119,7 @@ def kernel_rooflines(w, dev, iters):
     return roof
 
 
-def grad_slab_allreduce(x, world, rank, dev, iters=3):
+def grad_slab_allreduce(x, world, rank, dev, iters=2):
     """OPTION measured beside the hot path: one fused all-reduce of the scalars
     and the [B_global,T,D] gradient slab, so that every rank holds the whole gradient."""
     from pychain_amd.parallel import allreduce_grad_slab
