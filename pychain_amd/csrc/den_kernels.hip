@@ -1028,7 +1028,7 @@ inline size_t gamma2_lds_bytes(const DenArgs& a, int gamma_max_groups) {
   return sizeof(float) * (4 * (size_t)a.Hp + (a.fold_rows ? 6 : 2) * (size_t)((a.D + 3) & ~3) + (size_t)gamma_max_groups * 64 + 32);
 }
 inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
-  static const bool off = getenv("PYCHAIN_GAMMA16") != nullptr;        // tuning / test knob: force the one-frame kernel
+  const bool off = getenv("PYCHAIN_GAMMA16") != nullptr;               // tuning / test knob (read per call): force the one-frame kernel
   return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
          a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) <= 160 * 1024;
 }
