@@ -182,11 +182,19 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
   for (int s = 0; s < nseg && e == hipSuccess; s++) {
     a.phase_mask = 1; a.seg_begin = s ? a.seg_bound[s - 1] : 0; a.seg_end = s == nseg - 1 ? 0x7fffffff : a.seg_bound[s];
     e = launch_den(a, gmax, resident_slot_rows, st, why);
-    if (e == hipSuccess) e = hipEventRecord(side->seg[s], st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[s], 0);
-    if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
     a.phase_mask = 2; a.gam_seg = s; a.gam_nseg = nseg;
-    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
+    if (s < nseg - 1) {
+      if (e == hipSuccess) e = hipEventRecord(side->seg[s], st);
+      if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[s], 0);
+      if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
+      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
+    } else {
+      // the last occupancy launch has nothing to overlap with: it follows the last recursion segment in
+      // stream order on the caller's stream (no cross-stream event on the exposed part of the call);
+      // the numerator rows it folds in were finished long ago, but the caller's stream has to say so
+      if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(st, gamma_wait, 0);
+      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
+    }
   }
   if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
