@@ -17,18 +17,22 @@
 //             per-state sums are lane-private (one state per lane), per-frame totals are
 //             wave64 DPP reductions + one LDS hop.  Every normalised alpha'(t,.) / beta(t,.)
 //             row is streamed to HBM once.
-//   launch 2  den_gamma_kernel       time-parallel over all (sequence, frame-chunk) pairs:
+//   launch 2  den_gamma2_kernel / den_gamma_kernel   time-parallel over all (sequence,
+//             frame-chunk) pairs:
 //             gamma(t,n) = x(t,n) * sum_{arcs with pdf n} p * alpha'(t,src) * beta(t+1,dst),
 //             normalised so that each live frame sums to one (the invariant the reference
 //             checks at chain-computation.cc:381-390).  Arcs are grouped by pdf-id, so the
 //             occupancy is a lane-private sum: no atomics, deterministic, exact (the
 //             reference's CUDA path adds stochastically-thresholded atomics,
-//             chain-kernels.cu:53-87; parity target is its exact CPU path).
+//             chain-kernels.cu:53-87; parity target is its exact CPU path).  The shipped form
+//             evaluates two frames together (float2-interleaved operands, ds_read_b64 gathers,
+//             packed fma) and can fold the numerator's occupancies in; the one-frame form is
+//             the fallback for graphs that do not fit it.
 //
 // What bounds these kernels (profiles/): the recursion is a chain of T
-// dependent frame steps per workgroup; a step is instruction-issue bound on its CU
-// (SQ_ACTIVE_INST_* ~80 % of SIMD cycles), not HBM- or LDS-bandwidth bound, so the design
-// minimises instructions per arc and per frame.
+// dependent frame steps per workgroup; a step is the LDS gather time of the frame's arcs
+// (conflict-free by construction of the plan) plus barrier-separated serial phases, not HBM;
+// the occupancy pass is time-parallel and runs near the HBM roofline.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
