@@ -22,6 +22,7 @@ struct NumArgs {
   float* rows_ws;            // [B,T,K]    compact rows: occupancy of the u-th distinct pdf of the sequence
   int32_t* upd_ws;           // [B,K]      the distinct pdf-ids of a sequence's arcs, ascending
   int32_t* ucount_ws;        // [B]        how many
+  int32_t* uidx_ws;          // [B,K]      compact row of every arc (index of its pdf in upd_ws), -1 = unused arc
   int graph_stride;          // 1 = per-sequence graphs, 0 = shared
   int B, T, D, H, K;
   int grad_mode;

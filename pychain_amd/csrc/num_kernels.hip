@@ -218,7 +218,11 @@ __global__ __launch_bounds__(kOcNT) void num_prep_kernel(const NumArgs a) {
   __syncthreads();
   int u = scan[tid];
   int32_t* upd = a.upd_ws + (size_t)b * K;
-  for (int n = tid * per; n < min(D, (tid + 1) * per); n++) if (used[n]) upd[u++] = n;
+  for (int n = tid * per; n < min(D, (tid + 1) * per); n++) if (used[n]) { upd[u] = n; used[n] = u++; }
+  __syncthreads();
+  // every arc's row in the compact layout (index of its pdf among the distinct ones); unused arcs: -1
+  int32_t* uidx = a.uidx_ws + (size_t)b * K;
+  for (int k = tid; k < K; k += kOcNT) uidx[k] = k < Kused ? used[ft[3 * k + 2]] : -1;
 }
 
 // ------------------------------------------------------------------------------------
@@ -355,6 +359,117 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// launch 2, compact form for the fused ChainLoss: ONE WAVE PER FRAME, no workgroup barrier in the
+// frame loop.  The merge accumulator is indexed by the arc's compact row (num_prep_kernel), so a
+// wave needs U <= K 64-bit words instead of one per pdf; rows, accumulator and arc tables of four
+// waves fit LDS several times over, and a CU keeps a dozen frames in flight.
+// ------------------------------------------------------------------------------------
+constexpr int kOwFrames = 8;               // consecutive frames per wave
+__global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int K = a.K, D = a.D, T = a.T, H = a.H, Hq = (H + 1) & ~1;
+  const int t_wg = blockIdx.x * (4 * kOwFrames);
+  if (t_wg >= L) return;
+  char* p = smem_raw;
+  uint32_t* sd = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)K;                 // src | dst << 16
+  float* lp = reinterpret_cast<float*>(p); p += 4 * (size_t)K;
+  int32_t* pdf_u = reinterpret_cast<int32_t*>(p); p += 4 * (size_t)K;                // pdf | compact row << 16
+  p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~uintptr_t(15));
+  const size_t per_wave = 16 * (size_t)Hq + 8 * (size_t)K;
+  double* arow = reinterpret_cast<double*>(p + wave * per_wave);
+  double* brow = arow + Hq;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(brow + Hq);        // [U]
+  const size_t g = (size_t)b * a.graph_stride;
+  const int32_t* ft = a.fwd_trans + g * K * 3;
+  const float* fp = a.fwd_probs + g * K;
+  const int32_t* uidx = a.uidx_ws + (size_t)b * K;
+  const int U = a.ucount_ws[b];
+  int kused = 0;
+  for (int k = tid; k < K; k += kOcNT) {
+    const int u = uidx[k];
+    sd[k] = (uint32_t)ft[3 * k] | ((uint32_t)ft[3 * k + 1] << 16);
+    lp[k] = fp[k];
+    pdf_u[k] = ft[3 * k + 2] | (max(u, 0) << 16);
+    if (u >= 0) kused = k + 1;
+  }
+  for (int u = lane; u < U; u += 64) acc[u] = 0ull;
+  // used arcs are a prefix (fstext.cc:30-116 lays arcs out state by state): its length, over the workgroup
+  __shared__ int s_kused;
+  if (tid == 0) s_kused = 0;
+  __syncthreads();
+  atomicMax(&s_kused, kused);
+  __syncthreads();
+  const int Kused = s_kused;
+  const double logp = a.logp_ws[b];
+  const double* aws = a.alpha_ws + (size_t)b * (T + 1) * H;
+  const double* bws = a.beta_ws + (size_t)b * (T + 1) * H;
+  const float* xseq = a.x + (size_t)b * T * D;
+  int bad = 0;
+  const int t0 = t_wg + wave * kOwFrames, t1 = min(t0 + kOwFrames, L);
+  // Software pipeline: a wave has nobody to hide its own global latencies behind, so the rows and the
+  // nnet-output values of frame t+1 are loaded into registers while frame t is evaluated (kWX arcs and
+  // kWR row elements per lane are staged; larger graphs read the rest directly).
+  constexpr int kWX = 16, kWR = 8;
+  float px[kWX];
+  double pa[kWR], pb[kWR];
+#define NUM_OCCW_PREFETCH(t)                                                                       \
+  do {                                                                                             \
+    const float* xr_ = xseq + (size_t)(t) * D;                                                     \
+    _Pragma("unroll") for (int i = 0; i < kWX; i++) {                                              \
+      const int k = lane + 64 * i;                                                                 \
+      if (k < Kused) px[i] = xr_[pdf_u[k] & 0xffff];                                               \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < kWR; i++) {                                              \
+      const int h = lane + 64 * i;                                                                 \
+      if (h < H) { pa[i] = aws[(size_t)(t) * H + h]; pb[i] = bws[(size_t)((t) + 1) * H + h]; }     \
+    }                                                                                              \
+  } while (0)
+  // BetaGeneralFrame :204-271: occupancy = exp(alpha(t,src) + lp + x(t,pdf) + beta(t+1,dst) - logP)
+#define NUM_OCCW_ARC(k, xraw)                                                                      \
+  do {                                                                                             \
+    const uint32_t w = sd[k];                                                                      \
+    const float xv = __builtin_amdgcn_fmed3f((xraw), -30.f, 30.f);                                 \
+    const float v = fexp((float)((arow[w & 0xffffu] + brow[w >> 16] - logp) + ((double)lp[k] + (double)xv))); \
+    if (v > 0.f) {                                                                                 \
+      if (v <= 2.f) atomicAdd(&acc[pdf_u[k] >> 16], (unsigned long long)(v * kFixScale));          \
+      else bad = 1;                                                                                \
+    } else if (v != 0.f) {                                                                         \
+      bad = 1;                                  /* NaN */                                          \
+    }                                                                                              \
+  } while (0)
+  if (t0 < t1) NUM_OCCW_PREFETCH(t0);
+  for (int t = t0; t < t1; t++) {
+    const float* xrow = xseq + (size_t)t * D;
+#pragma unroll
+    for (int i = 0; i < kWR; i++) { const int h = lane + 64 * i; if (h < H) { arow[h] = pa[i]; brow[h] = pb[i]; } }
+    for (int h = lane + 64 * kWR; h < H; h += 64) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)(t + 1) * H + h]; }
+    float xc[kWX];
+#pragma unroll
+    for (int i = 0; i < kWX; i++) xc[i] = px[i];
+    if (t + 1 < t1) NUM_OCCW_PREFETCH(t + 1);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < kWX; i++) { const int k = lane + 64 * i; if (k < Kused) NUM_OCCW_ARC(k, xc[i]); }
+    for (int k = lane + 64 * kWX; k < Kused; k += 64) NUM_OCCW_ARC(k, xrow[pdf_u[k] & 0xffff]);
+    __builtin_amdgcn_wave_barrier();
+    float* crow = a.rows_ws + ((size_t)b * T + t) * K;
+    for (int u = lane; u < U; u += 64) {
+      const unsigned long long v = acc[u];
+      acc[u] = 0ull;
+      crow[u] = (float)v * kFixInv;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+#undef NUM_OCCW_ARC
+#undef NUM_OCCW_PREFETCH
+  if (bad) atomicAdd(a.bad, 1);
+}
+
+// ------------------------------------------------------------------------------------
 // compact rows -> an existing dense gradient: grad[b,t,pdf_u] += grad_scale * rows[b,t,u]
 // (time-parallel; the fused ChainLoss uses it when the occupancy pass cannot fold the numerator in)
 // ------------------------------------------------------------------------------------
@@ -429,7 +544,21 @@ hipError_t launch_num_scatter(const NumArgs& a, hipStream_t st, const char** why
   return hipGetLastError();
 }
 
+size_t num_occ_wave_lds_bytes(int H, int K) {
+  const size_t Hq = (H + 1) & ~1;
+  return 12 * (size_t)K + 16 + 4 * (16 * Hq + 8 * (size_t)K) + 64;
+}
+
 hipError_t launch_num_occ(const NumArgs& a, bool compact, hipStream_t st, const char** why) {
+  if (compact && a.D <= 65535 && a.K <= 32767 && num_occ_wave_lds_bytes(a.H, a.K) <= 64 * 1024) {
+    const size_t lds = num_occ_wave_lds_bytes(a.H, a.K);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(num_occ_wave_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int gx = (a.T + 4 * kOwFrames - 1) / (4 * kOwFrames);
+    hipLaunchKernelGGL(num_occ_wave_kernel, dim3(gx, a.B), dim3(kOcNT), lds, st, a);
+    return hipGetLastError();
+  }
   const size_t lds = num_occ_lds_bytes(a.H, a.K, a.D);
   if (lds > 160 * 1024) {
     *why = "pdf accumulators + numerator graph do not fit the 160 KiB LDS of one CU";
