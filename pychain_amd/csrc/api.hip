@@ -226,7 +226,7 @@ extern "C" int pychain_hip_den_forward_backward(
 }
 
 namespace {
-struct NumCarve { size_t alpha, beta, logp, rows, upd, ucount, uidx, total; };
+struct NumCarve { size_t alpha, beta, logp, rows, upd, ucount, uidx, frac, total; };
 NumCarve num_carve(int B, int T, int H, int K) {
   NumCarve c;
   c.alpha = 0;
@@ -236,7 +236,8 @@ NumCarve num_carve(int B, int T, int H, int K) {
   c.upd = c.rows + align256(4 * (size_t)B * T * K);
   c.ucount = c.upd + align256(4 * (size_t)B * K);
   c.uidx = c.ucount + align256(4 * (size_t)B);
-  c.total = c.uidx + align256(4 * (size_t)B * K) + 256;
+  c.frac = c.uidx + align256(4 * (size_t)B * K);
+  c.total = c.frac + align256(4 * (size_t)B * T * K) + 256;
   return c;
 }
 
@@ -271,7 +272,7 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_ws = (double*)(ws + c.alpha); a.beta_ws = (double*)(ws + c.beta); a.logp_ws = (double*)(ws + c.logp);
   a.rows_ws = (float*)(ws + c.rows); a.upd_ws = (int32_t*)(ws + c.upd); a.ucount_ws = (int32_t*)(ws + c.ucount);
-  a.uidx_ws = (int32_t*)(ws + c.uidx);
+  a.uidx_ws = (int32_t*)(ws + c.uidx); a.frac_ws = (float*)(ws + c.frac);
   return PYCHAIN_HIP_OK;
 }
 }  // namespace

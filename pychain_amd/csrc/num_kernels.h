@@ -19,6 +19,7 @@ struct NumArgs {
   double* alpha_ws;          // [B,T+1,H]  alpha(t,h): unnormalised log-probabilities (fp64)
   double* beta_ws;           // [B,T+1,H]  beta(t,h)
   double* logp_ws;           // [B]        sequence log-probability (fp64)
+  float* frac_ws;            // [B,T,K]    r_k(t): log-share of forward arc k in beta(t,src_k) (written by the backward pass)
   float* rows_ws;            // [B,T,K]    compact rows: occupancy of the u-th distinct pdf of the sequence
   int32_t* upd_ws;           // [B,K]      the distinct pdf-ids of a sequence's arcs, ascending
   int32_t* ucount_ws;        // [B]        how many

@@ -128,10 +128,16 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
     const float* xrow_next = xseq + (size_t)(have_next ? (fwd ? s : L - 1 - s) : 0) * D;
     const size_t trow = (size_t)(fwd ? s : L - s) * H;
     if (have_next) xq.load(xrow_next, D, tid);
+    // bwd also writes, per arc, its log-share of its source state's beta:  r_k(t) = term_k - beta(t,h) <= 0.
+    // That is all the occupancy pass needs from this frame's nnet-output row:
+    //   occupancy = exp(alpha(t,src) + beta(t,src) - logP + r_k(t)),  a small fp32 number instead of
+    // a second, scattered read of the row.
+    float* frow = fwd ? nullptr : a.frac_ws + ((size_t)b * T + (L - s)) * K;
     if (own) {
       Lse acc; acc.init();
-      acc.push(vin[w0.pk & 0xffffu] + ((double)w0.lp + (double)xcur[w0.pk >> 16]));
-      acc.push(vin[w1.pk & 0xffffu] + ((double)w1.lp + (double)xcur[w1.pk >> 16]));
+      const double e0 = vin[w0.pk & 0xffffu] + ((double)w0.lp + (double)xcur[w0.pk >> 16]);
+      const double e1 = vin[w1.pk & 0xffffu] + ((double)w1.lp + (double)xcur[w1.pk >> 16]);
+      acc.push(e0); acc.push(e1);
       for (int k = be.x + 2; k < be.y; k++) {
         const ArcW w = arc[k];
         acc.push(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]));
@@ -139,6 +145,14 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
       const double v = acc.value();
       vout[h0] = v;
       rows[trow + h0] = v;
+      if (!fwd) {
+        if (be.y - be.x > 0) frow[be.x] = (float)(e0 - v);
+        if (be.y - be.x > 1) frow[be.x + 1] = (float)(e1 - v);
+        for (int k = be.x + 2; k < be.y; k++) {
+          const ArcW w = arc[k];
+          frow[k] = (float)(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]) - v);
+        }
+      }
     }
     for (int h = h0 + kFbNT; h < H; h += kFbNT) {             // graphs with more than 512 states
       const int2 e2 = idx[h];
@@ -150,6 +164,11 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
       const double v = acc.value();
       vout[h] = v;
       rows[trow + h] = v;
+      if (!fwd)
+        for (int k = e2.x; k < e2.y; k++) {
+          const ArcW w = arc[k];
+          frow[k] = (float)(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]) - v);
+        }
     }
     if (have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
     __syncthreads();
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
     const double logp = a.logp_ws[b];
     const double* aws = a.alpha_ws + (size_t)b * (T + 1) * H;
     const double* bws = a.beta_ws + (size_t)b * (T + 1) * H;
-    const float* xseq = a.x + (size_t)b * T * D;
+    const float* fseq = a.frac_ws + (size_t)b * T * K;
     const int U = mode == kGradCompact ? a.ucount_ws[b] : 0;
     const int32_t* upd = a.upd_ws + (size_t)b * K;
     int bad = 0;
@@ -286,32 +305,33 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
     do {                                                                                           \
       _Pragma("unroll") for (int i = 0; i < kNR; i++) {                                            \
         const int h = tid + i * kOcNT;                                                             \
-        if (h < H) { pa[i] = aws[(size_t)(t) * H + h]; pb[i] = bws[(size_t)((t) + 1) * H + h]; }   \
+        if (h < H) { pa[i] = aws[(size_t)(t) * H + h]; pb[i] = bws[(size_t)(t) * H + h]; }         \
       }                                                                                            \
       _Pragma("unroll") for (int i = 0; i < kNX; i++) {                                            \
         const int k = tid + i * kOcNT;                                                             \
-        if (k < Kused) px[i] = xseq[(size_t)(t) * D + pdf[k]];                                     \
+        if (k < Kused) px[i] = fseq[(size_t)(t) * K + k];                                          \
       }                                                                                            \
     } while (0)
     NUM_OCC_PREFETCH(t_begin);
     for (int t = t_begin; t < t_live_end; t++) {
 #pragma unroll
       for (int i = 0; i < kNR; i++) { const int h = tid + i * kOcNT; if (h < H) { arow[h] = pa[i]; brow[h] = pb[i]; } }
-      for (int h = tid + kNR * kOcNT; h < H; h += kOcNT) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)(t + 1) * H + h]; }
+      for (int h = tid + kNR * kOcNT; h < H; h += kOcNT) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)t * H + h]; }
       float xcur[kNX];
 #pragma unroll
       for (int i = 0; i < kNX; i++) xcur[i] = px[i];
       if (t + 1 < t_live_end) NUM_OCC_PREFETCH(t + 1);
       __syncthreads();
-      const float* xrow = xseq + (size_t)t * D;
+      const float* frow = fseq + (size_t)t * K;
       float* grow = gseq + (size_t)t * D;
-      // BetaGeneralFrame :204-271: occupancy = exp(alpha(t,src) + lp + x(t,pdf) + beta(t+1,dst) - logP)
-#define NUM_OCC_ARC(k, xraw)                                                                       \
+      // BetaGeneralFrame :204-271: occupancy = exp(alpha(t,src) + [lp + x(t,pdf) + beta(t+1,dst)] - logP), the
+      // bracket being beta(t,src) + r_k(t) with the arc's log-share r from the backward pass (num_fb_kernel)
+#define NUM_OCC_ARC(k, rk)                                                                         \
       do {                                                                                         \
-        const uint32_t w = sd[k];                                                                  \
+        const int src = sd[k] & 0xffffu;                                                           \
         const int n = pdf[k];                                                                      \
-        const float xv = __builtin_amdgcn_fmed3f((xraw), -30.f, 30.f);                             \
-        const float v = fexp((float)((arow[w & 0xffffu] + brow[w >> 16] - logp) + ((double)lp[k] + (double)xv))); \
+        const double st = arow[src] + brow[src] - logp;          /* log occupancy of the source state */ \
+        const float v = st == -INFINITY ? 0.f : fexp((float)(st + (double)(rk)));                  \
         if (v > 0.f) {                                                                             \
           if (v <= 2.f) atomicAdd(&acc[n], (unsigned long long)(v * kFixScale));                   \
           else bad = 1;                                                                            \
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
       } while (0)
 #pragma unroll
       for (int i = 0; i < kNX; i++) { const int k = tid + i * kOcNT; if (k < Kused) NUM_OCC_ARC(k, xcur[i]); }
-      for (int k = tid + kNX * kOcNT; k < Kused; k += kOcNT) NUM_OCC_ARC(k, xrow[pdf[k]]);
+      for (int k = tid + kNX * kOcNT; k < Kused; k += kOcNT) NUM_OCC_ARC(k, frow[k]);
 #undef NUM_OCC_ARC
       __syncthreads();
       if (mode == PYCHAIN_HIP_GRAD_ACCUM) {
@@ -407,7 +427,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   const double logp = a.logp_ws[b];
   const double* aws = a.alpha_ws + (size_t)b * (T + 1) * H;
   const double* bws = a.beta_ws + (size_t)b * (T + 1) * H;
-  const float* xseq = a.x + (size_t)b * T * D;
+  const float* fseq = a.frac_ws + (size_t)b * T * K;
   int bad = 0;
   const int t0 = t_wg + wave * kOwFrames, t1 = min(t0 + kOwFrames, L);
   // Software pipeline: a wave has nobody to hide its own global latencies behind, so the rows and the
@@ -418,22 +438,22 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   double pa[kWR], pb[kWR];
 #define NUM_OCCW_PREFETCH(t)                                                                       \
   do {                                                                                             \
-    const float* xr_ = xseq + (size_t)(t) * D;                                                     \
+    const float* fr_ = fseq + (size_t)(t) * K;                                                     \
     _Pragma("unroll") for (int i = 0; i < kWX; i++) {                                              \
       const int k = lane + 64 * i;                                                                 \
-      if (k < Kused) px[i] = xr_[pdf_u[k] & 0xffff];                                               \
+      if (k < Kused) px[i] = fr_[k];                                                               \
     }                                                                                              \
     _Pragma("unroll") for (int i = 0; i < kWR; i++) {                                              \
       const int h = lane + 64 * i;                                                                 \
-      if (h < H) { pa[i] = aws[(size_t)(t) * H + h]; pb[i] = bws[(size_t)((t) + 1) * H + h]; }     \
+      if (h < H) { pa[i] = aws[(size_t)(t) * H + h]; pb[i] = bws[(size_t)(t) * H + h]; }           \
     }                                                                                              \
   } while (0)
-  // BetaGeneralFrame :204-271: occupancy = exp(alpha(t,src) + lp + x(t,pdf) + beta(t+1,dst) - logP)
-#define NUM_OCCW_ARC(k, xraw)                                                                      \
+  // occupancy = exp(alpha(t,src) + beta(t,src) - logP + r_k(t)), see num_occ_kernel
+#define NUM_OCCW_ARC(k, rk)                                                                        \
   do {                                                                                             \
-    const uint32_t w = sd[k];                                                                      \
-    const float xv = __builtin_amdgcn_fmed3f((xraw), -30.f, 30.f);                                 \
-    const float v = fexp((float)((arow[w & 0xffffu] + brow[w >> 16] - logp) + ((double)lp[k] + (double)xv))); \
+    const int src = sd[k] & 0xffffu;                                                               \
+    const double st = arow[src] + brow[src] - logp;                                                \
+    const float v = st == -INFINITY ? 0.f : fexp((float)(st + (double)(rk)));                      \
     if (v > 0.f) {                                                                                 \
       if (v <= 2.f) atomicAdd(&acc[pdf_u[k] >> 16], (unsigned long long)(v * kFixScale));          \
       else bad = 1;                                                                                \
@@ -443,10 +463,10 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   } while (0)
   if (t0 < t1) NUM_OCCW_PREFETCH(t0);
   for (int t = t0; t < t1; t++) {
-    const float* xrow = xseq + (size_t)t * D;
+    const float* frow = fseq + (size_t)t * K;
 #pragma unroll
     for (int i = 0; i < kWR; i++) { const int h = lane + 64 * i; if (h < H) { arow[h] = pa[i]; brow[h] = pb[i]; } }
-    for (int h = lane + 64 * kWR; h < H; h += 64) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)(t + 1) * H + h]; }
+    for (int h = lane + 64 * kWR; h < H; h += 64) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)t * H + h]; }
     float xc[kWX];
 #pragma unroll
     for (int i = 0; i < kWX; i++) xc[i] = px[i];
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < kWX; i++) { const int k = lane + 64 * i; if (k < Kused) NUM_OCCW_ARC(k, xc[i]); }
-    for (int k = lane + 64 * kWX; k < Kused; k += 64) NUM_OCCW_ARC(k, xrow[pdf_u[k] & 0xffff]);
+    for (int k = lane + 64 * kWX; k < Kused; k += 64) NUM_OCCW_ARC(k, frow[k]);
     __builtin_amdgcn_wave_barrier();
     float* crow = a.rows_ws + ((size_t)b * T + t) * K;
     for (int u = lane; u < U; u += 64) {
