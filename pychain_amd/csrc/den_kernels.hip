@@ -341,6 +341,9 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const int nsteps = fwd ? L : L - 1;
   const int j_begin = a.seg_begin, j_end = min(a.seg_end, nsteps);
   if (j_begin > 0 && j_begin >= nsteps) return;      // this sequence finished in an earlier segment
+#ifdef PYCHAIN_EXP_ONLY_DIR                          // timing experiment: 0 = alpha workgroups only, 1 = beta only
+  if ((int)fwd == PYCHAIN_EXP_ONLY_DIR) return;
+#endif
   const int Hp = a.Hp, H = a.H, D = a.D, Dp = (D + 3) & ~3;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
