@@ -308,8 +308,9 @@ __device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const 
       const float4 l = *reinterpret_cast<const float4*>(lk + i);
       v = make_float4(r.x * inv + coef * l.x, r.y * inv + coef * l.y, r.z * inv + coef * l.z, r.w * inv + coef * l.w);
     } else {
-      v = make_float4(i + 0 < H ? (r.x + add) * inv : 0.f, i + 1 < H ? (r.y + add) * inv : 0.f,
-                      i + 2 < H ? (r.z + add) * inv : 0.f, i + 3 < H ? (r.w + add) * inv : 0.f);
+      // (positions >= H are padding: nothing gathers them and the occupancy pass skips them, so they are
+      // allowed to carry add * inv instead of zero - masking costs 8 VALU per thread on the critical path)
+      v = make_float4((r.x + add) * inv, (r.y + add) * inv, (r.z + add) * inv, (r.w + add) * inv);
     }
     *reinterpret_cast<float4*>(cur + i) = v;
     if (row) *reinterpret_cast<float4*>(row + i) = v;
