@@ -373,6 +373,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const float* xseq = a.x + (size_t)b * a.T * D;
   float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
   const float coef = a.coef;
+  const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
 
   double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229
   int bad = 0;
@@ -434,7 +435,10 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     const int tn = fwd ? j + 1 : L - 2 - j;          /* nnet-output row of the NEXT step */                \
     const bool have_next = fwd ? (tn < L) : (tn >= 1);                                                      \
     const float* xrow_next = xseq + (size_t)(have_next ? tn : 0) * D;                                       \
-    if (kWithX && have_next) xq.load(xrow_next, D, tid);       /* in flight during the arc work */          \
+    if (kWithX && have_next) {                       /* in flight during the arc work */                    \
+      if constexpr (VEC == 4 && XCH > 0) xq.load_row(xbuf, have_next ? tn : 0, D, tid);                      \
+      else xq.load(xrow_next, D, tid);                                                                      \
+    }                                                                                                       \
     float s0 = 0.f, s1 = 0.f;                                                                               \
     if (kWithArcs)                                                                                          \
       tile_rows<R, 0, VOFF>(arcs, groups, tail_slots, lane, cur, xr + (VOFF) / 4, raw, nullptr, fwd ? nullptr : lk, s0, s1); \

@@ -77,18 +77,45 @@ __device__ __forceinline__ float mul_add_rn(float a, float b, float c) {
   return p + c;
 }
 
+// ---- buffer descriptor of one sequence's nnet-output [T, D] -------------------------------------
+// Rows are fetched with `buffer_load_dwordx4 vdst, voffset, srsrc, soffset offen`: the row is selected by
+// the SGPR soffset, the lane by a loop-invariant 32-bit voffset, so a frame's load writes NO address
+// VGPR.  (With a 64-bit VGPR address the per-frame address arithmetic overwrites registers an
+// outstanding store may still read, and the compiler drains every VMEM operation - the previous
+// frame's row store to HBM included - before the frame can start.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t XBuf;
+__device__ __forceinline__ XBuf make_xbuf(const float* seq, size_t bytes) {
+  const uint64_t v = reinterpret_cast<uint64_t>(seq);     // uniformity made provable: both halves through readfirstlane
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xffffffffull ? 0xffffffffull : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, (int)n, 0x00020000);
+}
+
 // ---- nnet-output row: global -> registers (early) -> LDS (late) ------------------
 template <int NT, int VEC, int XCH>
 struct XRow {
   float v[(VEC * XCH) > 0 ? (VEC * XCH) : 1];
+  // row t of the sequence behind `buf` (VEC == 4 only): see make_xbuf
+  __device__ __forceinline__ void load_row(XBuf buf, int t, int D, int tid) {
+    static_assert(VEC == 4 && XCH > 0, "buffer form: float4 chunks");
+    const int soff = __builtin_amdgcn_readfirstlane(t * D * 4);
+#pragma unroll
+    for (int c = 0; c < XCH; c++) {
+      const int e = (c * NT + tid) * 4;
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(buf, min(e, D - 4) * 4, soff, 0);   // lanes past the row re-read its end
+      v[c * 4 + 0] = __uint_as_float(q.x); v[c * 4 + 1] = __uint_as_float(q.y);
+      v[c * 4 + 2] = __uint_as_float(q.z); v[c * 4 + 3] = __uint_as_float(q.w);
+    }
+  }
   __device__ __forceinline__ void load(const float* __restrict__ row, int D, int tid) {
     if constexpr (XCH > 0) {
 #pragma unroll
       for (int c = 0; c < XCH; c++) {
         const int e = (c * NT + tid) * VEC;
         if constexpr (VEC == 4) {
-          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (e < D) q = *reinterpret_cast<const float4*>(row + e);
+          // unpredicated: lanes past the row re-read its last float4 (store() never uses them)
+          const float4 q = *reinterpret_cast<const float4*>(row + min(e, D - 4));
           v[c * 4 + 0] = q.x; v[c * 4 + 1] = q.y; v[c * 4 + 2] = q.z; v[c * 4 + 3] = q.w;
         } else {
           v[c] = e < D ? row[e] : 0.f;
