@@ -90,6 +90,7 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
       arc[k] = ArcW{(uint32_t)tr[3 * k + (fwd ? 0 : 1)] | ((uint32_t)tr[3 * k + 2] << 16), pr[k]};
   }
   const float* xseq = a.x + (size_t)b * T * D;
+  const XBuf xbuf = make_xbuf(xseq, (size_t)T * D * sizeof(float));
   double* rows = (fwd ? a.alpha_ws : a.beta_ws) + (size_t)b * (T + 1) * H;     // row t = alpha(t,.) / beta(t,.), fp64 log-prob
   const int2* idx = reinterpret_cast<const int2*>((fwd ? a.bwd_idx : a.fwd_idx) + g * H * 2);
 
@@ -125,9 +126,14 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
     const float* xcur = (s & 1) ? xr0 : xr1;
     float* xnext = (s & 1) ? xr1 : xr0;
     const bool have_next = s < L;
-    const float* xrow_next = xseq + (size_t)(have_next ? (fwd ? s : L - 1 - s) : 0) * D;
+    const int t_next = have_next ? (fwd ? s : L - 1 - s) : 0;
+    const float* xrow_next = xseq + (size_t)t_next * D;
     const size_t trow = (size_t)(fwd ? s : L - s) * H;
-    if (have_next) xq.load(xrow_next, D, tid);
+    if (have_next) {
+      // buffer form: no address VGPR is written per step, so the load does not wait for this step's row stores
+      if constexpr (VEC == 4 && XCH > 0) xq.load_row(xbuf, t_next, D, tid);
+      else xq.load(xrow_next, D, tid);
+    }
     // bwd also writes, per arc, its log-share of its source state's beta:  r_k(t) = term_k - beta(t,h) <= 0.
     // That is all the occupancy pass needs from this frame's nnet-output row:
     //   occupancy = exp(alpha(t,src) + beta(t,src) - logP + r_k(t)),  a small fp32 number instead of
