@@ -184,7 +184,8 @@ __device__ __forceinline__ void wave_priority_by_progress(int c) {
 #ifndef PYCHAIN_EXP_NOPRIO
   // highest for the first half of the chunks, then stepping down to 0 on the last one (measured best of
   // four schedules: equal quarters 3.76 ms, front-loaded 3.78, this 3.69, two levels 3.84)
-  auto level = [](int cc) { return cc * 2 / NC == 0 ? 3 : max(0, 2 - (cc - NC / 2) * 6 / NC); };
+  constexpr int N = NC > 0 ? NC : 1;
+  auto level = [](int cc) { return cc * 2 / N == 0 ? 3 : max(0, 2 - (cc - N / 2) * 6 / N); };
   const int lvl = level(c), prev = c > 0 ? level(c - 1) : -1;
   if (NC >= 4 && lvl != prev) {
     switch (lvl) {                               // (s_setprio takes an immediate)

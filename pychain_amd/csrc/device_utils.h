@@ -123,22 +123,29 @@ struct XRow {
       }
     }
   }
-  __device__ __forceinline__ void store(float* lds, const float* __restrict__ row, int D, int tid, int is_exp) {
-    if constexpr (XCH > 0) {
+  // `mode` is uniform: one branch per call, not a select per element
+  template <int MODE>
+  __device__ __forceinline__ void store_mode(float* lds, int D, int tid) {
 #pragma unroll
-      for (int c = 0; c < XCH; c++) {
-        const int e = (c * NT + tid) * VEC;
-        if (e < D) {
-          if constexpr (VEC == 4) {
-            float4 q;
-            q.x = clamp_exp(v[c * 4 + 0], is_exp); q.y = clamp_exp(v[c * 4 + 1], is_exp);
-            q.z = clamp_exp(v[c * 4 + 2], is_exp); q.w = clamp_exp(v[c * 4 + 3], is_exp);
-            *reinterpret_cast<float4*>(lds + e) = q;
-          } else {
-            lds[e] = clamp_exp(v[c], is_exp);
-          }
+    for (int c = 0; c < XCH; c++) {
+      const int e = (c * NT + tid) * VEC;
+      if (e < D) {
+        if constexpr (VEC == 4) {
+          float4 q;
+          q.x = clamp_exp(v[c * 4 + 0], MODE); q.y = clamp_exp(v[c * 4 + 1], MODE);
+          q.z = clamp_exp(v[c * 4 + 2], MODE); q.w = clamp_exp(v[c * 4 + 3], MODE);
+          *reinterpret_cast<float4*>(lds + e) = q;
+        } else {
+          lds[e] = clamp_exp(v[c], MODE);
         }
       }
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, const float* __restrict__ row, int D, int tid, int is_exp) {
+    if constexpr (XCH > 0) {
+      if (is_exp == kXExpClamp) store_mode<kXExpClamp>(lds, D, tid);
+      else if (is_exp == kXIdentity) store_mode<kXIdentity>(lds, D, tid);
+      else store_mode<kXClamp>(lds, D, tid);
     } else {  // any D: no register staging
       for (int e = tid; e < D; e += NT) lds[e] = clamp_exp(row[e], is_exp);
     }

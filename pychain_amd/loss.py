@@ -103,12 +103,14 @@ class ChainLossFunction(torch.autograd.Function):
         den_objf, num_objf, bad, state = native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
             with_grad=ctx.speculative, grad_scale=ctx.host_scale)
-        objf = -(num_objf.sum() - den_objf.sum()) * ctx.host_scale
+        objf = den_objf.sum() - num_objf.sum()           # = -(num - den), loss.py:100-102
+        if ctx.host_scale != 1.0:
+            objf = objf * ctx.host_scale
         if ctx.dev_norm is not None:
             objf = objf / ctx.dev_norm
         ctx.state = state
         ctx.in_dtype = input.dtype
-        ChainFunction.last_bad_count = bad.sum()
+        ChainFunction.last_bad_count = bad       # int32[2]: denominator, numerator; never synced here
         return objf
 
     overlap = True     # class-level switch: False = occupancy passes run in backward (no speculation)
@@ -120,7 +122,7 @@ class ChainLossFunction(torch.autograd.Function):
             grad = native.rescale_(ctx.state.grad, g)
         else:
             grad, bad = native.chain_loss_backward(ctx.state, ctx.host_scale, g)
-            ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad.sum()
+            ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad
         ctx.state = None          # release the stored trajectories
         return grad.to(ctx.in_dtype), None, None, None, None, None
 

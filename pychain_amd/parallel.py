@@ -53,11 +53,11 @@ def allreduce_stats(objf, n_frames, bad_count=None, group=None):
     """[objf, n_frames, n_bad] summed over all ranks with ONE collective (RCCL all_reduce
     over xGMI on GPUs, gloo on CPU).  Returns the fp32[3] buffer; no host sync."""
     dev = objf.device
-    buf = torch.zeros(3, dtype=torch.float32, device=dev)
-    buf[0] = objf.detach().float().reshape(())
-    buf[1] = torch.as_tensor(n_frames, device=dev).float().reshape(())
-    if bad_count is not None:
-        buf[2] = bad_count.to(dev).float().reshape(())
+    parts = [objf.detach().to(torch.float32).reshape(1),
+             torch.as_tensor(n_frames, device=dev).to(torch.float32).reshape(1),
+             bad_count.to(dev).sum(dtype=torch.float32).reshape(1) if bad_count is not None
+             else torch.zeros(1, dtype=torch.float32, device=dev)]
+    buf = torch.cat(parts)        # one small kernel, not a fill and three copies
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
