@@ -2,6 +2,7 @@
 // workspace carving, launches.  No allocation, no host synchronisation.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -178,6 +179,15 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
   for (int s = 0; s < nseg; s++) {
     const double frac = s == nseg - 1 ? 1.0 : 1.0 - 1.0 / (double)(2 << s);
     a.seg_bound[s] = s == nseg - 1 ? a.T : ((int)(frac * a.T) + 31) / 32 * 32;
+  }
+  if (const char* e = getenv("PYCHAIN_DEN_BOUNDS")) {   // experiment: "0.7,0.85" = ends of all segments but the last, as fractions of T
+    int s = 0;
+    for (const char* p = e; *p && s < nseg - 1; s++) {
+      char* q; const double f = strtod(p, &q);
+      if (q == p) break;
+      a.seg_bound[s] = std::min(a.T, ((int)(f * a.T) + 31) / 32 * 32);
+      p = *q == ',' ? q + 1 : q;
+    }
   }
   for (int s = 0; s < nseg && e == hipSuccess; s++) {
     a.phase_mask = 1; a.seg_begin = s ? a.seg_bound[s - 1] : 0; a.seg_end = s == nseg - 1 ? 0x7fffffff : a.seg_bound[s];

@@ -55,17 +55,43 @@ class ChainFunction(torch.autograd.Function):
             gstride = 0 if graphs.shared_graph is not None else 1
             objf, input_grad, bad = native.num_forward_backward(
                 gt, gstride, graphs.num_states, x, input_lengths, grad_mode=_lib.GRAD_LINEAR)
-        ctx.save_for_backward(input_grad)
+        # The occupancies are the gradient for an upstream gradient of 1.  backward() scales the
+        # buffer in place on the device (a no-op launch when the upstream gradient is exactly 1,
+        # i.e. `objf.backward()`) and hands it to autograd, instead of the reference's extra
+        # read+write pass over [B,T,D] (torch.mul, loss.py:85).  `retain_grad_buffer` = True keeps
+        # the reference's behaviour for callers that back-propagate twice (retain_graph=True).
+        if ChainFunction.retain_grad_buffer:
+            ctx.save_for_backward(input_grad)
+        else:
+            ctx.grad_buf = input_grad
         ctx.in_dtype = input.dtype   # fp16 / bf16 inputs are evaluated in fp32; the gradient goes back in their dtype
         ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
         ChainFunction.last_bad_count = bad
         return objf.sum()
 
+    retain_grad_buffer = False
+
     @staticmethod
     def backward(ctx, objf_grad):
-        input_grad, = ctx.saved_tensors
         # clamp is inside the Function and therefore not differentiated (loss.py:30,82-87)
-        return torch.mul(input_grad, objf_grad).to(ctx.in_dtype), None, None, None
+        if ctx.saved_tensors:
+            input_grad, = ctx.saved_tensors
+            return torch.mul(input_grad, objf_grad).to(ctx.in_dtype), None, None, None
+        grad = _take_grad_buffer(ctx, "grad_buf", "ChainFunction")
+        return native.rescale_(grad, objf_grad).to(ctx.in_dtype), None, None, None
+
+
+def _take_grad_buffer(ctx, attr, who):
+    """The gradient buffer written in forward, handed over ONCE (autograd then owns it: a leaf's
+    .grad takes it without a copy)."""
+    buf = getattr(ctx, attr, None)
+    if buf is None:
+        raise RuntimeError(
+            "%s.backward was called a second time: the gradient buffer was handed to autograd by the "
+            "first call.  Set pychain_amd.ChainFunction.retain_grad_buffer = True before the forward "
+            "pass (and ChainLoss(...).fused = False) to back-propagate more than once." % who)
+    setattr(ctx, attr, None)
+    return buf
 
 
 class ChainLossFunction(torch.autograd.Function):
@@ -118,12 +144,13 @@ class ChainLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, objf_grad):
         g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
+        state = _take_grad_buffer(ctx, "state", "ChainLossFunction")
         if ctx.speculative:
-            grad = native.rescale_(ctx.state.grad, g)
+            grad = native.rescale_(state.grad, g)
         else:
-            grad, bad = native.chain_loss_backward(ctx.state, ctx.host_scale, g)
+            grad, bad = native.chain_loss_backward(state, ctx.host_scale, g)
             ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad
-        ctx.state = None          # release the stored trajectories
+        state.grad = None         # the stored trajectories go with `state`
         return grad.to(ctx.in_dtype), None, None, None, None, None
 
 
