@@ -57,7 +57,7 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   (void)D;
   if (B <= 0 || T <= 0 || H <= 0) return 0;
   const size_t Hp = roundup64(H);
-  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256;
+  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ + 256;
 }
 
 namespace {
@@ -96,6 +96,8 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.alpha_store = (float*)ws;
   a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
   a.logsum_ws = (double*)(ws + align256(4 * (size_t)B * T * a.Hp) + align256(4 * (size_t)B * (T + 1) * a.Hp));
+  a.progress = (int32_t*)((char*)a.logsum_ws + align256(8 * (size_t)B));
+  a.sig_n = 0;
   a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_seg = 0; a.gam_nseg = 0;
   return PYCHAIN_HIP_OK;
 }
@@ -189,6 +191,33 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
       p = *q == ',' ? q + 1 : q;
     }
   }
+  if (!getenv("PYCHAIN_DEN_RELAUNCH")) {
+    // Gated schedule: ONE recursion launch; its workgroups count themselves into progress[s] when their
+    // steps below seg_bound[s] are done, and a one-wave gate kernel in front of occupancy launch s (side
+    // stream) waits for all 2B of them.  No relaunch of the persistent workgroups at the segment ends.
+    a.sig_n = nseg - 1;
+    e = hipMemsetAsync(a.progress, 0, 16 * sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // the gates must see the zeroed counters
+    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
+    a.phase_mask = 1; a.seg_begin = 0; a.seg_end = 0x7fffffff;
+    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
+    a.phase_mask = 2; a.gam_nseg = nseg;
+    for (int s = 0; s < nseg - 1 && e == hipSuccess; s++) {
+      a.gam_seg = s;
+      e = launch_den_gate(a.progress + s, 2 * a.B, a.bad, side->stream2);
+      if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
+      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
+    }
+    // the last occupancy launch follows the recursion in stream order on the caller's stream
+    a.gam_seg = nseg - 1;
+    if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(st, gamma_wait, 0);
+    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
+    if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
+    a.phase_mask = user_mask; a.gam_nseg = 0; a.sig_n = 0;
+    return e;
+  }
+  // Relaunch schedule (PYCHAIN_DEN_RELAUNCH=1): one recursion launch per segment, stream events in between.
   for (int s = 0; s < nseg && e == hipSuccess; s++) {
     a.phase_mask = 1; a.seg_begin = s ? a.seg_bound[s - 1] : 0; a.seg_end = s == nseg - 1 ? 0x7fffffff : a.seg_bound[s];
     e = launch_den(a, gmax, resident_slot_rows, st, why);

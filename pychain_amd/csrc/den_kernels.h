@@ -29,6 +29,11 @@ struct DenArgs {
   int gam_seg, gam_nseg;
   int seg_bound[16];         // recursion segment s covers steps [seg_bound[s-1], seg_bound[s]) (seg_bound[-1] = 0)
   double* logsum_ws;         // [B] running sum of log tot-alpha carried across recursion segments
+  // Progress signalling (the gated schedule): a recursion workgroup adds 1 to progress[s] once its steps
+  // [0, seg_bound[s]) are done and their rows are visible device-wide, s < sig_n; the occupancy launch of
+  // segment s is released by den_gate_kernel when progress[s] reaches 2B.  sig_n = 0: no signalling.
+  int32_t* progress;         // [16], zeroed before the recursion launch
+  int sig_n;
   float coef, grad_scale;
   const float* grad_scale_dev;   // optional device scalar multiplied into grad_scale (upstream autograd gradient)
   // Numerator fold (fused ChainLoss, two-frame occupancy kernel only): grad += fold_scale * occupancy of the
@@ -47,6 +52,10 @@ bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_r
 // shape is unsupported, a reason in *why.
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,
                       const char** why);
+
+// One wave that waits until *progress >= target (set by the recursion workgroups), so that what follows
+// it in stream order starts then; gives up after ~20 s and counts that in *bad.
+hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hipStream_t st);
 
 }  // namespace pychain_hip
 #endif

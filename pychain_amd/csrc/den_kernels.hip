@@ -300,7 +300,12 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
 // Normalise the frame's raw sums into the gather operand and stream the row to HBM, 16 bytes
 // per lane:  alpha: v = raw/tot + coef*leaky   (AlphaSum/AlphaDash, chain-computation.cc:97-110,178-194)
 //            beta:  v = (raw + coef*sum_i leaky_i raw_i)/sum_i raw_i  (Beta, :313-330; unit-sum scale)
-__device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const float* lk, float* cur, float* row,
+// The row also goes to the trajectory store behind `sbuf` (byte offset row_off, < 0 = not stored), with a
+// device-scope write-through store (sc1): the occupancy kernel may read it on another XCD while this
+// kernel is still running (gated schedule), and the row is not read again here, so it need not stay in
+// this XCD's L2.
+constexpr int kStoreDeviceScope = 16;    // cache-policy operand of the buffer store: sc1
+__device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const float* lk, float* cur, XBuf sbuf, int row_off,
                                               float inv, float coef, float add, int H, int Hp, int tid) {
   for (int i = tid * 4; i < Hp; i += kNT * 4) {
     const float4 r = *reinterpret_cast<const float4*>(raw + i);
@@ -314,7 +319,11 @@ __device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const 
       v = make_float4((r.x + add) * inv, (r.y + add) * inv, (r.z + add) * inv, (r.w + add) * inv);
     }
     *reinterpret_cast<float4*>(cur + i) = v;
-    if (row) *reinterpret_cast<float4*>(row + i) = v;
+    if (row_off >= 0) {
+      u32x4 q;
+      q.x = __float_as_uint(v.x); q.y = __float_as_uint(v.y); q.z = __float_as_uint(v.z); q.w = __float_as_uint(v.w);
+      __builtin_amdgcn_raw_buffer_store_b128(q, sbuf, i * 4, row_off, kStoreDeviceScope);
+    }
   }
 }
 
@@ -375,6 +384,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
   const float coef = a.coef;
   const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
+  const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));   // < 2 GiB: checked at launch
 
   double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229
   int bad = 0;
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     const float inv = __builtin_amdgcn_rcpf(tot);
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
     logsum += (double)fast_log(tot);
-    normalise_row(fwd, raw, lk, cur, store + (size_t)(fwd ? 0 : L) * Hp, inv, coef, coef * wtot, H, Hp, tid);
+    normalise_row(fwd, raw, lk, cur, sbuf, (fwd ? 0 : L) * Hp * 4, inv, coef, coef * wtot, H, Hp, tid);
   } else {
     // ---- resume a later time segment: the state vector is the row the previous segment stored last
     const float* row = store + (size_t)(fwd ? j_begin : L - j_begin) * Hp;
@@ -462,7 +472,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     const int tstore = fwd ? j + 1 : L - 1 - j;                                                             \
     const bool do_store = fwd ? (tstore < L) : true;                                                        \
     if (kWithNorm)                                                                                          \
-      normalise_row(fwd, raw, lk, cur, do_store ? store + (size_t)tstore * Hp : nullptr, inv, coef, coef * wtot, H, Hp, tid); \
+      normalise_row(fwd, raw, lk, cur, sbuf, do_store ? tstore * Hp * 4 : -1, inv, coef, coef * wtot, H, Hp, tid); \
     PH_ADD(3, pt); pt = PH_T();                                                                             \
     if (!DB && kWithX && have_next) xq.store(xr, xrow_next, D, tid, a.input_is_exp);                        \
     PH_ADD(4, pt); pt = PH_T();                                                                             \
@@ -490,15 +500,31 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 #else
   constexpr int kArcsOnly = 0;
 #endif
+  // Progress signal of the gated schedule: once the steps below seg_bound[s] are done, every wave waits for
+  // its own row stores (device-scope write-through, normalise_row: the L2s of the XCDs are not coherent with
+  // one another and the occupancy kernel runs on all of them), then one thread counts the workgroup in.
+  int next_sig = 0;
+  int next_bound = a.sig_n > 0 ? a.seg_bound[0] : 0x7fffffff;
+#define PYCHAIN_REC_SIGNAL(DONE)                                                                            \
+  while ((DONE) >= next_bound) {                                                                            \
+    __builtin_amdgcn_s_waitcnt(0);                     /* this wave's row stores are acknowledged */          \
+    __syncthreads();                                                                                        \
+    if (tid == 0) __hip_atomic_fetch_add(a.progress + next_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    next_sig++;                                                                                             \
+    next_bound = next_sig < a.sig_n ? a.seg_bound[next_sig] : 0x7fffffff;                                   \
+  }
   if constexpr (DB) {
     // segments start at even steps (seg bounds are multiples of 32), so step parity = buffer parity
     for (int jj = j_begin; jj < j_end; jj += 2) {      // (the macro declares `j`)
       PYCHAIN_REC_STEP(jj, 0);
       if (jj + 1 < j_end) PYCHAIN_REC_STEP(jj + 1, kXOff);
+      PYCHAIN_REC_SIGNAL(jj + 2);                      // bounds are even
     }
   } else {
-    for (int jj = j_begin; jj < j_end; jj++) PYCHAIN_REC_STEP(jj, 0);
+    for (int jj = j_begin; jj < j_end; jj++) { PYCHAIN_REC_STEP(jj, 0); PYCHAIN_REC_SIGNAL(jj + 1); }
   }
+  PYCHAIN_REC_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // a sequence shorter than a bound is done with it now
+#undef PYCHAIN_REC_SIGNAL
 #undef PYCHAIN_REC_STEP
 #ifdef PYCHAIN_PROFILE_PHASES
   if (lane == 0 && (b == 0))
@@ -1052,6 +1078,17 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
+__global__ void den_gate_kernel(const int32_t* progress, int target, int32_t* bad) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();              // 100 MHz
+  // (relaxed: an acquire here would invalidate this XCD's L2 on every poll; the kernel that follows in
+  // stream order acquires at its start)
+  while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > 2000000000ull) { atomicAdd(bad, 1); break; }   // 20 s: the recursion died
+  }
+}
+
 template <typename K>
 hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream_t st, int nthreads = kNT) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1119,6 +1156,11 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
 
 }  // namespace
 
+hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hipStream_t st) {
+  hipLaunchKernelGGL(den_gate_kernel, dim3(1), dim3(64), 0, st, progress, target, bad);
+  return hipGetLastError();
+}
+
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
   return gamma2_eligible(a, (resident_slot_rows >> 20) & 1023, gamma_max_groups);
 }
@@ -1131,6 +1173,11 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
   const size_t lds_gam = sizeof(float) * (2 * (size_t)a.Hp + 2 * (size_t)Dp + (size_t)gamma_max_groups * 64 + 16);
   if (lds_rec > 160 * 1024 || lds_gam > 160 * 1024) {
     *why = "state vector + nnet-output row do not fit the 160 KiB LDS of one CU";
+    return hipErrorInvalidValue;
+  }
+  // rows are addressed as 32-bit byte offsets into one sequence's slab (buffer loads / stores)
+  if ((size_t)a.T * a.D * 4 >= (size_t)1 << 31 || ((size_t)a.T + 1) * a.Hp * 4 >= (size_t)1 << 31) {
+    *why = "one sequence's nnet-output slab or state trajectory reaches 2 GiB";
     return hipErrorInvalidValue;
   }
   const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;

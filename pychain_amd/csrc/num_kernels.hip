@@ -543,6 +543,10 @@ hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
     *why = "numerator graph + nnet-output rows do not fit the 160 KiB LDS of one CU";
     return hipErrorInvalidValue;
   }
+  if ((size_t)a.T * a.D * 4 >= (size_t)1 << 31) {      // rows are addressed as 32-bit byte offsets (buffer loads)
+    *why = "one sequence's nnet-output slab reaches 2 GiB";
+    return hipErrorInvalidValue;
+  }
   const int D = a.D;
   if (D % 4 == 0) {
     if (D <= 4 * 2 * kFbNT) return launch_fb<4, 2>(a, lds, st);
