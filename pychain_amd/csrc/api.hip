@@ -187,7 +187,7 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
     for (const char* p = e; *p && s < nseg - 1; s++) {
       char* q; const double f = strtod(p, &q);
       if (q == p) break;
-      a.seg_bound[s] = std::min(a.T, ((int)(f * a.T) + 31) / 32 * 32);
+      a.seg_bound[s] = std::min(a.T, ((int)(std::max(f, 0.5) * a.T) + 31) / 32 * 32);   // nothing is computable before T/2
       p = *q == ',' ? q + 1 : q;
     }
   }

@@ -568,6 +568,35 @@ __device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const Den
   return t;
 }
 
+// Occupancy launches of the segments after the first only hold the outer frames of a sequence: a left
+// range [L-1-hi, L-1-lo) and a right range (lo, hi] (lo, hi = ends of the previous and of this segment).
+// Their grid is sized for those ranges (den_compact_grid_x) and block k takes the k-th chunk of
+// frames_per_block frames that meets them, instead of one workgroup per chunk of [0, T) of which most
+// would find nothing to do (an idle workgroup still needs a whole free CU to start).  The first launch
+// keeps the plain mapping: it also zeroes the padding of every chunk.  Returns -1: no chunk for this block.
+__device__ __forceinline__ int den_chunk_of_block(int k, int L, const DenArgs& a) {
+  if (a.gam_nseg == 0 || a.gam_seg == 0) return k;
+  const int fpb = a.frames_per_block;
+  const int lo = a.seg_bound[a.gam_seg - 1];
+  const int hi = a.gam_seg == a.gam_nseg - 1 ? 0x3fffffff : a.seg_bound[a.gam_seg];
+  const int a0 = max(0, L - 1 - hi), a1 = L - 1 - lo;          // left frames [a0, a1)
+  const int b0 = lo + 1, b1 = min(hi, L - 1);                   // right frames [b0, b1]
+  const int nl = a1 > a0 ? (a1 - 1) / fpb - a0 / fpb + 1 : 0;
+  if (k < nl) return a0 / fpb + k;
+  if (b1 < b0) return -1;
+  int c0 = b0 / fpb;
+  if (nl > 0 && c0 == (a1 - 1) / fpb) c0++;                     // that chunk went to the left range's last block
+  const int c = c0 + (k - nl);
+  return c <= b1 / fpb ? c : -1;
+}
+int den_compact_grid_x(const DenArgs& a) {
+  const int fpb = a.frames_per_block, full = (a.T + fpb - 1) / fpb;
+  if (a.gam_nseg == 0 || a.gam_seg == 0) return full;
+  const int lo = a.seg_bound[a.gam_seg - 1];
+  const int hi = a.gam_seg == a.gam_nseg - 1 ? a.T : a.seg_bound[a.gam_seg];
+  return std::min(full, 2 * ((hi - lo + fpb - 1) / fpb + 1));
+}
+
 // ------------------------------------------------------------------------------------
 // launch 2: occupancies (time-parallel)
 // ------------------------------------------------------------------------------------
@@ -587,7 +616,9 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const int b = blockIdx.y;
   const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
   const int Hp = a.Hp, D = a.D, Dp = (D + 3) & ~3;
-  const int t_begin = blockIdx.x * a.frames_per_block;
+  const int chunk = den_chunk_of_block(blockIdx.x, L, a);
+  if (chunk < 0) return;
+  const int t_begin = chunk * a.frames_per_block;
   const int t_end = min(t_begin + a.frames_per_block, a.T);
   float* gseq = a.grad + (size_t)b * a.T * D;
   const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
@@ -903,7 +934,9 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   const int b = blockIdx.y;
   const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
   const int Hp = a.Hp, D = a.D, T = a.T, Dp = (D + 3) & ~3;
-  const int t_begin = blockIdx.x * a.frames_per_block;          // frames_per_block is even
+  const int chunk = den_chunk_of_block(blockIdx.x, L, a);
+  if (chunk < 0) return;
+  const int t_begin = chunk * a.frames_per_block;               // frames_per_block is even
   const int t_end = min(t_begin + a.frames_per_block, T);
   float* gseq = a.grad + (size_t)b * T * D;
   const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
@@ -1180,7 +1213,7 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
     *why = "one sequence's nnet-output slab or state trajectory reaches 2 GiB";
     return hipErrorInvalidValue;
   }
-  const int gx = (a.T + a.frames_per_block - 1) / a.frames_per_block;
+  const int gx = den_compact_grid_x(a);
   const int D = a.D, r = resident_slot_rows;
   if (D % 4 == 0) {
     if (D <= 4 * 1 * kNT) return launch_r<4, 1>(a, r, lds_rec, lds_gam, gx, st, gamma_max_groups);
