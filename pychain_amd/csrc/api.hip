@@ -84,7 +84,6 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
     return fail(PYCHAIN_HIP_EWORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
                 pychain_hip_den_workspace_bytes(B, T, H, D));
   memset(&a, 0, sizeof(a));
-  memset(&a, 0, sizeof(a));
   a.plans = (const char*)plans_dev; a.plan_stride = plan_stride_bytes;
   a.x = nnet_output; a.lengths = seq_lengths; a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
   a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H);

@@ -62,8 +62,15 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-template <int VEC, int XCH>
-__global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
+// LD > 0: the workgroup has LD extra threads (whole waves) that do nothing but stage nnet-output rows
+// (request the row of step s+2, clamp and store the row of step s+1 to LDS, barrier).  Their code has no
+// branch between a load and its use and no stores to memory, so the compiler can wait for exactly the
+// loads it needs (s_waitcnt vmcnt(XCH)); in the LD = 0 form the same wave also issues the row and
+// log-share stores under divergent branches, every wait degenerates to vmcnt(0), and each step lasts a
+// round trip to HBM (1461 us for T = 1500; XCH then counts chunks of kFbNT threads).
+constexpr int kFbLd = 128;
+template <int VEC, int XCH, int LD>
+__global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
   {
     const int32_t* tr = (fwd ? a.bwd_trans : a.fwd_trans) + g * K * 3;
     const float* pr = (fwd ? a.bwd_probs : a.fwd_probs) + g * K;
-    for (int k = tid; k < K; k += kFbNT)
+    for (int k = tid; k < K; k += kFbNT + LD)
       arc[k] = ArcW{(uint32_t)tr[3 * k + (fwd ? 0 : 1)] | ((uint32_t)tr[3 * k + 2] << 16), pr[k]};
   }
   const float* xseq = a.x + (size_t)b * T * D;
@@ -96,21 +103,44 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
 
   // this thread's state(s): h = tid (+ kFbNT, ... for graphs with more than 512 states)
   const int h0 = tid;
-  const bool own = h0 < H;
+  const bool own = h0 < H && tid < kFbNT;
   int2 be = make_int2(0, 0);
   if (own) be = idx[h0];
-  XRow<kFbNT, VEC, XCH> xq;
+  XRow<LD ? LD : kFbNT, VEC, XCH> xq;
+  const int xt = LD ? tid - kFbNT : tid;            // this thread's index among the threads that stage rows
   {
     const float* xrow = xseq + (size_t)(fwd ? 0 : L - 1) * D;
-    xq.load(xrow, D, tid);
+    if (!LD || tid >= kFbNT) xq.load(xrow, D, xt);
     // AlphaFirstFrame :84-90 / BetaLastFrame :192-202 (unnormalised: beta(L,i) = final(i); 1/P enters the occupancy)
-    for (int h = tid; h < H; h += kFbNT) {
-      const double v = (double)(fwd ? a.initial : a.final_)[g * H + h];
-      va[h] = v; rows[(size_t)(fwd ? 0 : L) * H + h] = v;
-    }
-    xq.store(xr0, xrow, D, tid, kXClamp);
+    if (tid < kFbNT)
+      for (int h = tid; h < H; h += kFbNT) {
+        const double v = (double)(fwd ? a.initial : a.final_)[g * H + h];
+        va[h] = v; rows[(size_t)(fwd ? 0 : L) * H + h] = v;
+      }
+    if (!LD || tid >= kFbNT) xq.store(xr0, xrow, D, xt, kXClamp);
   }
   __syncthreads();
+  if constexpr (LD > 0) {
+    if (tid >= kFbNT) {
+      // ---- row-staging waves: step s gathers from xr0 (s odd) / xr1 (s even); rows past the last one are
+      // re-reads of a valid row into a buffer nobody gathers from (no branch around a load or its use)
+      static_assert(VEC == 4 && XCH > 0, "row-staging waves use the float4 buffer-load form");
+      XRow<LD, VEC, XCH> xq2;
+      auto row_of_step = [&](int s) { return fwd ? min(s, L) - 1 : max(L - s, 0); };
+      xq.load_row(xbuf, row_of_step(2), D, xt);
+      for (int s = 1; s <= L; s += 2) {
+        xq2.load_row(xbuf, row_of_step(s + 2), D, xt);
+        xq.store(xr1, nullptr, D, xt, kXClamp);      // row of step s+1
+        __syncthreads();
+        if (s + 1 <= L) {
+          xq.load_row(xbuf, row_of_step(s + 3), D, xt);
+          xq2.store(xr0, nullptr, D, xt, kXClamp);   // row of step s+2
+          __syncthreads();
+        }
+      }
+      return;
+    }
+  }
   // first two arcs of this thread's state in registers (the common left-to-right case needs no more)
   ArcW w0{0u, -INFINITY}, w1{0u, -INFINITY};
   if (own) {
@@ -129,7 +159,7 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
     const int t_next = have_next ? (fwd ? s : L - 1 - s) : 0;
     const float* xrow_next = xseq + (size_t)t_next * D;
     const size_t trow = (size_t)(fwd ? s : L - s) * H;
-    if (have_next) {
+    if (!LD && have_next) {
       // buffer form: no address VGPR is written per step, so the load does not wait for this step's row stores
       if constexpr (VEC == 4 && XCH > 0) xq.load_row(xbuf, t_next, D, tid);
       else xq.load(xrow_next, D, tid);
@@ -176,7 +206,7 @@ __global__ __launch_bounds__(kFbNT) void num_fb_kernel(const NumArgs a) {
           frow[k] = (float)(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]) - v);
         }
     }
-    if (have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
+    if (!LD && have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
     __syncthreads();
   }
   if (!fwd) return;
@@ -517,12 +547,12 @@ __global__ __launch_bounds__(kOcNT) void num_scatter_kernel(const NumArgs a) {
   }
 }
 
-template <int VEC, int XCH>
+template <int VEC, int XCH, int LD = 0>
 hipError_t launch_fb(const NumArgs& a, size_t lds, hipStream_t st) {
-  auto k = num_fb_kernel<VEC, XCH>;
+  auto k = num_fb_kernel<VEC, XCH, LD>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3(2 * a.B), dim3(kFbNT), lds, st, a);
+  hipLaunchKernelGGL(k, dim3(2 * a.B), dim3(kFbNT + LD), lds, st, a);
   return hipGetLastError();
 }
 
@@ -549,6 +579,10 @@ hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
   }
   const int D = a.D;
   if (D % 4 == 0) {
+    if (!getenv("PYCHAIN_NUM_NO_STAGING_WAVES")) {             // tuning / test knob (read per call)
+      if (D <= 4 * 4 * kFbLd) return launch_fb<4, 4, kFbLd>(a, lds, st);
+      if (D <= 4 * 8 * kFbLd) return launch_fb<4, 8, kFbLd>(a, lds, st);
+    }
     if (D <= 4 * 2 * kFbNT) return launch_fb<4, 2>(a, lds, st);
     if (D <= 4 * 8 * kFbNT) return launch_fb<4, 8>(a, lds, st);
   } else if (D <= 8 * kFbNT) {
