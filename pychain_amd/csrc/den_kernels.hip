@@ -34,6 +34,7 @@
 // (conflict-free by construction of the plan) plus barrier-separated serial phases, not HBM;
 // the occupancy pass is time-parallel and runs near the HBM roofline.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "den_kernels.h"
@@ -739,8 +740,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
 #pragma unroll
         for (int k = 0; k < VEC; k++) {
           const int e = (c * kNT + tid) * VEC + k;
-          g[c * VEC + k] = e < D ? xr[e] * q[e] : 0.f;
-          part += g[c * VEC + k];
+          g[c * VEC + k] = e < D ? product_into_sum(xr[e], q[e], part) : 0.f;
         }
     } else {
       for (int e = tid; e < D; e += kNT) part += xr[e] * q[e];
@@ -847,10 +847,13 @@ __device__ __forceinline__ void tile_store2(v2f acc, int pos, float* __restrict_
 }
 
 // q2[2*pdf + f] = sum_k p_k * U2[2*i0_k + f] * V2[2*i1_k + f]   (f = 0, 1: the two frames)
-template <int R>
+// `hook(c)` runs at the start of chunk c (c is a constant after unrolling): the occupancy kernel issues its
+// global loads for the next pair there, one per chunk, so that they pass through the CU's vector-memory
+// path (64 B per clock) while the gathers keep the LDS busy, instead of in one burst before the arc work.
+template <int R, typename Hook>
 __device__ __forceinline__ void tile_rows2(ArcRegs2<R>& ar, const GroupRegs& gr, const uint2* __restrict__ tail_slots,
                                            int lane, const float* __restrict__ U2, const float* __restrict__ V2,
-                                           float* __restrict__ q2, const int* __restrict__ row_map) {
+                                           float* __restrict__ q2, const int* __restrict__ row_map, Hook hook) {
   constexpr int kChunk = 4;
   static_assert(R % kChunk == 0 && R <= 64 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
@@ -867,6 +870,7 @@ __device__ __forceinline__ void tile_rows2(ArcRegs2<R>& ar, const GroupRegs& gr,
   for (int c = 0; c < NC; c++) {
     const int cb = c & 1;
     wave_priority_by_progress<NC>(c);
+    hook(c);
     if (c + 1 < NC) {
       ar.opaque4((c + 1) * kChunk);
 #pragma unroll
@@ -1023,12 +1027,34 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       }                                                                                          \
     }                                                                                            \
   } while (0)
+  // load number n of a pair's state rows: n = 4 * c + {0: alpha'(t), 1: alpha'(t+1), 2: beta(t+1), 3: beta(t+2)}
+  auto prefetch_one = [&](int n, int t) {
+    const int c = n >> 2, i = (c * kNT2 + tid) * 4;
+    if (c < UVC && i < Hp) {
+      switch (n & 3) {
+        case 0: ua[c] = *reinterpret_cast<const float4*>(aseq + (size_t)t * Hp + i); break;
+        case 1: ub[c] = *reinterpret_cast<const float4*>(aseq + (size_t)min(t + 1, T - 1) * Hp + i); break;
+        case 2: va[c] = *reinterpret_cast<const float4*>(bseq + (size_t)(t + 1) * Hp + i); break;
+        default: vb[c] = *reinterpret_cast<const float4*>(bseq + (size_t)min(t + 2, T) * Hp + i); break;
+      }
+    }
+  };
   GAMMA2_PREFETCH(t0);
   GAMMA2_COMMIT();
   __syncthreads();
   XRow<kNT2, 4, XCH> x0, x1;
   int npar = 0;
+#ifdef PYCHAIN_PROFILE_PHASES
+  unsigned long long g2ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g2t = PH_T();
+  int g2pairs = 0;
+#define G2PH(i) do { const unsigned long long n_ = PH_T(); g2ph[i] += n_ - g2t; g2t = n_; } while (0)
+#else
+#define G2PH(i) (void)0
+#endif
   while (t0 < t_live_end) {
+#ifdef PYCHAIN_PROFILE_PHASES
+    g2pairs++;
+#endif
     const bool valid0 = den_frame_in_launch(t0, t_live_end, L, a), valid1 = den_frame_in_launch(t0 + 1, t_live_end, L, a);
     int tn = t0 + 2;
     while (tn < t_live_end && !den_frame_in_launch(tn, t_live_end, L, a) && !den_frame_in_launch(tn + 1, t_live_end, L, a)) tn += 2;
@@ -1036,17 +1062,31 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
     x0.load(xseq + (size_t)t0 * D, D, tid);
     x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
-#ifndef PYCHAIN_EXPG_NO_LOAD
-    if (have_next) GAMMA2_PREFETCH(tn);
-#endif
     float r00 = 0.f, r01 = 0.f, r10 = 0.f, r11 = 0.f;  // numerator rows of this pair (in flight during the arc work)
     const float* fr0 = frows + (size_t)t0 * a.fold_K;
     const float* fr1 = frows + (size_t)min(t0 + 1, T - 1) * a.fold_K;
     if (pd0 >= 0) { r00 = fr0[tid]; r10 = fr1[tid]; }
     if (pd1 >= 0) { r01 = fr0[tid + kNT2]; r11 = fr1[tid + kNT2]; }
+    G2PH(0);
 #ifndef PYCHAIN_EXPG_NO_ARCS
-    tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap);
+    // the next pair's state rows are requested inside the arc loop, one load per chunk (a pair that is the
+    // last of its block re-reads its own rows: no branch per chunk)
+    const int tpre = have_next ? tn : t0;
+    tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap, [&](int c) {
+#ifndef PYCHAIN_EXPG_NO_LOAD
+      constexpr int NC = R / 4 > 0 ? R / 4 : 1;
+      // spread over the first chunks, two chunks apart where the loop is long enough
+      constexpr int kStep = NC >= 16 ? 2 : 1;
+      if (c % kStep == 0 && c / kStep < 4 * UVC) prefetch_one(c / kStep, tpre);
 #endif
+    });
+#else
+    const int tpre = have_next ? tn : t0;
+    for (int n = 0; n < 4 * UVC; n++) prefetch_one(n, tpre);
+#endif
+    if (R / 4 < 4 * UVC * (R / 4 >= 16 ? 2 : 1))          // arc loop shorter than the list of loads: the rest here
+      for (int n = (R / 4) / (R / 4 >= 16 ? 2 : 1); n < 4 * UVC; n++) prefetch_one(n, tpre);
+    G2PH(1);
     float* n2p = n2 + (npar ? 2 * Dp : 0);             // this buffer was last read two pairs ago
     if (fold) {
       if (pd0 >= 0) *reinterpret_cast<v2f*>(n2p + 2 * pd0) = v2f{r00, r10};
@@ -1054,29 +1094,37 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       for (int u = tid + 2 * kNT2; u < U; u += kNT2) *reinterpret_cast<v2f*>(n2p + 2 * upd[u]) = v2f{fr0[u], fr1[u]};
     }
     npar ^= 1;
+    G2PH(2);
     __syncthreads();                                   // q2 (and n2) complete; every gather of this pair is done
+    G2PH(3);
     float g0[4 * XCH], g1[4 * XCH];
     float part0 = 0.f, part1 = 0.f;
+    auto products = [&](auto mode) {                   // (the mode is uniform: one branch, not a select per element)
 #pragma unroll
-    for (int c = 0; c < XCH; c++) {
-      const int e = (c * kNT2 + tid) * 4;
-      float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
-      if (e < D) { qa = *reinterpret_cast<const float4*>(q2 + 2 * e); qb = *reinterpret_cast<const float4*>(q2 + 2 * e + 4); }
-      const float qf0[4] = {qa.x, qa.z, qb.x, qb.z}, qf1[4] = {qa.y, qa.w, qb.y, qb.w};
-
+      for (int c = 0; c < XCH; c++) {
+        const int e = (c * kNT2 + tid) * 4;
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+        if (e < D) { qa = *reinterpret_cast<const float4*>(q2 + 2 * e); qb = *reinterpret_cast<const float4*>(q2 + 2 * e + 4); }
+        const float qf0[4] = {qa.x, qa.z, qb.x, qb.z}, qf1[4] = {qa.y, qa.w, qb.y, qb.w};
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        g0[c * 4 + k] = e < D ? clamp_exp(x0.v[c * 4 + k], a.input_is_exp) * qf0[k] : 0.f;
-        g1[c * 4 + k] = e < D ? clamp_exp(x1.v[c * 4 + k], a.input_is_exp) * qf1[k] : 0.f;
-        part0 += g0[c * 4 + k]; part1 += g1[c * 4 + k];
+        for (int k = 0; k < 4; k++) {
+          g0[c * 4 + k] = e < D ? product_into_sum(clamp_exp(x0.v[c * 4 + k], decltype(mode)::value), qf0[k], part0) : 0.f;
+          g1[c * 4 + k] = e < D ? product_into_sum(clamp_exp(x1.v[c * 4 + k], decltype(mode)::value), qf1[k], part1) : 0.f;
+        }
       }
-    }
+    };
+    if (a.input_is_exp == kXExpClamp) products(std::integral_constant<int, kXExpClamp>{});
+    else if (a.input_is_exp == kXIdentity) products(std::integral_constant<int, kXIdentity>{});
+    else products(std::integral_constant<int, kXClamp>{});
     part0 = wave_sum(part0); part1 = wave_sum(part1);
     if (lane == 0) { red[wave] = part0; red[16 + wave] = part1; }
+    G2PH(4);
 #ifndef PYCHAIN_EXPG_NO_LOAD
     if (have_next) GAMMA2_COMMIT();                    // U2/V2 are free since the barrier above
 #endif
+    G2PH(5);
     __syncthreads();                                   // totals visible; next operands in place; q2 read
+    G2PH(6);
     const float tot0 = block_total(red, lane), tot1 = block_total(red + 16, lane);
     const float sc0 = gscale / tot0, sc1 = gscale / tot1;
     if (valid0 && (!(tot0 > 0.f) || !(sc0 - sc0 == 0.f))) bad = 1;
@@ -1104,7 +1152,14 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       }
     }
     t0 = tn;
+    G2PH(7);
   }
+#ifdef PYCHAIN_PROFILE_PHASES
+  if (lane == 0 && b == 0 && chunk == 20 && (wave == 0 || wave == 7))
+    printf("gamma2 wave %d pairs %d cycles/pair: issue-loads %llu arcs %llu fold %llu bar1 %llu products %llu commit %llu bar2 %llu scale+store %llu\n",
+           wave, g2pairs, g2ph[0] / g2pairs, g2ph[1] / g2pairs, g2ph[2] / g2pairs, g2ph[3] / g2pairs, g2ph[4] / g2pairs,
+           g2ph[5] / g2pairs, g2ph[6] / g2pairs, g2ph[7] / g2pairs);
+#endif
   // padded tail of a chunk that straddles the sequence end
   if (first_launch && t_live_end < t_end)
     for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT2) gseq[i] = 0.f;

@@ -71,6 +71,14 @@ __device__ __forceinline__ float mul_add_mul_rn(float a, float b, float c, float
   const float q = c * d;
   return p + q;
 }
+// g = a*b rounded, sum += g rounded: the one-frame and the two-frame occupancy kernel build their frame
+// totals from the same partial sums, and must not differ by where the compiler happens to form an fma
+__device__ __forceinline__ float product_into_sum(float a, float b, float& sum) {
+#pragma clang fp contract(off)
+  const float g = a * b;
+  sum = sum + g;
+  return g;
+}
 __device__ __forceinline__ float mul_add_rn(float a, float b, float c) {
 #pragma clang fp contract(off)
   const float p = a * b;
