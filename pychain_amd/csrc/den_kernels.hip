@@ -557,15 +557,24 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 // Which recursion segment makes frame t of a length-L sequence computable: its alpha'(t) row
 // exists once the forward recursion has run t steps, its beta(t+1) row once the backward
 // recursion has run L-1-t steps; segment s covers steps [seg_bound[s-1], seg_bound[s]).
-__device__ __forceinline__ int den_segment_of_frame(int t, int L, const DenArgs& a) {
-  const int need = max(t, L - 1 - t);               // recursion steps both directions must have run
-  int s = 0;
-  while (s < a.gam_nseg - 1 && a.seg_bound[s] < need) s++;
-  return s;
-}
-__device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const DenArgs& a) {
-  if (a.gam_nseg > 0)
-    while (t < t_end && den_segment_of_frame(t, L, a) != a.gam_seg) t++;
+// The frames of one occupancy launch, as a range of `need` = max(t, L-1-t): (lo, hi].  Read once per
+// workgroup (seg_bound[] lives in the kernel arguments: dependent scalar loads, and the frame loops ask
+// several times per frame).
+struct LaunchFrames {
+  int lo, hi;
+  __device__ __forceinline__ explicit LaunchFrames(const DenArgs& a) : lo(-1), hi(0x7fffffff) {
+    if (a.gam_nseg > 0) {
+      if (a.gam_seg > 0) lo = a.seg_bound[a.gam_seg - 1];
+      if (a.gam_seg < a.gam_nseg - 1) hi = a.seg_bound[a.gam_seg];
+    }
+  }
+  __device__ __forceinline__ bool has(int t, int L) const {
+    const int need = max(t, L - 1 - t);
+    return need > lo && need <= hi;
+  }
+};
+__device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const LaunchFrames& lf) {
+  while (t < t_end && !lf.has(t, L)) t++;
   return t;
 }
 
@@ -629,7 +638,8 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     return;
   }
   const int t_live_end = min(t_end, L);
-  const int t_first = den_next_frame(t_begin, t_live_end, L, a);
+  const LaunchFrames lf(a);
+  const int t_first = den_next_frame(t_begin, t_live_end, L, lf);
   if (t_first >= t_live_end) {                      // none of this chunk's frames belongs to this launch
     if (first_launch && t_live_end < t_end)
       for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     gframes++;
 #endif
     float* grow = gseq + (size_t)t * D;
-    const int t_next = den_next_frame(t + 1, t_live_end, L, a);
+    const int t_next = den_next_frame(t + 1, t_live_end, L, lf);
     const bool have_next = t_next < t_live_end;
 #ifndef PYCHAIN_EXPG_NO_LOAD
     if (have_next) GAMMA_PREFETCH(t_next);
@@ -924,8 +934,8 @@ __device__ __forceinline__ void tile_rows2(ArcRegs2<R>& ar, const GroupRegs& gr,
     tile_store2(v2f{0.f, 0.f}, __builtin_amdgcn_readlane(gr.base, g & 63) + lane, q2, row_map);
 }
 
-__device__ __forceinline__ bool den_frame_in_launch(int t, int t_live_end, int L, const DenArgs& a) {
-  return t < t_live_end && (a.gam_nseg == 0 || den_segment_of_frame(t, L, a) == a.gam_seg);
+__device__ __forceinline__ bool den_frame_in_launch(int t, int t_live_end, int L, const LaunchFrames& lf) {
+  return t < t_live_end && lf.has(t, L);
 }
 
 template <int XCH, int R>
@@ -946,8 +956,9 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
   const int t_live_end = min(t_end, L);
   // pairs (t0, t0+1), t0 even, with at least one frame of this launch
+  const LaunchFrames lf(a);
   int t0 = t_begin;
-  while (t0 < t_live_end && !den_frame_in_launch(t0, t_live_end, L, a) && !den_frame_in_launch(t0 + 1, t_live_end, L, a)) t0 += 2;
+  while (t0 < t_live_end && !den_frame_in_launch(t0, t_live_end, L, lf) && !den_frame_in_launch(t0 + 1, t_live_end, L, lf)) t0 += 2;
   if (t0 >= t_live_end) {                             // nothing to evaluate: padding of the first launch is exact zeros
     if (first_launch)
       for (size_t i = (size_t)max(t_begin, min(t_live_end, t_end)) * D + tid; i < (size_t)t_end * D; i += kNT2) gseq[i] = 0.f;
@@ -1055,9 +1066,9 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
 #ifdef PYCHAIN_PROFILE_PHASES
     g2pairs++;
 #endif
-    const bool valid0 = den_frame_in_launch(t0, t_live_end, L, a), valid1 = den_frame_in_launch(t0 + 1, t_live_end, L, a);
+    const bool valid0 = den_frame_in_launch(t0, t_live_end, L, lf), valid1 = den_frame_in_launch(t0 + 1, t_live_end, L, lf);
     int tn = t0 + 2;
-    while (tn < t_live_end && !den_frame_in_launch(tn, t_live_end, L, a) && !den_frame_in_launch(tn + 1, t_live_end, L, a)) tn += 2;
+    while (tn < t_live_end && !den_frame_in_launch(tn, t_live_end, L, lf) && !den_frame_in_launch(tn + 1, t_live_end, L, lf)) tn += 2;
     const bool have_next = tn < t_live_end;
     // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
     x0.load(xseq + (size_t)t0 * D, D, tid);
