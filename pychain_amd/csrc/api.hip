@@ -136,15 +136,14 @@ SideStream* side_stream_for_current_device() {
 // (2B persistent workgroups leave the other CUs free).  1 = no overlap.
 int den_segments(int T) {
   if (const char* e = getenv("PYCHAIN_DEN_SEGMENTS")) { int n = atoi(e); if (n >= 1 && n <= kMaxSegments) return n; }
-  // Measured at C3 (T=1500): 1 -> 6.02 ms, 2 -> 5.79, 3 -> 5.18, 4 -> 5.33 per call.  A recursion
-  // relaunch costs only ~12 us; what limits the overlap is CU time: after T/2 the occupancy pass has
-  // the ~128 idle CUs only (less the numerator's), on which its 1.4 ms of whole-chip work takes
-  // longer than the rest of the recursion, so the side stream - not the recursion - ends the call,
-  // and finer segments only add launches to it (delaying the side stream makes the call longer by
-  // exactly the delay).  The lever is the occupancy kernel's CU time, not the schedule.
-  // (whole step with the two-frame occupancy kernel, the numerator folded in and the recursion at 3.97 ms:
-  // 3 -> 4.43 ms, 4 -> 4.52, 5 -> 4.63)
-  if (T >= 1024) return 3;
+  // What limits the overlap is CU time: after T/2 the occupancy pass has the ~128 idle CUs only (less the
+  // numerator's), on which its ~1 ms of whole-chip work takes longer than the rest of the recursion, so
+  // the last launch (the frames that only become computable at the very end) is exposed.  Each further
+  // segment halves that launch but costs a launch (gate + kernel, ~0.05 ms of side-stream time).
+  // Measured at C3 (T=1500), whole step, gated schedule with compact grids:
+  //   3 -> 3.85 ms, 4 -> 3.74, 5 -> 3.81, 6 -> 3.90   (C4, T=2000: 3 -> 6.86, 4 -> 6.84, 5 -> 7.03)
+  // (history: with one recursion launch per segment and full occupancy grids it was 3 -> 4.43, 4 -> 4.52)
+  if (T >= 1024) return 4;
   if (T >= 256) return 2;
   return 1;
 }
