@@ -143,8 +143,10 @@ int den_segments(int T) {
   // Measured at C3 (T=1500), whole step, gated schedule with compact grids:
   //   3 -> 3.85 ms, 4 -> 3.74, 5 -> 3.81, 6 -> 3.90   (C4, T=2000: 3 -> 6.86, 4 -> 6.84, 5 -> 7.03)
   // (history: with one recursion launch per segment and full occupancy grids it was 3 -> 4.43, 4 -> 4.52)
-  if (T >= 1024) return 4;
-  if (T >= 256) return 2;
+  // shorter batches (B=64, same graph; ms per step for 1 / 2 / 3 / 4 segments): T=896: 2.79 / 2.71 / 2.42 / 2.37,
+  // T=640: 2.01 / 1.93 / 1.72 / 1.72, T=384: 1.21 / 1.22 / 1.07 / 1.11
+  if (T >= 768) return 4;
+  if (T >= 256) return 3;
   return 1;
 }
 
