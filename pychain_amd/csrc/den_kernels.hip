@@ -306,18 +306,27 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
 // kernel is still running (gated schedule), and the row is not read again here, so it need not stay in
 // this XCD's L2.
 constexpr int kStoreDeviceScope = 16;    // cache-policy operand of the buffer store: sc1
+// `cl0` = coef * leaky probs of this thread's first four states (constant over the frames: kept in
+// registers by the frame loop, `have_cl0`, instead of read from LDS and multiplied in every frame).
 __device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const float* lk, float* cur, XBuf sbuf, int row_off,
-                                              float inv, float coef, float add, int H, int Hp, int tid) {
+                                              float inv, float coef, float add, int H, int Hp, int tid,
+                                              bool have_cl0 = false, float4 cl0 = make_float4(0.f, 0.f, 0.f, 0.f)) {
   for (int i = tid * 4; i < Hp; i += kNT * 4) {
     const float4 r = *reinterpret_cast<const float4*>(raw + i);
     float4 v;
     if (fwd) {
-      const float4 l = *reinterpret_cast<const float4*>(lk + i);
-      v = make_float4(r.x * inv + coef * l.x, r.y * inv + coef * l.y, r.z * inv + coef * l.z, r.w * inv + coef * l.w);
+      float4 cl;
+      if (have_cl0 && i == tid * 4) cl = cl0;
+      else {
+        const float4 l = *reinterpret_cast<const float4*>(lk + i);
+        cl = make_float4(coef * l.x, coef * l.y, coef * l.z, coef * l.w);
+      }
+      v = make_float4(r.x * inv + cl.x, r.y * inv + cl.y, r.z * inv + cl.z, r.w * inv + cl.w);
     } else {
       // (positions >= H are padding: nothing gathers them and the occupancy pass skips them, so they are
       // allowed to carry add * inv instead of zero - masking costs 8 VALU per thread on the critical path)
-      v = make_float4((r.x + add) * inv, (r.y + add) * inv, (r.z + add) * inv, (r.w + add) * inv);
+      const float ai = add * inv;                     // (r + add) * inv as one fma per element
+      v = make_float4(__builtin_fmaf(r.x, inv, ai), __builtin_fmaf(r.y, inv, ai), __builtin_fmaf(r.z, inv, ai), __builtin_fmaf(r.w, inv, ai));
     }
     *reinterpret_cast<float4*>(cur + i) = v;
     if (row_off >= 0) {
@@ -428,6 +437,11 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   }
   __syncthreads();
 
+  float4 cl0 = make_float4(0.f, 0.f, 0.f, 0.f);       // coef * leaky probs of the states this thread normalises (alpha)
+  if (fwd && tid * 4 < Hp) {
+    const float4 l = *reinterpret_cast<const float4*>(lk + tid * 4);
+    cl0 = make_float4(coef * l.x, coef * l.y, coef * l.z, coef * l.w);
+  }
   // ---- general frames.  alpha: step j produces alpha'(j+1) from alpha'(j) and x(j), j = 0..L-1
   //                        beta:  step j produces beta(t) from beta(t+1) and x(t), t = L-1-j, j = 0..L-2
 #ifdef PYCHAIN_PROFILE_PHASES
@@ -469,11 +483,11 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     wtot = fwd ? 0.f : block_total(red + 16, lane);                                                         \
     const float inv = __builtin_amdgcn_rcpf(tot);                                                           \
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;                                                              \
-    logsum += (double)fast_log(tot);                                                                        \
+    if (fwd) logsum += (double)fast_log(tot);        /* only the alpha side reports a log-probability */     \
     const int tstore = fwd ? j + 1 : L - 1 - j;                                                             \
     const bool do_store = fwd ? (tstore < L) : true;                                                        \
     if (kWithNorm)                                                                                          \
-      normalise_row(fwd, raw, lk, cur, sbuf, do_store ? tstore * Hp * 4 : -1, inv, coef, coef * wtot, H, Hp, tid); \
+      normalise_row(fwd, raw, lk, cur, sbuf, do_store ? tstore * Hp * 4 : -1, inv, coef, coef * wtot, H, Hp, tid, true, cl0); \
     PH_ADD(3, pt); pt = PH_T();                                                                             \
     if (!DB && kWithX && have_next) xq.store(xr, xrow_next, D, tid, a.input_is_exp);                        \
     PH_ADD(4, pt); pt = PH_T();                                                                             \
