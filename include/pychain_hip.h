@@ -8,9 +8,16 @@
  *   - every function returns 0 on success, a negative PYCHAIN_HIP_E* code on
  *     error; pychain_hip_last_error() then holds a message (thread-local);
  *   - "dev" pointers are device memory, "host" pointers host memory;
- *   - all launches go to the caller's stream (`void* stream` is a hipStream_t);
- *     nothing synchronises with the host and nothing allocates: scratch memory
- *     is a caller-provided workspace sized by the *_workspace_bytes queries;
+ *   - all work is ordered on the caller's stream (`void* stream` is a hipStream_t):
+ *     a call may fork launches to two library-owned non-blocking side streams
+ *     (created once per device on first use - with their events the only hidden
+ *     state of the library) and joins them back with events before it returns, so
+ *     stream-ordered use is unchanged.  The denominator does this for T >= 256: its
+ *     time-parallel occupancy launches run beside the (single) recursion launch,
+ *     each released by a one-wave gate kernel that polls a progress counter the
+ *     recursion workgroups advance.  Nothing synchronises with the
+ *     host and nothing allocates: scratch memory is a caller-provided workspace
+ *     sized by the *_workspace_bytes queries;
  *   - float = IEEE fp32, indices int32, lengths int64 (the reference's dtypes,
  *     openfst_binding/src/fstext.cc:81-104, pychain/loss.py:41).
  *
