@@ -51,6 +51,13 @@ const char* pychain_hip_last_error(void);
  * non-finite normaliser instead of only flagging the call. */
 void        pychain_hip_set_verbose_level(int level);
 int         pychain_hip_get_verbose_level(void);
+
+/* Test hook (host only, no GPU): how the occupancy launch of time segment `seg` (of `nseg`, ends
+ * seg_bound[]) maps workgroups to 32-frame chunks of a length-L sequence.
+ * out[0] = grid.x, out[1 + k] = chunk of workgroup k or -1; returns 1 if frame t belongs to the
+ * launch, 0 if not, negative on bad arguments.  nseg = 0: the unsegmented launch. */
+int         pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg,
+                                         const int32_t* seg_bound, int seg, int32_t* out, int out_len);
 /* Measurement aid (bench.py): restrict pychain_hip_den_forward_backward to a subset of
  * its launches so each kernel can be bracketed by events on the caller's stream.
  * bit 0 = alpha/beta recursion launch, bit 1 = occupancy launch; default 3 = both.

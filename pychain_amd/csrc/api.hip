@@ -242,6 +242,13 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
 }
 }  // namespace
 
+extern "C" int pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg,
+                                            const int32_t* seg_bound, int seg, int32_t* out, int out_len) {
+  if (T <= 0 || L <= 0 || L > T || frames_per_block <= 0 || nseg < 0 || nseg > 16 || (nseg && !seg_bound) || seg < 0 || (nseg && seg >= nseg))
+    return fail(PYCHAIN_HIP_EINVAL, "debug_launch_map: bad arguments");
+  return den_debug_launch_map(T, L, t, frames_per_block, nseg, seg_bound, seg, out, out_len);
+}
+
 extern "C" int pychain_hip_den_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int H, int D,
     const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,

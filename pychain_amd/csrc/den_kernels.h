@@ -53,6 +53,10 @@ bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_r
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,
                       const char** why);
 
+// test hook behind pychain_hip_debug_launch_map (host code only)
+int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, const int* seg_bound, int seg,
+                         int* out, int out_len);
+
 // One wave that waits until *progress >= target (set by the recursion workgroups), so that what follows
 // it in stream order starts then; gives up after ~20 s and counts that in *bad.
 hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hipStream_t st);

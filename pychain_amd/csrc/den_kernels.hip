@@ -34,6 +34,7 @@
 // (conflict-free by construction of the plan) plus barrier-separated serial phases, not HBM;
 // the occupancy pass is time-parallel and runs near the HBM roofline.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <type_traits>
 #include <stdint.h>
 
@@ -576,14 +577,14 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 // several times per frame).
 struct LaunchFrames {
   int lo, hi;
-  __device__ __forceinline__ explicit LaunchFrames(const DenArgs& a) : lo(-1), hi(0x7fffffff) {
+  __host__ __device__ __forceinline__ explicit LaunchFrames(const DenArgs& a) : lo(-1), hi(0x7fffffff) {
     if (a.gam_nseg > 0) {
       if (a.gam_seg > 0) lo = a.seg_bound[a.gam_seg - 1];
       if (a.gam_seg < a.gam_nseg - 1) hi = a.seg_bound[a.gam_seg];
     }
   }
-  __device__ __forceinline__ bool has(int t, int L) const {
-    const int need = max(t, L - 1 - t);
+  __host__ __device__ __forceinline__ bool has(int t, int L) const {
+    const int need = t > L - 1 - t ? t : L - 1 - t;
     return need > lo && need <= hi;
   }
 };
@@ -598,13 +599,13 @@ __device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const Lau
 // frames_per_block frames that meets them, instead of one workgroup per chunk of [0, T) of which most
 // would find nothing to do (an idle workgroup still needs a whole free CU to start).  The first launch
 // keeps the plain mapping: it also zeroes the padding of every chunk.  Returns -1: no chunk for this block.
-__device__ __forceinline__ int den_chunk_of_block(int k, int L, const DenArgs& a) {
+__host__ __device__ __forceinline__ int den_chunk_of_block(int k, int L, const DenArgs& a) {
   if (a.gam_nseg == 0 || a.gam_seg == 0) return k;
   const int fpb = a.frames_per_block;
   const int lo = a.seg_bound[a.gam_seg - 1];
   const int hi = a.gam_seg == a.gam_nseg - 1 ? 0x3fffffff : a.seg_bound[a.gam_seg];
-  const int a0 = max(0, L - 1 - hi), a1 = L - 1 - lo;          // left frames [a0, a1)
-  const int b0 = lo + 1, b1 = min(hi, L - 1);                   // right frames [b0, b1]
+  const int a0 = L - 1 - hi > 0 ? L - 1 - hi : 0, a1 = L - 1 - lo;   // left frames [a0, a1)
+  const int b0 = lo + 1, b1 = hi < L - 1 ? hi : L - 1;          // right frames [b0, b1]
   const int nl = a1 > a0 ? (a1 - 1) / fpb - a0 / fpb + 1 : 0;
   if (k < nl) return a0 / fpb + k;
   if (b1 < b0) return -1;
@@ -1268,6 +1269,20 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
 }
 
 }  // namespace
+
+// Host-side view of the frame -> (occupancy launch, workgroup) mapping for the CPU tests (tests/test_api.py):
+// out[0] = grid.x of the launch, out[1 + k] = chunk of block k (or -1); returns 1 if frame t belongs to the launch.
+int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, const int* seg_bound, int seg,
+                         int* out, int out_len) {
+  DenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.T = T; a.frames_per_block = frames_per_block; a.gam_nseg = nseg; a.gam_seg = seg;
+  for (int s = 0; s < nseg && s < 16; s++) a.seg_bound[s] = seg_bound[s];
+  const int gx = den_compact_grid_x(a);
+  if (out && out_len > 0) out[0] = gx;
+  for (int k = 0; out && k < gx && 1 + k < out_len; k++) out[1 + k] = den_chunk_of_block(k, L, a);
+  return LaunchFrames(a).has(t, L) && t < L ? 1 : 0;
+}
 
 hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hipStream_t st) {
   hipLaunchKernelGGL(den_gate_kernel, dim3(1), dim3(64), 0, st, progress, target, bad);

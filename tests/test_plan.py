@@ -111,3 +111,42 @@ def test_batch_plans_shared_detection():
     assert dp.stride == 0 and np.array_equal(dp.blob.numpy(), _blob(g, 40))
     info = _plan.plan_info(_blob(g, 40))
     assert info["num_states"] == 20 and info["num_transitions"] == 60 and dp.slot_rows == info["slot_rows"] > 0
+
+
+def test_occupancy_launch_map_covers_every_frame_once():
+    """Every live frame of a sequence belongs to exactly one occupancy launch (time segment), and the
+    compact grid of that launch visits the 32-frame chunk that holds it exactly once - for ragged
+    lengths, every segment count and chunk size (host-side view of den_chunk_of_block /
+    den_compact_grid_x / LaunchFrames in csrc/den_kernels.hip)."""
+    import ctypes
+    import random
+    from pychain_amd import _lib
+    L_ = _lib.lib()
+    rng = random.Random(3)
+    out = (ctypes.c_int32 * 4096)()
+    for _ in range(300):
+        T = rng.randint(1, 700)
+        fpb = rng.choice([2, 8, 16, 32])
+        nseg = rng.randint(1, 6)
+        half = (T + 1) // 2
+        ends = sorted(min(T, (max(half, rng.randint(0, T)) + 31) // 32 * 32) for _ in range(nseg - 1)) + [T]
+        bounds = (ctypes.c_int32 * 16)(*ends)
+        L = rng.choice([1, T, rng.randint(1, T)])
+        owner = {}
+        for seg in range(nseg):
+            frames = [t for t in range(L)
+                      if L_.pychain_hip_debug_launch_map(T, L, t, fpb, nseg, bounds, seg, None, 0) == 1]
+            for t in frames:
+                assert t not in owner, (T, L, ends, t)
+                owner[t] = seg
+            rc = L_.pychain_hip_debug_launch_map(T, L, 0, fpb, nseg, bounds, seg, out, 4096)
+            assert rc >= 0
+            chunks = [out[1 + k] for k in range(out[0]) if out[1 + k] >= 0]
+            assert len(chunks) == len(set(chunks)), (T, L, ends, seg, chunks)
+            assert {t // fpb for t in frames} <= set(chunks), (T, L, ends, seg)
+            assert out[0] <= (T + fpb - 1) // fpb
+        assert sorted(owner) == list(range(L)), (T, L, ends)
+    # the unsegmented launch: one workgroup per chunk of [0, T), every frame belongs to it
+    assert L_.pychain_hip_debug_launch_map(100, 70, 69, 32, 0, None, 0, out, 4096) == 1
+    assert out[0] == 4 and [out[1 + k] for k in range(4)] == [0, 1, 2, 3]
+    assert L_.pychain_hip_debug_launch_map(100, 70, 69, 32, 3, None, 0, out, 4096) < 0      # bad arguments
