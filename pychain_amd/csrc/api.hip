@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/pychain_hip.h"
 #include "common.h"
@@ -109,13 +110,16 @@ constexpr int kMaxSegments = 16;
 struct SideStream {
   hipStream_t stream = nullptr, stream2 = nullptr;
   hipEvent_t fork = nullptr, join = nullptr, seg[kMaxSegments] = {}, join2 = nullptr;
+  bool ready = false;       // every stream and event below was created
 };
 SideStream* side_stream_for_current_device() {
   static SideStream table[64];
+  static std::mutex create_lock;              // first use on a device may come from several host threads
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideStream& s = table[dev];
-  if (!s.stream) {
+  std::lock_guard<std::mutex> guard(create_lock);
+  if (!s.ready) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
     // the occupancy launches only fill idle CUs: lowest priority, so that the persistent recursion
     // workgroups of the next segment (caller's stream) are dispatched first
@@ -127,6 +131,7 @@ SideStream* side_stream_for_current_device() {
     if (hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
     for (int i = 0; i < kMaxSegments; i++)
       if (hipEventCreateWithFlags(&s.seg[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    s.ready = true;
   }
   return &s;
 }
