@@ -4,10 +4,15 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--no-cpu-baseline]
 
 A step = one ChainLoss forward + backward (denominator + per-utterance numerators,
-x.grad produced) over one synthetic minibatch already resident in HBM.  For N > 1 the
-driver launches one rank per GPU (torch.distributed.run); every rank owns B utterances
-(weak scaling: global batch = N*B), and the only exchange per step is one RCCL all-reduce
-of [den_objf, num_objf, n_frames, n_bad].
+x.grad produced) over one synthetic minibatch already resident in HBM.  For N > 1 there is
+one rank per GPU: either the caller launched them (torch.distributed.run: WORLD_SIZE is
+set and must equal --gpus), or - WORLD_SIZE unset - this script re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1.  Every rank owns B
+utterances (weak scaling: global batch = N*B), and the only exchange per step is one RCCL
+all-reduce of [objf, n_frames, n_bad].
+
+`--dry-run` checks the launch / collective / JSON plumbing on a box without a GPU (gloo, the
+step is a no-op with a made-up frame count, "value" is meaningless and the line says so).
 
 Rank 0 prints ONE JSON line: the driver contract plus
   "roofline"     for the dominant kernel (den_recursion_kernel), measured here with HIP
@@ -41,7 +46,23 @@ def parse():
     ap.add_argument("--no-grad-slab", action="store_true",
                     help="skip the optional fused all-reduce of the gradient slab (N > 1 only)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="utterances in the CPU baseline sample")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="harness check without a GPU: gloo, no-op steps (tests/test_bench_launch.py)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: become `torch.distributed.run` with N ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def event_time_ms(fn, iters, stream):
@@ -143,32 +164,33 @@ def grad_slab_allreduce(x, world, rank, dev, iters=2):
             "note": "option, not in `value`: fused all_reduce(SUM) of 3 scalars + [B_global,T,D] fp32 slab"}
 
 
-def cpu_baseline(w, nsample):
-    """Reference CPU path (or its C restatement) on the first `nsample` utterances of the workload."""
-    import numpy as np
+def _cpu_sample(w, idx):
+    """CPU-resident (x, lengths, den graph batch, numerator graph batch) of the utterances `idx`."""
     from pychain_amd import ChainGraphBatch
-    torch.set_num_threads(1)
-    n = min(nsample, w["cfg"]["B"])
-    lengths = w["lengths"][:n].clone()
+    idx = torch.as_tensor(idx, dtype=torch.long)
+    lengths = w["lengths"].index_select(0, idx).clone()
     T = int(lengths.max())
-    x = w["x"][:n, :T].detach().float().cpu().contiguous()
-    frames = int(lengths.sum())
-    den_b = ChainGraphBatch(w["den_graph"], n)
+    x = w["x_cpu"].index_select(0, idx)[:, :T].contiguous()
+    den_b = ChainGraphBatch(w["den_graph"], int(idx.numel()))
     num_b = None
     if w["num_graphs"] is not None:
         num_b = ChainGraphBatch.__new__(ChainGraphBatch)
         num_b.__dict__.update(w["num_graphs"].__dict__)
-        num_b.reorder(torch.arange(n))
-        num_b.batch_size = n
-    kind = "port"
+        num_b._device_cache = {}
+        num_b.reorder(idx)
+        num_b.batch_size = int(idx.numel())
+    return x, lengths, den_b, num_b
+
+
+def _cpu_run(x, lengths, den_b, num_b):
+    """One evaluation of den (+ num) on the CPU: the reference binary when oracle/_ref holds it
+    (kind "reference"), else the C restatement (kind "port").  Lengths must be sorted descending."""
     try:
         import ref_loader
         ref = ref_loader.load() if ref_loader.available() else None
     except Exception:
         ref = None
-    t0 = time.perf_counter()
     if ref is not None:
-        kind = "reference"
         bs = torch.nn.utils.rnn.pack_padded_sequence(x, lengths, batch_first=True).batch_sizes
         xc = x.clamp(-30, 30)
         g = lambda t: t.contiguous()
@@ -185,22 +207,126 @@ def cpu_baseline(w, nsample):
                 g(num_b.initial_probs), g(num_b.final_probs), num_b.start_state, xc, bs, lengths,
                 num_b.num_states)
             out[1].exp()
-    else:
-        import oracle as orc
-        orc.chain_function(x, lengths, den_b)
-        if num_b is not None:
-            orc.chain_function(x, lengths, num_b)
+        return "reference"
+    import oracle as orc
+    orc.chain_function(x, lengths, den_b)
+    if num_b is not None:
+        orc.chain_function(x, lengths, num_b)
+    return "port"
+
+
+def _cpu_worker(rank, nworkers, w, idx, reps, barrier, out_q):
+    """All-cores leg: worker `rank` evaluates its share of the sample `reps` times, one thread."""
+    torch.set_num_threads(1)
+    mine = idx[rank::nworkers]
+    x, lengths, den_b, num_b = _cpu_sample(w, mine)
+    barrier.wait()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        kind = _cpu_run(x, lengths, den_b, num_b)
+    out_q.put((rank, time.perf_counter() - t0, int(lengths.sum()) * reps, kind))
+
+
+def cpu_baseline(w, nsample, all_cores=True):
+    """Reference CPU path (or its C restatement) on the first `nsample` utterances of the workload:
+    (i) one thread - the faithful counterpart of the reference, whose loops over sequences, states and
+    arcs are serial (chain-computation.cc:113-176); (ii) all host cores, utterances dealt to one
+    single-threaded worker process per core."""
+    torch.set_num_threads(1)
+    n = min(nsample, w["cfg"]["B"])
+    w = {k: w[k] for k in ("cfg", "lengths", "den_graph", "num_graphs")} | {
+        "x_cpu": w["x"].detach().float().cpu().contiguous().share_memory_()}
+    order = torch.argsort(w["lengths"], descending=True, stable=True)      # (already sorted in C1-C4)
+    sample = _cpu_sample(w, order[:n])
+    frames = int(sample[1].sum())
+    t0 = time.perf_counter()
+    kind = _cpu_run(*sample)
     dt = time.perf_counter() - t0
-    return {"value": round(frames / dt, 1), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "first %d utterances (%d frames) of the same %s batch, den%s, 1 thread, %.1f s"
-                      % (n, frames, w["cfg"]["name"], "+num" if num_b is not None else "", dt)}
+    res = {"value": round(frames / dt, 1), "unit": "frames/s", "cores": 1, "kind": kind,
+           "sample": "first %d utterances (%d frames) of the same %s batch, den%s, 1 thread, %.1f s"
+                     % (n, frames, w["cfg"]["name"], "+num" if sample[3] is not None else "", dt)}
+    if all_cores:
+        try:
+            res["all_cores"] = _cpu_all_cores(w, order, dt / n)
+        except Exception as e:            # a context figure: never lose the bench line to it
+            res["all_cores"] = {"error": str(e)[:200]}
+    return res
+
+
+def _cpu_all_cores(w, order, sec_per_utt):
+    import torch.multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nw = max(1, min(cores, int(order.numel())))
+    per = -(-int(order.numel()) // nw)                                    # utterances per worker
+    reps = max(1, min(20, int(8.0 / max(1e-3, sec_per_utt * per))))       # about 8 s of work per worker
+    ctx = mp.get_context("spawn")                                         # (fork after HIP init is unsafe)
+    barrier, q = ctx.Barrier(nw), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, nw, w, order, reps, barrier, q)) for r in range(nw)]
+    for p_ in procs:
+        p_.start()
+    got = []
+    deadline = time.time() + 180
+    while len(got) < nw:
+        try:
+            got.append(q.get(timeout=2))
+        except Exception:
+            if time.time() > deadline or any(p_.exitcode not in (None, 0) for p_ in procs):
+                for p_ in procs:
+                    p_.terminate()          # (our own children, by handle)
+                raise RuntimeError("cpu worker failed or timed out")
+    for p_ in procs:
+        p_.join()
+    tmax = max(g[1] for g in got)
+    frames = sum(g[2] for g in got)
+    return {"value": round(frames / tmax, 1), "unit": "frames/s", "cores": cores, "workers": nw, "kind": got[0][3],
+            "sample": "all %d utterances of the batch dealt to %d single-threaded worker processes, "
+                      "%d repetitions each, slowest worker %.1f s" % (int(order.numel()), nw, reps, tmax)}
+
+
+def dry_run(args, rank, world):
+    """The N-rank plumbing of main() with the GPU work taken out: gloo group, the per-step stats
+    all-reduce, max-over-ranks timing, ONE JSON line from rank 0."""
+    from pychain_amd.parallel import allreduce_stats
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    local_frames = 1000 + rank
+    for _ in range(args.warmup):
+        allreduce_stats(torch.zeros(()), float(local_frames), None)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = allreduce_stats(torch.tensor(-1.0), float(local_frames), None)
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "LF-MMI frames/sec (fwd+bwd)", "value": None, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax) / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+            "dry_run": True, "frames_per_step_all_ranks": float(stats[1]),
+            "config": {"workload": "dry run (no kernels)", "parallelism": "utterance-sharded dp%d" % world,
+                       "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the LF-MMI path has no CPU fallback")
     torch.cuda.set_device(local_rank)
