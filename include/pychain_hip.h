@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 7
+#define PYCHAIN_HIP_ABI_VERSION 8
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -63,6 +63,10 @@ int         pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_blo
  * bit 0 = alpha/beta recursion launch, bit 1 = occupancy launch; default 3 = both.
  * With a partial mask the outputs of the call are NOT meaningful. */
 void        pychain_hip_set_den_phase_mask(int mask);
+/* Test hook: 0 = the denominator recursions always run as den_recursion_kernel (rows normalised in a
+ * pass of their own, two barriers per frame); 1 (default) = as den_recursion_lazy_kernel wherever the
+ * shape allows.  Both forms must agree to rounding; the tests compare them. */
+void        pychain_hip_set_den_lazy(int on);
 
 /* ------------------------------------------------------------------------
  * Denominator graph plan  (host side, no GPU work).

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -23,6 +23,7 @@ _SIGNATURES = {
     "pychain_hip_set_verbose_level": (None, [_i]),
     "pychain_hip_get_verbose_level": (_i, []),
     "pychain_hip_set_den_phase_mask": (None, [_i]),
+    "pychain_hip_set_den_lazy": (None, [_i]),
     "pychain_hip_debug_launch_map": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i]),
     "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -81,6 +81,8 @@ def batch_plans(tensors, num_pdfs, device):
     blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
     hints = [plan_info(b)["slot_rows"] for b in blobs]
     slot_rows = sum(max((h >> sh) & 1023 for h in hints) << sh for sh in (0, 10, 20))
+    if all((h >> 30) & 1 for h in hints):      # every plan fits the lazy-normalisation recursion (<= 4 groups per wave)
+        slot_rows |= 1 << 30
     if same:
         return DevicePlan(torch.from_numpy(blobs[0]).to(device), 0, slot_rows, H)
     stride = (max(b.nbytes for b in blobs) + 255) // 256 * 256

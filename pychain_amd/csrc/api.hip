@@ -17,6 +17,7 @@
 namespace pychain_hip {
 int g_verbose_level = 0;
 int g_den_phase_mask = 3;
+int g_den_lazy = 1;            // test hook: 0 = never run the lazy-normalisation recursion
 char* last_error_buffer() {
   static thread_local char buf[512] = "";
   return buf;
@@ -34,6 +35,7 @@ extern "C" const char* pychain_hip_last_error(void) { return last_error_buffer()
 extern "C" void pychain_hip_set_verbose_level(int level) { g_verbose_level = level; }
 extern "C" int pychain_hip_get_verbose_level(void) { return g_verbose_level; }
 extern "C" void pychain_hip_set_den_phase_mask(int mask) { g_den_phase_mask = mask & 3; }
+extern "C" void pychain_hip_set_den_lazy(int on) { g_den_lazy = on ? 1 : 0; }
 
 extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]) {
   if (!host_blob || !info || blob_bytes < sizeof(PlanHeader))
@@ -51,6 +53,8 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (gm2 > 1023) gm2 = 1023;
   // launch hint, 10 bits each: recursion rows | occupancy rows (16 waves) << 10 | occupancy rows (8 waves) << 20
   info[4] = m | (gmm << 10) | (gm2 << 20);
+  // bit 30: every recursion wave owns at most 4 groups (what den_recursion_lazy_kernel keeps in registers)
+  if (hd->rec_max_wave_groups >= 1 && hd->rec_max_wave_groups <= 4) info[4] |= 1 << 30;
   return PYCHAIN_HIP_OK;
 }
 
@@ -58,7 +62,8 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   (void)D;
   if (B <= 0 || T <= 0 || H <= 0) return 0;
   const size_t Hp = roundup64(H);
-  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ + 256;
+  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ +
+         2 * align256(4 * (size_t)B * (T + 1)) /* per-frame scalars of lazy rows */ + 256;
 }
 
 namespace {
@@ -97,6 +102,9 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
   a.logsum_ws = (double*)(ws + align256(4 * (size_t)B * T * a.Hp) + align256(4 * (size_t)B * (T + 1) * a.Hp));
   a.progress = (int32_t*)((char*)a.logsum_ws + align256(8 * (size_t)B));
+  a.scal_a = (float*)((char*)a.progress + 256);
+  a.scal_b = (float*)((char*)a.scal_a + align256(4 * (size_t)B * (T + 1)));
+  a.lazy = 0;
   a.sig_n = 0;
   a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_seg = 0; a.gam_nseg = 0;
   return PYCHAIN_HIP_OK;
@@ -155,6 +163,12 @@ int den_segments(int T) {
   return 1;
 }
 
+// Which form the stored rows of this call have (decided from the same inputs by the forward call and by a
+// later chain_loss_backward on its workspace).
+bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
+  return g_den_lazy && !getenv("PYCHAIN_DEN_RELAUNCH") && den_lazy_eligible(a, resident_slot_rows);
+}
+
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
 // `gamma_wait`: event every occupancy launch has to wait for (the numerator rows it folds in), or null
 hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
@@ -162,6 +176,8 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
   const int gmax = (a.D + 63) / 64;
   const int user_mask = a.phase_mask;
   const int nseg = (occupancy && user_mask == 3) ? den_segments(a.T) : 1;
+  // the lazy-normalisation recursion runs a whole sequence in one launch: not with the relaunch schedule
+  a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   hipError_t e = hipSuccess;
   if (nseg <= 1) {
     const int mask = occupancy ? user_mask : (user_mask & 1);
@@ -451,6 +467,7 @@ int chain_loss_backward_impl(
                          grad_scale, (float*)den_ws, grad, bad_count, den_ws, den_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
+  da.lazy = den_call_is_lazy(da, resident_slot_rows) ? 1 : 0;
   NumArgs na;
   // the occupancy launch reads only the forward transitions / indices / log-probs of the graphs
   rc = fill_num_args(na, ft, fi, fp, ft, fi, fp, fp, fp,

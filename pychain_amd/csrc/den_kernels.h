@@ -17,6 +17,12 @@ struct DenArgs {
   int32_t* bad;              // [1]
   float* alpha_store;        // [B,T,Hp]    alpha'(t,.)/tot(t), alpha numbering
   float* beta_store;         // [B,T+1,Hp]  beta(t,.) (unit sum), beta numbering; row 0 unused
+  // Lazy-normalisation recursion (den_lazy.inc.h): the stored rows are un-normalised, a(t,.) and b(t,.), and
+  // the occupancy kernels rebuild alpha'(t,i) = a(t,i) + scal_a[t] * leaky(i) and beta(t,i) = b(t,i) + scal_b[t]
+  // (any per-frame scale of either gives the same posteriors).  lazy = 0: rows are stored normalised.
+  float* scal_a;             // [B,T+1]  tot(t) * coef
+  float* scal_b;             // [B,T+1]  coef * sum_i leaky(i) b(t,i)
+  int lazy;
   int B, T, D, H, Hp;
   int input_is_exp;
   int frames_per_block;      // gamma kernel: frames one workgroup handles
@@ -44,6 +50,10 @@ struct DenArgs {
   int fold_K;
   float fold_scale;
 };
+
+// true if the recursion of this call runs as den_recursion_lazy_kernel (decided once per call; the occupancy
+// launches - also those of a later chain_loss_backward on the same workspace - must be told: DenArgs::lazy)
+bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows);
 
 // true if launch_den would run the two-frame occupancy kernel (the only one that can fold the numerator in)
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);

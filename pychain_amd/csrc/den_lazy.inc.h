@@ -1,0 +1,336 @@
+// den_lazy.inc.h - the alpha / beta recursions with LAZY normalisation (included by den_kernels.hip
+// inside its anonymous namespace).  Replaces chain-computation.cc:97-110,150-194 (AlphaSum, AlphaDash,
+// AlphaGeneralFrame) and :289-330 (BetaDashGeneralFrame, Beta) like den_recursion_kernel does, with a
+// different frame structure: ONE barrier per frame and no normalise pass.
+//
+// den_recursion_kernel ends every frame with: wave sums -> barrier -> totals -> a pass over the state row
+// (LDS -> fma -> LDS + HBM) -> barrier: ~1500 cycles of latency chain per frame after
+// ~3400 cycles of arc work.  Here the state vector stays UN-normalised in LDS and the scalars of frame t
+// are applied one frame later, at the group ends of frame t+1, by when they have long been reduced:
+//
+//   alpha (chain-computation.cc:150-194):  a(t+1,j) = sum_k w_k a'(t,src_k) / tot(t),  a'(t,i) = a(t,i) + tot(t) cl(i),
+//          cl = coef * leaky, w_k = p_k x(t,pdf_k)
+//       =>  a(t+1,j) = [sum_k w_k a(t,src_k)] / tot(t) + [sum_k w_k cl(src_k)]
+//     LDS holds float2 {a(t,i), cl(i)}: ONE ds_read_b64 per arc gathers both, the two sums are the two
+//     halves of one packed fma, and 1/tot(t) multiplies the first at the group end.
+//   beta (:289-330):  b(t,i) = sum_k w_k B(t+1,dst_k),  B(t,i) = (b(t,i) + c(t)) / n(t),  c = coef sum_i leaky_i b(t,i),
+//          n(t) = sum_i b(t,i)  (any per-frame scale gives the same posteriors, chain-computation.h:91-98)
+//       =>  b(t,i) = ([sum_k w_k b(t+1,dst_k)] + c(t+1) [sum_k w_k]) / n(t+1)
+//     LDS holds float2 {b(t+1,i), 1}: the same arc loop serves both directions.
+//
+// What is streamed to HBM is the un-normalised row (a(t,.) / b(t,.)) plus ONE scalar per frame
+// (tot(t)*coef / c(t)); the occupancy kernels rebuild a'(t,i) = a(t,i) + [tot(t) coef] leaky(i) and
+// b(t,i) + c(t) when they stage the rows (DenArgs::lazy).  A row's values leave the lane that summed them:
+// no read-back from LDS.  The state vector and the nnet-output row are both double-buffered, so a frame
+// writes only buffers nobody reads until the barrier.
+//
+// LDS map (absolute byte addresses; the dynamic segment starts at 0, checked):
+//   [0, 32K)      state buffer 0: float2[<= 4096]       [32K, 64K)  state buffer 1
+//   [64K, 80K)    nnet-output buffer 0 (exp'd row)      [80K, 96K)  nnet-output buffer 1
+//   [96K, ...)    partial sums
+// An arc is two VGPRs as in den_recursion_kernel: {8*i0 | (kLzXField + 4*i1) << 16, p}; the buffer of a
+// frame is selected by the ds_read OFFSET field (0 / 32768 for the state, 16384 / 32768 for the row), which
+// costs no instruction.
+constexpr uint32_t kLzU1 = 32768, kLzX0 = 65536, kLzX1 = 81920, kLzXField = 49152, kLzRed = 98304;
+constexpr uint32_t kLzLk = kLzRed + 2 * 2 * 64 * 4;         // beta: leaky probs [<= 4096]
+constexpr uint32_t kLzBytes = kLzLk + 4096 * 4;
+constexpr int kLzMaxGroups = 4;          // groups (of 64 rows) one wave may own: their values stay in registers
+
+typedef float lz_v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const lz_v2f lz_lds_cv2f;
+typedef __attribute__((address_space(3))) float lz_lds_float;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+__device__ __forceinline__ lz_v2f lz_ld2(uint32_t byte_addr) { return *(lz_lds_cv2f*)(byte_addr); }
+__device__ __forceinline__ void lz_st1(uint32_t byte_addr, float v) { *(lz_lds_float*)(byte_addr) = v; }
+#pragma clang diagnostic pop
+
+template <int R>
+struct LazyArcs {
+  uint32_t pk[R];
+  float p[R];
+  __device__ __forceinline__ void load(int nslot_rows, const uint2* __restrict__ wave_slots) {
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      uint2 a = make_uint2(0u, 0u);                    // rows past the plan: p = 0, harmless addresses
+      if (s < nslot_rows) a = wave_slots[s * 64];
+      pk[s] = ((a.x & 0xffffu) << 3) | ((kLzXField + ((a.x >> 16) << 2)) << 16);
+      p[s] = __uint_as_float(a.y);
+    }
+  }
+  __device__ __forceinline__ void opaque4(int s) {
+    asm volatile("" : "+v"(pk[s]), "+v"(pk[s + 1]), "+v"(pk[s + 2]), "+v"(pk[s + 3]));
+  }
+  template <uint32_t UOFF, uint32_t VOFF>
+  __device__ __forceinline__ void gather(int s, lz_v2f& u, float& v) {
+    u = lz_ld2((pk[s] & 0xffffu) + UOFF);
+    v = lds_abs((pk[s] >> 16) + VOFF);
+  }
+};
+
+// what a wave carries from frame to frame besides its arcs
+struct LazyWave {
+  float inv, c;                 // 1 / total of the previous frame; beta: coef * leaky-weighted sum of the previous frame
+};
+
+// A group end inside the arc loop does the least it can: the row's new value into the state buffer the
+// next frame gathers from.  Totals and the HBM row are built after the arc phase from those LDS words
+// (lazy_frame_end): nothing of it is live in registers while the gather buffers are.
+template <bool FWD>
+__device__ __forceinline__ void lazy_group_end(const LazyWave& w, lz_v2f acc, uint32_t lds_dst) {
+  float val;
+  if constexpr (FWD) val = __builtin_fmaf(acc.x, w.inv, acc.y);
+  else val = __builtin_fmaf(w.c, acc.y, acc.x) * w.inv;
+  lz_st1(lds_dst, val);
+}
+
+// One frame of a recursion tile, lazy form: gathers from state buffer UOFF and nnet-output buffer VOFF,
+// writes the new values into state buffer UNEXT (byte offset).  Same software pipeline as tile_rows.
+template <int R, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT>
+__device__ __forceinline__ void lazy_tile(LazyArcs<R>& ar, const GroupRegs& gr, const LazyWave& w, int lane) {
+  constexpr int kChunk = 4;
+  static_assert(R % kChunk == 0 && R <= 64 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
+  constexpr int NC = R / kChunk;
+  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), cm = gr.chunkmask;
+  asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
+  lz_v2f acc = {0.f, 0.f};
+  lz_v2f ub[2][kChunk];
+  float vb[2][kChunk];
+  ar.opaque4(0);
+#pragma unroll
+  for (int k = 0; k < kChunk; k++) ar.template gather<UOFF, VOFF>(k, ub[0][k], vb[0][k]);
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int cb = c & 1;
+    wave_priority_by_progress<NC>(c);
+    if (c + 1 < NC) {
+      ar.opaque4((c + 1) * kChunk);
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) ar.template gather<UOFF, VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    lz_v2f nacc = acc;
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) {
+      const float wk = ar.p[c * kChunk + k] * vb[cb][k];
+      nacc = __builtin_elementwise_fma(lz_v2f{wk, wk}, ub[cb][k], nacc);
+    }
+    if (__builtin_expect(((cm >> c) & 1u) != 0u, 0)) {         // a chunk with a group end (a few per frame) redoes it
+      nacc = acc;
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) {
+        const int sidx = c * kChunk + k;
+        const float wk = ar.p[sidx] * vb[cb][k];
+        nacc = __builtin_elementwise_fma(lz_v2f{wk, wk}, ub[cb][k], nacc);
+        if (((sidx < 32 ? m_lo : m_hi) >> (sidx & 31)) & 1u) {
+          const uint32_t lo_before = sidx < 32 ? (m_lo & ((1u << (sidx & 31)) - 1u)) : m_lo;
+          const uint32_t hi_before = sidx < 32 ? 0u : (m_hi & ((1u << (sidx & 31)) - 1u));
+          const int g = __builtin_popcount(lo_before) + __builtin_popcount(hi_before);
+          const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
+          lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
+          nacc = lz_v2f{0.f, 0.f};
+        }
+      }
+    }
+    acc = nacc;
+  }
+}
+
+// One (sequence, direction).  The direction is a template parameter and the kernel branches ONCE, at its
+// top: with both directions in one body the register allocator keeps a second copy of every arc register
+// across the (uniform) direction branches.
+template <int R, bool fwd>
+__device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int nsteps = fwd ? L : L - 1;
+  const int Hp = a.Hp, D = a.D;
+  const char* plan = a.plans + (size_t)b * a.plan_stride;
+  const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
+  const TilePlan tp = fwd ? hd->alpha : hd->beta;
+  const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
+  const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
+  const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
+
+  float* U0 = reinterpret_cast<float*>(smem_raw);                  // float2[4096]; buffer 1 at + kLzU1 bytes
+  float* X0 = reinterpret_cast<float*>(smem_raw + kLzX0);
+  float* red = reinterpret_cast<float*>(smem_raw + kLzRed);        // [parity][which][64]
+  int bad = lds_addr(smem_raw) != 0u ? 1 : 0;                      // the packed arc addresses are absolute
+
+  GroupRegs groups;
+  groups.load<R>(we, gtab, lane);
+  const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
+  LazyArcs<R> arcs;
+  arcs.load(groups.nslots, wave_slots);
+
+  const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
+  const float* start_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_init_a : hd->off_final_b));
+  const float* xseq = a.x + (size_t)b * a.T * D;
+  float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
+  float* scal = (fwd ? a.scal_a : a.scal_b) + (size_t)b * (a.T + 1);
+  const float coef = a.coef;
+  const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
+  const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));
+  const XBuf cbuf = make_xbuf(scal, (size_t)(a.T + 1) * sizeof(float));
+
+  LazyWave w;
+  // group g of this wave: rows base_g .. base_g + 63 (lane l owns row base_g + l)
+  int gbase[kLzMaxGroups];
+#pragma unroll
+  for (int g = 0; g < kLzMaxGroups; g++) gbase[g] = g < groups.ngroups ? __builtin_amdgcn_readlane(groups.base, g) : 0;
+  float* LK = reinterpret_cast<float*>(smem_raw + kLzLk);
+  if (groups.ngroups > kLzMaxGroups || groups.nslots > R) bad = 1;   // the host checks the plan before choosing this kernel
+
+  // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
+  double logsum = 0.0;
+  XRow<kNT, 4, 1> xq;
+  {
+    float p0 = 0.f, p1 = 0.f;
+    for (int i = tid; i < 4096; i += kNT) {
+      float s = 0.f, second = fwd ? 0.f : 1.f, l = 0.f;
+      if (i < Hp) { s = start_g[i]; l = leaky_g[i]; if (fwd) second = coef * l; }
+      *reinterpret_cast<lz_v2f*>(U0 + 2 * i) = lz_v2f{s, second};
+      *reinterpret_cast<lz_v2f*>(U0 + kLzU1 / 4 + 2 * i) = lz_v2f{0.f, second};
+      if (!fwd) LK[i] = l;
+      p0 += s; p1 += s * l;
+    }
+    const int t0 = fwd ? 0 : L - 1;
+    xq.load(xseq + (size_t)t0 * D, D, tid);
+    xq.store(X0, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    p0 = wave_sum(p0); p1 = wave_sum(p1);
+    if (lane == 0) { red[wave] = p0; red[64 + wave] = p1; }
+    if (tid >= 16 && tid < 64) { red[tid] = 0.f; red[64 + tid] = 0.f; }
+    __syncthreads();
+    const float tot = wave_sum(red[lane]), wtot = wave_sum(red[64 + lane]);
+    w.inv = __builtin_amdgcn_rcpf(tot);
+    w.c = coef * wtot;
+    if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;
+    if (fwd) logsum = (double)fast_log(tot);
+    // the start row and its scalar (alpha row 0 / beta row L)
+    const int t_start = fwd ? 0 : L;
+    // (device-scope write-through like every row: an occupancy launch may read them on another XCD while
+    // this kernel is still running)
+    for (int i = tid; i < Hp; i += kNT)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(start_g[i]), sbuf, i * 4, t_start * Hp * 4, kStoreDeviceScope);
+    if (tid == 0)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fwd ? tot * coef : w.c), cbuf, 0, t_start * 4, kStoreDeviceScope);
+    __syncthreads();                                                 // red is rewritten by the first frame
+  }
+
+  int next_sig = 0;
+  int next_bound = a.sig_n > 0 ? a.seg_bound[0] : 0x7fffffff;
+#define PYCHAIN_LZ_SIGNAL(DONE)                                                                             \
+  while ((DONE) >= next_bound) {                                                                            \
+    __builtin_amdgcn_s_waitcnt(0);                     /* this wave's row stores are acknowledged */          \
+    __syncthreads();                                                                                        \
+    if (tid == 0) __hip_atomic_fetch_add(a.progress + next_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    next_sig++;                                                                                             \
+    next_bound = next_sig < a.sig_n ? a.seg_bound[next_sig] : 0x7fffffff;                                   \
+  }
+
+  // One frame step j: alpha produces a(j+1,.) from a(j,.) and x(j); beta produces b(t,.), t = L-1-j, from b(t+1,.) and x(t).
+#define PYCHAIN_LZ_STEP(J, PAR, FWDC)                                                                       \
+  do {                                                                                                      \
+    const int j = (J);                                                                                      \
+    /* thread and lane index made opaque per frame: everything derived from them (LDS and buffer offsets) is */ \
+    /* then recomputed here with a few VALU instead of living in ~8 VGPRs across the arc loop */            \
+    int tq = tid;                                                                                           \
+    asm volatile("" : "+v"(tq));                                                                            \
+    const int lq = tq & 63;                                                                                 \
+    constexpr uint32_t UOFF = (PAR) ? kLzU1 : 0u, UNEXT = (PAR) ? 0u : kLzU1;                               \
+    constexpr uint32_t VOFF = (PAR) ? 32768u : 16384u;       /* kLzXField + VOFF = nnet-output buffer PAR */ \
+    const int tn = (FWDC) ? j + 1 : L - 2 - j;               /* nnet-output row of the NEXT step */          \
+    const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
+    if (have_next) xq.load_row(xbuf, tn, D, tq);             /* in flight during the arc work */             \
+    lazy_tile<R, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq);                                           \
+    /* this frame's values of the lane's rows back from LDS (and, beta, their leaky probs): in flight during */ \
+    /* the exp of the nnet-output row below */                                                              \
+    float val[kLzMaxGroups], lkv[kLzMaxGroups];                                                             \
+    {                                                                                                       \
+      const int lane8 = lq * 8;                                                                             \
+      _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++) {                                            \
+        val[g] = 0.f; lkv[g] = 0.f;                                                                         \
+        if (g < groups.ngroups) {                                                                           \
+          val[g] = lds_abs(UNEXT + gbase[g] * 8 + lane8);                                                   \
+          if (!(FWDC)) lkv[g] = lds_abs(kLzLk + gbase[g] * 4 + (lane8 >> 1));                               \
+        }                                                                                                   \
+      }                                                                                                     \
+    }                                                                                                       \
+    /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
+    if (have_next) xq.store(X0 + ((PAR) ? 0 : 4096), xseq, D, tq, a.input_is_exp);                          \
+    /* the row leaves for HBM (issued after the wait for the nnet-output row: a wait that covered these */  \
+    /* stores would last a round trip to HBM) */                                                            \
+    const int tstore = (FWDC) ? j + 1 : L - 1 - j;                                                          \
+    const bool do_store = (FWDC) ? (tstore < L) : true;                                                     \
+    float s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                       \
+    float s1 = 0.f;                                                                                         \
+    if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
+    if (do_store) {                                                                                         \
+      const int row_off = __builtin_amdgcn_readfirstlane(tstore * Hp * 4);                                  \
+      const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
+      _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++)                                              \
+        if (g < groups.ngroups)                                                                             \
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[g]), sbuf, lane4, row_off + gbase[g] * 4, kStoreDeviceScope); \
+    }                                                                                                       \
+    /* totals: four row sums per wave before the barrier, the rest of the reduction after it */             \
+    {                                                                                                       \
+      const float r0 = dpp_row_sum(s0);                                                                     \
+      red[(PAR) * 128 + wave * 4 + (lq >> 4)] = r0;                                                         \
+      if (!(FWDC)) { const float r1 = dpp_row_sum(s1); red[(PAR) * 128 + 64 + wave * 4 + (lq >> 4)] = r1; } \
+    }                                                                                                       \
+    __syncthreads();                                         /* every gather of this frame is done; the new vector is complete */ \
+    const float tot = wave_sum(red[(PAR) * 128 + lq]);                                                      \
+    w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
+    if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;                                                            \
+    float sc;                                                                                               \
+    if (FWDC) { sc = tot * coef; if (tstore < L && wave == 0) logsum += (double)fast_log(tot); }            \
+    else { w.c = coef * wave_sum(red[(PAR) * 128 + 64 + lq]); sc = w.c; }                                   \
+    if (do_store && tq == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), cbuf, 0, tstore * 4, kStoreDeviceScope); \
+    last_tot = tot;                                                                                         \
+  } while (0)
+
+  float last_tot = 1.f;
+  for (int jj = 0; jj < nsteps; jj += 2) {
+    PYCHAIN_LZ_STEP(jj, 0, fwd);
+    if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
+    PYCHAIN_LZ_SIGNAL(jj + 2);
+  }
+  PYCHAIN_LZ_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // a sequence shorter than a bound is done with it now
+#undef PYCHAIN_LZ_SIGNAL
+#undef PYCHAIN_LZ_STEP
+
+  if constexpr (fwd) {
+    // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i a'(L,i) final(i) + sum_{t<L} log tot(t),
+    // a'(L,i) = a(L,i) + tot(L) cl(i); the vector of step L-1 sits in buffer (L & 1)
+    const float* fin = reinterpret_cast<const float*>(plan + hd->off_final_a);
+    const float* UL = U0 + ((nsteps & 1) ? kLzU1 / 4 : 0);
+    float f = 0.f;
+    for (int i = tid; i < Hp; i += kNT) {
+      const lz_v2f u = *reinterpret_cast<const lz_v2f*>(UL + 2 * i);
+      f += __builtin_fmaf(last_tot, u.y, u.x) * fin[i];
+    }
+    f = wave_sum(f);
+    __syncthreads();
+    if (lane == 0) red[wave] = f;
+    if (tid >= 16 && tid < 64) red[tid] = 0.f;
+    __syncthreads();
+    const float fs = wave_sum(red[lane]);
+    if (tid == 0) {
+      const float objf = (float)(logsum + (double)fast_log(fs));
+      a.objf[b] = objf;
+      if (!(fs > 0.f) || !(objf - objf == 0.f)) bad = 1;
+    }
+  }
+  if (bad && lane == 0) atomicAdd(a.bad, 1);
+}
+
+template <int R>
+__global__ __launch_bounds__(kNT) void den_recursion_lazy_kernel(const DenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, true>(a, smem_raw, blockIdx.x);
+  else lazy_recursion<R, false>(a, smem_raw, blockIdx.x - a.B);
+}

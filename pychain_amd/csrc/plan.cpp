@@ -390,6 +390,10 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
       const int pos = g * 64 + l;
       if (pos < (int)order.size()) t.gsl[g] = std::max(t.gsl[g], (int)rows[order[pos]].size());
     }
+  // a recursion group without arcs still gets one (all-padding) slot-row: every group then has a group end
+  // in every frame, which is where the lazy-normalisation kernel writes a row's value (zeros here)
+  if (own_layout >= 0)
+    for (int g = 0; g < ng; g++) t.gsl[g] = std::max(t.gsl[g], 1);
   // freedom 2: spare slot-rows per group.  The kernels keep 16, 32 or 40 slot-rows of a wave in
   // registers and walk all of them every frame, so slack is free up to the next of those sizes:
   // take the smallest size that leaves room for >= 2 spare rows per group, then as many (<= slack)
@@ -503,6 +507,8 @@ extern "C" int64_t pychain_hip_den_plan_build(
   memset(&hd, 0, sizeof(hd));
   hd.magic = PLAN_MAGIC; hd.version = PLAN_VERSION;
   hd.H = H; hd.K = K; hd.D = D; hd.Hp = Hp;
+  for (const BuiltTile* t : {&ta, &tb})
+    for (const WaveEntry& we : t->waves) hd.rec_max_wave_groups = std::max(hd.rec_max_wave_groups, we.ngroups);
   auto place_tile = [&](TilePlan& tp, const BuiltTile& t) {
     tp.ngroups = (int)t.groups.size(); tp.nwaves = (int)t.waves.size();
     tp.total_slot_rows = t.total_slot_rows; tp.max_wave_slot_rows = t.max_wave; tp.nrows = t.nrows;

@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 5
+#define PLAN_VERSION 6
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -67,7 +67,7 @@ struct PlanHeader {
   int32_t magic, version;
   int32_t H, K, D, Hp;
   int32_t total_bytes;
-  int32_t reserved0;
+  int32_t rec_max_wave_groups; // most groups any wave of the alpha / beta plans owns
   TilePlan alpha, beta, gamma;
   int32_t off_init_a;          // float[Hp]  initial_probs, alpha numbering
   int32_t off_leaky_a;         // float[Hp]  leaky_probs,   alpha numbering

@@ -10,7 +10,11 @@ w = syn.make_workload(name, device=dev)
 plan = _plan.graph_plan(w["den_graph"], w["cfg"]["D"], dev)
 Ld = w["lengths"].to(dev)
 L = _lib.lib()
-call = lambda: native.den_forward_backward(plan, w["x"], Ld, 1e-5)
+if os.environ.get("TIME_DEN_LAZY") is not None:
+    L.pychain_hip_set_den_lazy(int(os.environ["TIME_DEN_LAZY"]))
+isexp = bool(int(os.environ.get("TIME_DEN_ISEXP", "0")))
+xin = w["x"].clamp(-30, 30).exp() if isexp else w["x"]
+call = lambda: native.den_forward_backward(plan, xin, Ld, 1e-5, input_is_exp=isexp)
 call(); torch.cuda.synchronize()
 modes = (("recursion", 1), ("gamma", 2), ("both", 3))
 if os.environ.get("TIME_DEN_ONLY"):
