@@ -46,9 +46,14 @@ extern "C" {
 
 int         pychain_hip_abi_version(void);
 const char* pychain_hip_last_error(void);
-/* base.h:34-42 / pychain.cc:134.  The reference re-runs its invariant checks on
- * every frame when level >= 1; here level >= 1 makes the kernels count every
- * non-finite normaliser instead of only flagging the call. */
+/* base.h:34-42 / pychain.cc:134.  `ok` (here: bad_count == 0) carries the reference's invariant checks
+ * (chain-computation.cc:345-391, chain-log-domain-computation.cc:283-304): alpha'.beta' and the frame's
+ * derivative sum within 5 % of 1, restated for this library's free per-frame scales as
+ *   log G(t) + la[t] + lb[t+2] = log P(sequence)   (denominator; G = un-normalised occupancy total of frame t,
+ *   la / lb = log-scales the two recursions have divided out), sum of a frame's occupancies = 1 (numerator),
+ * plus: no normaliser or total is non-finite or non-positive.  Level 0 checks frame 0 of every sequence (as the
+ * reference does), level >= 1 every frame; at level >= 1 the occupancy launches of the denominator are not
+ * overlapped with the recursions (the check needs both finished), results are bit-identical. */
 void        pychain_hip_set_verbose_level(int level);
 int         pychain_hip_get_verbose_level(void);
 

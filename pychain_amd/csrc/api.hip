@@ -63,7 +63,9 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   if (B <= 0 || T <= 0 || H <= 0) return 0;
   const size_t Hp = roundup64(H);
   return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ +
-         2 * align256(4 * (size_t)B * (T + 1)) /* per-frame scalars of lazy rows */ + 256;
+         2 * align256(4 * (size_t)B * (T + 1)) /* per-frame scalars of lazy rows */ +
+         2 * align256(4 * (size_t)B * (T + 2)) /* per-frame log-scales (invariant check) */ +
+         align256(4 * (size_t)B * T) /* frame totals to check */ + 256;
 }
 
 namespace {
@@ -104,7 +106,11 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.progress = (int32_t*)((char*)a.logsum_ws + align256(8 * (size_t)B));
   a.scal_a = (float*)((char*)a.progress + 256);
   a.scal_b = (float*)((char*)a.scal_a + align256(4 * (size_t)B * (T + 1)));
+  a.la = (float*)((char*)a.scal_b + align256(4 * (size_t)B * (T + 1)));
+  a.lb = (float*)((char*)a.la + align256(4 * (size_t)B * (T + 2)));
+  a.gtot = (float*)((char*)a.lb + align256(4 * (size_t)B * (T + 2)));
   a.lazy = 0;
+  a.check_objf = nullptr; a.check_all = g_verbose_level >= 1 ? 1 : 0;
   a.sig_n = 0;
   a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_seg = 0; a.gam_nseg = 0;
   return PYCHAIN_HIP_OK;
@@ -171,13 +177,17 @@ bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
 
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
 // `gamma_wait`: event every occupancy launch has to wait for (the numerator rows it folds in), or null
-hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
-                   hipEvent_t gamma_wait = nullptr) {
+hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
+                            hipEvent_t gamma_wait) {
   const int gmax = (a.D + 63) / 64;
   const int user_mask = a.phase_mask;
-  const int nseg = (occupancy && user_mask == 3) ? den_segments(a.T) : 1;
+  const int nseg = (occupancy && user_mask == 3 && !a.check_all) ? den_segments(a.T) : 1;
   // the lazy-normalisation recursion runs a whole sequence in one launch: not with the relaunch schedule
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
+  // invariant check of the occupancy launches (DenArgs::la): needs this call's objf and log-scales; on every
+  // frame (verbose level >= 1) it also needs the recursions finished before any occupancy launch
+  const bool relaunch = getenv("PYCHAIN_DEN_RELAUNCH") != nullptr;
+  a.check_objf = (occupancy && user_mask == 3 && !(relaunch && nseg > 1)) ? a.objf : nullptr;
   hipError_t e = hipSuccess;
   if (nseg <= 1) {
     const int mask = occupancy ? user_mask : (user_mask & 1);
@@ -261,6 +271,13 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
   a.phase_mask = user_mask; a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_nseg = 0;
   return e;
 }
+// ... and, behind all of them on the caller's stream, the reference's invariant check (DenArgs::la)
+hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
+                   hipEvent_t gamma_wait = nullptr) {
+  hipError_t e = run_den_launches(a, resident_slot_rows, occupancy, st, why, gamma_wait);
+  if (e == hipSuccess) e = launch_den_check(a, st);
+  return e;
+}
 }  // namespace
 
 extern "C" int pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg,
@@ -336,6 +353,7 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
   a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
   a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 32;
+  a.check_all = g_verbose_level >= 1 ? 1 : 0;
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_ws = (double*)(ws + c.alpha); a.beta_ws = (double*)(ws + c.beta); a.logp_ws = (double*)(ws + c.logp);
   a.rows_ws = (float*)(ws + c.rows); a.upd_ws = (int32_t*)(ws + c.upd); a.ucount_ws = (int32_t*)(ws + c.ucount);

@@ -341,6 +341,24 @@ __device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const 
 // natural log on the v_log_f32 unit (1 ulp of log2): all lanes, no divergent libm call
 __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.693147182464599609375f; }
 
+// The reference's `ok` (BetaGeneralFrameDebug, chain-computation.cc:345-391): alpha'.beta' and the frame's
+// derivative sum within 5 % of 1.  With free per-frame scales the same statement reads
+// log G(t) + la[t] + lb[t+2] = log P (DenArgs::la); true = violated (also for NaN).
+// The occupancy kernels only record G(t) (the recursions may still be running, and with them objf and the
+// log-scales of other frames, when an overlapped occupancy launch evaluates frame 0 of a short sequence);
+// den_check_kernel compares after the last launch of the call.
+__device__ __forceinline__ void den_record_frame_total(const DenArgs& a, int b, int t, float frame_total) {
+  a.gtot[(size_t)b * a.T + t] = frame_total;
+}
+__global__ void den_check_kernel(const DenArgs a) {
+  const int b = blockIdx.y;
+  const int t = a.check_all ? blockIdx.x * blockDim.x + threadIdx.x : 0;
+  const int L = (int)a.lengths[b];
+  if (t >= L || (!a.check_all && threadIdx.x != 0)) return;
+  const float est = fast_log(a.gtot[(size_t)b * a.T + t]) + a.la[(size_t)b * (a.T + 2) + t] + a.lb[(size_t)b * (a.T + 2) + t + 2];
+  if (!(fabsf(est - a.check_objf[b]) <= 0.0487901642f)) atomicAdd(a.bad, 1);     // log(1.05); NaN counts
+}
+
 // block total of per-wave partials: red[16] in LDS (entries >= kNW stay zero)
 __device__ __forceinline__ float block_total(const float* red, int lane) { return dpp_row_sum(red[lane & 15]); }
 
@@ -397,7 +415,8 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));   // < 2 GiB: checked at launch
 
-  double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229
+  double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229; beta: sum_t log of its own normaliser
+  float* lsc = (fwd ? a.la : a.lb) + (size_t)b * (a.T + 2);   // log-scales for the invariant check (DenArgs::la)
   int bad = 0;
   float tot, wtot;
   XRow<kNT, VEC, XCH> xq;
@@ -423,6 +442,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     const float inv = __builtin_amdgcn_rcpf(tot);
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
     logsum += (double)fast_log(tot);
+    if (tid == 0) { if (fwd) lsc[0] = (float)logsum; else lsc[L + 1] = (float)logsum; }
     normalise_row(fwd, raw, lk, cur, sbuf, (fwd ? 0 : L) * Hp * 4, inv, coef, coef * wtot, H, Hp, tid);
   } else {
     // ---- resume a later time segment: the state vector is the row the previous segment stored last
@@ -484,8 +504,9 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     wtot = fwd ? 0.f : block_total(red + 16, lane);                                                         \
     const float inv = __builtin_amdgcn_rcpf(tot);                                                           \
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;                                                              \
-    if (fwd) logsum += (double)fast_log(tot);        /* only the alpha side reports a log-probability */     \
+    logsum += (double)fast_log(tot);                 /* alpha: the log-probability; both: the scale divided out so far */ \
     const int tstore = fwd ? j + 1 : L - 1 - j;                                                             \
+    if (tid == 0) lsc[fwd ? tstore : tstore + 1] = (float)logsum;                                           \
     const bool do_store = fwd ? (tstore < L) : true;                                                        \
     if (kWithNorm)                                                                                          \
       normalise_row(fwd, raw, lk, cur, sbuf, do_store ? tstore * Hp * 4 : -1, inv, coef, coef * wtot, H, Hp, tid, true, cl0); \
@@ -800,6 +821,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     const float tot = block_total(red, lane);
     const float sc = gscale / tot;
     if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
+    if (a.check_objf && (t == 0 || a.check_all) && tid == 0) den_record_frame_total(a, b, t, tot);
     if constexpr (XCH > 0) {
 #pragma unroll
       for (int c = 0; c < XCH; c++) {
@@ -1195,6 +1217,10 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     const float sc0 = gscale / tot0, sc1 = gscale / tot1;
     if (valid0 && (!(tot0 > 0.f) || !(sc0 - sc0 == 0.f))) bad = 1;
     if (valid1 && (!(tot1 > 0.f) || !(sc1 - sc1 == 0.f))) bad = 1;
+    if (a.check_objf && tid == 0) {
+      if (valid0 && (t0 == 0 || a.check_all)) den_record_frame_total(a, b, t0, tot0);
+      if (valid1 && a.check_all) den_record_frame_total(a, b, t0 + 1, tot1);
+    }
     float* grow0 = gseq + (size_t)t0 * D;
     float* grow1 = grow0 + D;
 #pragma unroll
@@ -1341,6 +1367,12 @@ int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, co
   if (out && out_len > 0) out[0] = gx;
   for (int k = 0; out && k < gx && 1 + k < out_len; k++) out[1 + k] = den_chunk_of_block(k, L, a);
   return LaunchFrames(a).has(t, L) && t < L ? 1 : 0;
+}
+
+hipError_t launch_den_check(const DenArgs& a, hipStream_t st) {
+  if (!a.check_objf) return hipSuccess;
+  hipLaunchKernelGGL(den_check_kernel, dim3(a.check_all ? (a.T + 255) / 256 : 1, a.B), dim3(a.check_all ? 256 : 64), 0, st, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hipStream_t st) {

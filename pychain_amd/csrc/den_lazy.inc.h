@@ -172,6 +172,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const float* xseq = a.x + (size_t)b * a.T * D;
   float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
   float* scal = (fwd ? a.scal_a : a.scal_b) + (size_t)b * (a.T + 1);
+  float* lsc = (fwd ? a.la : a.lb) + (size_t)b * (a.T + 2);       // log-scales for the invariant check (DenArgs::la)
   const float coef = a.coef;
   const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));
@@ -209,7 +210,13 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     w.inv = __builtin_amdgcn_rcpf(tot);
     w.c = coef * wtot;
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;
-    if (fwd) logsum = (double)fast_log(tot);
+    // log-scales divided out so far: alpha row t carries sum_{tau<t} log tot(tau) (la[t]); the beta row
+    // that frame t's occupancy reads, b(t+1,.) + c(t+1), carries sum_{tau>=t+2} log n(tau) (lb[t+2])
+    if (tid == 0) {
+      if (fwd) lsc[0] = 0.f;
+      else { lsc[L + 1] = 0.f; lsc[L] = fast_log(tot); }
+    }
+    logsum = (double)fast_log(tot);
     // the start row and its scalar (alpha row 0 / beta row L)
     const int t_start = fwd ? 0 : L;
     // (device-scope write-through like every row: an occupancy launch may read them on another XCD while
@@ -287,8 +294,13 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;                                                            \
     float sc;                                                                                               \
-    if (FWDC) { sc = tot * coef; if (tstore < L && wave == 0) logsum += (double)fast_log(tot); }            \
+    if (FWDC) sc = tot * coef;                                                                              \
     else { w.c = coef * wave_sum(red[(PAR) * 128 + 64 + lq]); sc = w.c; }                                   \
+    if (wave == 0) {                                         /* (wave 0 keeps the running log-scale) */      \
+      if ((FWDC) && do_store && tq == 0) lsc[tstore] = (float)logsum;         /* before tot(tstore) joins it */ \
+      if (!(FWDC) || tstore < L) logsum += (double)fast_log(tot);                                           \
+      if (!(FWDC) && tq == 0) lsc[tstore] = (float)logsum;                                                  \
+    }                                                                                                       \
     if (do_store && tq == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), cbuf, 0, tstore * 4, kStoreDeviceScope); \
     last_tot = tot;                                                                                         \
   } while (0)

@@ -56,10 +56,13 @@ __device__ __forceinline__ float exp_bounded(float c) {
 //   kXIdentity  v                      denominator fed exp'd input (pychain_C.forward_backward contract)
 //   kXClamp     clamp(v,-30,30)        numerator (log domain)
 enum { kXExpClamp = 0, kXIdentity = 1, kXClamp = 2 };
+// NaN stays NaN (torch.clamp / exp propagate it, loss.py:30,43; v_med3_f32 alone would turn it into -30
+// and a diverged network would look healthy): one compare + select per element.
 __device__ __forceinline__ float clamp_exp(float v, int mode) {
   if (mode == kXIdentity) return v;
   const float c = __builtin_amdgcn_fmed3f(v, -30.f, 30.f);
-  return mode == kXClamp ? c : exp_bounded(c);
+  const float r = mode == kXClamp ? c : exp_bounded(c);
+  return v != v ? v : r;
 }
 
 // a*b + c*d and a*b + c with every product ROUNDED before the sum (no fma contraction: HIP compiles

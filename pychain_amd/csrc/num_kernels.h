@@ -30,6 +30,9 @@ struct NumArgs {
   int frames_per_block;      // occupancy kernel
   float grad_scale;
   const float* grad_scale_dev;   // optional device scalar multiplied into grad_scale
+  // BetaGeneralFrameDebug, chain-log-domain-computation.cc:283-304: a frame's occupancies must sum to 1 within
+  // 5 % (and be finite); checked at t == 0 always, on every frame when check_all (verbose level >= 1)
+  int check_all;
 };
 
 size_t num_fb_lds_bytes(int H, int K, int D);

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(p); p += 8 * (size_t)Dp;     // [Dp]
     double* arow = reinterpret_cast<double*>(p); p += 8 * (size_t)((H + 1) & ~1);                  // alpha(t,.)
     double* brow = reinterpret_cast<double*>(p); p += 8 * (size_t)((H + 1) & ~1);                  // beta(t+1,.)
-    int* s_kmax_p = reinterpret_cast<int*>(p); p += 16;
+    int* s_kmax_p = reinterpret_cast<int*>(p);
+    float* s_fsum = reinterpret_cast<float*>(p + 8); p += 16;
     uint32_t* sd = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)K;                             // src | dst << 16
     float* lp = reinterpret_cast<float*>(p); p += 4 * (size_t)K;
     uint16_t* pdf = reinterpret_cast<uint16_t*>(p);                                                // [K]
@@ -354,9 +355,12 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
       for (int i = 0; i < kNR; i++) { const int h = tid + i * kOcNT; if (h < H) { arow[h] = pa[i]; brow[h] = pb[i]; } }
       for (int h = tid + kNR * kOcNT; h < H; h += kOcNT) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)t * H + h]; }
       float xcur[kNX];
+      float fsum = 0.f;                                 // this thread's share of the frame's occupancy total
 #pragma unroll
       for (int i = 0; i < kNX; i++) xcur[i] = px[i];
       if (t + 1 < t_live_end) NUM_OCC_PREFETCH(t + 1);
+      const bool check = t == 0 || a.check_all;         // the reference's `ok` (NumArgs::check_all)
+      if (check && tid == 0) *s_fsum = 0.f;
       __syncthreads();
       const float* frow = fseq + (size_t)t * K;
       float* grow = gseq + (size_t)t * D;
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
         const int n = pdf[k];                                                                      \
         const double st = arow[src] + brow[src] - logp;          /* log occupancy of the source state */ \
         const float v = st == -INFINITY ? 0.f : fexp((float)(st + (double)(rk)));                  \
+        fsum += v;                                                                                 \
         if (v > 0.f) {                                                                             \
           if (v <= 2.f) atomicAdd(&acc[n], (unsigned long long)(v * kFixScale));                   \
           else bad = 1;                                                                            \
@@ -379,7 +384,12 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
       for (int i = 0; i < kNX; i++) { const int k = tid + i * kOcNT; if (k < Kused) NUM_OCC_ARC(k, xcur[i]); }
       for (int k = tid + kNX * kOcNT; k < Kused; k += kOcNT) NUM_OCC_ARC(k, frow[k]);
 #undef NUM_OCC_ARC
+      if (check) {
+        const float ws = wave_sum(fsum);
+        if ((tid & 63) == 0) atomicAdd(s_fsum, ws);
+      }
       __syncthreads();
+      if (check && tid == 0 && !(fabsf(*s_fsum - 1.f) <= 0.05f)) bad = 1;
       if (mode == PYCHAIN_HIP_GRAD_ACCUM) {
         for (int k = tid; k < Kused; k += kOcNT) {
           const int n = pdf[k];
@@ -490,6 +500,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
     const int src = sd[k] & 0xffffu;                                                               \
     const double st = arow[src] + brow[src] - logp;                                                \
     const float v = st == -INFINITY ? 0.f : fexp((float)(st + (double)(rk)));                      \
+    fsum += v;                                                                                     \
     if (v > 0.f) {                                                                                 \
       if (v <= 2.f) atomicAdd(&acc[pdf_u[k] >> 16], (unsigned long long)(v * kFixScale));          \
       else bad = 1;                                                                                \
@@ -504,6 +515,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
     for (int i = 0; i < kWR; i++) { const int h = lane + 64 * i; if (h < H) { arow[h] = pa[i]; brow[h] = pb[i]; } }
     for (int h = lane + 64 * kWR; h < H; h += 64) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)t * H + h]; }
     float xc[kWX];
+    float fsum = 0.f;                                   // this lane's share of the frame's occupancy total
 #pragma unroll
     for (int i = 0; i < kWX; i++) xc[i] = px[i];
     if (t + 1 < t1) NUM_OCCW_PREFETCH(t + 1);
@@ -511,6 +523,10 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
 #pragma unroll
     for (int i = 0; i < kWX; i++) { const int k = lane + 64 * i; if (k < Kused) NUM_OCCW_ARC(k, xc[i]); }
     for (int k = lane + 64 * kWX; k < Kused; k += 64) NUM_OCCW_ARC(k, frow[k]);
+    if (t == 0 || a.check_all) {                        // the reference's `ok`: the frame's occupancies sum to 1 within 5 %
+      const float ftot = wave_sum(fsum);
+      if (!(fabsf(ftot - 1.f) <= 0.05f)) bad = 1;
+    }
     __builtin_amdgcn_wave_barrier();
     float* crow = a.rows_ws + ((size_t)b * T + t) * K;
     for (int u = lane; u < U; u += 64) {
