@@ -72,6 +72,13 @@ void        pychain_hip_set_den_phase_mask(int mask);
  * pass of their own, two barriers per frame); 1 (default) = as den_recursion_lazy_kernel wherever the
  * shape allows.  Both forms must agree to rounding; the tests compare them. */
 void        pychain_hip_set_den_lazy(int on);
+/* Test / tuning options (process-wide; nothing on the call path reads the environment).  value NULL or ""
+ * clears.  Names: "den_segments" (n time segments of the denominator, 1 = no overlap), "den_bounds"
+ * ("0.7,0.85": their ends as fractions of T), "den_relaunch" (one recursion launch per segment instead of
+ * progress counters + gate kernels), "no_fold" (numerator accumulated into the stored gradient instead of
+ * folded into the occupancy launch), "gamma16" (one-frame occupancy kernel), "num_no_staging_waves".
+ * Every combination gives the same results to rounding (the tests compare them); unknown name: EINVAL. */
+int         pychain_hip_set_option(const char* name, const char* value);
 
 /* ------------------------------------------------------------------------
  * Denominator graph plan  (host side, no GPU work).

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "pychain_hip_get_verbose_level": (_i, []),
     "pychain_hip_set_den_phase_mask": (None, [_i]),
     "pychain_hip_set_den_lazy": (None, [_i]),
+    "pychain_hip_set_option": (_i, [ctypes.c_char_p, ctypes.c_char_p]),
     "pychain_hip_debug_launch_map": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i]),
     "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -72,7 +73,31 @@ def lib():
         if v != ABI_VERSION:
             raise ImportError("pychain_amd: libpychain_hip.so has ABI %d, expected %d" % (v, ABI_VERSION))
         _lib = l
+        # tuning scripts set PYCHAIN_<OPTION> in the environment: read ONCE here, never on the call path
+        for name in OPTIONS:
+            v = os.environ.get("PYCHAIN_" + name.upper())
+            if v:
+                l.pychain_hip_set_option(name.encode(), v.encode())
     return _lib
+
+
+OPTIONS = ("den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves")
+
+
+class option(object):
+    """`with _lib.option("den_segments", 3): ...` - a test / tuning option of the library for the duration
+    of a block (include/pychain_hip.h: pychain_hip_set_option)."""
+
+    def __init__(self, name, value=1):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        check(lib().pychain_hip_set_option(self.name.encode(), str(self.value).encode()), "pychain_hip_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        lib().pychain_hip_set_option(self.name.encode(), None)
+        return False
 
 
 class PychainHipError(RuntimeError):

@@ -5,6 +5,9 @@ Replaces the reference's per-call `.cuda()` of eleven graph tensors
 the device for as long as the ChainGraph object lives.
 """
 import ctypes
+import hashlib
+import os
+import tempfile
 
 import numpy as np
 import torch
@@ -30,8 +33,9 @@ def _np(t, dtype):
 
 def build_plan_blob(forward_transitions, forward_transition_indices, forward_transition_probs,
                     backward_transitions, backward_transition_indices, backward_transition_probs,
-                    leaky_probs, initial_probs, final_probs, num_pdfs):
-    """Host tensors of ONE graph -> numpy uint8 plan blob (pychain_hip_den_plan_build)."""
+                    leaky_probs, initial_probs, final_probs, num_pdfs, use_cache=True):
+    """Host tensors of ONE graph -> numpy uint8 plan blob (pychain_hip_den_plan_build), through the
+    on-disk cache."""
     arrs = [_np(forward_transitions, np.int32), _np(forward_transition_indices, np.int32),
             _np(forward_transition_probs, np.float32),
             _np(backward_transitions, np.int32), _np(backward_transition_indices, np.int32),
@@ -41,11 +45,34 @@ def build_plan_blob(forward_transitions, forward_transition_indices, forward_tra
     K = arrs[0].shape[0]
     ptrs = [a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
     L = _lib.lib()
+    cdir = _cache_dir() if use_cache and K >= 256 else None       # (tiny graphs compile in microseconds)
+    path = None
+    if cdir is not None:
+        path = os.path.join(cdir, _plan_key(arrs, num_pdfs) + ".plan")
+        try:
+            blob = np.fromfile(path, dtype=np.uint8)
+            if blob.nbytes >= 32:
+                info = np.zeros(8, dtype=np.int32)
+                rc = L.pychain_hip_den_plan_info(blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes,
+                                                 info.ctypes.data_as(ctypes.c_void_p))
+                if rc == 0 and (int(info[0]), int(info[1]), int(info[2]), int(info[3])) == (H, K, int(num_pdfs), blob.nbytes):
+                    return blob
+        except (OSError, ValueError):
+            pass
     need = _lib.check(L.pychain_hip_den_plan_build(*ptrs, H, K, int(num_pdfs), None, 0), "den_plan_build")
     blob = np.zeros(int(need), dtype=np.uint8)
     _lib.check(L.pychain_hip_den_plan_build(*ptrs, H, K, int(num_pdfs),
                                             blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes),
                "den_plan_build")
+    if path is not None:
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            fd, tmp = tempfile.mkstemp(dir=cdir, suffix=".tmp")
+            with os.fdopen(fd, "wb") as f:
+                f.write(blob.tobytes())
+            os.replace(tmp, path)
+        except OSError:
+            pass                      # a read-only home directory only costs the compile time
     return blob
 
 
@@ -57,17 +84,67 @@ def plan_info(blob):
                 bytes=int(info[3]), slot_rows=int(info[4]))
 
 
+# ---- on-disk cache of compiled plans -------------------------------------------------------------
+# Compiling the C3 graph takes ~5 s (slot-order annealing); N ranks of a data-parallel job and every
+# restart would each pay it.  A plan is a pure function of the nine graph tensors, the pdf count, the plan
+# format version and the compiler knobs, so it is stored under a hash of exactly those
+# ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans; "0" / "off" disables).  Writes are
+# atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.
+_KNOBS = ("PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL")
+
+
+def _cache_dir():
+    d = os.environ.get("PYCHAIN_PLAN_CACHE_DIR")
+    if d is not None and d.strip().lower() in ("", "0", "off", "none"):
+        return None
+    return d or os.path.join(os.path.expanduser("~"), ".cache", "pychain_amd", "plans")
+
+
+def _plan_key(arrays, num_pdfs):
+    h = hashlib.sha256()
+    h.update(b"pychain_amd plan v%d abi %d pdfs %d" % (_plan_format_version(), _lib.ABI_VERSION, int(num_pdfs)))
+    for k in _KNOBS:
+        h.update(("%s=%s;" % (k, os.environ.get(k, ""))).encode())
+    for a in arrays:
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _plan_format_version():
+    # PLAN_VERSION of csrc/plan_format.h as the library reports it in a plan header (bytes 4..8)
+    global _PLAN_VERSION
+    if _PLAN_VERSION is None:
+        t = torch.tensor
+        blob = build_plan_blob(t([[0, 0, 0]], dtype=torch.int32), t([[0, 1]], dtype=torch.int32), t([1.0]),
+                               t([[0, 0, 0]], dtype=torch.int32), t([[0, 1]], dtype=torch.int32), t([1.0]),
+                               t([1.0]), t([1.0]), t([1.0]), 1, use_cache=False)
+        _PLAN_VERSION = int(np.frombuffer(blob[4:8].tobytes(), dtype=np.int32)[0])
+    return _PLAN_VERSION
+
+
+_PLAN_VERSION = None
+
+
+def _tensor_versions(graph):
+    """(data_ptr, _version) of the nine graph tensors: an in-place edit (final_probs.fill_, new leaky
+    probs) or a replaced tensor makes the cached plan stale."""
+    return tuple((getattr(graph, n).data_ptr(), getattr(graph, n)._version) for n in _NAMES)
+
+
 def graph_plan(graph, num_pdfs, device):
-    """DevicePlan of a ChainGraph (shared denominator), cached on the graph."""
+    """DevicePlan of a ChainGraph (shared denominator), cached on the graph until one of its tensors
+    is modified or replaced."""
     key = (str(device), int(num_pdfs))
     if not hasattr(graph, "_plan_cache"):
         graph._plan_cache = {}
+    ver = _tensor_versions(graph)
     hit = graph._plan_cache.get(key)
-    if hit is None:
+    if hit is None or hit[0] != ver:
         blob = build_plan_blob(*[getattr(graph, n) for n in _NAMES], num_pdfs)
-        hit = DevicePlan(torch.from_numpy(blob).to(device), 0, plan_info(blob)["slot_rows"], graph.num_states)
-        graph._plan_cache[key] = hit
-    return hit
+        plan = DevicePlan(torch.from_numpy(blob).to(device), 0, plan_info(blob)["slot_rows"], graph.num_states)
+        graph._plan_cache[key] = hit = (ver, plan)
+    return hit[1]
 
 
 def batch_plans(tensors, num_pdfs, device):

@@ -6,7 +6,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 
 #include "../../include/pychain_hip.h"
 #include "common.h"
@@ -23,6 +25,15 @@ char* last_error_buffer() {
   return buf;
 }
 namespace {
+std::mutex g_option_lock;
+std::map<std::string, std::string>& option_table() { static std::map<std::string, std::string> t; return t; }
+}  // namespace
+const char* option(const char* name) {
+  std::lock_guard<std::mutex> guard(g_option_lock);
+  auto it = option_table().find(name);
+  return it == option_table().end() ? nullptr : it->second.c_str();   // (values are only replaced by set_option: test threads)
+}
+namespace {
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 int roundup64(int x) { return (x + 63) / 64 * 64; }
 }  // namespace
@@ -36,6 +47,16 @@ extern "C" void pychain_hip_set_verbose_level(int level) { g_verbose_level = lev
 extern "C" int pychain_hip_get_verbose_level(void) { return g_verbose_level; }
 extern "C" void pychain_hip_set_den_phase_mask(int mask) { g_den_phase_mask = mask & 3; }
 extern "C" void pychain_hip_set_den_lazy(int on) { g_den_lazy = on ? 1 : 0; }
+extern "C" int pychain_hip_set_option(const char* name, const char* value) {
+  static const char* const known[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves"};
+  if (!name) return fail(PYCHAIN_HIP_EINVAL, "set_option: null name");
+  bool ok = false;
+  for (const char* k : known) ok = ok || strcmp(k, name) == 0;
+  if (!ok) return fail(PYCHAIN_HIP_EINVAL, "set_option: unknown option '%s'", name);
+  std::lock_guard<std::mutex> guard(g_option_lock);
+  if (value && *value) option_table()[name] = value; else option_table().erase(name);
+  return PYCHAIN_HIP_OK;
+}
 
 extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]) {
   if (!host_blob || !info || blob_bytes < sizeof(PlanHeader))
@@ -117,8 +138,8 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
 }
 }  // namespace
 
-// ---- library-owned side streams (the only hidden state): one for the numerator recursion,
-// one for the occupancy launches that overlap the denominator recursion ------------------
+// ---- library-owned side streams (the only hidden state besides the option table): one for the numerator
+// recursion, one for the occupancy launches that overlap the denominator recursion ------------------
 namespace {
 constexpr int kMaxSegments = 16;
 struct SideStream {
@@ -126,13 +147,16 @@ struct SideStream {
   hipEvent_t fork = nullptr, join = nullptr, seg[kMaxSegments] = {}, join2 = nullptr;
   bool ready = false;       // every stream and event below was created
 };
-SideStream* side_stream_for_current_device() {
-  static SideStream table[64];
-  static std::mutex create_lock;              // first use on a device may come from several host threads
+// One set per (device, caller's stream): two calls in flight on two streams of one device must not share
+// the side streams' events (a second hipEventRecord would move the event the first call still waits for),
+// and calls on ONE stream are ordered, so they may.  Entries live for the life of the process.
+SideStream* side_streams_for(hipStream_t caller) {
+  static std::map<std::pair<int, hipStream_t>, SideStream> table;
+  static std::mutex create_lock;              // first use may come from several host threads
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream& s = table[dev];
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> guard(create_lock);
+  SideStream& s = table[std::make_pair(dev, caller)];
   if (!s.ready) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
     // the occupancy launches only fill idle CUs: lowest priority, so that the persistent recursion
@@ -154,7 +178,7 @@ SideStream* side_stream_for_current_device() {
 // whose alpha'/beta rows already exist runs on idle CUs WHILE the recursions continue
 // (2B persistent workgroups leave the other CUs free).  1 = no overlap.
 int den_segments(int T) {
-  if (const char* e = getenv("PYCHAIN_DEN_SEGMENTS")) { int n = atoi(e); if (n >= 1 && n <= kMaxSegments) return n; }
+  if (const char* e = option("den_segments")) { int n = atoi(e); if (n >= 1 && n <= kMaxSegments) return n; }
   // What limits the overlap is CU time: after T/2 the occupancy pass has the ~128 idle CUs only (less the
   // numerator's), on which its ~1 ms of whole-chip work takes longer than the rest of the recursion, so
   // the last launch (the frames that only become computable at the very end) is exposed.  Each further
@@ -172,7 +196,7 @@ int den_segments(int T) {
 // Which form the stored rows of this call have (decided from the same inputs by the forward call and by a
 // later chain_loss_backward on its workspace).
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
-  return g_den_lazy && !getenv("PYCHAIN_DEN_RELAUNCH") && den_lazy_eligible(a, resident_slot_rows);
+  return g_den_lazy && !option("den_relaunch") && den_lazy_eligible(a, resident_slot_rows);
 }
 
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
@@ -186,7 +210,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   // invariant check of the occupancy launches (DenArgs::la): needs this call's objf and log-scales; on every
   // frame (verbose level >= 1) it also needs the recursions finished before any occupancy launch
-  const bool relaunch = getenv("PYCHAIN_DEN_RELAUNCH") != nullptr;
+  const bool relaunch = option("den_relaunch") != nullptr;
   a.check_objf = (occupancy && user_mask == 3 && !(relaunch && nseg > 1)) ? a.objf : nullptr;
   hipError_t e = hipSuccess;
   if (nseg <= 1) {
@@ -204,7 +228,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     a.phase_mask = user_mask;
     return e;
   }
-  SideStream* side = side_stream_for_current_device();
+  SideStream* side = side_streams_for(st);
   if (!side) { *why = "cannot create the side streams"; return hipErrorInvalidValue; }
   // Frame t becomes computable after max(t, L-1-t) recursion steps, i.e. nothing before T/2 and
   // then ever faster: segment ends at T/2, 3T/4, 7T/8, ... so every occupancy launch but the
@@ -213,7 +237,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     const double frac = s == nseg - 1 ? 1.0 : 1.0 - 1.0 / (double)(2 << s);
     a.seg_bound[s] = s == nseg - 1 ? a.T : ((int)(frac * a.T) + 31) / 32 * 32;
   }
-  if (const char* e = getenv("PYCHAIN_DEN_BOUNDS")) {   // experiment: "0.7,0.85" = ends of all segments but the last, as fractions of T
+  if (const char* e = option("den_bounds")) {   // experiment: "0.7,0.85" = ends of all segments but the last, as fractions of T
     int s = 0;
     for (const char* p = e; *p && s < nseg - 1; s++) {
       char* q; const double f = strtod(p, &q);
@@ -222,7 +246,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
       p = *q == ',' ? q + 1 : q;
     }
   }
-  if (!getenv("PYCHAIN_DEN_RELAUNCH")) {
+  if (!option("den_relaunch")) {
     // Gated schedule: ONE recursion launch; its workgroups count themselves into progress[s] when their
     // steps below seg_bound[s] are done, and a one-wave gate kernel in front of occupancy launch s (side
     // stream) waits for all 2B of them.  No relaunch of the persistent workgroups at the segment ends.
@@ -248,7 +272,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     a.phase_mask = user_mask; a.gam_nseg = 0; a.sig_n = 0;
     return e;
   }
-  // Relaunch schedule (PYCHAIN_DEN_RELAUNCH=1): one recursion launch per segment, stream events in between.
+  // Relaunch schedule (option den_relaunch): one recursion launch per segment, stream events in between.
   for (int s = 0; s < nseg && e == hipSuccess; s++) {
     a.phase_mask = 1; a.seg_begin = s ? a.seg_bound[s - 1] : 0; a.seg_end = s == nseg - 1 ? 0x7fffffff : a.seg_bound[s];
     e = launch_den(a, gmax, resident_slot_rows, st, why);
@@ -415,14 +439,14 @@ extern "C" int pychain_hip_chain_loss_forward(
                      grad ? grad : (float*)num_ws, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  SideStream* side = side_stream_for_current_device();
+  SideStream* side = side_streams_for(st);
   if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "%s: cannot create the side stream", who);
   const char* why = nullptr;
   hipError_t e = hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st);
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
-  const bool no_fold = getenv("PYCHAIN_NO_FOLD") != nullptr;               // test / tuning knob (read per call)
+  const bool no_fold = option("no_fold") != nullptr;                      // test / tuning option
   const bool fold = grad && !no_fold && den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
   if (fold) {
     da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;

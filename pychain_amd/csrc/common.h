@@ -10,6 +10,10 @@ namespace pychain_hip {
 char* last_error_buffer();          // thread-local, 512 bytes (api.hip)
 extern int g_verbose_level;
 
+// Test / tuning options set through pychain_hip_set_option (api.hip); nullptr = not set.  Nothing on the call
+// path reads the environment.
+const char* option(const char* name);
+
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -38,6 +38,7 @@
 #include <type_traits>
 #include <stdint.h>
 
+#include "common.h"
 #include "den_kernels.h"
 #include "device_utils.h"
 #include "plan_format.h"
@@ -353,7 +354,7 @@ __device__ __forceinline__ void den_record_frame_total(const DenArgs& a, int b, 
 __global__ void den_check_kernel(const DenArgs a) {
   const int b = blockIdx.y;
   const int t = a.check_all ? blockIdx.x * blockDim.x + threadIdx.x : 0;
-  const int L = (int)a.lengths[b];
+  const int L = seq_len(a.lengths, b, a.T);
   if (t >= L || (!a.check_all && threadIdx.x != 0)) return;
   const float est = fast_log(a.gtot[(size_t)b * a.T + t]) + a.la[(size_t)b * (a.T + 2) + t] + a.lb[(size_t)b * (a.T + 2) + t + 2];
   if (!(fabsf(est - a.check_objf[b]) <= 0.0487901642f)) atomicAdd(a.bad, 1);     // log(1.05); NaN counts
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool fwd = blockIdx.x < (unsigned)a.B;
   const int b = fwd ? blockIdx.x : blockIdx.x - a.B;
-  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int nsteps = fwd ? L : L - 1;
   const int j_begin = a.seg_begin, j_end = min(a.seg_end, nsteps);
   if (j_begin > 0 && j_begin >= nsteps) return;      // this sequence finished in an earlier segment
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 
   double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229; beta: sum_t log of its own normaliser
   float* lsc = (fwd ? a.la : a.lb) + (size_t)b * (a.T + 2);   // log-scales for the invariant check (DenArgs::la)
-  int bad = 0;
+  int bad = (fwd && a.seg_begin == 0 && seq_len_bad(a.lengths, b, a.T)) ? 1 : 0;
   float tot, wtot;
   XRow<kNT, VEC, XCH> xq;
   if (tid < 32) red[tid] = 0.f;
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
-  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int Hp = a.Hp, D = a.D, Dp = (D + 3) & ~3;
   const int chunk = den_chunk_of_block(blockIdx.x, L, a);
   if (chunk < 0) return;
@@ -1005,7 +1006,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
-  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int Hp = a.Hp, D = a.D, T = a.T, Dp = (D + 3) & ~3;
   const int chunk = den_chunk_of_block(blockIdx.x, L, a);
   if (chunk < 0) return;
@@ -1282,7 +1283,7 @@ inline size_t gamma2_lds_bytes(const DenArgs& a, int gamma_max_groups) {
   return sizeof(float) * (4 * (size_t)a.Hp + (a.fold_rows ? 6 : 2) * (size_t)((a.D + 3) & ~3) + (size_t)gamma_max_groups * 64 + 32);
 }
 inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
-  const bool off = getenv("PYCHAIN_GAMMA16") != nullptr;               // tuning / test knob (read per call): force the one-frame kernel
+  const bool off = option("gamma16") != nullptr;                       // test / tuning option: force the one-frame kernel
   return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
          a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) <= 160 * 1024;
 }

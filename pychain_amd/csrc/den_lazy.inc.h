@@ -146,7 +146,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int nsteps = fwd ? L : L - 1;
   const int Hp = a.Hp, D = a.D;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
@@ -160,6 +160,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   float* X0 = reinterpret_cast<float*>(smem_raw + kLzX0);
   float* red = reinterpret_cast<float*>(smem_raw + kLzRed);        // [parity][which][64]
   int bad = lds_addr(smem_raw) != 0u ? 1 : 0;                      // the packed arc addresses are absolute
+  if (fwd && seq_len_bad(a.lengths, b, a.T)) bad = 1;
 
   GroupRegs groups;
   groups.load<R>(we, gtab, lane);

@@ -18,6 +18,18 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 __device__ __forceinline__ float lds_abs(uint32_t byte_addr) { return *(lds_cfloat*)(byte_addr); }
 #pragma clang diagnostic pop
 
+// A sequence length as the kernels use it: clamped to [1, T].  Lengths that live on the device are never seen
+// by the host-side validation (that would be a sync); an out-of-range one must not turn into out-of-bounds
+// reads and writes.  The recursion kernels also count it into `bad` (seq_len_bad).
+__device__ __forceinline__ int seq_len(const int64_t* lengths, int b, int T) {
+  const int64_t l = lengths[b];
+  return l < 1 ? 1 : (l > T ? T : (int)l);
+}
+__device__ __forceinline__ bool seq_len_bad(const int64_t* lengths, int b, int T) {
+  const int64_t l = lengths[b];
+  return l < 1 || l > T;
+}
+
 // ---- wave64 reductions on DPP (no LDS traffic, unlike __shfl_xor = ds_bpermute) --------
 #define PYCHAIN_DPP_ADD(v, ctrl) \
   ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true)))

@@ -26,6 +26,7 @@
 
 #include "../../include/pychain_hip.h"
 #include "device_utils.h"
+#include "common.h"
 #include "num_kernels.h"
 
 namespace pychain_hip {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool fwd = blockIdx.x < (unsigned)a.B;
   const int b = fwd ? blockIdx.x : blockIdx.x - a.B;
-  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int H = a.H, K = a.K, D = a.D, T = a.T, Dp = (D + 3) & ~3;
   const size_t g = (size_t)b * a.graph_stride;
 
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
     const float objf = (float)logp;
     a.objf[b] = objf;
     a.logp_ws[b] = logp;
-    if (!(objf - objf == 0.f)) atomicAdd(a.bad, 1);
+    if (!(objf - objf == 0.f) || seq_len_bad(a.lengths, b, a.T)) atomicAdd(a.bad, 1);
   }
 }
 
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  const int L = (int)a.lengths[b];
+  const int L = seq_len(a.lengths, b, a.T);
   const int K = a.K, D = a.D, T = a.T, H = a.H, Dp = (D + 3) & ~3;
   const int t_begin = blockIdx.x * a.frames_per_block;
   const int t_end = min(t_begin + a.frames_per_block, T);
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
-  const int L = __builtin_amdgcn_readfirstlane((int)a.lengths[b]);
+  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int K = a.K, D = a.D, T = a.T, H = a.H, Hq = (H + 1) & ~1;
   const int t_wg = blockIdx.x * (4 * kOwFrames);
   if (t_wg >= L) return;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kOcNT) void num_scatter_kernel(const NumArgs a) {
   const int tid = threadIdx.x, b = blockIdx.y;
-  const int L = (int)a.lengths[b], K = a.K, T = a.T, D = a.D;
+  const int L = seq_len(a.lengths, b, a.T), K = a.K, T = a.T, D = a.D;
   const int t_begin = blockIdx.x * a.frames_per_block;
   const int t_end = min(min(t_begin + a.frames_per_block, T), L);
   const int U = a.ucount_ws[b];
@@ -595,7 +596,7 @@ hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
   }
   const int D = a.D;
   if (D % 4 == 0) {
-    if (!getenv("PYCHAIN_NUM_NO_STAGING_WAVES")) {             // tuning / test knob (read per call)
+    if (!option("num_no_staging_waves")) {                     // test / tuning option
       if (D <= 4 * 4 * kFbLd) return launch_fb<4, 4, kFbLd>(a, lds, st);
       if (D <= 4 * 8 * kFbLd) return launch_fb<4, 8, kFbLd>(a, lds, st);
     }

@@ -189,7 +189,9 @@ class ChainGraphBatch(object):
     def device_tensors(self, device):
         """Contiguous device copies of the per-sequence tensors, cached until
         `reorder`.  Replaces the per-call `.cuda()` of chain-computation.cc:77-89."""
-        key = str(device)
+        # (data_ptr, _version) of every tensor: an in-place edit or a replaced attribute re-stages
+        key = (str(device),) + tuple((getattr(self, n).data_ptr(), getattr(self, n)._version)
+                                     for n in _TENSORS[:-1] if getattr(self, n) is not None)
         hit = self._device_cache.get(key)
         if hit is None:
             hit = {}

@@ -34,6 +34,12 @@ class ChainFunction(torch.autograd.Function):
                 "input batch size ({}) does not equal to graph batch size ({})"
                 .format(B, graphs.batch_size))
         x = input.detach()
+        objf, input_grad, bad = ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient)
+        return ChainFunction._forward_tail(ctx, input, x, input_lengths, graphs, leaky_coefficient, objf, input_grad, bad)
+
+    @staticmethod
+    def _occupancies(x, input_lengths, graphs, leaky_coefficient):
+        """(objf per sequence, occupancies = gradient for an upstream gradient of 1, bad_count)."""
         D = x.size(2)
         if not graphs.log_domain:   # usually the denominator
             if graphs.shared_graph is not None:
@@ -55,15 +61,22 @@ class ChainFunction(torch.autograd.Function):
             gstride = 0 if graphs.shared_graph is not None else 1
             objf, input_grad, bad = native.num_forward_backward(
                 gt, gstride, graphs.num_states, x, input_lengths, grad_mode=_lib.GRAD_LINEAR)
+        return objf, input_grad, bad
+
+    @staticmethod
+    def _forward_tail(ctx, input, x, input_lengths, graphs, leaky_coefficient, objf, input_grad, bad):
         # The occupancies are the gradient for an upstream gradient of 1.  backward() scales the
         # buffer in place on the device (a no-op launch when the upstream gradient is exactly 1,
         # i.e. `objf.backward()`) and hands it to autograd, instead of the reference's extra
-        # read+write pass over [B,T,D] (torch.mul, loss.py:85).  `retain_grad_buffer` = True keeps
-        # the reference's behaviour for callers that back-propagate twice (retain_graph=True).
+        # read+write pass over [B,T,D] (torch.mul, loss.py:85).  A SECOND backward over the same graph
+        # (retain_graph=True; the reference allows it, loss.py:82-87) finds the buffer gone - autograd
+        # owns it, it may be x.grad by now - and evaluates the occupancies again from the inputs kept
+        # here by reference.  `retain_grad_buffer` = True keeps a private copy instead (reference cost).
         if ChainFunction.retain_grad_buffer:
             ctx.save_for_backward(input_grad)
         else:
             ctx.grad_buf = input_grad
+            ctx.again = lambda: ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient)[1]
         ctx.in_dtype = input.dtype   # fp16 / bf16 inputs are evaluated in fp32; the gradient goes back in their dtype
         ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
         ChainFunction.last_bad_count = bad
@@ -77,19 +90,16 @@ class ChainFunction(torch.autograd.Function):
         if ctx.saved_tensors:
             input_grad, = ctx.saved_tensors
             return torch.mul(input_grad, objf_grad).to(ctx.in_dtype), None, None, None
-        grad = _take_grad_buffer(ctx, "grad_buf", "ChainFunction")
+        grad = _take_grad_buffer(ctx, "grad_buf")
+        if grad is None:
+            grad = ctx.again()               # second backward over a retained graph: evaluate again
         return native.rescale_(grad, objf_grad).to(ctx.in_dtype), None, None, None
 
 
-def _take_grad_buffer(ctx, attr, who):
+def _take_grad_buffer(ctx, attr):
     """The gradient buffer written in forward, handed over ONCE (autograd then owns it: a leaf's
-    .grad takes it without a copy)."""
+    .grad takes it without a copy); None when it is gone."""
     buf = getattr(ctx, attr, None)
-    if buf is None:
-        raise RuntimeError(
-            "%s.backward was called a second time: the gradient buffer was handed to autograd by the "
-            "first call.  Set pychain_amd.ChainFunction.retain_grad_buffer = True before the forward "
-            "pass (and ChainLoss(...).fused = False) to back-propagate more than once." % who)
     setattr(ctx, attr, None)
     return buf
 
@@ -135,6 +145,11 @@ class ChainLossFunction(torch.autograd.Function):
         if ctx.dev_norm is not None:
             objf = objf / ctx.dev_norm
         ctx.state = state
+        # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
+        spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)
+        ctx.again = lambda: native.chain_loss_forward(
+            plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
+            with_grad=spec, grad_scale=hscale)[3]
         ctx.in_dtype = input.dtype
         ChainFunction.last_bad_count = bad       # int32[2]: denominator, numerator; never synced here
         return objf
@@ -144,13 +159,16 @@ class ChainLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, objf_grad):
         g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
-        state = _take_grad_buffer(ctx, "state", "ChainLossFunction")
+        state = _take_grad_buffer(ctx, "state")
+        if state is None:
+            state = ctx.again()
         if ctx.speculative:
             grad = native.rescale_(state.grad, g)
         else:
             grad, bad = native.chain_loss_backward(state, ctx.host_scale, g)
             ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad
         state.grad = None         # the stored trajectories go with `state`
+        state.den_ws = state.num_ws = None
         return grad.to(ctx.in_dtype), None, None, None, None, None
 
 

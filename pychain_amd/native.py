@@ -21,12 +21,23 @@ def _require_device(t, what):
 
 
 def _workspace(nbytes, device, tag="a"):
-    key = (str(device), tag)
+    """Scratch for the stored trajectories, reused from call to call.  Keyed by the CALLER'S STREAM as well:
+    calls on one stream are ordered, so the next one may overwrite what the previous one left; calls on
+    two streams of one device run concurrently and must not share it.  (A replaced buffer goes back to the
+    caching allocator, which hands it out again only in the stream order of its allocation.)"""
+    key = (str(device), _stream(device), tag)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
+
+
+def release_workspaces():
+    """Drop every cached workspace (several GB at C3 sizes) and the memoised plans / graph uploads of the
+    pychain_C-compatible surface."""
+    _ws_cache.clear()
+    _compat_cache.clear()
 
 
 def _stream(device):
@@ -233,9 +244,39 @@ _GRAPH6 = ["forward_transitions", "forward_transition_indices", "forward_transit
 
 
 def _check_contiguous(**named):
-    for n, t in named.items():   # pychain.cc:24,42-54
-        if not t.is_contiguous():
-            raise RuntimeError("%s must be contiguous" % n)
+    """CHECK_CONTIGUOUS of pychain.cc:24,42-54,95-107: every tensor argument, RuntimeError with the
+    reference's message.  One extension: the stride-0 batch views of `ChainGraphBatch(one_graph, B)`
+    (the reference materialises them with .repeat, graph.py:104-119; here they are views of the single
+    graph) count as contiguous when each row is - code that hands them on unchanged must keep working."""
+    for n, t in named.items():
+        if t.is_contiguous():
+            continue
+        if t.dim() >= 1 and t.stride(0) == 0 and t[0].is_contiguous():
+            continue
+        raise RuntimeError("%s must be contiguous" % n)
+
+
+# The reference's loss.py calls pychain_C on EVERY training step with the same graph tensors.  Compiling the
+# denominator plan (seconds for a C3-size graph) or re-uploading the numerator graphs per call would make
+# that pattern ~1000x slower than the kernels, so both are memoised on what identifies the inputs:
+# (data_ptr, _version, shape) of every tensor + pdf count + device.  A few entries, least recently used out.
+_compat_cache = {}
+_COMPAT_CACHE_ENTRIES = 8
+
+
+def _tensors_key(tensors, extra):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) for t in tensors) + tuple(extra)
+
+
+def _compat_cached(kind, tensors, extra, build):
+    key = (kind,) + _tensors_key(tensors, extra)
+    hit = _compat_cache.pop(key, None)
+    if hit is None:
+        hit = (build(), list(tensors))        # the tensors are kept alive: their data_ptr cannot be recycled
+    _compat_cache[key] = hit                  # (re-)inserted last = most recently used
+    while len(_compat_cache) > _COMPAT_CACHE_ENTRIES:
+        _compat_cache.pop(next(iter(_compat_cache)))
+    return hit[0]
 
 
 def forward_backward(forward_transitions, forward_transition_indices, forward_transition_probs,
@@ -244,14 +285,19 @@ def forward_backward(forward_transitions, forward_transition_indices, forward_tr
                      batch_sizes, sequence_lengths, num_states, leaky_hmm_coefficient=1.0e-05):
     """Same contract as `pychain_C.forward_backward`: pre-exponentiated input, returns
     [objf (0-dim), nnet_output_grad [B,T,D], ok (bool[1])]."""
-    _check_contiguous(exp_nnet_output=exp_nnet_output, batch_sizes=batch_sizes,
-                      sequence_lengths=sequence_lengths)
-    tensors = dict(zip(_GRAPH6 + ["leaky_probs", "initial_probs", "final_probs"],
-                       [forward_transitions, forward_transition_indices, forward_transition_probs,
-                        backward_transitions, backward_transition_indices, backward_transition_probs,
-                        leaky_probs, initial_probs, final_probs]))
+    _check_contiguous(forward_transitions=forward_transitions, forward_transition_indices=forward_transition_indices,
+                      forward_transition_probs=forward_transition_probs, backward_transitions=backward_transitions,
+                      backward_transition_indices=backward_transition_indices,
+                      backward_transition_probs=backward_transition_probs, leaky_probs=leaky_probs,
+                      exp_nnet_output=exp_nnet_output, batch_sizes=batch_sizes, sequence_lengths=sequence_lengths,
+                      initial_probs=initial_probs, final_probs=final_probs, start_state=start_state)
+    names = _GRAPH6 + ["leaky_probs", "initial_probs", "final_probs"]
+    vals = [forward_transitions, forward_transition_indices, forward_transition_probs,
+            backward_transitions, backward_transition_indices, backward_transition_probs,
+            leaky_probs, initial_probs, final_probs]
     D = exp_nnet_output.shape[2]
-    plan = _plan.batch_plans(tensors, D, exp_nnet_output.device)
+    dev = exp_nnet_output.device
+    plan = _compat_cached("den", vals, (D, str(dev)), lambda: _plan.batch_plans(dict(zip(names, vals)), D, dev))
     objf, grad, bad = den_forward_backward(plan, exp_nnet_output, sequence_lengths,
                                            leaky_hmm_coefficient, input_is_exp=True)
     return [objf.sum(), grad, bad == 0]
@@ -263,12 +309,18 @@ def forward_backward_log_domain(forward_transitions, forward_transition_indices,
                                 batch_sizes, sequence_lengths, num_states):
     """Same contract as `pychain_C.forward_backward_log_domain`: returns
     [objf, log-grad [B,T,D] (-inf where zero), ok]."""
-    _check_contiguous(nnet_output=nnet_output, batch_sizes=batch_sizes, sequence_lengths=sequence_lengths)
+    _check_contiguous(forward_transitions=forward_transitions, forward_transition_indices=forward_transition_indices,
+                      forward_transition_probs=forward_transition_probs, backward_transitions=backward_transitions,
+                      backward_transition_indices=backward_transition_indices,
+                      backward_transition_probs=backward_transition_probs, nnet_output=nnet_output,
+                      batch_sizes=batch_sizes, sequence_lengths=sequence_lengths, initial_probs=initial_probs,
+                      final_probs=final_probs, start_state=start_state)
     dev = nnet_output.device
     vals = [forward_transitions, forward_transition_indices, forward_transition_probs,
             backward_transitions, backward_transition_indices, backward_transition_probs,
             initial_probs, final_probs]
-    gt = {n: t.contiguous().to(dev) for n, t in zip(_GRAPH6 + ["initial_probs", "final_probs"], vals)}
+    gt = _compat_cached("num", vals, (str(dev),), lambda: {
+        n: t.contiguous().to(dev) for n, t in zip(_GRAPH6 + ["initial_probs", "final_probs"], vals)})
     objf, lgrad, bad = num_forward_backward(gt, 1, num_states, nnet_output, sequence_lengths,
                                             grad_mode=_lib.GRAD_LOG)
     return [objf.sum(), lgrad, bad == 0]

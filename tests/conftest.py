@@ -10,6 +10,8 @@ ORACLE = os.path.join(REPO, "oracle")
 if ORACLE not in sys.path:
     sys.path.insert(0, ORACLE)
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# compiled plans are not cached on disk under test (tests of the cache point it at a temp directory)
+os.environ.setdefault("PYCHAIN_PLAN_CACHE_DIR", "off")
 
 
 def pytest_configure(config):

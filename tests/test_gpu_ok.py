@@ -87,7 +87,7 @@ def test_nan_network_output_is_not_ok():
     loss = ChainLoss(w["den_graph"], 1e-5)(xx, w["lengths"], w["num_graphs"])
     loss.backward()
     torch.cuda.synchronize()
-    assert int(ChainFunction.last_bad_count.sum().item()) > 0 and np.isnan(float(loss))
+    assert int(ChainFunction.last_bad_count.sum().item()) > 0 and np.isnan(float(loss.detach()))
     # the other sequence is untouched by its neighbour's NaN
     assert bool(torch.isfinite(xx.grad[0]).all())
 

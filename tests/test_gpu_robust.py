@@ -1,0 +1,135 @@
+"""Hidden state and argument handling of the HIP path: two calls in flight on two streams of one
+device, lengths that only the device knows, the per-step pattern of code written against pychain_C
+(pychain/loss.py:44-76 calls it every step with the same graph tensors), the reference's
+CHECK_CONTIGUOUS (pychain.cc:24,42-54,95-107)."""
+import numpy as np
+import pytest
+import torch
+
+from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, _lib, _plan, native, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_two_calls_in_flight_on_two_streams():
+    """The side streams / events and the cached workspace are per (device, caller's stream): two fused
+    ChainLoss steps issued back to back on two streams give what they give one after the other."""
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = [torch.tensor([400, 390, 300, 120]), torch.tensor([410, 200, 199, 3])]
+    xs = [syn.make_input(4, int(l.max()), cfg["D"], seed=51 + i, device=DEV) for i, l in enumerate(L)]
+    nums = [syn.make_num_graphs(l.tolist(), cfg["D"], seed=600 + 10 * i) for i, l in enumerate(L)]
+    crit = ChainLoss(den, 1e-5)
+
+    def step(i):
+        xx = xs[i].clone().requires_grad_(True)
+        loss = crit(xx, L[i], nums[i])
+        loss.backward()
+        return loss.detach(), xx.grad, ChainFunction.last_bad_count
+    ref = [step(0), step(1)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(3):
+        outs = [None, None]
+        for i in (0, 1):
+            streams[i].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[i]):
+                outs[i] = step(i)
+        for s in streams:
+            torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert torch.equal(outs[i][0], ref[i][0]) and torch.equal(outs[i][1], ref[i][1]), (rep, i)
+            assert int(outs[i][2].sum()) == 0
+
+
+def test_device_lengths_out_of_range_are_clamped_and_flagged():
+    """Lengths on the device are not validated on the host (no sync): a value outside [1, T] is clamped
+    by the kernels - no out-of-bounds access - and reported through bad_count."""
+    w = syn.make_workload("C1")
+    x = w["x"].to(DEV)
+    T = x.size(1)
+    for bad_len in (T + 7, 0, -3):
+        Ld = torch.tensor([T, bad_len], device=DEV)
+        clamped = torch.tensor([T, min(max(bad_len, 1), T)])
+        for graphs in (ChainGraphBatch(w["den_graph"], 2), w["num_graphs"]):
+            xx = x.clone().requires_grad_(True)
+            ChainFunction.apply(xx, Ld, graphs, 1e-5).backward()
+            bad = int(ChainFunction.last_bad_count.sum().item())
+            xr = x.clone().requires_grad_(True)
+            ChainFunction.apply(xr, clamped, graphs, 1e-5).backward()
+            assert bad > 0
+            assert torch.equal(xx.grad[0], xr.grad[0])             # the healthy sequence is untouched
+        with pytest.raises(ValueError):                            # host lengths ARE validated
+            ChainFunction.apply(x.clone().requires_grad_(True), torch.tensor([T, bad_len]),
+                                ChainGraphBatch(w["den_graph"], 2), 1e-5)
+
+
+def _raw_args(w, den_b, xin):
+    bs = torch.nn.utils.rnn.pack_padded_sequence(w["x"], w["lengths"], batch_first=True).batch_sizes
+    return [den_b.forward_transitions, den_b.forward_transition_indices, den_b.forward_transition_probs,
+            den_b.backward_transitions, den_b.backward_transition_indices, den_b.backward_transition_probs,
+            den_b.leaky_probs, den_b.initial_probs, den_b.final_probs, den_b.start_state, xin, bs,
+            w["lengths"], den_b.num_states, 1e-5]
+
+
+def test_pychain_C_surface_compiles_a_graph_once(monkeypatch):
+    """Code written against the reference calls pychain_C.forward_backward on every step with the same
+    graph tensors: the plan is compiled (and the numerator graphs are uploaded) on the first call only;
+    an in-place edit of a graph tensor is seen."""
+    w = syn.make_workload("C1")
+    den_b = ChainGraphBatch(w["den_graph"], 2)            # stride-0 views: accepted like .repeat copies
+    x = w["x"].to(DEV).clamp(-30, 30).exp()
+    native.release_workspaces()
+    calls = []
+    real = _plan.batch_plans
+    monkeypatch.setattr(_plan, "batch_plans", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    a = native.forward_backward(*_raw_args(w, den_b, x))
+    b = native.forward_backward(*_raw_args(w, den_b, x))
+    assert len(calls) == 1
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and bool(a[2].all())
+    w["den_graph"].final_probs.mul_(0.5)                   # the views share its storage
+    c = native.forward_backward(*_raw_args(w, den_b, x))
+    assert len(calls) == 2 and not torch.equal(a[0], c[0])
+    w["den_graph"].final_probs.mul_(2.0)
+    # numerator graphs: uploaded once
+    nb = w["num_graphs"]
+    bs = torch.nn.utils.rnn.pack_padded_sequence(w["x"], w["lengths"], batch_first=True).batch_sizes
+    nargs = [nb.forward_transitions, nb.forward_transition_indices, nb.forward_transition_probs,
+             nb.backward_transitions, nb.backward_transition_indices, nb.backward_transition_probs,
+             nb.initial_probs, nb.final_probs, nb.start_state, w["x"].to(DEV).clamp(-30, 30), bs, w["lengths"],
+             nb.num_states]
+    n0 = len(native._compat_cache)
+    r1 = native.forward_backward_log_domain(*nargs)
+    r2 = native.forward_backward_log_domain(*nargs)
+    assert len(native._compat_cache) == n0 + 1 and torch.equal(r1[1], r2[1])
+
+
+def test_check_contiguous_like_the_reference():
+    w = syn.make_workload("C1")
+    den_b = ChainGraphBatch(w["den_graph"], 2)
+    x = w["x"].to(DEV).clamp(-30, 30).exp()
+    args = _raw_args(w, den_b, x)
+    names = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
+             "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+             "leaky_probs", "initial_probs", "final_probs", "start_state", "exp_nnet_output",
+             "batch_sizes", "sequence_lengths"]
+    for i, name in enumerate(names):
+        t = args[i]
+        if t.dim() == 1:
+            nc = torch.stack([t, t], dim=1)[:, 0]                          # stride 2
+        else:
+            nc = t.contiguous().transpose(-1, -2).contiguous().transpose(-1, -2) if t.size(-1) > 1 and t.size(-2) > 1 else None
+        if nc is None or nc.is_contiguous():
+            continue
+        bad_args = list(args)
+        bad_args[i] = nc
+        with pytest.raises(RuntimeError, match=name + " must be contiguous"):
+            native.forward_backward(*bad_args)
+
+
+def test_unknown_option_is_an_error():
+    with pytest.raises(_lib.PychainHipError, match="unknown option"):
+        with _lib.option("no_such_option"):
+            pass

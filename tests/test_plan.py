@@ -150,3 +150,44 @@ def test_occupancy_launch_map_covers_every_frame_once():
     assert L_.pychain_hip_debug_launch_map(100, 70, 69, 32, 0, None, 0, out, 4096) == 1
     assert out[0] == 4 and [out[1 + k] for k in range(4)] == [0, 1, 2, 3]
     assert L_.pychain_hip_debug_launch_map(100, 70, 69, 32, 3, None, 0, out, 4096) < 0      # bad arguments
+
+
+def test_plan_disk_cache_round_trip(tmp_path, monkeypatch):
+    """A compiled plan is stored under a hash of the graph tensors, the pdf count and the compiler knobs
+    and read back byte-identical; a changed tensor or knob is a different entry; a damaged file is ignored."""
+    import os
+    from pychain_amd import _plan, synthetic as syn
+    monkeypatch.setenv("PYCHAIN_PLAN_CACHE_DIR", str(tmp_path))
+    den = syn.make_den_graph(300, 2500, 512, seed=5)
+    args = [getattr(den, n) for n in _plan._NAMES]
+    a = _plan.build_plan_blob(*args, 512)
+    files = os.listdir(tmp_path)
+    assert len(files) == 1 and files[0].endswith(".plan")
+    b = _plan.build_plan_blob(*args, 512)
+    assert (a == b).all()
+    c = _plan.build_plan_blob(*args, 512, use_cache=False)
+    assert (a == c).all()
+    # another pdf count, another final vector: new entries
+    _plan.build_plan_blob(*args, 640)
+    den.final_probs.mul_(0.5)
+    _plan.build_plan_blob(*[getattr(den, n) for n in _plan._NAMES], 512)
+    assert len(os.listdir(tmp_path)) == 3
+    # a truncated entry is recompiled, not trusted
+    path = os.path.join(tmp_path, files[0])
+    with open(path, "r+b") as f:
+        f.truncate(100)
+    den.final_probs.mul_(2.0)
+    d = _plan.build_plan_blob(*[getattr(den, n) for n in _plan._NAMES], 512)
+    assert (a == d).all() and os.path.getsize(path) == a.nbytes
+
+
+def test_graph_plan_follows_in_place_edits():
+    """The plan cached on a ChainGraph is rebuilt when one of its tensors is modified in place."""
+    import torch
+    from pychain_amd import _plan, synthetic as syn
+    den = syn.make_den_graph(40, 200, 64, seed=2)
+    p1 = _plan.graph_plan(den, 64, torch.device("cpu"))
+    assert _plan.graph_plan(den, 64, torch.device("cpu")) is p1
+    den.final_probs.fill_(0.25)
+    p2 = _plan.graph_plan(den, 64, torch.device("cpu"))
+    assert p2 is not p1 and not torch.equal(p1.blob, p2.blob)
