@@ -7,8 +7,9 @@
 //
 // OpenFST itself is not part of the reference tree; the on-disk format read here is OpenFST's
 // published binary layout for VectorFst<StdArc> (FstHeader + per-state {final weight, arc count,
-// arcs{ilabel, olabel, weight, nextstate}}).  Parity of the reader is pinned only by round-trip
-// tests (write -> read) - the reference holds no FST files.
+// arcs{ilabel, olabel, weight, nextstate}}).  The reference holds no FST files: the reader is pinned by
+// files assembled byte by byte from that layout (tests/golden/make_fst_bytes.py: plain file, header
+// flags / unknown state count, two FSTs inside a Kaldi ark) and by write -> read round trips.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -61,19 +62,23 @@ extern "C" void* pychain_hip_fst_read(const char* filename, int64_t byte_offset)
       !read_exact(f, &start, 8) || !read_exact(f, &nstates, 8) || !read_exact(f, &narcs, 8))
     return bail("truncated header");
   if (flags & 3) return bail("embedded symbol tables are not supported");
-  if (version < 2 || nstates < 0 || nstates > (int64_t)1 << 31) return bail("unsupported version or size");
+  if (version < 2 || nstates < -1 || nstates > (int64_t)1 << 31) return bail("unsupported version or size");
   fst->start = start;
-  fst->final_.resize((size_t)nstates);
-  fst->arcs.resize((size_t)nstates);
-  for (int64_t s = 0; s < nstates; s++) {
+  // nstates == -1 (kNoStateId): the writer could not seek back to fill the count in; states follow until
+  // the stream ends (VectorFstImpl::Read stops at the first final weight it cannot read)
+  for (int64_t s = 0; nstates < 0 || s < nstates; s++) {
     float fw; int64_t na;
-    if (!read_exact(f, &fw, 4) || !read_exact(f, &na, 8) || na < 0 || na > (int64_t)1 << 31) return bail("truncated state");
-    fst->final_[(size_t)s] = fw;
-    fst->arcs[(size_t)s].resize((size_t)na);
-    if (na && !read_exact(f, fst->arcs[(size_t)s].data(), sizeof(Arc) * (size_t)na)) return bail("truncated arcs");
-    for (const Arc& a : fst->arcs[(size_t)s])
-      if (a.nextstate < 0 || a.nextstate >= nstates) return bail("arc to a state out of range");
+    if (!read_exact(f, &fw, 4)) { if (nstates < 0) break; return bail("truncated state"); }
+    if (!read_exact(f, &na, 8) || na < 0 || na > (int64_t)1 << 31) return bail("truncated state");
+    fst->final_.push_back(fw);
+    fst->arcs.emplace_back((size_t)na);
+    if (na && !read_exact(f, fst->arcs.back().data(), sizeof(Arc) * (size_t)na)) return bail("truncated arcs");
   }
+  const int64_t ns = (int64_t)fst->final_.size();
+  if (start < -1 || start >= ns) return bail("start state out of range");
+  for (const auto& row : fst->arcs)
+    for (const Arc& a : row)
+      if (a.nextstate < 0 || a.nextstate >= ns) return bail("arc to a state out of range");
   fclose(f);
   return fst;
 }

@@ -279,13 +279,21 @@ class StdVectorFst(object):
         if version < 2:
             raise IOError("unsupported vector FST version %d" % version)
         fst = cls()
-        for _ in range(nstates):
-            fw, na = rd("<fq")
+        n = 0
+        while nstates < 0 or n < nstates:          # -1: unknown, states follow until the stream ends
+            b = f.read(4)
+            if len(b) != 4:
+                if nstates < 0:
+                    break
+                raise IOError("truncated FST in " + name)
+            (fw,) = struct.unpack("<f", b)
+            (na,) = rd("<q")
             st = fst.add_state()
             fst._final[st] = fw
             for _a in range(na):
                 il, ol, w, ns = rd("<iifi")
                 fst._arcs[st].append((il, ol, w, ns))
+            n += 1
         fst._start = start
         return fst
 

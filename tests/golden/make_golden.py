@@ -12,13 +12,17 @@ What runs:
   * Python layer: the reference's own pychain/loss.py and pychain/graph.py,
     imported from /root/reference (ChainFunction, ChainLoss, ChainGraphBatch).
 
-What does NOT run: `simplefst` (openfst_binding/, needs OpenFST which this image
-lacks).  pychain/graph.py imports it at module scope, so an EMPTY placeholder
-module is registered purely to let that import succeed; `ChainGraph.__init__`
-(the only user of simplefst) is never called - reference ChainGraph objects are
-created with `__new__` and populated with the tensors of this repo's
-fst_to_tensor restatement.  The FST->tensor layout is therefore NOT pinned by
-these fixtures (DESIGN.md says so); everything downstream of the tensors is.
+What does NOT run: the reference's `simplefst` (openfst_binding/, needs OpenFST which
+this image lacks).  pychain/graph.py imports it at module scope, so a placeholder
+module is registered to let that import succeed.  For G1-G5 / A5 reference ChainGraph
+objects are created with `__new__` and populated with the tensors of this repo's
+fst_to_tensor restatement.  For A4 (`gen_chaingraph_init`) the reference's REAL
+`ChainGraph.__init__` (pychain/graph.py:25-70) is executed for every
+(initial_mode, final_mode, log_domain) combination, with the placeholder's
+`StdVectorFst` pointing at this repo's restatement for the three calls it makes
+(fst_to_tensor, start_state, set_leaky_probs - SURVEY.md Appendix A.3): the mode
+handling of the constructor is pinned by the reference, the FST->tensor layout is not
+(it needs OpenFST; DESIGN.md says so).
 
 Fixtures are data only: inputs + the reference's outputs (.npz).
 """
@@ -274,7 +278,44 @@ def gen_containers():
     save("a5_containers", **out)
 
 
+# ---------------------------------------------------------------- A4: the reference's ChainGraph.__init__
+def gen_chaingraph_init():
+    # start state 2 (not 0), three final states with different weights, a state without out-arcs
+    arcs = [(0, 1, 3, -0.4), (0, 0, 1, -1.1), (1, 3, 0, -0.7), (2, 0, 2, -0.2), (2, 1, 4, -1.6), (3, 3, 5, -0.9),
+            (3, 4, 6, -0.5), (1, 4, 2, -1.2)]
+    fst = StdVectorFst.from_arcs(5, 2, arcs, {4: -0.3, 3: -1.5, 1: 0.0})
+    sys.modules["simplefst"].StdVectorFst = StdVectorFst        # what the reference constructor calls into
+    out = {"arcs": np.array(arcs, dtype=np.float64), "num_states": np.int64(5), "start": np.int64(2),
+           "final_states": np.array([4, 3, 1]), "final_weights": np.array([-0.3, -1.5, 0.0])}
+    try:
+        for log_domain in (False, True):
+            for initial_mode in ("fst", "leaky"):
+                for final_mode in ("fst", "ones"):
+                    tag = "%s_%s_%d__" % (initial_mode, final_mode, int(log_domain))
+                    try:
+                        g = RefChainGraph(fst, initial_mode=initial_mode, final_mode=final_mode, log_domain=log_domain)
+                    except AssertionError as e:
+                        out[tag + "raises"] = np.array(str(e))
+                        continue
+                    out.update(graph_arrays(g, tag))
+                    out[tag + "num_states"] = np.int64(g.num_states)
+                    out[tag + "num_transitions"] = np.int64(g.num_transitions)
+                    out[tag + "is_empty"] = np.bool_(g.is_empty)
+                    out[tag + "leaky_is_none"] = np.bool_(g.leaky_probs is None)
+        try:
+            RefChainGraph(StdVectorFst.from_arcs(2, 0, [], {1: 0.0}))
+            out["empty_raises"] = np.array("")
+        except Exception as e:          # graph.py:70
+            out["empty_raises"] = np.array(str(e))
+    finally:
+        del sys.modules["simplefst"].StdVectorFst
+    save("a4_chaingraph_init", **out)
+
+
 if __name__ == "__main__":
+    gen_chaingraph_init()
+    if "--only-a4" in sys.argv:
+        sys.exit(0)
     gen_c1()
     gen_variants()
     gen_medium()
