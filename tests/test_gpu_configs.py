@@ -1,0 +1,107 @@
+"""BASELINE.json configs the parity suite did not reach at full size: C4 (B=32, T=2000, 8408 pdfs - the
+"HBM-roofline" configuration: 4 time segments, gate kernels, the wide-row recursion and the one-frame
+occupancy kernel at scale), the training example run end to end, half-precision network outputs
+against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from helpers import rel_err
+from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c4_full_size_properties():
+    """C4 at full size through size-independent properties (the oracle would need minutes): every live
+    frame's occupancies sum to one, ok, bit-reproducible run to run, and the same gradient with and
+    without the overlapped schedule."""
+    from pychain_amd import _lib
+    w = syn.make_workload("C4", device=DEV)
+    B, T = w["cfg"]["B"], w["cfg"]["T"]
+    gb = ChainGraphBatch(w["den_graph"], B)
+    grads, objfs = [], []
+    for rep in range(2):
+        xx = w["x"].clone().requires_grad_(True)
+        o = ChainFunction.apply(xx, w["lengths"], gb, 1e-5)
+        o.backward()
+        assert int(ChainFunction.last_bad_count.sum()) == 0
+        grads.append(xx.grad)
+        objfs.append(float(o.detach()))
+    assert torch.equal(grads[0], grads[1]) and objfs[0] == objfs[1] and np.isfinite(objfs[0])
+    rows = grads[0].sum(-1)
+    assert torch.allclose(rows, torch.ones_like(rows), atol=3e-4)
+    assert float(grads[0].min()) >= 0.0
+    del grads[1]
+    with _lib.option("den_segments", 1):
+        xx = w["x"].clone().requires_grad_(True)
+        ChainFunction.apply(xx, w["lengths"], gb, 1e-5).backward()
+    assert torch.equal(xx.grad, grads[0])
+
+
+def test_c4_full_length_slice_vs_oracle():
+    """B = 3 at C4's full T = 2000 and D = 8408 (one sequence shorter): four time segments, the gated
+    schedule, the recursion form for rows wider than 16 KiB and the one-frame occupancy kernel, against
+    the fp32 restatement of the reference."""
+    cfg = syn.CONFIGS["C4"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([2000, 2000, 1377])
+    x = syn.make_input(3, 2000, cfg["D"], seed=77)
+    xx = x.to(DEV).requires_grad_(True)
+    o = ChainFunction.apply(xx, L, ChainGraphBatch(den, 3), 1e-5)
+    o.backward()
+    assert int(ChainFunction.last_bad_count.sum()) == 0
+    ro, rg = orc.chain_function(x, L, ChainGraphBatch(den, 3), 1e-5)
+    assert abs(float(o.detach()) - ro) <= 1e-4 * abs(ro)
+    assert rel_err(xx.grad.cpu().numpy(), rg) <= 1e-4
+    assert bool((xx.grad[2, 1377:] == 0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_precision_network_output_vs_oracle(dtype):
+    """fp16 / bf16 nnet_output (an autocast training loop): the HIP path evaluates the ROUNDED values in
+    fp32 - so does the oracle here, fed the same rounded values - and returns the gradient in the
+    input's dtype: agreement to the rounding of that dtype, loss to 1e-4."""
+    w = syn.make_workload("C1")
+    xh = w["x"].to(dtype)                                           # the rounding happens here, once
+    xx = xh.to(DEV).requires_grad_(True)
+    loss = ChainLoss(w["den_graph"], 1e-5)(xx, w["lengths"], w["num_graphs"])
+    loss.backward()
+    assert xx.grad.dtype == dtype and int(ChainFunction.last_bad_count.sum()) == 0
+    ref_l, ref_g = orc.chain_loss(xh.float(), w["lengths"], w["den_graph"], w["num_graphs"], 1e-5, avg=True)
+    assert abs(float(loss.detach()) - float(ref_l)) <= 1e-4 * abs(float(ref_l))
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11      # half an ulp of the returned dtype, relative
+    assert rel_err(xx.grad.float().cpu().numpy(), ref_g) <= eps + 1e-4
+
+
+def test_training_example_runs_and_the_loss_falls():
+    """examples/train_tdnn.py (pychain_example-style loop: TDNN -> ChainLoss -> AdamW through the
+    `pychain` alias package) for 8 steps on one GPU; the script asserts that the loss went down."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "examples", "train_tdnn.py"), "--steps", "8",
+                        "--batch", "8", "--frames", "120"], capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "loss" in r.stdout and "-> " in r.stdout
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU box)")
+def test_training_example_two_ranks_over_rccl():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(REPO, "examples", "train_tdnn.py"), "--steps", "8", "--batch", "8",
+                        "--frames", "120"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "on 2 GPU(s)" in r.stdout

@@ -1,4 +1,5 @@
-"""Diagnostic: error of the HIP path and of the f32 oracle against the f64 oracle, den and num apart."""
+"""Diagnostic: error of the HIP path and of the f32 oracle against the f64 oracle, den and num apart
+(C3 graph, 4 ragged utterances up to T = 1500; output kept as profiles/r02_parity_c3.txt)."""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [REPO, os.path.join(REPO, "oracle")]
