@@ -85,8 +85,8 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   const size_t Hp = roundup64(H);
   return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ +
          2 * align256(4 * (size_t)B * (T + 1)) /* per-frame scalars of lazy rows */ +
-         2 * align256(4 * (size_t)B * (T + 2)) /* per-frame log-scales (invariant check) */ +
-         align256(4 * (size_t)B * T) /* frame totals to check */ + 256;
+         2 * align256(4 * (size_t)B * (T + 2)) /* per-frame totals of the two recursions */ +
+         align256(4 * (size_t)B * T) /* frame totals to check */ + align256(4 * (size_t)B) /* final dot products */ + 256;
 }
 
 namespace {
@@ -127,11 +127,12 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.progress = (int32_t*)((char*)a.logsum_ws + align256(8 * (size_t)B));
   a.scal_a = (float*)((char*)a.progress + 256);
   a.scal_b = (float*)((char*)a.scal_a + align256(4 * (size_t)B * (T + 1)));
-  a.la = (float*)((char*)a.scal_b + align256(4 * (size_t)B * (T + 1)));
-  a.lb = (float*)((char*)a.la + align256(4 * (size_t)B * (T + 2)));
-  a.gtot = (float*)((char*)a.lb + align256(4 * (size_t)B * (T + 2)));
+  a.tot_a = (float*)((char*)a.scal_b + align256(4 * (size_t)B * (T + 1)));
+  a.tot_b = (float*)((char*)a.tot_a + align256(4 * (size_t)B * (T + 2)));
+  a.gtot = (float*)((char*)a.tot_b + align256(4 * (size_t)B * (T + 2)));
+  a.fin_dot = (float*)((char*)a.gtot + align256(4 * (size_t)B * T));
   a.lazy = 0;
-  a.check_objf = nullptr; a.check_all = g_verbose_level >= 1 ? 1 : 0;
+  a.check = 0; a.check_all = g_verbose_level >= 1 ? 1 : 0;
   a.sig_n = 0;
   a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_seg = 0; a.gam_nseg = 0;
   return PYCHAIN_HIP_OK;
@@ -208,10 +209,8 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   const int nseg = (occupancy && user_mask == 3 && !a.check_all) ? den_segments(a.T) : 1;
   // the lazy-normalisation recursion runs a whole sequence in one launch: not with the relaunch schedule
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
-  // invariant check of the occupancy launches (DenArgs::la): needs this call's objf and log-scales; on every
-  // frame (verbose level >= 1) it also needs the recursions finished before any occupancy launch
-  const bool relaunch = option("den_relaunch") != nullptr;
-  a.check_objf = (occupancy && user_mask == 3 && !(relaunch && nseg > 1)) ? a.objf : nullptr;
+  // the invariant check (DenArgs::tot_a) needs the recursions and the occupancy launches of ONE call
+  a.check = (occupancy && user_mask == 3) ? 1 : 0;
   hipError_t e = hipSuccess;
   if (nseg <= 1) {
     const int mask = occupancy ? user_mask : (user_mask & 1);
@@ -295,11 +294,12 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   a.phase_mask = user_mask; a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_nseg = 0;
   return e;
 }
-// ... and, behind all of them on the caller's stream, the reference's invariant check (DenArgs::la)
+// ... and, behind all of them on the caller's stream, den_finish_kernel: objf from the per-frame totals and
+// the reference's invariant check (DenArgs::tot_a)
 hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
                    hipEvent_t gamma_wait = nullptr) {
   hipError_t e = run_den_launches(a, resident_slot_rows, occupancy, st, why, gamma_wait);
-  if (e == hipSuccess) e = launch_den_check(a, st);
+  if (e == hipSuccess && (a.phase_mask & 1)) e = launch_den_finish(a, st);       // objf (+ the check) from the stored totals
   return e;
 }
 }  // namespace

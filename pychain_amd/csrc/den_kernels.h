@@ -23,16 +23,19 @@ struct DenArgs {
   float* scal_a;             // [B,T+1]  tot(t) * coef
   float* scal_b;             // [B,T+1]  coef * sum_i leaky(i) b(t,i)
   int lazy;
-  // The reference's invariant check (BetaGeneralFrameDebug, chain-computation.cc:345-391: alpha'.beta' and the
-  // frame's derivative sum must be 1 within 5 %, at t == 0 always and on every frame when verbose >= 1), restated
-  // for per-frame scales that are free: frame t's un-normalised occupancy total G(t) obeys
-  //     log G(t) + la[t] + lb[t + 2] = log P(sequence)            for every t,
-  // la / lb = the log-scales the two recursions have divided out so far (each kernel stores them in the index
-  // convention of its rows).  The occupancy kernels compare against objf and count violations in `bad`.
-  float* la;                 // [B,T+2]
-  float* lb;                 // [B,T+2]
+  // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
+  // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
+  //     objf = sum_t log tot_a(t) + log fin_dot        (ComputeTotLogLike, chain-computation.cc:209-230)
+  // and runs the reference's invariant check (BetaGeneralFrameDebug, :345-391: alpha'.beta' and the frame's
+  // derivative sum within 5 % of 1, at t == 0 always and on every frame when verbose >= 1), restated for
+  // per-frame scales that are free: frame t's un-normalised occupancy total G(t) obeys
+  //     log G(t) + [log-scale divided out of the alpha row t] + [... of the beta row t+1] = objf     for every t.
+  // No log, no fp64 and no serial sum sits in a recursion's frame loop.
+  float* tot_a;              // [B,T+2]  alpha: tot(t), t = 0 .. L (lazy rows: t < L)
+  float* tot_b;              // [B,T+2]  beta:  n(t),   t = L .. 1
+  float* fin_dot;            // [B]      sum_i alpha'(L,i) final(i) in the scale of the last alpha row (NaN: a NaN network output was seen)
   float* gtot;               // [B,T]  G(t) of the frames to check, written by the occupancy kernels
-  const float* check_objf;   // [B] per-sequence objf of the same call, or null: no check
+  int check;                 // the occupancy launches of this call record G(t) and den_finish_kernel checks
   int check_all;             // 0: frame 0 only; 1: every frame (verbose level >= 1)
   int B, T, D, H, Hp;
   int input_is_exp;
@@ -78,8 +81,9 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
 int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, const int* seg_bound, int seg,
                          int* out, int out_len);
 
-// The check itself (DenArgs::la), after every launch of the call: one thread per (sequence, frame to check).
-hipError_t launch_den_check(const DenArgs& a, hipStream_t st);
+// After the last launch of a call: objf from the stored totals + the invariant check (DenArgs::tot_a).
+// One workgroup per sequence.
+hipError_t launch_den_finish(const DenArgs& a, hipStream_t st);
 
 // One wave that waits until *progress >= target (set by the recursion workgroups), so that what follows
 // it in stream order starts then; gives up after ~20 s and counts that in *bad.

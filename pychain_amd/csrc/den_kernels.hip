@@ -345,19 +345,79 @@ __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_log
 // The reference's `ok` (BetaGeneralFrameDebug, chain-computation.cc:345-391): alpha'.beta' and the frame's
 // derivative sum within 5 % of 1.  With free per-frame scales the same statement reads
 // log G(t) + la[t] + lb[t+2] = log P (DenArgs::la); true = violated (also for NaN).
-// The occupancy kernels only record G(t) (the recursions may still be running, and with them objf and the
-// log-scales of other frames, when an overlapped occupancy launch evaluates frame 0 of a short sequence);
-// den_check_kernel compares after the last launch of the call.
+// The occupancy kernels only record G(t) (the recursions may still be running when an overlapped occupancy
+// launch evaluates frame 0 of a short sequence); den_finish_kernel compares after the last launch of the call.
 __device__ __forceinline__ void den_record_frame_total(const DenArgs& a, int b, int t, float frame_total) {
   a.gtot[(size_t)b * a.T + t] = frame_total;
 }
-__global__ void den_check_kernel(const DenArgs a) {
-  const int b = blockIdx.y;
-  const int t = a.check_all ? blockIdx.x * blockDim.x + threadIdx.x : 0;
+
+// objf and the invariant check from the stored per-frame totals (DenArgs::tot_a).  One workgroup per sequence.
+//   rows of den_recursion_lazy_kernel: alpha row t carries prod_{tau<t} tot(tau); the beta row frame t's occupancy
+//       reads, b(t+1,.) + c(t+1), carries prod_{tau>=t+2} n(tau); objf = sum_{t<L} log tot(t) + log fin_dot
+//   rows of den_recursion_kernel (normalised): alpha'(t)/tot(t) carries prod_{tau<=t} tot(tau); beta(t+1) carries
+//       prod_{tau>=t+1} n(tau); objf = sum_{t<=L} log tot(t) + log fin_dot
+constexpr int kFinNT = 256;
+__global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
+  __shared__ double sh[kFinNT];
+  __shared__ double sh_total_a, sh_total_b;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int L = seq_len(a.lengths, b, a.T);
-  if (t >= L || (!a.check_all && threadIdx.x != 0)) return;
-  const float est = fast_log(a.gtot[(size_t)b * a.T + t]) + a.la[(size_t)b * (a.T + 2) + t] + a.lb[(size_t)b * (a.T + 2) + t + 2];
-  if (!(fabsf(est - a.check_objf[b]) <= 0.0487901642f)) atomicAdd(a.bad, 1);     // log(1.05); NaN counts
+  const float* ta = a.tot_a + (size_t)b * (a.T + 2);
+  const float* tb = a.tot_b + (size_t)b * (a.T + 2);
+  const int na = a.lazy ? L : L + 1;                       // alpha totals 0 .. na-1 make up the log-probability
+  // (the math library's log: this is off every critical path and feeds a value compared at 1e-4 relative)
+  double sa = 0.0, sb = 0.0;
+  for (int t = tid; t < na; t += kFinNT) sa += log((double)ta[t]);
+  for (int t = tid + 1; t <= L; t += kFinNT) sb += log((double)tb[t]);
+  sh[tid] = sa;
+  __syncthreads();
+  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
+  if (tid == 0) sh_total_a = sh[0];
+  __syncthreads();
+  sh[tid] = sb;
+  __syncthreads();
+  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
+  if (tid == 0) sh_total_b = sh[0];
+  __syncthreads();
+  const double logp = sh_total_a + log((double)a.fin_dot[b]);
+  const float objf = (float)logp;
+  int bad = 0;
+  if (tid == 0) {
+    a.objf[b] = objf;
+    if (!(objf - objf == 0.f)) bad = 1;                    // -inf (the graph cannot end), NaN
+  }
+  if (a.check) {
+    // frame t: PA(t) = log-scale of its alpha row, SB(t) = log-scale of the beta row it reads
+    //   lazy: PA(t) = sum_{tau<t} log tot(tau),  SB(t) = sum_{tau>=t+2} log n(tau)
+    //   else: PA(t) = sum_{tau<=t},              SB(t) = sum_{tau>=t+1}
+    const float* g = a.gtot + (size_t)b * a.T;
+    if (!a.check_all) {
+      if (tid == 0) {
+        const double pa = a.lazy ? 0.0 : log((double)ta[0]);
+        const double sbt = sh_total_b - (a.lazy && L >= 1 ? log((double)tb[1]) : 0.0);   // lazy: tau >= 2; else tau >= 1
+        const double est = log((double)g[0]) + pa + sbt;
+        if (!(fabs(est - logp) <= 0.0487901642)) bad = 1;  // log(1.05); NaN counts
+      }
+    } else {
+      // every frame: thread `tid` walks frames tid*per .. with running sums started from its chunk's prefix
+      const int per = (L + kFinNT - 1) / kFinNT;
+      const int t0 = tid * per, t1 = min(t0 + per, L);
+      double ca = 0.0, cb = 0.0;                            // sum_{tau<t0} log tot(tau), sum_{tau<=t0} log n(tau) (tau >= 1)
+      for (int t = 0; t < t0; t++) ca += log((double)ta[t]);
+      for (int t = 1; t <= t0 && t <= L; t++) cb += log((double)tb[t]);
+      for (int t = t0; t < t1; t++) {
+        const double lt = log((double)ta[t]);
+        // cb = sum_{1<=tau<=t} log n(tau)
+        const double pa = a.lazy ? ca : ca + lt;
+        const double upto = a.lazy ? cb + (t + 1 <= L ? log((double)tb[t + 1]) : 0.0) : cb;   // sum_{tau<=t+1} / sum_{tau<=t}
+        const double est = log((double)g[t]) + pa + (sh_total_b - upto);
+        if (!(fabs(est - logp) <= 0.0487901642)) bad = 1;
+        ca += lt;
+        if (t + 1 <= L) cb += log((double)tb[t + 1]);
+      }
+    }
+  }
+  if (bad) atomicAdd(a.bad, 1);
 }
 
 // block total of per-wave partials: red[16] in LDS (entries >= kNW stay zero)
@@ -416,8 +476,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));   // < 2 GiB: checked at launch
 
-  double logsum = 0.0;                 // sum_t log tot-alpha(t), chain-computation.cc:216-229; beta: sum_t log of its own normaliser
-  float* lsc = (fwd ? a.la : a.lb) + (size_t)b * (a.T + 2);   // log-scales for the invariant check (DenArgs::la)
+  float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2);   // per-frame totals for den_finish_kernel (DenArgs::tot_a)
   int bad = (fwd && a.seg_begin == 0 && seq_len_bad(a.lengths, b, a.T)) ? 1 : 0;
   float tot, wtot;
   XRow<kNT, VEC, XCH> xq;
@@ -434,6 +493,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     {
       const int t0 = fwd ? 0 : L - 1;                 // first nnet-output row this side consumes
       xq.load(xseq + (size_t)t0 * D, D, tid);
+      if (fwd && xq.has_nan()) bad = 2;                // a NaN network output: not ok, NaN log-probability
       xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
     }
     __syncthreads();                                   // red zeroed
@@ -442,8 +502,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     tot = block_total(red, lane); wtot = block_total(red + 16, lane);
     const float inv = __builtin_amdgcn_rcpf(tot);
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
-    logsum += (double)fast_log(tot);
-    if (tid == 0) { if (fwd) lsc[0] = (float)logsum; else lsc[L + 1] = (float)logsum; }
+    if (tid == 0) totv[fwd ? 0 : L] = tot;
     normalise_row(fwd, raw, lk, cur, sbuf, (fwd ? 0 : L) * Hp * 4, inv, coef, coef * wtot, H, Hp, tid);
   } else {
     // ---- resume a later time segment: the state vector is the row the previous segment stored last
@@ -455,7 +514,6 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     const int t0 = fwd ? j_begin : L - 1 - j_begin;
     xq.load(xseq + (size_t)t0 * D, D, tid);
     xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);   // j_begin is even: buffer 0
-    if (fwd) logsum = a.logsum_ws[b];
   }
   __syncthreads();
 
@@ -492,7 +550,10 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
       tile_rows<R, 0, VOFF>(arcs, groups, tail_slots, lane, cur, xr + (VOFF) / 4, raw, nullptr, fwd ? nullptr : lk, s0, s1); \
     else { s0 = 1.f; s1 = 1.f; }                                                                            \
     /* double-buffered: the other buffer was last read in the previous step, which every wave has left */   \
-    if (DB && kWithX && have_next) xq.store(xr + (kXOff - (VOFF)) / 4, xrow_next, D, tid, a.input_is_exp);  \
+    if (DB && kWithX && have_next) {                                                                        \
+      if (fwd && xq.has_nan()) bad = 2;                                                                     \
+      xq.store(xr + (kXOff - (VOFF)) / 4, xrow_next, D, tid, a.input_is_exp);                               \
+    }                                                                                                       \
     if (kArcsOnly) { if (s0 == 12345.f) raw[tid] = s0; if (kArcsOnly == 2) __syncthreads(); break; }        \
     PH_ADD(0, pt); pt = PH_T();                                                                             \
     s0 = wave_sum(s0);                                                                                      \
@@ -505,14 +566,16 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     wtot = fwd ? 0.f : block_total(red + 16, lane);                                                         \
     const float inv = __builtin_amdgcn_rcpf(tot);                                                           \
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;                                                              \
-    logsum += (double)fast_log(tot);                 /* alpha: the log-probability; both: the scale divided out so far */ \
     const int tstore = fwd ? j + 1 : L - 1 - j;                                                             \
-    if (tid == 0) lsc[fwd ? tstore : tstore + 1] = (float)logsum;                                           \
+    if (tid == 0) totv[tstore] = tot;                /* the scale divided out of this frame (den_finish_kernel) */ \
     const bool do_store = fwd ? (tstore < L) : true;                                                        \
     if (kWithNorm)                                                                                          \
       normalise_row(fwd, raw, lk, cur, sbuf, do_store ? tstore * Hp * 4 : -1, inv, coef, coef * wtot, H, Hp, tid, true, cl0); \
     PH_ADD(3, pt); pt = PH_T();                                                                             \
-    if (!DB && kWithX && have_next) xq.store(xr, xrow_next, D, tid, a.input_is_exp);                        \
+    if (!DB && kWithX && have_next) {                                                                       \
+      if (fwd && xq.has_nan()) bad = 2;                                                                     \
+      xq.store(xr, xrow_next, D, tid, a.input_is_exp);                                                      \
+    }                                                                                                       \
     PH_ADD(4, pt); pt = PH_T();                                                                             \
     __syncthreads();                                                                                        \
     PH_ADD(5, pt);                                                                                          \
@@ -571,21 +634,21 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
            ph[3] / max(1, j_end - j_begin), ph[4] / max(1, j_end - j_begin), ph[5] / max(1, j_end - j_begin));
 #endif
 
-  if (j_end < nsteps) {                              // more segments follow: park the running log-sum
-    if (fwd && tid == 0) a.logsum_ws[b] = logsum;
-  } else if (fwd) {
+  if (j_end >= nsteps && fwd) {
     // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i alpha'(L,i) final(i) + sum_t log tot(t)
     const float* fin = reinterpret_cast<const float*>(plan + hd->off_final_a);
     float f = 0.f;
     for (int i = tid; i < Hp; i += kNT) f += cur[i] * fin[i];
     f = wave_sum(f);
     if (lane == 0) red[wave] = f;
+    if (tid == 0) red[16] = 0.f;
+    __syncthreads();
+    if (bad == 2) red[16] = 1.f;                       // somebody staged a NaN network output
     __syncthreads();
     const float fs = block_total(red, lane);
     if (tid == 0) {
-      const float objf = (float)(logsum + (double)fast_log(fs));
-      a.objf[b] = objf;
-      if (!(fs > 0.f) || !(objf - objf == 0.f)) bad = 1;
+      a.fin_dot[b] = red[16] != 0.f ? __builtin_nanf("") : fs;       // den_finish_kernel: objf = sum_t log tot(t) + log of this
+      if (!(fs > 0.f)) bad = 1;
     }
   }
   if (bad && lane == 0) atomicAdd(a.bad, 1);
@@ -822,7 +885,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     const float tot = block_total(red, lane);
     const float sc = gscale / tot;
     if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
-    if (a.check_objf && (t == 0 || a.check_all) && tid == 0) den_record_frame_total(a, b, t, tot);
+    if (a.check && (t == 0 || a.check_all) && tid == 0) den_record_frame_total(a, b, t, tot);
     if constexpr (XCH > 0) {
 #pragma unroll
       for (int c = 0; c < XCH; c++) {
@@ -1218,7 +1281,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     const float sc0 = gscale / tot0, sc1 = gscale / tot1;
     if (valid0 && (!(tot0 > 0.f) || !(sc0 - sc0 == 0.f))) bad = 1;
     if (valid1 && (!(tot1 > 0.f) || !(sc1 - sc1 == 0.f))) bad = 1;
-    if (a.check_objf && tid == 0) {
+    if (a.check && tid == 0) {
       if (valid0 && (t0 == 0 || a.check_all)) den_record_frame_total(a, b, t0, tot0);
       if (valid1 && a.check_all) den_record_frame_total(a, b, t0 + 1, tot1);
     }
@@ -1370,9 +1433,8 @@ int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, co
   return LaunchFrames(a).has(t, L) && t < L ? 1 : 0;
 }
 
-hipError_t launch_den_check(const DenArgs& a, hipStream_t st) {
-  if (!a.check_objf) return hipSuccess;
-  hipLaunchKernelGGL(den_check_kernel, dim3(a.check_all ? (a.T + 255) / 256 : 1, a.B), dim3(a.check_all ? 256 : 64), 0, st, a);
+hipError_t launch_den_finish(const DenArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(den_finish_kernel, dim3(a.B), dim3(kFinNT), 0, st, a);
   return hipGetLastError();
 }
 

@@ -173,7 +173,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const float* xseq = a.x + (size_t)b * a.T * D;
   float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
   float* scal = (fwd ? a.scal_a : a.scal_b) + (size_t)b * (a.T + 1);
-  float* lsc = (fwd ? a.la : a.lb) + (size_t)b * (a.T + 2);       // log-scales for the invariant check (DenArgs::la)
+  float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2);  // per-frame totals for den_finish_kernel (DenArgs::tot_a)
   const float coef = a.coef;
   const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));
@@ -188,7 +188,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   if (groups.ngroups > kLzMaxGroups || groups.nslots > R) bad = 1;   // the host checks the plan before choosing this kernel
 
   // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
-  double logsum = 0.0;
   XRow<kNT, 4, 1> xq;
   {
     float p0 = 0.f, p1 = 0.f;
@@ -202,6 +201,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     }
     const int t0 = fwd ? 0 : L - 1;
     xq.load(xseq + (size_t)t0 * D, D, tid);
+    if (fwd && xq.has_nan()) bad = 2;
     xq.store(X0, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     if (lane == 0) { red[wave] = p0; red[64 + wave] = p1; }
@@ -211,13 +211,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     w.inv = __builtin_amdgcn_rcpf(tot);
     w.c = coef * wtot;
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;
-    // log-scales divided out so far: alpha row t carries sum_{tau<t} log tot(tau) (la[t]); the beta row
-    // that frame t's occupancy reads, b(t+1,.) + c(t+1), carries sum_{tau>=t+2} log n(tau) (lb[t+2])
-    if (tid == 0) {
-      if (fwd) lsc[0] = 0.f;
-      else { lsc[L + 1] = 0.f; lsc[L] = fast_log(tot); }
-    }
-    logsum = (double)fast_log(tot);
+    if (tid == 0) totv[fwd ? 0 : L] = tot;
     // the start row and its scalar (alpha row 0 / beta row L)
     const int t_start = fwd ? 0 : L;
     // (device-scope write-through like every row: an occupancy launch may read them on another XCD while
@@ -269,7 +263,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       }                                                                                                     \
     }                                                                                                       \
     /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
-    if (have_next) xq.store(X0 + ((PAR) ? 0 : 4096), xseq, D, tq, a.input_is_exp);                          \
+    if (have_next) {                                                                                        \
+      if ((FWDC) && xq.has_nan()) bad = 2;                   /* a NaN network output: not ok, NaN log-probability */ \
+      xq.store(X0 + ((PAR) ? 0 : 4096), xseq, D, tq, a.input_is_exp);                                       \
+    }                                                                                                       \
     /* the row leaves for HBM (issued after the wait for the nnet-output row: a wait that covered these */  \
     /* stores would last a round trip to HBM) */                                                            \
     const int tstore = (FWDC) ? j + 1 : L - 1 - j;                                                          \
@@ -297,11 +294,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     float sc;                                                                                               \
     if (FWDC) sc = tot * coef;                                                                              \
     else { w.c = coef * wave_sum(red[(PAR) * 128 + 64 + lq]); sc = w.c; }                                   \
-    if (wave == 0) {                                         /* (wave 0 keeps the running log-scale) */      \
-      if ((FWDC) && do_store && tq == 0) lsc[tstore] = (float)logsum;         /* before tot(tstore) joins it */ \
-      if (!(FWDC) || tstore < L) logsum += (double)fast_log(tot);                                           \
-      if (!(FWDC) && tq == 0) lsc[tstore] = (float)logsum;                                                  \
-    }                                                                                                       \
+    if (tq == 0) totv[tstore] = tot;                         /* (alpha: tstore == L is written and never read) */ \
     if (do_store && tq == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), cbuf, 0, tstore * 4, kStoreDeviceScope); \
     last_tot = tot;                                                                                         \
   } while (0)
@@ -330,12 +323,14 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();
     if (lane == 0) red[wave] = f;
     if (tid >= 16 && tid < 64) red[tid] = 0.f;
+    if (tid == 0) red[64] = 0.f;
+    __syncthreads();
+    if (bad == 2) red[64] = 1.f;                      // somebody staged a NaN network output
     __syncthreads();
     const float fs = wave_sum(red[lane]);
     if (tid == 0) {
-      const float objf = (float)(logsum + (double)fast_log(fs));
-      a.objf[b] = objf;
-      if (!(fs > 0.f) || !(objf - objf == 0.f)) bad = 1;
+      a.fin_dot[b] = red[64] != 0.f ? __builtin_nanf("") : fs;       // den_finish_kernel: objf = sum_t log tot(t) + log of this
+      if (!(fs > 0.f)) bad = 1;
     }
   }
   if (bad && lane == 0) atomicAdd(a.bad, 1);

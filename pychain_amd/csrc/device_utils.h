@@ -68,13 +68,16 @@ __device__ __forceinline__ float exp_bounded(float c) {
 //   kXIdentity  v                      denominator fed exp'd input (pychain_C.forward_backward contract)
 //   kXClamp     clamp(v,-30,30)        numerator (log domain)
 enum { kXExpClamp = 0, kXIdentity = 1, kXClamp = 2 };
-// NaN stays NaN (torch.clamp / exp propagate it, loss.py:30,43; v_med3_f32 alone would turn it into -30
-// and a diverged network would look healthy): one compare + select per element.
+// (v_med3_f32 turns a NaN into -30: the rows are watched for NaN separately, XRow::has_nan, by the one
+// workgroup per sequence that reports its log-probability - a select per element here costs the recursions
+// 4 % because the row's VALU work sits on their critical path.)
 __device__ __forceinline__ float clamp_exp(float v, int mode) {
   if (mode == kXIdentity) return v;
   const float c = __builtin_amdgcn_fmed3f(v, -30.f, 30.f);
-  const float r = mode == kXClamp ? c : exp_bounded(c);
-  return v != v ? v : r;
+  // numerator rows: NaN stays NaN (it reaches the log-probability only if an arc of the utterance's graph
+  // emits that pdf, as in the reference); their staging is not on a critical path
+  if (mode == kXClamp) return v != v ? v : c;
+  return exp_bounded(c);
 }
 
 // a*b + c*d and a*b + c with every product ROUNDED before the sum (no fma contraction: HIP compiles
@@ -145,6 +148,18 @@ struct XRow {
         }
       }
     }
+  }
+  // true if one of the staged elements is NaN (torch.clamp / exp propagate it to the loss, loss.py:30,43;
+  // the fused clamp would hide it).  One unordered compare per PAIR of elements.
+  __device__ __forceinline__ bool has_nan() const {
+    bool n = false;
+    if constexpr (XCH > 0) {
+      constexpr int N = VEC * XCH;
+#pragma unroll
+      for (int i = 0; i + 1 < N; i += 2) n = n || __builtin_isunordered(v[i], v[i + 1]);
+      if (N & 1) n = n || v[N - 1] != v[N - 1];
+    }
+    return n;
   }
   // `mode` is uniform: one branch per call, not a select per element
   template <int MODE>
