@@ -84,7 +84,6 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   if (B <= 0 || T <= 0 || H <= 0) return 0;
   const size_t Hp = roundup64(H);
   return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ +
-         2 * align256(4 * (size_t)B * (T + 1)) /* per-frame scalars of lazy rows */ +
          2 * align256(4 * (size_t)B * (T + 2)) /* per-frame totals of the two recursions */ +
          align256(4 * (size_t)B * T) /* frame totals to check */ + align256(4 * (size_t)B) /* final dot products */ + 256;
 }
@@ -125,9 +124,7 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
   a.logsum_ws = (double*)(ws + align256(4 * (size_t)B * T * a.Hp) + align256(4 * (size_t)B * (T + 1) * a.Hp));
   a.progress = (int32_t*)((char*)a.logsum_ws + align256(8 * (size_t)B));
-  a.scal_a = (float*)((char*)a.progress + 256);
-  a.scal_b = (float*)((char*)a.scal_a + align256(4 * (size_t)B * (T + 1)));
-  a.tot_a = (float*)((char*)a.scal_b + align256(4 * (size_t)B * (T + 1)));
+  a.tot_a = (float*)((char*)a.progress + 256);
   a.tot_b = (float*)((char*)a.tot_a + align256(4 * (size_t)B * (T + 2)));
   a.gtot = (float*)((char*)a.tot_b + align256(4 * (size_t)B * (T + 2)));
   a.fin_dot = (float*)((char*)a.gtot + align256(4 * (size_t)B * T));

@@ -17,11 +17,9 @@ struct DenArgs {
   int32_t* bad;              // [1]
   float* alpha_store;        // [B,T,Hp]    alpha'(t,.)/tot(t), alpha numbering
   float* beta_store;         // [B,T+1,Hp]  beta(t,.) (unit sum), beta numbering; row 0 unused
-  // Lazy-normalisation recursion (den_lazy.inc.h): the stored rows are un-normalised, a(t,.) and b(t,.), and
-  // the occupancy kernels rebuild alpha'(t,i) = a(t,i) + scal_a[t] * leaky(i) and beta(t,i) = b(t,i) + scal_b[t]
-  // (any per-frame scale of either gives the same posteriors).  lazy = 0: rows are stored normalised.
-  float* scal_a;             // [B,T+1]  tot(t) * coef
-  float* scal_b;             // [B,T+1]  coef * sum_i leaky(i) b(t,i)
+  // 1: the recursions of this call ran as den_recursion_lazy_kernel (den_lazy.inc.h): rows stored as a'(t,.) and
+  // b(t,.) + c(t), each in a per-frame scale of its own; 0: as den_recursion_kernel (rows normalised).  The
+  // occupancy kernels read either form as it is; den_finish_kernel needs to know which scales were divided out.
   int lazy;
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability

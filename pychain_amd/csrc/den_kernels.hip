@@ -773,9 +773,6 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   const float* xseq = a.x + (size_t)b * a.T * D;
   const float* aseq = a.alpha_store + (size_t)b * a.T * Hp;
   const float* bseq = a.beta_store + (size_t)b * (a.T + 1) * Hp;
-  const float* sca = a.scal_a + (size_t)b * (a.T + 1);           // lazy rows only
-  const float* scb = a.scal_b + (size_t)b * (a.T + 1);
-  const float* leaky_a = reinterpret_cast<const float*>(plan + hd->off_leaky_a);
 
   if (tid < 16) red[tid] = 0.f;
   for (int i = tid; i < Dp; i += kNT) q[i] = 0.f;   // pdfs without arcs stay zero forever
@@ -790,11 +787,9 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   float4 ureg[kUV], vreg[kUV];
   const bool uv_in_regs = Hp <= kUV * 4 * kNT;
   // (macros, not lambdas: by-reference captures would put the staging registers on the stack)
-  float lz_sa = 0.f, lz_sb = 0.f;                    // per-frame scalars of lazy rows, requested with the rows
 #define GAMMA_PREFETCH(t)                                                                     \
   do {                                                                                        \
     xq.load(xseq + (size_t)(t) * D, D, tid);                                                  \
-    if (a.lazy) { lz_sa = sca[(t)]; lz_sb = scb[(t) + 1]; }                                   \
     if (uv_in_regs) {                                                                         \
       const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
       const float* br_ = bseq + (size_t)((t) + 1) * Hp;                                       \
@@ -808,33 +803,18 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
 #define GAMMA_COMMIT(t)                                                                       \
   do {                                                                                        \
     xq.store(xr, xseq + (size_t)(t) * D, D, tid, a.input_is_exp);                             \
-    /* lazy rows (den_lazy.inc.h): alpha'(t,i) = a(t,i) + scal_a[t] leaky(i), beta(t+1,i) = b(t+1,i) + scal_b[t+1] */ \
-    const float sa_ = lz_sa, sb_ = lz_sb;                                                     \
     if (uv_in_regs) {                                                                         \
       _Pragma("unroll") for (int c = 0; c < kUV; c++) {                                       \
         const int i = (c * kNT + tid) * 4;                                                    \
-        if (i < Hp) {                                                                         \
-          float4 u_ = ureg[c], v_ = vreg[c];                                                  \
-          if (a.lazy) {                                                                       \
-            const float4 l_ = *reinterpret_cast<const float4*>(leaky_a + i);                  \
-            u_ = make_float4(__builtin_fmaf(sa_, l_.x, u_.x), __builtin_fmaf(sa_, l_.y, u_.y), __builtin_fmaf(sa_, l_.z, u_.z), __builtin_fmaf(sa_, l_.w, u_.w)); \
-            v_ = make_float4(v_.x + sb_, v_.y + sb_, v_.z + sb_, v_.w + sb_);                 \
-          }                                                                                   \
-          *reinterpret_cast<float4*>(U + i) = u_;                                             \
-          *reinterpret_cast<float4*>(V + i) = v_; }                                           \
+        if (i < Hp) { *reinterpret_cast<float4*>(U + i) = ureg[c];                            \
+                      *reinterpret_cast<float4*>(V + i) = vreg[c]; }                          \
       }                                                                                       \
     } else {                                                                                  \
       const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
       const float* br_ = bseq + (size_t)((t) + 1) * Hp;                                       \
       for (int i = tid * 4; i < Hp; i += kNT * 4) {                                           \
-        float4 u_ = *reinterpret_cast<const float4*>(ar_ + i), v_ = *reinterpret_cast<const float4*>(br_ + i); \
-        if (a.lazy) {                                                                         \
-          const float4 l_ = *reinterpret_cast<const float4*>(leaky_a + i);                    \
-          u_ = make_float4(__builtin_fmaf(sa_, l_.x, u_.x), __builtin_fmaf(sa_, l_.y, u_.y), __builtin_fmaf(sa_, l_.z, u_.z), __builtin_fmaf(sa_, l_.w, u_.w)); \
-          v_ = make_float4(v_.x + sb_, v_.y + sb_, v_.z + sb_, v_.w + sb_);                   \
-        }                                                                                     \
-        *reinterpret_cast<float4*>(U + i) = u_;                                               \
-        *reinterpret_cast<float4*>(V + i) = v_;                                               \
+        *reinterpret_cast<float4*>(U + i) = *reinterpret_cast<const float4*>(ar_ + i);        \
+        *reinterpret_cast<float4*>(V + i) = *reinterpret_cast<const float4*>(br_ + i);        \
       }                                                                                       \
     }                                                                                         \
   } while (0)
@@ -1113,9 +1093,6 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   const float* xseq = a.x + (size_t)b * T * D;
   const float* aseq = a.alpha_store + (size_t)b * T * Hp;
   const float* bseq = a.beta_store + (size_t)b * (T + 1) * Hp;
-  const float* sca = a.scal_a + (size_t)b * (T + 1);             // lazy rows only
-  const float* scb = a.scal_b + (size_t)b * (T + 1);
-  const float* leaky_a = reinterpret_cast<const float*>(plan + hd->off_leaky_a);
 
   if (tid < 32) red[tid] = 0.f;
   for (int i = tid; i < 2 * Dp; i += kNT2) q2[i] = 0.f;          // pdfs without arcs stay zero forever
@@ -1152,21 +1129,15 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       }                                                                                          \
     }                                                                                            \
   } while (0)
-  // lazy rows (den_lazy.inc.h): alpha'(t,i) = a(t,i) + scal_a[t] leaky(i), beta(t,i) = b(t,i) + scal_b[t]
 #define GAMMA2_COMMIT()                                                                          \
   do {                                                                                           \
-    const float sa0_ = lz_s[0], sa1_ = lz_s[1], sb0_ = lz_s[2], sb1_ = lz_s[3];                  \
     _Pragma("unroll") for (int c = 0; c < UVC; c++) {                                            \
       const int i = (c * kNT2 + tid) * 4;                                                        \
       if (i < Hp) {                                                                              \
-        float4 l_ = make_float4(0.f, 0.f, 0.f, 0.f);                                             \
-        if (a.lazy) l_ = *reinterpret_cast<const float4*>(leaky_a + i);                          \
-        const float4 p_ = make_float4(__builtin_fmaf(sa0_, l_.x, ua[c].x), __builtin_fmaf(sa0_, l_.y, ua[c].y), __builtin_fmaf(sa0_, l_.z, ua[c].z), __builtin_fmaf(sa0_, l_.w, ua[c].w)); \
-        const float4 q_ = make_float4(__builtin_fmaf(sa1_, l_.x, ub[c].x), __builtin_fmaf(sa1_, l_.y, ub[c].y), __builtin_fmaf(sa1_, l_.z, ub[c].z), __builtin_fmaf(sa1_, l_.w, ub[c].w)); \
-        *reinterpret_cast<float4*>(U2 + 2 * i) = make_float4(p_.x, q_.x, p_.y, q_.y);            \
-        *reinterpret_cast<float4*>(U2 + 2 * i + 4) = make_float4(p_.z, q_.z, p_.w, q_.w);        \
-        *reinterpret_cast<float4*>(V2 + 2 * i) = make_float4(va[c].x + sb0_, vb[c].x + sb1_, va[c].y + sb0_, vb[c].y + sb1_); \
-        *reinterpret_cast<float4*>(V2 + 2 * i + 4) = make_float4(va[c].z + sb0_, vb[c].z + sb1_, va[c].w + sb0_, vb[c].w + sb1_); \
+        *reinterpret_cast<float4*>(U2 + 2 * i) = make_float4(ua[c].x, ub[c].x, ua[c].y, ub[c].y); \
+        *reinterpret_cast<float4*>(U2 + 2 * i + 4) = make_float4(ua[c].z, ub[c].z, ua[c].w, ub[c].w); \
+        *reinterpret_cast<float4*>(V2 + 2 * i) = make_float4(va[c].x, vb[c].x, va[c].y, vb[c].y); \
+        *reinterpret_cast<float4*>(V2 + 2 * i + 4) = make_float4(va[c].z, vb[c].z, va[c].w, vb[c].w); \
       }                                                                                          \
     }                                                                                            \
   } while (0)
@@ -1182,14 +1153,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       }
     }
   };
-  // the four per-frame scalars of a pair's lazy rows, requested with the rows (uniform addresses)
-  float lz_s[4] = {0.f, 0.f, 0.f, 0.f};
-#define GAMMA2_SCALARS(t)                                                                        \
-  do {                                                                                           \
-    if (a.lazy) { lz_s[0] = sca[(t)]; lz_s[1] = sca[min((t) + 1, T - 1)]; lz_s[2] = scb[(t) + 1]; lz_s[3] = scb[min((t) + 2, T)]; } \
-  } while (0)
   GAMMA2_PREFETCH(t0);
-  GAMMA2_SCALARS(t0);
   GAMMA2_COMMIT();
   __syncthreads();
   XRow<kNT2, 4, XCH> x0, x1;
@@ -1222,7 +1186,6 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     // the next pair's state rows are requested inside the arc loop, one load per chunk (a pair that is the
     // last of its block re-reads its own rows: no branch per chunk)
     const int tpre = have_next ? tn : t0;
-    GAMMA2_SCALARS(tpre);
     tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap, [&](int c) {
 #ifndef PYCHAIN_EXPG_NO_LOAD
       constexpr int NC = R / 4 > 0 ? R / 4 : 1;
@@ -1233,7 +1196,6 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     });
 #else
     const int tpre = have_next ? tn : t0;
-    GAMMA2_SCALARS(tpre);
     for (int n = 0; n < 4 * UVC; n++) prefetch_one(n, tpre);
 #endif
     if (R / 4 < 4 * UVC * (R / 4 >= 16 ? 2 : 1))          // arc loop shorter than the list of loads: the rest here

@@ -18,11 +18,13 @@
 //       =>  b(t,i) = ([sum_k w_k b(t+1,dst_k)] + c(t+1) [sum_k w_k]) / n(t+1)
 //     LDS holds float2 {b(t+1,i), 1}: the same arc loop serves both directions.
 //
-// What is streamed to HBM is the un-normalised row (a(t,.) / b(t,.)) plus ONE scalar per frame
-// (tot(t)*coef / c(t)); the occupancy kernels rebuild a'(t,i) = a(t,i) + [tot(t) coef] leaky(i) and
-// b(t,i) + c(t) when they stage the rows (DenArgs::lazy).  A row's values leave the lane that summed them:
-// no read-back from LDS.  The state vector and the nnet-output row are both double-buffered, so a frame
-// writes only buffers nobody reads until the barrier.
+// What is streamed to HBM is a'(t,.) = a(t,.) + tot(t) cl(.) and b(t,.) + c(t): the rows the occupancy pass
+// gathers from, each in a per-frame scale of its own (any scale gives the same posteriors), so the occupancy
+// kernels read them as they are.  tot(t) / c(t) only exist after the frame's barrier: a row goes out ONE FRAME
+// LATE, at the end of the next frame, from the state buffer that frame gathered from (one ds_read_b64 per
+// group gives {a, cl} / {b, 1}); the last beta row is flushed after the loop.  The per-frame totals are stored
+// for den_finish_kernel (log-probability, invariant check).  The state vector and the nnet-output row are both
+// double-buffered, so a frame writes only buffers nobody reads until the barrier.
 //
 // LDS map (absolute byte addresses; the dynamic segment starts at 0, checked):
 //   [0, 32K)      state buffer 0: float2[<= 4096]       [32K, 64K)  state buffer 1
@@ -71,6 +73,7 @@ struct LazyArcs {
 // what a wave carries from frame to frame besides its arcs
 struct LazyWave {
   float inv, c;                 // 1 / total of the previous frame; beta: coef * leaky-weighted sum of the previous frame
+  float sprev;                  // the scalar that completes the row in the gather buffer: alpha tot(t), beta c(t)
 };
 
 // A group end inside the arc loop does the least it can: the row's new value into the state buffer the
@@ -172,12 +175,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const float* start_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_init_a : hd->off_final_b));
   const float* xseq = a.x + (size_t)b * a.T * D;
   float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
-  float* scal = (fwd ? a.scal_a : a.scal_b) + (size_t)b * (a.T + 1);
   float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2);  // per-frame totals for den_finish_kernel (DenArgs::tot_a)
   const float coef = a.coef;
   const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));
-  const XBuf cbuf = make_xbuf(scal, (size_t)(a.T + 1) * sizeof(float));
 
   LazyWave w;
   // group g of this wave: rows base_g .. base_g + 63 (lane l owns row base_g + l)
@@ -211,15 +212,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     w.inv = __builtin_amdgcn_rcpf(tot);
     w.c = coef * wtot;
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;
+    w.sprev = fwd ? tot : w.c;                         // the start row (alpha row 0 / beta row L) goes out at the end of frame 0
     if (tid == 0) totv[fwd ? 0 : L] = tot;
-    // the start row and its scalar (alpha row 0 / beta row L)
-    const int t_start = fwd ? 0 : L;
-    // (device-scope write-through like every row: an occupancy launch may read them on another XCD while
-    // this kernel is still running)
-    for (int i = tid; i < Hp; i += kNT)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(start_g[i]), sbuf, i * 4, t_start * Hp * 4, kStoreDeviceScope);
-    if (tid == 0)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fwd ? tot * coef : w.c), cbuf, 0, t_start * 4, kStoreDeviceScope);
     __syncthreads();                                                 // red is rewritten by the first frame
   }
 
@@ -249,15 +243,18 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
     if (have_next) xq.load_row(xbuf, tn, D, tq);             /* in flight during the arc work */             \
     lazy_tile<R, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq);                                           \
-    /* this frame's values of the lane's rows back from LDS (and, beta, their leaky probs): in flight during */ \
-    /* the exp of the nnet-output row below */                                                              \
+    /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
+    /* lane's rows (and, beta, their leaky probs) for the totals, and the rows of the PREVIOUS frame - the  */ \
+    /* buffer this frame gathered from - which leave for HBM now that their scalar is known */              \
     float val[kLzMaxGroups], lkv[kLzMaxGroups];                                                             \
+    lz_v2f prow[kLzMaxGroups];                                                                              \
     {                                                                                                       \
       const int lane8 = lq * 8;                                                                             \
       _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++) {                                            \
-        val[g] = 0.f; lkv[g] = 0.f;                                                                         \
+        val[g] = 0.f; lkv[g] = 0.f; prow[g] = lz_v2f{0.f, 0.f};                                             \
         if (g < groups.ngroups) {                                                                           \
           val[g] = lds_abs(UNEXT + gbase[g] * 8 + lane8);                                                   \
+          prow[g] = lz_ld2(UOFF + gbase[g] * 8 + lane8);                                                    \
           if (!(FWDC)) lkv[g] = lds_abs(kLzLk + gbase[g] * 4 + (lane8 >> 1));                               \
         }                                                                                                   \
       }                                                                                                     \
@@ -267,20 +264,21 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       if ((FWDC) && xq.has_nan()) bad = 2;                   /* a NaN network output: not ok, NaN log-probability */ \
       xq.store(X0 + ((PAR) ? 0 : 4096), xseq, D, tq, a.input_is_exp);                                       \
     }                                                                                                       \
-    /* the row leaves for HBM (issued after the wait for the nnet-output row: a wait that covered these */  \
-    /* stores would last a round trip to HBM) */                                                            \
-    const int tstore = (FWDC) ? j + 1 : L - 1 - j;                                                          \
-    const bool do_store = (FWDC) ? (tstore < L) : true;                                                     \
-    float s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                       \
-    float s1 = 0.f;                                                                                         \
-    if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
-    if (do_store) {                                                                                         \
-      const int row_off = __builtin_amdgcn_readfirstlane(tstore * Hp * 4);                                  \
+    /* (stores issued after the wait for the nnet-output row: a wait that covered them would last a round */ \
+    /* trip to HBM).  Row of the previous frame: alpha row j, beta row L - j */                             \
+    {                                                                                                       \
+      const int trow = (FWDC) ? j : L - j;                                                                  \
+      const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
       const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
       _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++)                                              \
         if (g < groups.ngroups)                                                                             \
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val[g]), sbuf, lane4, row_off + gbase[g] * 4, kStoreDeviceScope); \
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow[g].y, prow[g].x)), sbuf, lane4, \
+                                                row_off + gbase[g] * 4, kStoreDeviceScope);                 \
     }                                                                                                       \
+    const int tstore = (FWDC) ? j + 1 : L - 1 - j;           /* the row this frame produced */               \
+    float s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                       \
+    float s1 = 0.f;                                                                                         \
+    if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
     /* totals: four row sums per wave before the barrier, the rest of the reduction after it */             \
     {                                                                                                       \
       const float r0 = dpp_row_sum(s0);                                                                     \
@@ -291,11 +289,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const float tot = wave_sum(red[(PAR) * 128 + lq]);                                                      \
     w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;                                                            \
-    float sc;                                                                                               \
-    if (FWDC) sc = tot * coef;                                                                              \
-    else { w.c = coef * wave_sum(red[(PAR) * 128 + 64 + lq]); sc = w.c; }                                   \
+    if (FWDC) w.sprev = tot;                                                                                \
+    else { w.c = coef * wave_sum(red[(PAR) * 128 + 64 + lq]); w.sprev = w.c; }                              \
     if (tq == 0) totv[tstore] = tot;                         /* (alpha: tstore == L is written and never read) */ \
-    if (do_store && tq == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), cbuf, 0, tstore * 4, kStoreDeviceScope); \
     last_tot = tot;                                                                                         \
   } while (0)
 
@@ -303,7 +299,18 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   for (int jj = 0; jj < nsteps; jj += 2) {
     PYCHAIN_LZ_STEP(jj, 0, fwd);
     if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
-    PYCHAIN_LZ_SIGNAL(jj + 2);
+    PYCHAIN_LZ_SIGNAL(jj + 1);                                // (rows lag one step: after jj + 2 steps the rows of steps < jj + 1 are out)
+  }
+  if constexpr (!fwd) {
+    // the last beta row (row L - nsteps: row 1, or the start row if the sequence has one frame) never saw a next frame
+    const float* UL = U0 + ((nsteps & 1) ? kLzU1 / 4 : 0);
+    const int row_off = (L - nsteps) * Hp * 4;
+    for (int g = 0; g < kLzMaxGroups; g++)
+      if (g < groups.ngroups) {
+        const lz_v2f u = *reinterpret_cast<const lz_v2f*>(UL + 2 * (gbase[g] + lane));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, u.y, u.x)), sbuf, lane * 4,
+                                              row_off + gbase[g] * 4, kStoreDeviceScope);
+      }
   }
   PYCHAIN_LZ_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // a sequence shorter than a bound is done with it now
 #undef PYCHAIN_LZ_SIGNAL

@@ -74,10 +74,7 @@ enum { kXExpClamp = 0, kXIdentity = 1, kXClamp = 2 };
 __device__ __forceinline__ float clamp_exp(float v, int mode) {
   if (mode == kXIdentity) return v;
   const float c = __builtin_amdgcn_fmed3f(v, -30.f, 30.f);
-  // numerator rows: NaN stays NaN (it reaches the log-probability only if an arc of the utterance's graph
-  // emits that pdf, as in the reference); their staging is not on a critical path
-  if (mode == kXClamp) return v != v ? v : c;
-  return exp_bounded(c);
+  return mode == kXClamp ? c : exp_bounded(c);
 }
 
 // a*b + c*d and a*b + c with every product ROUNDED before the sum (no fma contraction: HIP compiles
@@ -183,9 +180,23 @@ struct XRow {
     if constexpr (XCH > 0) {
       if (is_exp == kXExpClamp) store_mode<kXExpClamp>(lds, D, tid);
       else if (is_exp == kXIdentity) store_mode<kXIdentity>(lds, D, tid);
-      else store_mode<kXClamp>(lds, D, tid);
+      else {
+        store_mode<kXClamp>(lds, D, tid);
+        // numerator rows: a NaN stays a NaN in LDS (it reaches the log-probability only if an arc of the
+        // utterance's graph emits that pdf, as in the reference).  Rare path: the common one pays one compare
+        // per pair of elements, not a select per element.
+        if (has_nan()) {
+#pragma unroll
+          for (int c = 0; c < XCH; c++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) {
+              const int e = (c * NT + tid) * VEC + k;
+              if (e < D && v[c * VEC + k] != v[c * VEC + k]) lds[e] = v[c * VEC + k];
+            }
+        }
+      }
     } else {  // any D: no register staging
-      for (int e = tid; e < D; e += NT) lds[e] = clamp_exp(row[e], is_exp);
+      for (int e = tid; e < D; e += NT) { const float r = row[e]; lds[e] = (is_exp == kXClamp && r != r) ? r : clamp_exp(r, is_exp); }
     }
   }
 };
