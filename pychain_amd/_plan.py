@@ -90,7 +90,7 @@ def plan_info(blob):
 # format version and the compiler knobs, so it is stored under a hash of exactly those
 # ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans; "0" / "off" disables).  Writes are
 # atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.
-_KNOBS = ("PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL")
+_KNOBS = ("PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT")
 
 
 def _cache_dir():

@@ -1325,6 +1325,7 @@ inline int pick_r(const DenArgs& a, int rows, int lds_words) {
   if (rows <= 0 || (PYCHAIN_ARC_PACKED && lds_words * 4 > 65535)) return 0;   // packed 16-bit LDS addresses
   if (rows <= 16) return 16;
   if (rows <= 32) return 32;
+  if (rows <= PLAN_RESIDENT_FIT && kMaxResident > PLAN_RESIDENT_FIT) return PLAN_RESIDENT_FIT;
   return kMaxResident;
 }
 
@@ -1341,6 +1342,7 @@ hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
   const int rows = hint & 1023;
   if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16>, a, grid, kLzBytes, st);
   if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32>, a, grid, kLzBytes, st);
+  if (rows <= PLAN_RESIDENT_FIT) return launch_one(den_recursion_lazy_kernel<PLAN_RESIDENT_FIT>, a, grid, kLzBytes, st);
   return launch_one(den_recursion_lazy_kernel<kMaxResident>, a, grid, kLzBytes, st);
 }
 
@@ -1358,6 +1360,7 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
       case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0, DB>, a, grid, lds_rec, st); break;
       case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16, DB>, a, grid, lds_rec, st); break;
       case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32, DB>, a, grid, lds_rec, st); break;
+      case PLAN_RESIDENT_FIT: e = launch_one(den_recursion_kernel<VEC, XCH, PLAN_RESIDENT_FIT, DB>, a, grid, lds_rec, st); break;
       default: e = launch_one(den_recursion_kernel<VEC, XCH, kMaxResident, DB>, a, grid, lds_rec, st); break;
     }
     if (e != hipSuccess) return e;

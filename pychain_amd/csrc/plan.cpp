@@ -374,6 +374,41 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, int 
   return o;
 }
 
+// Spare slot-rows per group such that no wave exceeds `target` rows: start from the uniform slack that fills
+// the budget, take a row back from the fullest wave's most padded group while a wave is over, then hand rows
+// out again (smallest groups first) where they still fit.  Groups of fewer than 4 rows get none (as with_slack).
+std::vector<int> fit_slack(const std::vector<int>& base, int nwaves, int target) {
+  const int ng = (int)base.size();
+  long total = 0, elig = 0;
+  for (int g = 0; g < ng; g++) { total += base[g]; if (base[g] >= 4) elig++; }
+  std::vector<int> sl(ng, 0);
+  if (elig == 0) return base;
+  const int k0 = (int)std::max(0L, std::min(4L, ((long)target * nwaves - total) / elig));
+  for (int g = 0; g < ng; g++) if (base[g] >= 4) sl[g] = k0;
+  auto rows = [&]() { std::vector<int> v = base; for (int g = 0; g < ng; g++) v[g] += sl[g]; return v; };
+  for (int iter = 0; iter < 4 * ng; iter++) {
+    const std::vector<int> v = rows();
+    const auto deal = deal_groups(v, nwaves);
+    int wmax = 0, mx = -1;
+    for (int w = 0; w < nwaves; w++) { int n = 0; for (int g : deal[w]) n += v[g]; if (n > mx) { mx = n; wmax = w; } }
+    if (mx <= target) break;
+    int pick = -1;
+    for (int g : deal[wmax]) if (sl[g] > 0 && (pick < 0 || sl[g] > sl[pick] || (sl[g] == sl[pick] && v[g] > v[pick]))) pick = g;
+    if (pick < 0) break;                                   // nothing left to take back: the caller checks the result
+    sl[pick]--;
+  }
+  if (max_wave_rows(rows(), nwaves) > target) return base;
+  std::vector<int> order(ng);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return base[a] + sl[a] < base[b] + sl[b]; });
+  for (int g : order) {
+    if (base[g] < 4 || sl[g] >= 4) continue;
+    sl[g]++;
+    if (max_wave_rows(rows(), nwaves) > target) sl[g]--;
+  }
+  return rows();
+}
+
 std::vector<int> sort_by_degree(const std::vector<int>& deg, const std::vector<int>& ids) {
   std::vector<int> o = ids;
   std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return deg[a] > deg[b]; });
@@ -403,6 +438,19 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
   static const int kResident[3] = {PLAN_RESIDENT_0, PLAN_RESIDENT_1, PLAN_RESIDENT_2};
   const int base = max_wave_rows(t.gsl, nwaves);
   if (base > kResident[2]) return;                                  // the tail is streamed anyway
+  // A loop of PLAN_RESIDENT_FIT rows instead of PLAN_RESIDENT_2 saves a tenth of the arc instructions (every
+  // wave walks all resident rows every frame) if about two spare rows per group still fit: uniform slack does
+  // not land on the wave budget (C3: slack 2 -> 576 rows = 36 x 16, but whole groups deal to 37), a fitted one
+  // does.  MEASURED SLOWER at C3 and therefore off by default (PYCHAIN_PLAN_FIT=36 enables it): 36 rows at 2.44
+  // modelled LDS cycles per half slot-row run 3.64 ms (3.57 with 2.5x the annealing) against 3.52 ms for 40 rows
+  // at 2.15 - the frame follows the LDS cycles (+5 %), not the instruction count (-10 %).
+  const long fit_target = env_long("PYCHAIN_PLAN_FIT", 0);
+  if (fit_target > kResident[1] && fit_target < kResident[2] && base <= fit_target) {
+    std::vector<int> fitted = fit_slack(t.gsl, nwaves, (int)fit_target);
+    long spare = 0, ngr = 0;
+    for (size_t g = 0; g < fitted.size(); g++) if (t.gsl[g] >= 4) { spare += fitted[g] - t.gsl[g]; ngr++; }
+    if (ngr > 0 && 4 * spare >= 7 * ngr) { t.gsl = fitted; return; }   // >= 1.75 spare rows per group on average
+  }
   int chosen = 0;
   for (int ri = 0; ri < 3 && chosen == 0; ri++) {
     if (base > kResident[ri]) continue;

@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 6
+#define PLAN_VERSION 7
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -38,6 +38,7 @@
 #define PLAN_RESIDENT_0 16
 #define PLAN_RESIDENT_1 32
 #define PLAN_RESIDENT_2 40
+#define PLAN_RESIDENT_FIT 36   // between the last two: reached with per-group slack fitted to the wave budget (plan.cpp: fit_slack)
 #define PLAN_GAM2_WAVES 8      // the gamma plan again, scheduled for the two-frame occupancy kernel (8 waves x 256 VGPRs)
 
 struct TilePlan {              // all offsets are bytes from the start of the blob
