@@ -15,8 +15,10 @@ all-reduce of [objf, n_frames, n_bad].
 step is a no-op with a made-up frame count, "value" is meaningless and the line says so).
 
 Rank 0 prints ONE JSON line: the driver contract plus
-  "roofline"     for the dominant kernel (den_recursion_kernel), measured here with HIP
-                 events on the launch stream; algorithmic bytes are stated in DESIGN.md §4;
+  "roofline"     for the dominant kernel (the denominator's alpha/beta recursion launch), measured here with
+                 HIP events on the launch stream; algorithmic bytes are stated in DESIGN.md §4; `traffic` is
+                 the HBM byte count of the SAME launch from the committed rocprofv3 PMC passes
+                 (profiles/r*_hbm_traffic.json, `traffic_source` names the file), not re-measured per run;
   "cpu_baseline" the reference's own CPU path (oracle/_ref, kind "reference") or, when that
                  binary is absent, the C restatement (kind "port"), timed on a bounded
                  sample of the same workload on this box's host cores (N=1 only).
@@ -104,21 +106,27 @@ def kernel_rooflines(w, dev, iters):
     ms_rec, ms_gam = out["den_recursion_kernel"], out["den_gamma_kernel"]
     two_frame = D % 4 == 0 and D <= 4096 and H <= 4032 and not os.environ.get("PYCHAIN_GAMMA16")
     occ_name = "den_gamma2_kernel" if two_frame else "den_gamma_kernel"
-    # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, summary committed
-    # under profiles/): only quoted when it was measured on this very workload
-    traffic = None
-    try:
-        with open(os.path.join(REPO, "profiles", "r01_hbm_traffic.json")) as f:
-            tj = json.load(f)
-        if tj.get("workload") == cfg.get("name") and tj.get("frames") == frames:
-            traffic = tj["den_recursion_kernel"]["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    rec_name = "den_recursion_lazy_kernel" if L.pychain_hip_den_recursion_is_lazy(plan.slot_rows, H, D) else "den_recursion_kernel"
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, summary committed under
+    # profiles/ by tools/profile_round.sh): the newest file measured on this very workload and kernel
+    traffic, traffic_source = None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+            if tj.get("workload") == cfg.get("name") and tj.get("frames") == frames and rec_name in tj:
+                traffic = tj[rec_name]["hbm_bytes_per_launch"]
+                traffic_source = "profiles/" + os.path.basename(path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch; not re-measured in this run)"
+                break
+        except Exception:
+            continue
     roof = {
-        "bound": "hbm", "kernel": "den_recursion_kernel",
+        "bound": "hbm", "kernel": rec_name,
         "achieved": round(bytes_rec / (ms_rec * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(bytes_rec / (ms_rec * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-        "traffic": traffic, "ms_per_launch": round(ms_rec, 4), "algorithmic_bytes_per_launch": bytes_rec,
+        "traffic": traffic, "traffic_source": traffic_source,
+        "ms_per_launch": round(ms_rec, 4), "algorithmic_bytes_per_launch": bytes_rec,
         # the occupancy launch is den_gamma2_kernel (two frames per pass) where the graph fits it
         # (pdf count <= 4096 and a multiple of 4, <= 4032 states), else den_gamma_kernel
         "other_kernels": {occ_name: {"ms_per_launch": round(ms_gam, 4),

@@ -72,6 +72,9 @@ void        pychain_hip_set_den_phase_mask(int mask);
  * pass of their own, two barriers per frame); 1 (default) = as den_recursion_lazy_kernel wherever the
  * shape allows.  Both forms must agree to rounding; the tests compare them. */
 void        pychain_hip_set_den_lazy(int on);
+/* 1 if a denominator call with this plan hint (pychain_hip_den_plan_info: info[4]) and these sizes runs its
+ * recursions as den_recursion_lazy_kernel, 0 if as den_recursion_kernel (measurement tools label by it). */
+int         pychain_hip_den_recursion_is_lazy(int resident_slot_rows, int H, int D);
 /* Test / tuning options (process-wide; nothing on the call path reads the environment).  value NULL or ""
  * clears.  Names: "den_segments" (n time segments of the denominator, 1 = no overlap), "den_bounds"
  * ("0.7,0.85": their ends as fractions of T), "den_relaunch" (one recursion launch per segment instead of

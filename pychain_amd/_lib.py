@@ -24,6 +24,7 @@ _SIGNATURES = {
     "pychain_hip_get_verbose_level": (_i, []),
     "pychain_hip_set_den_phase_mask": (None, [_i]),
     "pychain_hip_set_den_lazy": (None, [_i]),
+    "pychain_hip_den_recursion_is_lazy": (_i, [_i, _i, _i]),
     "pychain_hip_set_option": (_i, [ctypes.c_char_p, ctypes.c_char_p]),
     "pychain_hip_debug_launch_map": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i]),
     "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),

@@ -47,6 +47,12 @@ extern "C" void pychain_hip_set_verbose_level(int level) { g_verbose_level = lev
 extern "C" int pychain_hip_get_verbose_level(void) { return g_verbose_level; }
 extern "C" void pychain_hip_set_den_phase_mask(int mask) { g_den_phase_mask = mask & 3; }
 extern "C" void pychain_hip_set_den_lazy(int on) { g_den_lazy = on ? 1 : 0; }
+extern "C" int pychain_hip_den_recursion_is_lazy(int resident_slot_rows, int H, int D) {
+  DenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H = H; a.Hp = roundup64(H); a.D = D;
+  return (g_den_lazy && !option("den_relaunch") && den_lazy_eligible(a, resident_slot_rows)) ? 1 : 0;
+}
 extern "C" int pychain_hip_set_option(const char* name, const char* value) {
   static const char* const known[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves"};
   if (!name) return fail(PYCHAIN_HIP_EINVAL, "set_option: null name");

@@ -14,4 +14,5 @@ cd $R
 python tools/rocpd_stats.py gpurun_out/prof_${tag}/bench_results.db gpurun_out/${tag}_kernel_stats.md
 python tools/rocpd_stats.py gpurun_out/prof_${tag}_unseg/bench_results.db gpurun_out/${tag}_unseg_kernel_stats.md
 python tools/pmc_report.py gpurun_out/pmc_${tag}_FETCH_SIZE/p_results.db gpurun_out/pmc_${tag}_WRITE_SIZE/p_results.db > gpurun_out/${tag}_pmc.txt 2>&1
+python tools/traffic_json.py gpurun_out/pmc_${tag}_FETCH_SIZE/p_results.db gpurun_out/pmc_${tag}_WRITE_SIZE/p_results.db C3 76684 gpurun_out/${tag}_hbm_traffic.json > /dev/null 2>&1
 tail -2 gpurun_out/prof_${tag}.log; cat gpurun_out/${tag}_pmc.txt; ls gpurun_out/prof_${tag} gpurun_out/pmc_${tag}_FETCH_SIZE
