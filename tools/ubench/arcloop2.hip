@@ -291,18 +291,16 @@ int main() {
   hipMalloc(&out, 1 << 20); hipMalloc(&cyc, 8); hipMalloc(&idx, 4 << 20);
   hipMalloc(&xg, (size_t)T * kD * 4); hipMalloc(&store, (size_t)T * kHp * 4);
   hipMemset(xg, 0, (size_t)T * kD * 4);
-  run<16, 36, 3, S_SHIPPED>("shipped frame", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_SHIPPED, O_CHEAPEXP>("shipped, cheap exp", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_SHIPPED, O_XINTER>("shipped, x in chunks", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_SHIPPED, O_XINTER | O_CHEAPEXP>("shipped, x in chunks, cheap exp", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_LAZY>("lazy", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_LAZY, O_LATESTORE>("lazy, late store", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_LAZY, O_LATESTORE | O_XINTER>("lazy, late store, x in chunks", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_LAZY, O_LATESTORE | O_XINTER | O_CHEAPEXP>("lazy, late store, x in chunks, cheap exp", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_LAZY, O_LATESTORE | O_XINTER | O_CHEAPEXP | O_ROWSUM4>("lazy, late store, x chunks, cheap exp, rowsum4", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_LAZY, O_LATESTORE | O_CHEAPEXP | O_ROWSUM4>("lazy, late store, cheap exp, rowsum4", out, cyc, idx, xg, store, T);
-  run<16, 32, 3, S_LAZY, O_LATESTORE | O_XINTER | O_CHEAPEXP | O_ROWSUM4>("lazy, late store, x chunks, cheap exp, rowsum4", out, cyc, idx, xg, store, T);
-  run<16, 40, 3, S_LAZY, O_LATESTORE | O_XINTER | O_CHEAPEXP | O_ROWSUM4>("lazy, late store, x chunks, cheap exp, rowsum4", out, cyc, idx, xg, store, T);
-  run<16, 36, 3, S_LAZY, O_LATESTORE | A_NOX | A_NOXLOAD | O_ROWSUM4>("lazy, late store, rowsum4, no x at all", out, cyc, idx, xg, store, T);
+  // waves per workgroup at equal total slot-rows (640): what the per-wave serial chains of a frame cost
+  run<16, 40, 3, S_SHIPPED>("shipped frame", out, cyc, idx, xg, store, T);
+  run<12, 52, 4, S_SHIPPED>("shipped frame", out, cyc, idx, xg, store, T);
+  run<8, 80, 6, S_SHIPPED>("shipped frame", out, cyc, idx, xg, store, T);
+  run<16, 40, 3, S_LAZY, O_LATESTORE | O_ROWSUM4>("lazy, late store, rowsum4", out, cyc, idx, xg, store, T);
+  run<12, 52, 4, S_LAZY, O_LATESTORE | O_ROWSUM4>("lazy, late store, rowsum4", out, cyc, idx, xg, store, T);
+  run<8, 80, 6, S_LAZY, O_LATESTORE | O_ROWSUM4>("lazy, late store, rowsum4", out, cyc, idx, xg, store, T);
+  run<8, 72, 6, S_LAZY, O_LATESTORE | O_ROWSUM4>("lazy, late store, rowsum4", out, cyc, idx, xg, store, T);
+  run<4, 160, 12, S_LAZY, O_LATESTORE | O_ROWSUM4>("lazy, late store, rowsum4", out, cyc, idx, xg, store, T);
+  run<8, 80, 6, S_LAZY, O_LATESTORE | O_ROWSUM4 | A_NOX | A_NOXLOAD>("lazy, no x at all", out, cyc, idx, xg, store, T);
+  run<16, 40, 3, S_LAZY, O_LATESTORE | O_ROWSUM4 | A_NOX | A_NOXLOAD>("lazy, no x at all", out, cyc, idx, xg, store, T);
   return 0;
 }
