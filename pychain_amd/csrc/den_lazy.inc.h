@@ -228,6 +228,16 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     next_bound = next_sig < a.sig_n ? a.seg_bound[next_sig] : 0x7fffffff;                                   \
   }
 
+  // -DPYCHAIN_PROFILE_PHASES: cycles per phase of a frame step, per wave (s_memtime: the sums live in SGPRs), printed
+  // for sequence 0 when the kernel ends (tools/phase_timers.sh; the table of DESIGN.md §4)
+#ifdef PYCHAIN_PROFILE_PHASES
+  unsigned long long lzph[6] = {0, 0, 0, 0, 0, 0}, lzt = 0;
+#define LZ_PH0() lzt = PH_T()
+#define LZ_PH(i) do { const unsigned long long t_ = PH_T(); lzph[i] += t_ - lzt; lzt = t_; } while (0)
+#else
+#define LZ_PH0() (void)0
+#define LZ_PH(i) (void)0
+#endif
   // One frame step j: alpha produces a(j+1,.) from a(j,.) and x(j); beta produces b(t,.), t = L-1-j, from b(t+1,.) and x(t).
 #define PYCHAIN_LZ_STEP(J, PAR, FWDC)                                                                       \
   do {                                                                                                      \
@@ -241,8 +251,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     constexpr uint32_t VOFF = (PAR) ? 32768u : 16384u;       /* kLzXField + VOFF = nnet-output buffer PAR */ \
     const int tn = (FWDC) ? j + 1 : L - 2 - j;               /* nnet-output row of the NEXT step */          \
     const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
+    LZ_PH0();                                                                                               \
     if (have_next) xq.load_row(xbuf, tn, D, tq);             /* in flight during the arc work */             \
     lazy_tile<R, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq);                                           \
+    LZ_PH(0);                                                /* arc phase */                                 \
     /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
     /* lane's rows (and, beta, their leaky probs) for the totals, and the rows of the PREVIOUS frame - the  */ \
     /* buffer this frame gathered from - which leave for HBM now that their scalar is known */              \
@@ -264,6 +276,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       if ((FWDC) && xq.has_nan()) bad = 2;                   /* a NaN network output: not ok, NaN log-probability */ \
       xq.store(X0 + ((PAR) ? 0 : 4096), xseq, D, tq, a.input_is_exp);                                       \
     }                                                                                                       \
+    LZ_PH(1);                                                /* LDS re-reads issued, nnet-output row clamped / exp'd / stored */ \
     /* (stores issued after the wait for the nnet-output row: a wait that covered them would last a round */ \
     /* trip to HBM).  Row of the previous frame: alpha row j, beta row L - j */                             \
     {                                                                                                       \
@@ -285,7 +298,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       red[(PAR) * 128 + wave * 4 + (lq >> 4)] = r0;                                                         \
       if (!(FWDC)) { const float r1 = dpp_row_sum(s1); red[(PAR) * 128 + 64 + wave * 4 + (lq >> 4)] = r1; } \
     }                                                                                                       \
+    LZ_PH(2);                                                /* previous row completed and stored, row sums */ \
     __syncthreads();                                         /* every gather of this frame is done; the new vector is complete */ \
+    LZ_PH(3);                                                /* wait at the barrier */                       \
     const float tot = wave_sum(red[(PAR) * 128 + lq]);                                                      \
     w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;                                                            \
@@ -293,6 +308,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     else { w.c = coef * wave_sum(red[(PAR) * 128 + 64 + lq]); w.sprev = w.c; }                              \
     if (tq == 0) totv[tstore] = tot;                         /* (alpha: tstore == L is written and never read) */ \
     last_tot = tot;                                                                                         \
+    LZ_PH(4);                                                /* totals, reciprocal */                        \
   } while (0)
 
   float last_tot = 1.f;
@@ -315,6 +331,15 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   PYCHAIN_LZ_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // a sequence shorter than a bound is done with it now
 #undef PYCHAIN_LZ_SIGNAL
 #undef PYCHAIN_LZ_STEP
+#ifdef PYCHAIN_PROFILE_PHASES
+  if (lane == 0 && b == 0) {
+    const unsigned long long n = (unsigned long long)max(1, nsteps);
+    printf("lazy dir %d wave %2d rows %2d steps %d cycles/step: arcs %llu rereads+x %llu rowstore+sums %llu barrier %llu totals %llu\n",
+           (int)fwd, wave, groups.nslots, nsteps, lzph[0] / n, lzph[1] / n, lzph[2] / n, lzph[3] / n, lzph[4] / n);
+  }
+#endif
+#undef LZ_PH
+#undef LZ_PH0
 
   if constexpr (fwd) {
     // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i a'(L,i) final(i) + sum_{t<L} log tot(t),

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Cycles per phase of a frame step of den_recursion_lazy_kernel (s_memtime, per wave, sequence 0 of C3).
+# Run HERE to build the instrumented library, then on the GPU box:  tools/phase_timers.sh run > gpurun_out/phase_timers.txt
+# (tools/variants/ is scratch: git-ignored .so files travel with gpurun)
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+if [ "$1" = "run" ]; then
+  PYCHAIN_HIP_LIB=$ROOT/tools/variants/phases.so TIME_DEN_ONLY=recursion PYCHAIN_DEN_SEGMENTS=1 python $ROOT/tools/time_den.py C3 2>&1 | grep -E "^lazy dir|recursion ms" | sort | uniq -c | sort -k3,3n -k5,5n
+else
+  mkdir -p $ROOT/tools/variants
+  cd $ROOT/pychain_amd/csrc
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fno-slp-vectorize -DPYCHAIN_PROFILE_PHASES -I $ROOT/include \
+    plan.cpp fst.cpp den_kernels.hip num_kernels.hip api.hip -o $ROOT/tools/variants/phases.so
+  echo built $ROOT/tools/variants/phases.so
+fi
