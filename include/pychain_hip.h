@@ -79,7 +79,9 @@ int         pychain_hip_den_recursion_is_lazy(int resident_slot_rows, int H, int
  * clears.  Names: "den_segments" (n time segments of the denominator, 1 = no overlap), "den_bounds"
  * ("0.7,0.85": their ends as fractions of T), "den_relaunch" (one recursion launch per segment instead of
  * progress counters + gate kernels), "no_fold" (numerator accumulated into the stored gradient instead of
- * folded into the occupancy launch), "gamma16" (one-frame occupancy kernel), "num_no_staging_waves".
+ * folded into the occupancy launch), "gamma16" (one-frame occupancy kernel), "num_no_staging_waves", "den_pair"
+ * ("1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of the CU
+ * count in sequences on, i.e. B >= 96 on 256 CUs - results are bit-identical to den_recursion_kernel's).
  * Every combination gives the same results to rounding (the tests compare them); unknown name: EINVAL. */
 int         pychain_hip_set_option(const char* name, const char* value);
 

@@ -82,7 +82,7 @@ def lib():
     return _lib
 
 
-OPTIONS = ("den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves")
+OPTIONS = ("den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves", "den_pair")
 
 
 class option(object):

@@ -54,7 +54,7 @@ extern "C" int pychain_hip_den_recursion_is_lazy(int resident_slot_rows, int H, 
   return (g_den_lazy && !option("den_relaunch") && den_lazy_eligible(a, resident_slot_rows)) ? 1 : 0;
 }
 extern "C" int pychain_hip_set_option(const char* name, const char* value) {
-  static const char* const known[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves"};
+  static const char* const known[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves", "den_pair"};
   if (!name) return fail(PYCHAIN_HIP_EINVAL, "set_option: null name");
   bool ok = false;
   for (const char* k : known) ok = ok || strcmp(k, name) == 0;
@@ -199,8 +199,30 @@ int den_segments(int T) {
 
 // Which form the stored rows of this call have (decided from the same inputs by the forward call and by a
 // later chain_loss_backward on its workspace).
+// Two sequences per recursion workgroup (den_pair.inc.h) pay once the 2B one-sequence workgroups would fill the
+// chip: the recursions then run on half of it and the occupancy launches and the numerator on the other half.
+// Option den_pair: "1" wherever the shape allows (the tests), "0" never.
+int device_cu_count() {
+  static std::mutex lock;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> guard(lock);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  return cus[dev] = n;
+}
+bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
+  if (option("den_relaunch") || !den_pair_eligible(a, resident_slot_rows)) return false;
+  if (const char* o = option("den_pair")) return atoi(o) != 0;
+  // measured on the C3 graph (tools/time_step.py B 1500): B = 96 +3.5 %, B = 128 +27 %, B = 256 +13 %; below 3/4 of the
+  // CUs the one-sequence workgroups leave enough of the chip to the occupancy launches and their chain is shorter
+  return 8 * a.B >= 3 * device_cu_count();
+}
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
-  return g_den_lazy && !option("den_relaunch") && den_lazy_eligible(a, resident_slot_rows);
+  return g_den_lazy && !option("den_relaunch") && den_lazy_eligible(a, resident_slot_rows) && !den_call_is_pair(a, resident_slot_rows);
 }
 
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
@@ -212,6 +234,9 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   const int nseg = (occupancy && user_mask == 3 && !a.check_all) ? den_segments(a.T) : 1;
   // the lazy-normalisation recursion runs a whole sequence in one launch: not with the relaunch schedule
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
+  // two sequences per workgroup once the 2B one-sequence workgroups would fill the chip (option den_pair: 1 always
+  // where the shape allows, 0 never); rows in den_recursion_kernel's form
+  a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
   // the invariant check (DenArgs::tot_a) needs the recursions and the occupancy launches of ONE call
   a.check = (occupancy && user_mask == 3) ? 1 : 0;
   hipError_t e = hipSuccess;
@@ -261,7 +286,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     a.phase_mask = 2; a.gam_nseg = nseg;
     for (int s = 0; s < nseg - 1 && e == hipSuccess; s++) {
       a.gam_seg = s;
-      e = launch_den_gate(a.progress + s, 2 * a.B, a.bad, side->stream2);
+      e = launch_den_gate(a.progress + s, den_recursion_blocks(a), a.bad, side->stream2);
       if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
       if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
     }

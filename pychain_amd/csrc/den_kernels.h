@@ -21,6 +21,9 @@ struct DenArgs {
   // b(t,.) + c(t), each in a per-frame scale of its own; 0: as den_recursion_kernel (rows normalised).  The
   // occupancy kernels read either form as it is; den_finish_kernel needs to know which scales were divided out.
   int lazy;
+  // 1: the recursions run as den_recursion_pair_kernel (den_pair.inc.h): two sequences per workgroup, ceil(B/2)
+  // workgroups per direction; rows as den_recursion_kernel stores them (lazy = 0).  Shared plan only.
+  int pair;
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
   //     objf = sum_t log tot_a(t) + log fin_dot        (ComputeTotLogLike, chain-computation.cc:209-230)
@@ -66,6 +69,9 @@ struct DenArgs {
 // true if the recursion of this call runs as den_recursion_lazy_kernel (decided once per call; the occupancy
 // launches - also those of a later chain_loss_backward on the same workspace - must be told: DenArgs::lazy)
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows);
+// ... as den_recursion_pair_kernel (DenArgs::pair); den_pair_blocks: its grid = what a progress counter reaches
+bool den_pair_eligible(const DenArgs& a, int resident_slot_rows);
+int den_recursion_blocks(const DenArgs& a);
 
 // true if launch_den would run the two-frame occupancy kernel (the only one that can fold the numerator in)
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);

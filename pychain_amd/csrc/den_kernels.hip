@@ -655,6 +655,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
 }
 
 #include "den_lazy.inc.h"
+#include "den_pair.inc.h"
 
 // Which recursion segment makes frame t of a length-L sequence computable: its alpha'(t) row
 // exists once the forward recursion has run t steps, its beta(t+1) row once the backward
@@ -1346,10 +1347,28 @@ hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
   return launch_one(den_recursion_lazy_kernel<kMaxResident>, a, grid, kLzBytes, st);
 }
 
+// Two sequences per workgroup (den_pair.inc.h): one plan for all sequences, nnet-output rows and state vectors
+// within its fixed LDS map, every arc of a plan wave in registers, the whole sequence in one launch.
+inline bool pair_shape_ok(const DenArgs& a, int hint) {
+  const int rows = hint & 1023;
+  return a.plan_stride == 0 && a.D % 4 == 0 && a.D <= 4096 && a.Hp <= 4096 && rows > 0 && rows <= kMaxResident &&
+         PLAN_REC_WAVES == 16 && a.B >= 2;
+}
+hipError_t launch_pair(const DenArgs& a, int hint, hipStream_t st) {
+  const dim3 grid(2 * ((a.B + 1) / 2));
+  const int rows = hint & 1023;
+  if (rows <= 16) return launch_one(den_recursion_pair_kernel<16>, a, grid, kPrBytes, st, kPrNT);
+  if (rows <= 32) return launch_one(den_recursion_pair_kernel<32>, a, grid, kPrBytes, st, kPrNT);
+  return launch_one(den_recursion_pair_kernel<kMaxResident>, a, grid, kPrBytes, st, kPrNT);
+}
+
 template <int VEC, int XCH>
 hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, int gx, hipStream_t st, int gamma_max_groups) {
   hipError_t e = hipSuccess;
-  if ((a.phase_mask & 1) && a.lazy) {
+  if ((a.phase_mask & 1) && a.pair) {
+    e = launch_pair(a, hint, st);
+    if (e != hipSuccess) return e;
+  } else if ((a.phase_mask & 1) && a.lazy) {
     e = launch_lazy(a, hint, st);
     if (e != hipSuccess) return e;
   } else if (a.phase_mask & 1) {
@@ -1409,6 +1428,8 @@ hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hi
 }
 
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows); }
+bool den_pair_eligible(const DenArgs& a, int resident_slot_rows) { return pair_shape_ok(a, resident_slot_rows); }
+int den_recursion_blocks(const DenArgs& a) { return a.pair ? 2 * ((a.B + 1) / 2) : 2 * a.B; }
 
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
   return gamma2_eligible(a, (resident_slot_rows >> 20) & 1023, gamma_max_groups);
