@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, _lib, synthetic as syn
+from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, _lib, _plan, native, synthetic as syn
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -92,7 +92,7 @@ def test_pair_kernel_flags_the_right_sequence(one_sequence_form):
         objf = ChainFunction.apply(xx, L, ChainGraphBatch(den, 4), 1e-5)      # the sum over sequences: NaN
         objf.backward()
         torch.cuda.synchronize()
-        assert np.isnan(float(objf)) and int(ChainFunction.last_bad_count.sum().item()) > 0
+        assert np.isnan(float(objf.detach())) and int(ChainFunction.last_bad_count.sum().item()) > 0
         assert torch.equal(xx.grad[0], g0[0]) and torch.equal(xx.grad[2:], g0[2:])
         Ld = torch.tensor([64, 99, 50, 0], device=DEV)
         xr = x.clone().requires_grad_(True)
@@ -100,3 +100,28 @@ def test_pair_kernel_flags_the_right_sequence(one_sequence_form):
         torch.cuda.synchronize()
         assert int(ChainFunction.last_bad_count.sum().item()) > 0
         assert torch.equal(xr.grad[0], g0[0]) and torch.equal(xr.grad[2], g0[2])
+
+
+def test_pair_kernel_with_the_check_on_every_frame_and_with_exponentiated_input(one_sequence_form):
+    """verbose level 1 runs the reference's consistency check on every frame (one launch, no segments): healthy input
+    stays ok; the pychain_C contract (input already exp'd) takes the same kernel."""
+    den = syn.make_den_graph(300, 2500, 512, seed=5)
+    L = torch.tensor([300, 280, 33])
+    x = syn.make_input(3, 300, 512, seed=31, device=DEV)
+    o0, g0, bad0 = _den(x, L, den, pair=True)
+    native.set_verbose_level(1)
+    try:
+        o1, g1, bad1 = _den(x, L, den, pair=True)
+    finally:
+        native.set_verbose_level(0)
+    assert bad0 == 0 and bad1 == 0 and torch.equal(o0, o1) and torch.equal(g0, g1)
+    plan = _plan.graph_plan(den, 512, torch.device(DEV))
+    xe = x.clamp(-30, 30).exp()
+    Ld = L.to(DEV)
+    outs = []
+    for pair in ("0", "1"):
+        with _lib.option("den_pair", pair):
+            r = native.den_forward_backward(plan, xe, Ld, 1e-5, input_is_exp=True)
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in r[:2]])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
