@@ -196,15 +196,26 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     }
   };
   // v = raw normalised (normalise_row's formulas), to the gather operand and - where the sequence is live - to its row
-  // of the trajectory store; four states per thread (Hp <= 4096 = one pass)
-  auto normalise = [&](lz_v2f inv, lz_v2f add, int rowA, int rowB, int tq) {
+  // of the trajectory store; four states per thread (Hp <= 4096 = one pass).  In two parts: the raw sums (and the
+  // leaky probs) are requested from LDS BEFORE the totals are reduced - they do not depend on them, and the
+  // reduction is a latency chain of its own.
+  auto normalise_read = [&](int tq, lz_v4f& nr01, lz_v4f& nr23, lz_v4f& nlk) {
+    const int i = tq * 4;
+    nr01 = nr23 = nlk = lz_v4f{0.f, 0.f, 0.f, 0.f};
+    if (i < Hp) {
+      nr01 = lz_ld4(kPrRaw + (uint32_t)i * 8u);
+      nr23 = lz_ld4(kPrRaw + (uint32_t)i * 8u + 16u);
+      if (fwd) nlk = lz_ld4(kPrLk + (uint32_t)i * 4u);
+    }
+  };
+  auto normalise = [&](lz_v2f inv, lz_v2f add, int rowA, int rowB, int tq, lz_v4f nr01, lz_v4f nr23, lz_v4f nlk) {
     const int i = tq * 4;
     if (i < Hp) {
-      const lz_v4f r01 = lz_ld4(kPrRaw + (uint32_t)i * 8u), r23 = lz_ld4(kPrRaw + (uint32_t)i * 8u + 16u);
+      const lz_v4f r01 = nr01, r23 = nr23;
       float va[4], vb[4];
       const float ra[4] = {r01.x, r01.z, r23.x, r23.z}, rb[4] = {r01.y, r01.w, r23.y, r23.w};
       if (fwd) {
-        const lz_v4f l = lz_ld4(kPrLk + (uint32_t)i * 4u);
+        const lz_v4f l = nlk;
         const float cl[4] = {coef * l.x, coef * l.y, coef * l.z, coef * l.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) { va[k] = ra[k] * inv.x + cl[k]; vb[k] = rb[k] * inv.y + cl[k]; }
@@ -247,11 +258,13 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();                                   // red zeroed
     if (lane == 0) { red[wave] = p0; red[2 * 16 + wave] = p1; }
     __syncthreads();
+    lz_v4f nr01, nr23, nlk;
+    normalise_read(tid, nr01, nr23, nlk);
     const float tot = total(0), wtot = total(2);
     const float inv = __builtin_amdgcn_rcpf(tot);
     if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
     if (tid == 0) { totA[fwd ? 0 : LA] = tot; if (haveB) totB[fwd ? 0 : LB] = tot; }
-    normalise(lz_v2f{inv, inv}, lz_v2f{coef * wtot, coef * wtot}, fwd ? 0 : LA, haveB ? (fwd ? 0 : LB) : -1, tid);
+    normalise(lz_v2f{inv, inv}, lz_v2f{coef * wtot, coef * wtot}, fwd ? 0 : LA, haveB ? (fwd ? 0 : LB) : -1, tid, nr01, nr23, nlk);
   }
   __syncthreads();
 
@@ -290,6 +303,15 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     next_bound = next_sig < a.sig_n ? a.seg_bound[next_sig] : 0x7fffffff;                                   \
   }
 
+  // -DPYCHAIN_PROFILE_PHASES: cycles per phase of a frame step, per wave (tools/phase_timers.sh pair)
+#ifdef PYCHAIN_PROFILE_PHASES
+  unsigned long long prph[6] = {0, 0, 0, 0, 0, 0}, prt = 0;
+#define PR_PH0() prt = PH_T()
+#define PR_PH(i) do { const unsigned long long t_ = PH_T(); prph[i] += t_ - prt; prt = t_; } while (0)
+#else
+#define PR_PH0() (void)0
+#define PR_PH(i) (void)0
+#endif
   // One frame step j of both sequences; VOFF = the nnet-output buffer it gathers from (even steps 0, odd steps 1).
 #define PYCHAIN_PR_STEP(J, VOFF)                                                                            \
   do {                                                                                                      \
@@ -300,6 +322,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     asm volatile("" : "+v"(tq));                                                                            \
     const int lq = tq & 63;                                                                                 \
     const bool liveA = j < nA, liveB = j < nB;                                                              \
+    PR_PH0();                                                                                               \
     /* nnet-output rows of the NEXT step (a sequence that has none re-reads a row that exists) */            \
     const int tnA = fwd ? j + 1 : LA - 2 - j, tnB = fwd ? j + 1 : LB - 2 - j;                               \
     const bool nextA = fwd ? tnA < LA : tnA >= 1, nextB = haveB && (fwd ? tnB < LB : tnB >= 1);             \
@@ -307,9 +330,11 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     xqB.load_row(xbufB, min(max(tnB, 0), a.T - 1), D, tq);                                                  \
     lz_v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f};                                                                \
     pair_tile<R, fwd, VOFF>(arcs, groups, pairmask, lq, s0, s1);                                            \
+    PR_PH(0);                                          /* arc phase */                                       \
     /* the other buffer was last read in the previous step, which every wave has left */                    \
     if (fwd) { if (nextA && xqA.has_nan()) nanA = true; if (nextB && xqB.has_nan()) nanB = true; }          \
     stage_rows((VOFF) ? kPrX0 : kPrX1, tq);                                                                 \
+    PR_PH(1);                                          /* nnet-output rows clamped / exp'd / stored */       \
     {                                                                                                       \
       const float a0 = wave_sum(s0.x), b0 = wave_sum(s0.y);                                                 \
       if (lane == 0) { red[wave] = a0; red[16 + wave] = b0; }                                               \
@@ -318,7 +343,11 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
         if (lane == 0) { red[32 + wave] = a1; red[48 + wave] = b1; }                                        \
       }                                                                                                     \
     }                                                                                                       \
+    PR_PH(2);                                          /* wave sums */                                       \
     __syncthreads();                                   /* every gather of this frame is done */              \
+    PR_PH(3);                                          /* wait at barrier 1 */                               \
+    lz_v4f nr01, nr23, nlk;                                                                                 \
+    normalise_read(tq, nr01, nr23, nlk);                                                                    \
     const lz_v2f tot = {total(0), total(1)};                                                                \
     lz_v2f wtot = {0.f, 0.f};                                                                               \
     if (!fwd) wtot = lz_v2f{total(2), total(3)};                                                            \
@@ -328,8 +357,10 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     const int tsA = fwd ? j + 1 : LA - 1 - j, tsB = fwd ? j + 1 : LB - 1 - j;                               \
     if (tid == 0) { if (liveA) totA[tsA] = tot.x; if (liveB) totB[tsB] = tot.y; }                           \
     normalise(inv, lz_v2f{coef * wtot.x, coef * wtot.y}, (liveA && (!fwd || tsA < LA)) ? tsA : -1,          \
-              (liveB && (!fwd || tsB < LB)) ? tsB : -1, tq);                                                \
+              (liveB && (!fwd || tsB < LB)) ? tsB : -1, tq, nr01, nr23, nlk);                               \
+    PR_PH(4);                                          /* totals, normalise pass, row stores */              \
     __syncthreads();                                                                                        \
+    PR_PH(5);                                          /* wait at barrier 2 */                               \
     if (fwd && (j + 1 == nA || j + 1 == nB)) final_dot(j + 1 == nA, haveB && j + 1 == nB);                  \
   } while (0)
 
@@ -341,6 +372,15 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
   PYCHAIN_PR_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // sequences shorter than a bound are done with it now
 #undef PYCHAIN_PR_SIGNAL
 #undef PYCHAIN_PR_STEP
+#ifdef PYCHAIN_PROFILE_PHASES
+  if (lane == 0 && p == 0) {
+    const unsigned long long n = (unsigned long long)max(1, nmax);
+    printf("pair dir %d wave %2d rows %2d steps %d cycles/step: arcs %llu x %llu wsums %llu bar1 %llu normalise %llu bar2 %llu\n",
+           (int)fwd, wave, groups.nslots, nmax, prph[0] / n, prph[1] / n, prph[2] / n, prph[3] / n, prph[4] / n, prph[5] / n);
+  }
+#endif
+#undef PR_PH
+#undef PR_PH0
   if ((bad || nanA || nanB) && lane == 0) atomicAdd(a.bad, 1);
 }
 
