@@ -89,8 +89,8 @@ __device__ __forceinline__ void lazy_group_end(const LazyWave& w, lz_v2f acc, ui
 
 // One frame of a recursion tile, lazy form: gathers from state buffer UOFF and nnet-output buffer VOFF,
 // writes the new values into state buffer UNEXT (byte offset).  Same software pipeline as tile_rows.
-template <int R, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT>
-__device__ __forceinline__ void lazy_tile(LazyArcs<R>& ar, const GroupRegs& gr, const LazyWave& w, int lane) {
+template <int R, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook>
+__device__ __forceinline__ void lazy_tile(LazyArcs<R>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers) {
   constexpr int kChunk = 4;
   static_assert(R % kChunk == 0 && R <= 64 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
@@ -111,6 +111,9 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R>& ar, const GroupRegs& gr, 
 #pragma unroll
       for (int k = 0; k < kChunk; k++) ar.template gather<UOFF, VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
     }
+    // the previous frame's totals (w.inv, w.c: first needed at the first group end) are reduced HERE, behind the
+    // gathers of the first two chunks, instead of between the barrier and the first gather
+    if (c == 0) after_first_gathers();
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -217,6 +220,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();                                                 // red is rewritten by the first frame
   }
 
+  float last_tot = 1.f;
   int next_sig = 0;
   int next_bound = a.sig_n > 0 ? a.seg_bound[0] : 0x7fffffff;
 #define PYCHAIN_LZ_SIGNAL(DONE)                                                                             \
@@ -238,6 +242,18 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 #define LZ_PH0() (void)0
 #define LZ_PH(i) (void)0
 #endif
+  // Totals of frame step JP (partial sums in red[PARP]): the normaliser of the next frame, the scalar that completes the
+  // row JP produced, the total den_finish_kernel reads.  tstore = the row step JP produced (alpha: L is written, never read).
+#define PYCHAIN_LZ_TOTALS(PARP, JP, FWDC, LQ, TQ)                                                           \
+  do {                                                                                                      \
+    const float tot = wave_sum(red[(PARP) * 128 + (LQ)]);                                                   \
+    w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
+    if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;                                                            \
+    if (FWDC) w.sprev = tot;                                                                                \
+    else { w.c = coef * wave_sum(red[(PARP) * 128 + 64 + (LQ)]); w.sprev = w.c; }                           \
+    if ((TQ) == 0) totv[(FWDC) ? (JP) + 1 : L - 1 - (JP)] = tot;                                            \
+    last_tot = tot;                                                                                         \
+  } while (0)
   // One frame step j: alpha produces a(j+1,.) from a(j,.) and x(j); beta produces b(t,.), t = L-1-j, from b(t+1,.) and x(t).
 #define PYCHAIN_LZ_STEP(J, PAR, FWDC)                                                                       \
   do {                                                                                                      \
@@ -253,7 +269,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
     LZ_PH0();                                                                                               \
     if (have_next) xq.load_row(xbuf, tn, D, tq);             /* in flight during the arc work */             \
-    lazy_tile<R, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq);                                           \
+    lazy_tile<R, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, [&]() {                                     \
+      if (j > 0) PYCHAIN_LZ_TOTALS((PAR) ^ 1, j - 1, (FWDC), lq, tq);   /* (step 0: the start vector's, above) */ \
+    });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
     /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
     /* lane's rows (and, beta, their leaky probs) for the totals, and the rows of the PREVIOUS frame - the  */ \
@@ -288,7 +306,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow[g].y, prow[g].x)), sbuf, lane4, \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
     }                                                                                                       \
-    const int tstore = (FWDC) ? j + 1 : L - 1 - j;           /* the row this frame produced */               \
     float s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                       \
     float s1 = 0.f;                                                                                         \
     if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
@@ -301,22 +318,15 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     LZ_PH(2);                                                /* previous row completed and stored, row sums */ \
     __syncthreads();                                         /* every gather of this frame is done; the new vector is complete */ \
     LZ_PH(3);                                                /* wait at the barrier */                       \
-    const float tot = wave_sum(red[(PAR) * 128 + lq]);                                                      \
-    w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
-    if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;                                                            \
-    if (FWDC) w.sprev = tot;                                                                                \
-    else { w.c = coef * wave_sum(red[(PAR) * 128 + 64 + lq]); w.sprev = w.c; }                              \
-    if (tq == 0) totv[tstore] = tot;                         /* (alpha: tstore == L is written and never read) */ \
-    last_tot = tot;                                                                                         \
-    LZ_PH(4);                                                /* totals, reciprocal */                        \
+    /* (this frame's totals: reduced by the next step behind its first gathers, or after the loop) */       \
   } while (0)
 
-  float last_tot = 1.f;
   for (int jj = 0; jj < nsteps; jj += 2) {
     PYCHAIN_LZ_STEP(jj, 0, fwd);
     if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
     PYCHAIN_LZ_SIGNAL(jj + 1);                                // (rows lag one step: after jj + 2 steps the rows of steps < jj + 1 are out)
   }
+  if (nsteps > 0) PYCHAIN_LZ_TOTALS((nsteps - 1) & 1, nsteps - 1, fwd, lane, tid);   // the last step's
   if constexpr (!fwd) {
     // the last beta row (row L - nsteps: row 1, or the start row if the sequence has one frame) never saw a next frame
     const float* UL = U0 + ((nsteps & 1) ? kLzU1 / 4 : 0);
@@ -331,6 +341,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   PYCHAIN_LZ_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // a sequence shorter than a bound is done with it now
 #undef PYCHAIN_LZ_SIGNAL
 #undef PYCHAIN_LZ_STEP
+#undef PYCHAIN_LZ_TOTALS
 #ifdef PYCHAIN_PROFILE_PHASES
   if (lane == 0 && b == 0) {
     const unsigned long long n = (unsigned long long)max(1, nsteps);
