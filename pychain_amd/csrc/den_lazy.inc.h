@@ -271,20 +271,28 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if (have_next) xq.load_row(xbuf, tn, D, tq);             /* in flight during the arc work */             \
     lazy_tile<R, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, [&]() {                                     \
       if (j > 0) PYCHAIN_LZ_TOTALS((PAR) ^ 1, j - 1, (FWDC), lq, tq);   /* (step 0: the start vector's, above) */ \
+      /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) - it sits in the buffer this */ \
+      /* frame gathers from - is completed and leaves for HBM, also behind the first gathers */              \
+      const int trow = (FWDC) ? j : L - j;                                                                  \
+      const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
+      const int lane4 = lq * 4, lane8 = lq * 8;              /* one VGPR of addresses, the group in the SGPR offset */ \
+      _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++)                                              \
+        if (g < groups.ngroups) {                                                                           \
+          const lz_v2f prow = lz_ld2(UOFF + gbase[g] * 8 + lane8);                                          \
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow.y, prow.x)), sbuf, lane4, \
+                                                row_off + gbase[g] * 4, kStoreDeviceScope);                 \
+        }                                                                                                   \
     });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
     /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
-    /* lane's rows (and, beta, their leaky probs) for the totals, and the rows of the PREVIOUS frame - the  */ \
-    /* buffer this frame gathered from - which leave for HBM now that their scalar is known */              \
+    /* lane's rows (and, beta, their leaky probs) for the totals */                                         \
     float val[kLzMaxGroups], lkv[kLzMaxGroups];                                                             \
-    lz_v2f prow[kLzMaxGroups];                                                                              \
     {                                                                                                       \
       const int lane8 = lq * 8;                                                                             \
       _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++) {                                            \
-        val[g] = 0.f; lkv[g] = 0.f; prow[g] = lz_v2f{0.f, 0.f};                                             \
+        val[g] = 0.f; lkv[g] = 0.f;                                                                         \
         if (g < groups.ngroups) {                                                                           \
           val[g] = lds_abs(UNEXT + gbase[g] * 8 + lane8);                                                   \
-          prow[g] = lz_ld2(UOFF + gbase[g] * 8 + lane8);                                                    \
           if (!(FWDC)) lkv[g] = lds_abs(kLzLk + gbase[g] * 4 + (lane8 >> 1));                               \
         }                                                                                                   \
       }                                                                                                     \
@@ -295,17 +303,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       xq.store(X0 + ((PAR) ? 0 : 4096), xseq, D, tq, a.input_is_exp);                                       \
     }                                                                                                       \
     LZ_PH(1);                                                /* LDS re-reads issued, nnet-output row clamped / exp'd / stored */ \
-    /* (stores issued after the wait for the nnet-output row: a wait that covered them would last a round */ \
-    /* trip to HBM).  Row of the previous frame: alpha row j, beta row L - j */                             \
-    {                                                                                                       \
-      const int trow = (FWDC) ? j : L - j;                                                                  \
-      const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
-      const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
-      _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++)                                              \
-        if (g < groups.ngroups)                                                                             \
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow[g].y, prow[g].x)), sbuf, lane4, \
-                                                row_off + gbase[g] * 4, kStoreDeviceScope);                 \
-    }                                                                                                       \
     float s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                       \
     float s1 = 0.f;                                                                                         \
     if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
