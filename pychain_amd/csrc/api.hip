@@ -406,6 +406,7 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
   a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 32;
   a.check_all = g_verbose_level >= 1 ? 1 : 0;
+  a.watch_nan = 1;                                   // (the fused loss clears it: NumArgs::watch_nan)
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_ws = (double*)(ws + c.alpha); a.beta_ws = (double*)(ws + c.beta); a.logp_ws = (double*)(ws + c.logp);
   a.rows_ws = (float*)(ws + c.rows); a.upd_ws = (int32_t*)(ws + c.upd); a.ucount_ws = (int32_t*)(ws + c.ucount);
@@ -466,6 +467,7 @@ extern "C" int pychain_hip_chain_loss_forward(
                      B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM, -grad_scale, num_objf,
                      grad ? grad : (float*)num_ws, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
+  na.watch_nan = 0;              // the denominator's alpha workgroups watch every element of every row (NumArgs::watch_nan)
   hipStream_t st = (hipStream_t)stream;
   SideStream* side = side_streams_for(st);
   if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "%s: cannot create the side stream", who);

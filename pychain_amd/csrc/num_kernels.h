@@ -33,6 +33,11 @@ struct NumArgs {
   // BetaGeneralFrameDebug, chain-log-domain-computation.cc:283-304: a frame's occupancies must sum to 1 within
   // 5 % (and be finite); checked at t == 0 always, on every frame when check_all (verbose level >= 1)
   int check_all;
+  // 1: a NaN network output stays a NaN in the staged rows (torch.clamp keeps it, loss.py:30: it reaches the
+  // log-probability if an arc of the utterance emits that pdf).  0: the fused loss - there the denominator's alpha
+  // workgroups watch every element of every row and turn the loss into NaN, and the row-staging waves, whose
+  // instruction count sets the pace of a numerator step, skip the check (num_fb 8 % faster).
+  int watch_nan;
 };
 
 size_t num_fb_lds_bytes(int H, int K, int D);

@@ -109,6 +109,16 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
   if (own) be = idx[h0];
   XRow<LD ? LD : kFbNT, VEC, XCH> xq;
   const int xt = LD ? tid - kFbNT : tid;            // this thread's index among the threads that stage rows
+  // a row, clamped, into LDS; NaNs kept only where nobody else watches for them (NumArgs::watch_nan)
+  const bool watch_nan = a.watch_nan != 0;
+  auto stage = [&](auto& xr, float* lds, const float* row, int t) {
+    if constexpr (XCH > 0) {
+      if (watch_nan) xr.store(lds, row, D, t, kXClamp);
+      else xr.template store_mode<kXClamp>(lds, D, t);
+    } else {
+      xr.store(lds, row, D, t, kXClamp);
+    }
+  };
   {
     const float* xrow = xseq + (size_t)(fwd ? 0 : L - 1) * D;
     if (!LD || tid >= kFbNT) xq.load(xrow, D, xt);
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
         const double v = (double)(fwd ? a.initial : a.final_)[g * H + h];
         va[h] = v; rows[(size_t)(fwd ? 0 : L) * H + h] = v;
       }
-    if (!LD || tid >= kFbNT) xq.store(xr0, xrow, D, xt, kXClamp);
+    if (!LD || tid >= kFbNT) stage(xq, xr0, xrow, xt);
   }
   __syncthreads();
   if constexpr (LD > 0) {
@@ -131,11 +141,11 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
       xq.load_row(xbuf, row_of_step(2), D, xt);
       for (int s = 1; s <= L; s += 2) {
         xq2.load_row(xbuf, row_of_step(s + 2), D, xt);
-        xq.store(xr1, nullptr, D, xt, kXClamp);      // row of step s+1
+        stage(xq, xr1, nullptr, xt);                 // row of step s+1
         __syncthreads();
         if (s + 1 <= L) {
           xq.load_row(xbuf, row_of_step(s + 3), D, xt);
-          xq2.store(xr0, nullptr, D, xt, kXClamp);   // row of step s+2
+          stage(xq2, xr0, nullptr, xt);              // row of step s+2
           __syncthreads();
         }
       }
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
           frow[k] = (float)(vin[w.pk & 0xffffu] + ((double)w.lp + (double)xcur[w.pk >> 16]) - v);
         }
     }
-    if (!LD && have_next) xq.store(xnext, xrow_next, D, tid, kXClamp);
+    if (!LD && have_next) stage(xq, xnext, xrow_next, tid);
     __syncthreads();
   }
   if (!fwd) return;
