@@ -6,6 +6,11 @@ README.md:9), on synthetic data: a small TDNN -> ChainLoss -> AdamW, one process
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \\
         examples/train_tdnn.py --steps 30                                     # 8 GPUs, RCCL over xGMI
 
+`--backend gloo --device cpu --loss-cls module:Class` runs the same wiring (DistributedDataParallel around the
+model, ShardedChainLoss, optimizer step) without a GPU, with the per-rank loss evaluated by a stand-in the CALLER
+names: the HIP loss has no CPU form, and this example does not know one (tests/test_parallel.py passes its
+oracle-backed test class).
+
 Data parallelism as DESIGN.md §6 describes it: every rank owns its utterances, the loss kernels run
 on the local shard only, DDP all-reduces the PARAMETER gradients, and the only LF-MMI-specific
 collective is the 3-float all-reduce of ShardedChainLoss (global loss value / frame normaliser).
@@ -50,27 +55,44 @@ def main():
     ap.add_argument("--arcs", type=int, default=3000)
     ap.add_argument("--feat-dim", type=int, default=40)
     ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--max-num-states", type=int, default=80)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" is RCCL on ROCm')
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
+    ap.add_argument("--loss-cls", default=None,
+                    help="module:Class of a ChainLoss(den_graph, leaky, avg=False) stand-in for the per-rank loss")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.device == "cuda":
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.device == "cuda":
+            dist.init_process_group(args.backend, device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    loss_cls = None
+    if args.loss_cls:
+        import importlib
+        mod, _, attr = args.loss_cls.partition(":")
+        loss_cls = getattr(importlib.import_module(mod), attr)
 
     torch.manual_seed(0)
-    model = TDNN(args.feat_dim, 256, args.pdfs).to(dev)
+    model = TDNN(args.feat_dim, args.hidden, args.pdfs).to(dev)
     if world > 1:
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank] if args.device == "cuda" else None)
     opt = torch.optim.AdamW(model.parameters(), lr=args.lr)
     den_graph = syn.make_den_graph(args.states, args.arcs, args.pdfs, seed=0)      # the shared "phone LM"
-    criterion = ShardedChainLoss(den_graph, leaky_coefficient=1e-5, avg=True)
+    criterion = ShardedChainLoss(den_graph, leaky_coefficient=1e-5, avg=True, loss_cls=loss_cls)
 
     # a fixed synthetic training set per rank: features correlated with the numerator alignment
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
     lengths = syn.make_lengths(args.batch, args.frames, "ragged", seed=7 + rank)
-    num_graphs = syn.make_num_graphs(lengths.tolist(), args.pdfs, seed=500 + 1000 * rank, max_states=80)
+    num_graphs = syn.make_num_graphs(lengths.tolist(), args.pdfs, seed=500 + 1000 * rank, max_states=args.max_num_states)
     feats = torch.randn(args.batch, args.frames, args.feat_dim, generator=gen, device=dev)
     first = last = None
     for step in range(args.steps):
@@ -84,8 +106,11 @@ def main():
         last = float(loss)
         if rank == 0 and (step % 5 == 0 or step == args.steps - 1):
             print("step %3d  LF-MMI loss per frame %.4f" % (step, last), flush=True)
+    # the loss value is the GLOBAL one on every rank (ShardedChainLoss: one 3-float all-reduce per step)
+    print("rank %d of %d: global loss %.6f -> %.6f" % (rank, world, first, last), flush=True)
     if rank == 0:
-        print("loss %.4f -> %.4f over %d steps on %d GPU(s)" % (first, last, args.steps, world))
+        print("loss %.4f -> %.4f over %d steps on %d %s" % (first, last, args.steps, world,
+                                                             "GPU(s)" if args.device == "cuda" else "CPU rank(s)"))
         assert last < first, "the loss did not go down"
     if world > 1:
         dist.destroy_process_group()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 8
+#define PYCHAIN_HIP_ABI_VERSION 9
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -72,18 +72,38 @@ void        pychain_hip_set_den_phase_mask(int mask);
  * pass of their own, two barriers per frame); 1 (default) = as den_recursion_lazy_kernel wherever the
  * shape allows.  Both forms must agree to rounding; the tests compare them. */
 void        pychain_hip_set_den_lazy(int on);
-/* 1 if a denominator call with this plan hint (pychain_hip_den_plan_info: info[4]) and these sizes runs its
- * recursions as den_recursion_lazy_kernel, 0 if as den_recursion_kernel (measurement tools label by it). */
-int         pychain_hip_den_recursion_is_lazy(int resident_slot_rows, int H, int D);
-/* Test / tuning options (process-wide; nothing on the call path reads the environment).  value NULL or ""
- * clears.  Names: "den_segments" (n time segments of the denominator, 1 = no overlap), "den_bounds"
- * ("0.7,0.85": their ends as fractions of T), "den_relaunch" (one recursion launch per segment instead of
- * progress counters + gate kernels), "no_fold" (numerator accumulated into the stored gradient instead of
- * folded into the occupancy launch), "gamma16" (one-frame occupancy kernel), "num_no_staging_waves", "den_pair"
- * ("1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of the CU
- * count in sequences on, i.e. B >= 96 on 256 CUs - results are bit-identical to den_recursion_kernel's).
- * Every combination gives the same results to rounding (the tests compare them); unknown name: EINVAL. */
+/* Which kernels a denominator call with this plan hint (pychain_hip_den_plan_info: info[4]), these sizes and the
+ * calling thread's current options would launch: "recursion,occupancy" into buf, e.g.
+ * "den_recursion_lazy_kernel,den_gamma2_kernel".  Recursion: den_recursion_lazy_kernel (16 waves, D <= 4096),
+ * den_recursion_lazy_kernel<wide> (8 waves, D <= 9216), den_recursion_pair_kernel (two sequences per workgroup,
+ * shared plan, B >= 3/8 of the CU count), den_recursion_kernel (everything else).  Measurement tools and the
+ * kernel-selection test label by it.  plans_shared = 1: one plan for all sequences (plan stride 0). */
+int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states, int num_pdfs, int B, int plans_shared,
+                                         char* buf, size_t buf_bytes);
+/* Settings.  A call reads them ONCE when it starts (process-wide defaults overlaid with the calling thread's
+ * overrides), so another thread changing one cannot tear a call in flight, and nothing on the call path reads the
+ * environment.  pychain_hip_set_option sets the process-wide default (value NULL or "" clears it);
+ * pychain_hip_set_thread_option overrides it for the calling host thread only (value NULL removes the override,
+ * "" = unset for this thread); pychain_hip_get_option copies the value in effect for the calling thread into buf and
+ * returns its length (0 = unset).  pychain_hip_set_verbose_level / _set_den_phase_mask / _set_den_lazy are the
+ * process-wide "verbose" / "den_phase_mask" / "den_lazy".  Names:
+ *   "verbose" (base.h:34-42), "den_phase_mask", "den_lazy",
+ *   "den_segments" (n time segments of the denominator, 1 = no overlap), "den_bounds" ("0.7,0.85": their ends as
+ *   fractions of T), "den_relaunch" (one recursion launch per segment instead of progress counters + gate kernels),
+ *   "no_fold" (numerator accumulated into the stored gradient instead of folded into the occupancy launch),
+ *   "gamma16" (one-frame occupancy kernel), "num_no_staging_waves",
+ *   "den_pair" ("1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of
+ *   the CU count in sequences on, i.e. B >= 96 on 256 CUs - results are bit-identical to den_recursion_kernel's),
+ *   "den_wide" ("1": the 8-wave lazy recursion wherever the shape allows, "0": never; default: where the 16-wave one
+ *   does not fit, i.e. 4096 < D <= 9216), "gamma_tiled", "force_general" (the streamed general kernels even where a
+ *   fast one fits),
+ *   "debug_corrupt_row" ("den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the
+ *   recursions and the occupancy pass, so that the 5 % invariant of chain-computation.cc:363-390 /
+ *   chain-log-domain-computation.cc:289-303 can be seen to fire: `ok` false at t = 0, at any t at verbose >= 1).
+ * Every combination but the last gives the same results to rounding (the tests compare them); unknown name: EINVAL. */
 int         pychain_hip_set_option(const char* name, const char* value);
+int         pychain_hip_set_thread_option(const char* name, const char* value);
+int         pychain_hip_get_option(const char* name, char* buf, size_t buf_bytes);
 
 /* ------------------------------------------------------------------------
  * Denominator graph plan  (host side, no GPU work).
@@ -122,7 +142,9 @@ int64_t pychain_hip_den_plan_build(
  *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers), three
  *           10-bit fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
  *           and for 8 waves (20-29); combine several plans by taking the max of each field
+ *           bit 30: every recursion wave owns few enough row groups for the lazy-normalisation recursions
  *   info[5..7] reserved (0)
+ * A blob whose payload does not match the checksum in its header (a damaged or foreign cache file) is EINVAL.
  */
 int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]);
 

@@ -6,10 +6,11 @@ touches the CPU checker.
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -24,8 +25,10 @@ _SIGNATURES = {
     "pychain_hip_get_verbose_level": (_i, []),
     "pychain_hip_set_den_phase_mask": (None, [_i]),
     "pychain_hip_set_den_lazy": (None, [_i]),
-    "pychain_hip_den_recursion_is_lazy": (_i, [_i, _i, _i]),
+    "pychain_hip_den_kernel_names": (_i, [_i, _i, _i, _i, _i, ctypes.c_char_p, _sz]),
     "pychain_hip_set_option": (_i, [ctypes.c_char_p, ctypes.c_char_p]),
+    "pychain_hip_set_thread_option": (_i, [ctypes.c_char_p, ctypes.c_char_p]),
+    "pychain_hip_get_option": (_i, [ctypes.c_char_p, ctypes.c_char_p, _sz]),
     "pychain_hip_debug_launch_map": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i]),
     "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -82,23 +85,53 @@ def lib():
     return _lib
 
 
-OPTIONS = ("den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves", "den_pair")
+OPTIONS = ("den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves", "den_pair",
+           "den_wide", "gamma_tiled", "force_general", "verbose", "den_phase_mask", "den_lazy", "debug_corrupt_row")
+
+_thread_values = threading.local()       # what this thread's overrides currently are (for restoring)
+
+
+def get_option(name):
+    """The value of a library option in effect for the calling thread (None = unset)."""
+    buf = ctypes.create_string_buffer(256)
+    n = check(lib().pychain_hip_get_option(name.encode(), buf, 256), "pychain_hip_get_option")
+    return buf.value.decode() if n > 0 else None
 
 
 class option(object):
-    """`with _lib.option("den_segments", 3): ...` - a test / tuning option of the library for the duration
-    of a block (include/pychain_hip.h: pychain_hip_set_option)."""
+    """`with _lib.option("den_segments", 3): ...` - a test / tuning option of the library for the duration of a
+    block, FOR THE CALLING THREAD ONLY (include/pychain_hip.h: pychain_hip_set_thread_option); the previous
+    override - or the process-wide default, e.g. one taken from PYCHAIN_<NAME> at load time - is back afterwards."""
 
     def __init__(self, name, value=1):
         self.name, self.value = name, value
 
     def __enter__(self):
-        check(lib().pychain_hip_set_option(self.name.encode(), str(self.value).encode()), "pychain_hip_set_option")
+        d = _thread_values.__dict__.setdefault("v", {})
+        self.prev = d.get(self.name)
+        d[self.name] = str(self.value)
+        check(lib().pychain_hip_set_thread_option(self.name.encode(), str(self.value).encode()),
+              "pychain_hip_set_thread_option")
         return self
 
     def __exit__(self, *exc):
-        lib().pychain_hip_set_option(self.name.encode(), None)
+        d = _thread_values.__dict__.setdefault("v", {})
+        if self.prev is None:
+            d.pop(self.name, None)
+            lib().pychain_hip_set_thread_option(self.name.encode(), None)
+        else:
+            d[self.name] = self.prev
+            lib().pychain_hip_set_thread_option(self.name.encode(), self.prev.encode())
         return False
+
+
+def den_kernel_names(slot_rows, num_states, num_pdfs, batch, plans_shared=True):
+    """("recursion kernel", "occupancy kernel") a denominator call of this shape would launch."""
+    buf = ctypes.create_string_buffer(128)
+    check(lib().pychain_hip_den_kernel_names(int(slot_rows), int(num_states), int(num_pdfs), int(batch),
+                                             int(bool(plans_shared)), buf, 128), "pychain_hip_den_kernel_names")
+    rec, occ = buf.value.decode().split(",")
+    return rec, occ
 
 
 class PychainHipError(RuntimeError):

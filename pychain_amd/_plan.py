@@ -55,6 +55,7 @@ def build_plan_blob(forward_transitions, forward_transition_indices, forward_tra
                 info = np.zeros(8, dtype=np.int32)
                 rc = L.pychain_hip_den_plan_info(blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes,
                                                  info.ctypes.data_as(ctypes.c_void_p))
+                # (plan_info also verifies the checksum of the payload behind the header)
                 if rc == 0 and (int(info[0]), int(info[1]), int(info[2]), int(info[3])) == (H, K, int(num_pdfs), blob.nbytes):
                     return blob
         except (OSError, ValueError):
@@ -66,7 +67,7 @@ def build_plan_blob(forward_transitions, forward_transition_indices, forward_tra
                "den_plan_build")
     if path is not None:
         try:
-            os.makedirs(cdir, exist_ok=True)
+            os.makedirs(cdir, mode=0o700, exist_ok=True)
             fd, tmp = tempfile.mkstemp(dir=cdir, suffix=".tmp")
             with os.fdopen(fd, "wb") as f:
                 f.write(blob.tobytes())
@@ -87,9 +88,10 @@ def plan_info(blob):
 # ---- on-disk cache of compiled plans -------------------------------------------------------------
 # Compiling the C3 graph takes ~5 s (slot-order annealing); N ranks of a data-parallel job and every
 # restart would each pay it.  A plan is a pure function of the nine graph tensors, the pdf count, the plan
-# format version and the compiler knobs, so it is stored under a hash of exactly those
-# ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans; "0" / "off" disables).  Writes are
-# atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.
+# format version, the compiler knobs and the library build, so it is stored under a hash of exactly those
+# ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans, created 0700; "0" / "off" disables).  Writes are
+# atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.  A file is only
+# believed if its header matches the request AND its payload matches the checksum in the header.
 _KNOBS = ("PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT")
 
 
@@ -100,9 +102,26 @@ def _cache_dir():
     return d or os.path.join(os.path.expanduser("~"), ".cache", "pychain_amd", "plans")
 
 
+_BUILD_ID = None
+
+
+def _build_id():
+    """sha256 of the library file: a rebuilt plan compiler (other annealing, other slack rules) must not be served
+    plans its predecessor wrote, whether or not somebody remembered to bump PLAN_VERSION."""
+    global _BUILD_ID
+    if _BUILD_ID is None:
+        h = hashlib.sha256()
+        with open(_lib.LIB_PATH, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        _BUILD_ID = h.hexdigest()[:24]
+    return _BUILD_ID
+
+
 def _plan_key(arrays, num_pdfs):
     h = hashlib.sha256()
-    h.update(b"pychain_amd plan v%d abi %d pdfs %d" % (_plan_format_version(), _lib.ABI_VERSION, int(num_pdfs)))
+    h.update(b"pychain_amd plan v%d abi %d pdfs %d build %s" % (_plan_format_version(), _lib.ABI_VERSION, int(num_pdfs),
+                                                                 _build_id().encode()))
     for k in _KNOBS:
         h.update(("%s=%s;" % (k, os.environ.get(k, ""))).encode())
     for a in arrays:

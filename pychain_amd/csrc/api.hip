@@ -17,50 +17,130 @@
 #include "plan_format.h"
 
 namespace pychain_hip {
-int g_verbose_level = 0;
-int g_den_phase_mask = 3;
-int g_den_lazy = 1;            // test hook: 0 = never run the lazy-normalisation recursion
 char* last_error_buffer() {
   static thread_local char buf[512] = "";
   return buf;
 }
 namespace {
+// ---- settings: process-wide defaults + per-thread overrides, snapshotted per call (common.h:CallKnobs) ----------
 std::mutex g_option_lock;
-std::map<std::string, std::string>& option_table() { static std::map<std::string, std::string> t; return t; }
-}  // namespace
-const char* option(const char* name) {
-  std::lock_guard<std::mutex> guard(g_option_lock);
-  auto it = option_table().find(name);
-  return it == option_table().end() ? nullptr : it->second.c_str();   // (values are only replaced by set_option: test threads)
+typedef std::map<std::string, std::string> OptionTable;
+OptionTable& process_options() { static OptionTable t; return t; }
+OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
+const char* const kKnownOptions[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves",
+                                     "den_pair", "den_wide", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
+                                     "den_lazy", "debug_corrupt_row"};
+bool known_option(const char* name) {
+  if (!name) return false;
+  for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
+  return false;
 }
-namespace {
+// effective value of one option as a COPY (the tables may change under another thread's set_option)
+bool option_value(const char* name, std::string* out) {
+  const OptionTable& th = thread_options();
+  auto it = th.find(name);
+  if (it != th.end()) { if (it->second.empty()) return false; *out = it->second; return true; }
+  std::lock_guard<std::mutex> guard(g_option_lock);
+  const OptionTable& pr = process_options();
+  auto ip = pr.find(name);
+  if (ip == pr.end()) return false;
+  *out = ip->second;
+  return true;
+}
+int option_int(const char* name, int dflt) {
+  std::string v;
+  return option_value(name, &v) ? atoi(v.c_str()) : dflt;
+}
+bool option_set(const char* name) { std::string v; return option_value(name, &v); }
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 int roundup64(int x) { return (x + 63) / 64 * 64; }
 }  // namespace
+
+CallKnobs call_knobs() {
+  CallKnobs k;
+  memset(&k, 0, sizeof(k));
+  k.verbose = option_int("verbose", 0);
+  k.den_phase_mask = option_int("den_phase_mask", 3) & 3;
+  k.den_lazy = option_int("den_lazy", 1) ? 1 : 0;
+  k.den_segments = option_int("den_segments", 0);
+  k.den_relaunch = option_set("den_relaunch");
+  k.no_fold = option_set("no_fold");
+  k.gamma16 = option_set("gamma16");
+  k.num_no_staging_waves = option_set("num_no_staging_waves");
+  k.den_pair = option_int("den_pair", -1);
+  k.den_wide = option_int("den_wide", -1);
+  k.gamma_tiled = option_int("gamma_tiled", -1);
+  k.force_general = option_int("force_general", 0) ? 1 : 0;
+  std::string v;
+  if (option_value("den_bounds", &v)) {       // "0.7,0.85" = ends of all segments but the last, as fractions of T
+    for (const char* p = v.c_str(); *p && k.nbounds < 16;) {
+      char* q; const double f = strtod(p, &q);
+      if (q == p) break;
+      k.bounds[k.nbounds++] = f;
+      p = *q == ',' ? q + 1 : q;
+    }
+  }
+  if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
+    char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
+    if (sscanf(v.c_str(), "%3[a-z],%d,%d,%f", what, &b, &t, &sc) == 4 && b >= 0 && t >= 0) {
+      k.corrupt_what = strcmp(what, "den") == 0 ? 1 : (strcmp(what, "num") == 0 ? 2 : 0);
+      k.corrupt_b = b; k.corrupt_t = t; k.corrupt_scale = sc;
+    }
+  }
+  return k;
+}
 }  // namespace pychain_hip
 
 using namespace pychain_hip;
 
 extern "C" int pychain_hip_abi_version(void) { return PYCHAIN_HIP_ABI_VERSION; }
 extern "C" const char* pychain_hip_last_error(void) { return last_error_buffer(); }
-extern "C" void pychain_hip_set_verbose_level(int level) { g_verbose_level = level; }
-extern "C" int pychain_hip_get_verbose_level(void) { return g_verbose_level; }
-extern "C" void pychain_hip_set_den_phase_mask(int mask) { g_den_phase_mask = mask & 3; }
-extern "C" void pychain_hip_set_den_lazy(int on) { g_den_lazy = on ? 1 : 0; }
-extern "C" int pychain_hip_den_recursion_is_lazy(int resident_slot_rows, int H, int D) {
+extern "C" int pychain_hip_set_option(const char* name, const char* value) {
+  if (!known_option(name)) return fail(PYCHAIN_HIP_EINVAL, "set_option: unknown option '%s'", name ? name : "(null)");
+  std::lock_guard<std::mutex> guard(g_option_lock);
+  if (value && *value) process_options()[name] = value; else process_options().erase(name);
+  return PYCHAIN_HIP_OK;
+}
+extern "C" int pychain_hip_set_thread_option(const char* name, const char* value) {
+  if (!known_option(name)) return fail(PYCHAIN_HIP_EINVAL, "set_thread_option: unknown option '%s'", name ? name : "(null)");
+  if (value) thread_options()[name] = value; else thread_options().erase(name);
+  return PYCHAIN_HIP_OK;
+}
+extern "C" int pychain_hip_get_option(const char* name, char* buf, size_t buf_bytes) {
+  if (!known_option(name)) return fail(PYCHAIN_HIP_EINVAL, "get_option: unknown option '%s'", name ? name : "(null)");
+  std::string v;
+  if (!option_value(name, &v)) return 0;
+  if (buf && buf_bytes > 0) { strncpy(buf, v.c_str(), buf_bytes - 1); buf[buf_bytes - 1] = 0; }
+  return (int)v.size();
+}
+static void set_process_int(const char* name, int v) {
+  char s[32];
+  snprintf(s, sizeof(s), "%d", v);
+  pychain_hip_set_option(name, s);
+}
+extern "C" void pychain_hip_set_verbose_level(int level) { set_process_int("verbose", level); }
+extern "C" int pychain_hip_get_verbose_level(void) { return call_knobs().verbose; }
+extern "C" void pychain_hip_set_den_phase_mask(int mask) { set_process_int("den_phase_mask", mask & 3); }
+extern "C" void pychain_hip_set_den_lazy(int on) { set_process_int("den_lazy", on ? 1 : 0); }
+
+namespace {
+bool den_call_is_pair(const DenArgs& a, int resident_slot_rows);
+bool den_call_is_wide(const DenArgs& a, int resident_slot_rows);
+bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows);
+}  // namespace
+extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D, int B, int plans_shared,
+                                            char* buf, size_t buf_bytes) {
+  if (!buf || buf_bytes == 0 || H <= 0 || D <= 0 || B <= 0) return fail(PYCHAIN_HIP_EINVAL, "den_kernel_names: bad arguments");
   DenArgs a;
   memset(&a, 0, sizeof(a));
-  a.H = H; a.Hp = roundup64(H); a.D = D;
-  return (g_den_lazy && !option("den_relaunch") && den_lazy_eligible(a, resident_slot_rows)) ? 1 : 0;
-}
-extern "C" int pychain_hip_set_option(const char* name, const char* value) {
-  static const char* const known[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves", "den_pair"};
-  if (!name) return fail(PYCHAIN_HIP_EINVAL, "set_option: null name");
-  bool ok = false;
-  for (const char* k : known) ok = ok || strcmp(k, name) == 0;
-  if (!ok) return fail(PYCHAIN_HIP_EINVAL, "set_option: unknown option '%s'", name);
-  std::lock_guard<std::mutex> guard(g_option_lock);
-  if (value && *value) option_table()[name] = value; else option_table().erase(name);
+  a.knobs = call_knobs();
+  a.H = H; a.Hp = roundup64(H); a.D = D; a.B = B; a.frames_per_block = 32;
+  a.plan_stride = plans_shared ? 0 : 256;
+  a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
+  a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
+  a.wide = a.lazy && den_call_is_wide(a, resident_slot_rows) ? 1 : 0;
+  snprintf(buf, buf_bytes, "%s,%s", den_recursion_kernel_name(a, resident_slot_rows),
+           den_occupancy_kernel_name(a, (D + 63) / 64, resident_slot_rows));
   return PYCHAIN_HIP_OK;
 }
 
@@ -68,8 +148,13 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (!host_blob || !info || blob_bytes < sizeof(PlanHeader))
     return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: null or truncated blob");
   const PlanHeader* hd = (const PlanHeader*)host_blob;
-  if (hd->magic != PLAN_MAGIC || hd->version != PLAN_VERSION || (size_t)hd->total_bytes > blob_bytes)
+  if (hd->magic != PLAN_MAGIC || hd->version != PLAN_VERSION || (size_t)hd->total_bytes > blob_bytes ||
+      (size_t)hd->total_bytes < sizeof(PlanHeader))
     return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: not a plan of this library version");
+  // the kernels follow the blob's offsets, wave tables and packed LDS addresses unchecked: a blob that comes back from a
+  // file (the on-disk plan cache) must be the bytes pychain_hip_den_plan_build wrote
+  if ((int32_t)plan_payload_hash(host_blob, (size_t)hd->total_bytes) != hd->payload_hash)
+    return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: plan payload does not match its checksum (corrupted or foreign file)");
   memset(info, 0, 8 * sizeof(int32_t));
   info[0] = hd->H; info[1] = hd->K; info[2] = hd->D; info[3] = hd->total_bytes;
   int m = hd->alpha.max_wave_slot_rows;
@@ -123,7 +208,8 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H);
   a.input_is_exp = input_is_exp ? 1 : 0;
   a.frames_per_block = 32;      // measured at C3: 16 and 64 are both 1-3 % slower
-  a.phase_mask = g_den_phase_mask;
+  a.knobs = call_knobs();
+  a.phase_mask = a.knobs.den_phase_mask;
   a.coef = leaky_hmm_coefficient; a.grad_scale = grad_scale;
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_store = (float*)ws;
@@ -135,7 +221,7 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.gtot = (float*)((char*)a.tot_b + align256(4 * (size_t)B * (T + 2)));
   a.fin_dot = (float*)((char*)a.gtot + align256(4 * (size_t)B * T));
   a.lazy = 0;
-  a.check = 0; a.check_all = g_verbose_level >= 1 ? 1 : 0;
+  a.check = 0; a.check_all = a.knobs.verbose >= 1 ? 1 : 0;
   a.sig_n = 0;
   a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_seg = 0; a.gam_nseg = 0;
   return PYCHAIN_HIP_OK;
@@ -181,8 +267,9 @@ SideStream* side_streams_for(hipStream_t caller) {
 // Number of time segments the denominator is cut into so that the occupancy pass of the frames
 // whose alpha'/beta rows already exist runs on idle CUs WHILE the recursions continue
 // (2B persistent workgroups leave the other CUs free).  1 = no overlap.
-int den_segments(int T) {
-  if (const char* e = option("den_segments")) { int n = atoi(e); if (n >= 1 && n <= kMaxSegments) return n; }
+int den_segments(const DenArgs& a) {
+  const int T = a.T;
+  if (a.knobs.den_segments >= 1 && a.knobs.den_segments <= kMaxSegments) return a.knobs.den_segments;
   // What limits the overlap is CU time: after T/2 the occupancy pass has the ~128 idle CUs only (less the
   // numerator's), on which its ~1 ms of whole-chip work takes longer than the rest of the recursion, so
   // the last launch (the frames that only become computable at the very end) is exposed.  Each further
@@ -215,14 +302,30 @@ int device_cu_count() {
   return cus[dev] = n;
 }
 bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
-  if (option("den_relaunch") || !den_pair_eligible(a, resident_slot_rows)) return false;
-  if (const char* o = option("den_pair")) return atoi(o) != 0;
+  if (a.knobs.den_relaunch || !den_pair_eligible(a, resident_slot_rows)) return false;
+  if (a.knobs.den_pair >= 0) return a.knobs.den_pair != 0;
   // measured on the C3 graph (tools/time_step.py B 1500): B = 96 +3.5 %, B = 128 +27 %, B = 256 +13 %; below 3/4 of the
   // CUs the one-sequence workgroups leave enough of the chip to the occupancy launches and their chain is shorter
   return 8 * a.B >= 3 * device_cu_count();
 }
+// the 8-wave shape of the lazy recursion: where the 16-wave shape does not fit (D > 4096); option den_wide: "1" wherever
+// the shape allows (measurements, tests), "0" never
+bool den_call_is_wide(const DenArgs& a, int resident_slot_rows) {
+  if (!den_wide_eligible(a, resident_slot_rows) || a.knobs.den_wide == 0) return false;
+  return a.knobs.den_wide > 0 || !den_lazy_eligible(a, resident_slot_rows);
+}
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
-  return g_den_lazy && !option("den_relaunch") && den_lazy_eligible(a, resident_slot_rows) && !den_call_is_pair(a, resident_slot_rows);
+  return a.knobs.den_lazy && !a.knobs.den_relaunch && !den_call_is_pair(a, resident_slot_rows) &&
+         (den_lazy_eligible(a, resident_slot_rows) || den_call_is_wide(a, resident_slot_rows));
+}
+
+// option debug_corrupt_row: row[0..n) *= scale, between the recursion and the occupancy launches
+__global__ void scale_row_kernel(float* row, int n, float scale) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) row[i] *= scale;
+}
+hipError_t launch_scale_row(float* row, int n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(scale_row_kernel, dim3(1), dim3(256), 0, st, row, n, scale);
+  return hipGetLastError();
 }
 
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
@@ -231,9 +334,12 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
                             hipEvent_t gamma_wait) {
   const int gmax = (a.D + 63) / 64;
   const int user_mask = a.phase_mask;
-  const int nseg = (occupancy && user_mask == 3 && !a.check_all) ? den_segments(a.T) : 1;
+  // (a corrupted row - option debug_corrupt_row - is written between the recursion and the occupancy launches: no overlap)
+  const bool corrupt = a.knobs.corrupt_what == 1 && a.knobs.corrupt_b < a.B && a.knobs.corrupt_t < a.T;
+  const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt) ? den_segments(a) : 1;
   // the lazy-normalisation recursion runs a whole sequence in one launch: not with the relaunch schedule
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
+  a.wide = a.lazy && den_call_is_wide(a, resident_slot_rows) ? 1 : 0;
   // two sequences per workgroup once the 2B one-sequence workgroups would fill the chip (option den_pair: 1 always
   // where the shape allows, 0 never); rows in den_recursion_kernel's form
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
@@ -242,10 +348,12 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   hipError_t e = hipSuccess;
   if (nseg <= 1) {
     const int mask = occupancy ? user_mask : (user_mask & 1);
-    if (gamma_wait && (mask & 2)) {
+    if ((gamma_wait || corrupt) && (mask & 2)) {
       a.phase_mask = mask & 1;
       if (a.phase_mask) e = launch_den(a, gmax, resident_slot_rows, st, why);
-      if (e == hipSuccess) e = hipStreamWaitEvent(st, gamma_wait, 0);
+      if (e == hipSuccess && corrupt && a.phase_mask)
+        e = launch_scale_row(a.alpha_store + ((size_t)a.knobs.corrupt_b * a.T + a.knobs.corrupt_t) * a.Hp, a.Hp, a.knobs.corrupt_scale, st);
+      if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(st, gamma_wait, 0);
       a.phase_mask = 2;
       if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
     } else {
@@ -264,16 +372,9 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     const double frac = s == nseg - 1 ? 1.0 : 1.0 - 1.0 / (double)(2 << s);
     a.seg_bound[s] = s == nseg - 1 ? a.T : ((int)(frac * a.T) + 31) / 32 * 32;
   }
-  if (const char* e = option("den_bounds")) {   // experiment: "0.7,0.85" = ends of all segments but the last, as fractions of T
-    int s = 0;
-    for (const char* p = e; *p && s < nseg - 1; s++) {
-      char* q; const double f = strtod(p, &q);
-      if (q == p) break;
-      a.seg_bound[s] = std::min(a.T, ((int)(std::max(f, 0.5) * a.T) + 31) / 32 * 32);   // nothing is computable before T/2
-      p = *q == ',' ? q + 1 : q;
-    }
-  }
-  if (!option("den_relaunch")) {
+  for (int s = 0; s < a.knobs.nbounds && s < nseg - 1; s++)   // option den_bounds: ends of all segments but the last, as fractions of T
+    a.seg_bound[s] = std::min(a.T, ((int)(std::max(a.knobs.bounds[s], 0.5) * a.T) + 31) / 32 * 32);   // nothing is computable before T/2
+  if (!a.knobs.den_relaunch) {
     // Gated schedule: ONE recursion launch; its workgroups count themselves into progress[s] when their
     // steps below seg_bound[s] are done, and a one-wave gate kernel in front of occupancy launch s (side
     // stream) waits for all 2B of them.  No relaunch of the persistent workgroups at the segment ends.
@@ -405,7 +506,12 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
   a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
   a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 32;
-  a.check_all = g_verbose_level >= 1 ? 1 : 0;
+  const CallKnobs knobs = call_knobs();
+  a.check_all = knobs.verbose >= 1 ? 1 : 0;
+  a.no_staging_waves = knobs.num_no_staging_waves;
+  if (knobs.corrupt_what == 2 && knobs.corrupt_b < B && knobs.corrupt_t < T) {
+    a.corrupt_b = knobs.corrupt_b; a.corrupt_t = knobs.corrupt_t; a.corrupt_log = logf(knobs.corrupt_scale);
+  } else a.corrupt_b = -1;
   a.watch_nan = 1;                                   // (the fused loss clears it: NumArgs::watch_nan)
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_ws = (double*)(ws + c.alpha); a.beta_ws = (double*)(ws + c.beta); a.logp_ws = (double*)(ws + c.logp);
@@ -439,6 +545,7 @@ extern "C" int pychain_hip_num_forward_backward(
     return fail(PYCHAIN_HIP_ELAUNCH, "num_forward_backward: hipMemsetAsync failed");
   const char* why = nullptr;
   hipError_t e = launch_num_fb(a, st, &why);
+  if (e == hipSuccess && a.corrupt_b >= 0) e = launch_num_corrupt(a, st);
   if (e == hipSuccess) e = launch_num_occ(a, false, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "num_forward_backward: %s",
@@ -476,7 +583,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
-  const bool no_fold = option("no_fold") != nullptr;                      // test / tuning option
+  const bool no_fold = da.knobs.no_fold != 0;                             // test / tuning option
   const bool fold = grad && !no_fold && den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
   if (fold) {
     da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
@@ -487,6 +594,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
   if (e == hipSuccess && grad) e = launch_num_prep(na, side->stream, &why);
   if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
+  if (e == hipSuccess && na.corrupt_b >= 0) e = launch_num_corrupt(na, side->stream);
   if (e == hipSuccess && grad) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
   da.phase_mask = 3;
@@ -540,6 +648,7 @@ int chain_loss_backward_impl(
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
   da.lazy = den_call_is_lazy(da, resident_slot_rows) ? 1 : 0;
+  da.wide = da.lazy && den_call_is_wide(da, resident_slot_rows) ? 1 : 0;
   NumArgs na;
   // the occupancy launch reads only the forward transitions / indices / log-probs of the graphs
   rc = fill_num_args(na, ft, fi, fp, ft, fi, fp, fp, fp,

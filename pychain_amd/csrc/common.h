@@ -1,4 +1,4 @@
-// common.h - error reporting shared by the host-side translation units.
+// common.h - error reporting and per-call knobs shared by the host-side translation units.
 #ifndef PYCHAIN_HIP_COMMON_H_
 #define PYCHAIN_HIP_COMMON_H_
 
@@ -8,11 +8,33 @@
 namespace pychain_hip {
 
 char* last_error_buffer();          // thread-local, 512 bytes (api.hip)
-extern int g_verbose_level;
 
-// Test / tuning options set through pychain_hip_set_option (api.hip); nullptr = not set.  Nothing on the call
-// path reads the environment.
-const char* option(const char* name);
+// Everything a call takes from the library's settings, read ONCE when the call starts (api.hip:call_knobs):
+// the process-wide defaults (pychain_hip_set_option, pychain_hip_set_verbose_level, ...) overlaid with the
+// calling thread's overrides (pychain_hip_set_thread_option).  The launch code and the kernels see only this
+// snapshot - a second host thread that changes a setting while a call is being enqueued cannot tear it, and a
+// validation loop at verbose level 1 in one thread does not slow a training loop in another.
+// Nothing on the call path reads the environment.
+struct CallKnobs {
+  int verbose;                // reference's verbose level (base.h:34-42): >= 1 checks every frame
+  int den_phase_mask;         // bit 0 recursion launch, bit 1 occupancy launches (measurement aid)
+  int den_lazy;               // 0: never the lazy-normalisation recursions
+  int den_segments;           // 0 = automatic
+  int den_relaunch, no_fold, gamma16, num_no_staging_waves;
+  int den_pair;               // -1 automatic, 0 never, 1 wherever the shape allows
+  int den_wide;               // -1 automatic, 0 never, 1 wherever the shape allows (8-wave lazy recursion)
+  int gamma_tiled;            // -1 automatic, 0 never, 1 wherever the shape allows (two-frame occupancy kernel tiled over pdfs)
+  int force_general;          // 1: the streamed general kernels even where a fast one fits (tests)
+  int nbounds;
+  double bounds[16];          // den_bounds: segment ends as fractions of T
+  // debug_corrupt_row = "den|num,b,t,scale": one stored alpha row is scaled before the occupancy pass reads it,
+  // so that the reference's 5 % invariant (chain-computation.cc:363-390, chain-log-domain-computation.cc:289-303)
+  // can be seen to fire
+  int corrupt_what;           // 0 none, 1 denominator, 2 numerator
+  int corrupt_b, corrupt_t;
+  float corrupt_scale;
+};
+CallKnobs call_knobs();
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;

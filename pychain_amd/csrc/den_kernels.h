@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.h"
+
 namespace pychain_hip {
 
 struct DenArgs {
@@ -24,6 +26,8 @@ struct DenArgs {
   // 1: the recursions run as den_recursion_pair_kernel (den_pair.inc.h): two sequences per workgroup, ceil(B/2)
   // workgroups per direction; rows as den_recursion_kernel stores them (lazy = 0).  Shared plan only.
   int pair;
+  // 1: the lazy recursions run in their 8-wave shape (den_lazy.inc.h: LzWide - nnet-output rows of up to 9216 pdfs)
+  int wide;
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
   //     objf = sum_t log tot_a(t) + log fin_dot        (ComputeTotLogLike, chain-computation.cc:209-230)
@@ -64,11 +68,18 @@ struct DenArgs {
   const int32_t* fold_ucount;    // [B]
   int fold_K;
   float fold_scale;
+  CallKnobs knobs;               // this call's snapshot of the library settings (host side only)
 };
 
 // true if the recursion of this call runs as den_recursion_lazy_kernel (decided once per call; the occupancy
 // launches - also those of a later chain_loss_backward on the same workspace - must be told: DenArgs::lazy)
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows);
+// ... in its 8-wave shape (DenArgs::wide); checked before den_lazy_eligible, which is the 16-wave shape
+bool den_wide_eligible(const DenArgs& a, int resident_slot_rows);
+// names of the kernels launch_den would run for this call: recursion, occupancy (measurement tools and the
+// kernel-selection test label by them)
+const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows);
+const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
 // ... as den_recursion_pair_kernel (DenArgs::pair); den_pair_blocks: its grid = what a progress counter reaches
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows);
 int den_recursion_blocks(const DenArgs& a);

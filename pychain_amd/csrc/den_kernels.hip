@@ -136,6 +136,7 @@ struct ArcRegs {
 struct GroupRegs {
   int base, n;
   unsigned long long endmask;
+  uint32_t endmask2;        // ... slot-rows 64 .. 95 (the 8-wave recursion keeps up to 80)
   uint32_t chunkmask;       // bit c = chunk c of the resident slot-rows contains a group end
   int ngroups, nslots;      // of this wave
   int tail_g, tail_rem;     // group / slot-rows left in it when the streamed tail (slot-row R) starts
@@ -146,7 +147,7 @@ struct GroupRegs {
     const int first = __builtin_amdgcn_readfirstlane(we.first_group);
     base = 0; n = 0;
     if (lane < ngroups) { const GroupEntry e = gtab[first + lane]; base = e.out_base; n = e.nslots; }
-    endmask = 0ull; tail_g = 0; tail_rem = 0;
+    endmask = 0ull; endmask2 = 0u; tail_g = 0; tail_rem = 0;
     int cum = 0;
     bool tail_set = false;
     for (int gi = 0; gi < ngroups; gi++) {
@@ -155,11 +156,14 @@ struct GroupRegs {
         if (!tail_set && cum + cnt > R) { tail_g = gi; tail_rem = cum + cnt - (cum > R ? cum : R); tail_set = true; }
         cum += cnt;
         if (cum - 1 < R && cum - 1 < 64) endmask |= 1ull << (cum - 1);
+        else if (cum - 1 < R && cum - 1 < 96) endmask2 |= 1u << (cum - 1 - 64);
       }
     }
     chunkmask = 0u;
     for (int c = 0; c * PYCHAIN_CHUNK < 64; c++)
       if ((endmask >> (c * PYCHAIN_CHUNK)) & ((1ull << PYCHAIN_CHUNK) - 1ull)) chunkmask |= 1u << c;
+    for (int c = 0; c * PYCHAIN_CHUNK < 32; c++)
+      if ((endmask2 >> (c * PYCHAIN_CHUNK)) & ((1u << PYCHAIN_CHUNK) - 1u)) chunkmask |= 1u << (c + 64 / PYCHAIN_CHUNK);
   }
 };
 
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));   // < 2 GiB: checked at launch
 
   float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2);   // per-frame totals for den_finish_kernel (DenArgs::tot_a)
-  int bad = (fwd && a.seg_begin == 0 && seq_len_bad(a.lengths, b, a.T)) ? 1 : 0;
+  int bad = (fwd && a.seg_begin == 0 && seq_len_bad(a.lengths, b, a.T)) ? 1 : 0;   // bit 0 not ok, bit 1 a NaN network output (den_lazy.inc.h)
   float tot, wtot;
   XRow<kNT, VEC, XCH> xq;
   if (tid < 32) red[tid] = 0.f;
@@ -493,15 +497,15 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     {
       const int t0 = fwd ? 0 : L - 1;                 // first nnet-output row this side consumes
       xq.load(xseq + (size_t)t0 * D, D, tid);
-      if (fwd && xq.has_nan()) bad = 2;                // a NaN network output: not ok, NaN log-probability
-      xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+      if (fwd && xq.has_nan()) bad |= 2;               // a NaN network output: not ok, NaN log-probability
+      if (xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp) && fwd) bad |= 2;
     }
     __syncthreads();                                   // red zeroed
     if (lane == 0) { red[wave] = p0; red[16 + wave] = p1; }
     __syncthreads();
     tot = block_total(red, lane); wtot = block_total(red + 16, lane);
     const float inv = __builtin_amdgcn_rcpf(tot);
-    if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;
+    if (!(tot > 0.f) || !(inv > 0.f)) bad |= 1;
     if (tid == 0) totv[fwd ? 0 : L] = tot;
     normalise_row(fwd, raw, lk, cur, sbuf, (fwd ? 0 : L) * Hp * 4, inv, coef, coef * wtot, H, Hp, tid);
   } else {
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     else { s0 = 1.f; s1 = 1.f; }                                                                            \
     /* double-buffered: the other buffer was last read in the previous step, which every wave has left */   \
     if (DB && kWithX && have_next) {                                                                        \
-      if (fwd && xq.has_nan()) bad = 2;                                                                     \
+      if (fwd && xq.has_nan()) bad |= 2;                                                                    \
       xq.store(xr + (kXOff - (VOFF)) / 4, xrow_next, D, tid, a.input_is_exp);                               \
     }                                                                                                       \
     if (kArcsOnly) { if (s0 == 12345.f) raw[tid] = s0; if (kArcsOnly == 2) __syncthreads(); break; }        \
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     tot = block_total(red, lane);                                                                           \
     wtot = fwd ? 0.f : block_total(red + 16, lane);                                                         \
     const float inv = __builtin_amdgcn_rcpf(tot);                                                           \
-    if (!(tot > 0.f) || !(inv > 0.f)) bad = 1;                                                              \
+    if (!(tot > 0.f) || !(inv > 0.f)) bad |= 1;                                                             \
     const int tstore = fwd ? j + 1 : L - 1 - j;                                                             \
     if (tid == 0) totv[tstore] = tot;                /* the scale divided out of this frame (den_finish_kernel) */ \
     const bool do_store = fwd ? (tstore < L) : true;                                                        \
@@ -573,8 +577,8 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
       normalise_row(fwd, raw, lk, cur, sbuf, do_store ? tstore * Hp * 4 : -1, inv, coef, coef * wtot, H, Hp, tid, true, cl0); \
     PH_ADD(3, pt); pt = PH_T();                                                                             \
     if (!DB && kWithX && have_next) {                                                                       \
-      if (fwd && xq.has_nan()) bad = 2;                                                                     \
-      xq.store(xr, xrow_next, D, tid, a.input_is_exp);                                                      \
+      if (fwd && xq.has_nan()) bad |= 2;                                                                    \
+      if (xq.store(xr, xrow_next, D, tid, a.input_is_exp) && fwd) bad |= 2;   /* (rows staged without registers) */ \
     }                                                                                                       \
     PH_ADD(4, pt); pt = PH_T();                                                                             \
     __syncthreads();                                                                                        \
@@ -643,12 +647,12 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     if (lane == 0) red[wave] = f;
     if (tid == 0) red[16] = 0.f;
     __syncthreads();
-    if (bad == 2) red[16] = 1.f;                       // somebody staged a NaN network output
+    if (bad & 2) red[16] = 1.f;                        // somebody staged a NaN network output
     __syncthreads();
     const float fs = block_total(red, lane);
     if (tid == 0) {
       a.fin_dot[b] = red[16] != 0.f ? __builtin_nanf("") : fs;       // den_finish_kernel: objf = sum_t log tot(t) + log of this
-      if (!(fs > 0.f)) bad = 1;
+      if (!(fs > 0.f)) bad |= 1;
     }
   }
   if (bad && lane == 0) atomicAdd(a.bad, 1);
@@ -1309,7 +1313,7 @@ inline size_t gamma2_lds_bytes(const DenArgs& a, int gamma_max_groups) {
   return sizeof(float) * (4 * (size_t)a.Hp + (a.fold_rows ? 6 : 2) * (size_t)((a.D + 3) & ~3) + (size_t)gamma_max_groups * 64 + 32);
 }
 inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
-  const bool off = option("gamma16") != nullptr;                       // test / tuning option: force the one-frame kernel
+  const bool off = a.knobs.gamma16 != 0;                               // test / tuning option: force the one-frame kernel
   return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
          a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) <= 160 * 1024;
 }
@@ -1330,21 +1334,40 @@ inline int pick_r(const DenArgs& a, int rows, int lds_words) {
   return kMaxResident;
 }
 
-// The lazy-normalisation recursion (den_lazy.inc.h) serves the shape the benchmarks run: nnet-output row and
-// state vector within its fixed LDS map, every arc of a wave in registers, at most kLzMaxGroups groups per
-// wave (bit 30 of the plan hint), the whole sequence in one launch.
+// The lazy-normalisation recursion (den_lazy.inc.h) in its 16-wave shape serves the shape the benchmarks run: nnet-output
+// row and state vector within its fixed LDS map, every arc of a wave in registers, at most LzNarrow::kMaxGroups groups
+// per wave (bit 30 of the plan hint), the whole sequence in one launch.
 inline bool lazy_shape_ok(const DenArgs& a, int hint) {
   const int rows = hint & 1023;
-  return ((hint >> 30) & 1) && a.D % 4 == 0 && a.D <= 4096 && a.Hp <= 4096 && rows > 0 && rows <= kMaxResident &&
-         PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
+  return ((hint >> 30) & 1) && a.D % 4 == 0 && a.D <= (int)LzNarrow::kMaxPdfs && a.Hp <= (int)LzNarrow::kMaxStates && rows > 0 &&
+         rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
 }
 hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
   const dim3 grid(2 * a.B);
   const int rows = hint & 1023;
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16>, a, grid, kLzBytes, st);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32>, a, grid, kLzBytes, st);
-  if (rows <= PLAN_RESIDENT_FIT) return launch_one(den_recursion_lazy_kernel<PLAN_RESIDENT_FIT>, a, grid, kLzBytes, st);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident>, a, grid, kLzBytes, st);
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, LzNarrow>, a, grid, kLzBytes, st);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, LzNarrow>, a, grid, kLzBytes, st);
+  if (rows <= PLAN_RESIDENT_FIT) return launch_one(den_recursion_lazy_kernel<PLAN_RESIDENT_FIT, LzNarrow>, a, grid, kLzBytes, st);
+  return launch_one(den_recursion_lazy_kernel<kMaxResident, LzNarrow>, a, grid, kLzBytes, st);
+}
+// ... and in its 8-wave shape (LzWide): the plan's 8-wave dealing joins the 16 waves in pairs, so a wave owns at most
+// twice the slot-rows and twice the groups of the 16-wave hint.  Chosen where the 16-wave shape does not fit (D > 4096).
+inline bool wide_shape_ok(const DenArgs& a, int hint) {
+  const int rows = hint & 1023;
+  return ((hint >> 30) & 1) && a.D % 4 == 0 && a.D <= (int)LzWide<5>::kMaxPdfs && a.Hp <= (int)LzWide<5>::kMaxStates && rows > 0 &&
+         rows <= 40 && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
+}
+template <int XCH>
+hipError_t launch_wide_x(const DenArgs& a, int rows, hipStream_t st) {
+  const dim3 grid(2 * a.B);
+  typedef LzWide<XCH> M;
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<32, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<64, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+  return launch_one(den_recursion_lazy_kernel<80, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+}
+hipError_t launch_wide(const DenArgs& a, int hint, hipStream_t st) {
+  const int rows = hint & 1023;
+  return a.D <= (int)LzWide<2>::kMaxPdfs ? launch_wide_x<2>(a, rows, st) : launch_wide_x<5>(a, rows, st);
 }
 
 // Two sequences per workgroup (den_pair.inc.h): one plan for all sequences, nnet-output rows and state vectors
@@ -1369,7 +1392,7 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
     e = launch_pair(a, hint, st);
     if (e != hipSuccess) return e;
   } else if ((a.phase_mask & 1) && a.lazy) {
-    e = launch_lazy(a, hint, st);
+    e = a.wide ? launch_wide(a, hint, st) : launch_lazy(a, hint, st);
     if (e != hipSuccess) return e;
   } else if (a.phase_mask & 1) {
     const dim3 grid(2 * a.B);
@@ -1428,6 +1451,16 @@ hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hi
 }
 
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows); }
+bool den_wide_eligible(const DenArgs& a, int resident_slot_rows) { return wide_shape_ok(a, resident_slot_rows); }
+const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
+  (void)resident_slot_rows;
+  if (a.pair) return "den_recursion_pair_kernel";
+  if (a.lazy) return a.wide ? "den_recursion_lazy_kernel<wide>" : "den_recursion_lazy_kernel";
+  return "den_recursion_kernel";
+}
+const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 1023, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
+}
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows) { return pair_shape_ok(a, resident_slot_rows); }
 int den_recursion_blocks(const DenArgs& a) { return a.pair ? 2 * ((a.B + 1) / 2) : 2 * a.B; }
 

@@ -26,17 +26,40 @@
 // for den_finish_kernel (log-probability, invariant check).  The state vector and the nnet-output row are both
 // double-buffered, so a frame writes only buffers nobody reads until the barrier.
 //
-// LDS map (absolute byte addresses; the dynamic segment starts at 0, checked):
-//   [0, 32K)      state buffer 0: float2[<= 4096]       [32K, 64K)  state buffer 1
-//   [64K, 80K)    nnet-output buffer 0 (exp'd row)      [80K, 96K)  nnet-output buffer 1
-//   [96K, ...)    partial sums
-// An arc is two VGPRs as in den_recursion_kernel: {8*i0 | (kLzXField + 4*i1) << 16, p}; the buffer of a
-// frame is selected by the ds_read OFFSET field (0 / 32768 for the state, 16384 / 32768 for the row), which
-// costs no instruction.
-constexpr uint32_t kLzU1 = 32768, kLzX0 = 65536, kLzX1 = 81920, kLzXField = 49152, kLzRed = 98304;
-constexpr uint32_t kLzLk = kLzRed + 2 * 2 * 64 * 4;         // beta: leaky probs [<= 4096]
-constexpr uint32_t kLzBytes = kLzLk + 4096 * 4;
-constexpr int kLzMaxGroups = 4;          // groups (of 64 rows) one wave may own: their values stay in registers
+// Two workgroup shapes share this code (template parameter MAP):
+//   LzNarrow  16 waves x 128 VGPRs, <= 40 slot-rows per wave, D <= 4096: the shape of C1 - C3 (measured fastest there);
+//   LzWide     8 waves x 256 VGPRs, <= 80 slot-rows per wave (the plan's 8-wave dealing: pairs of the 16 waves), nnet-output
+//              rows of up to 9216 pdfs: five float4 of a row per thread stay in registers across the arc loop, which the
+//              128-VGPR shape cannot afford (C4: D = 8408).
+// LDS maps (absolute byte addresses; the dynamic segment starts at 0, checked).  An arc is two VGPRs as in
+// den_recursion_kernel: {kUField + 8*i0 | (kXField + 4*i1) << 16, p}; the buffer of a frame is selected by the ds_read
+// OFFSET field (16 bits: buffer base - field base, <= 65535), which costs no instruction.
+struct LzNarrow {
+  //   [0, 32K)    state buffer 0: float2[<= 4096]       [32K, 64K)  state buffer 1
+  //   [64K, 80K)  nnet-output buffer 0 (exp'd row)      [80K, 96K)  nnet-output buffer 1
+  //   [96K, ...)  partial sums, beta's leaky probs
+  static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 1;
+  static constexpr uint32_t kU0 = 0, kU1 = 32768, kX0 = 65536, kX1 = 81920, kUField = 0, kXField = 49152;
+  static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
+  static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
+};
+template <int XCH>
+struct LzWide {
+  //   [0, 36K)    nnet-output buffer 0: float[<= 9216]  [36K, 72K)  nnet-output buffer 1
+  //   [72K, 96K)  state buffer 0: float2[<= 3072]       [96K, 120K) state buffer 1
+  //   [120K, ...) beta's leaky probs, partial sums
+  static constexpr int kWaves = 8, kMaxGroups = 8, kXch = XCH;
+  static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
+  static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = XCH * 4 * 8 * 64 < 9216 ? XCH * 4 * 8 * 64 : 9216;
+  static constexpr uint32_t kLk = 122880, kRed = kLk + kMaxStates * 4, kBytes = kRed + 2 * 2 * 64 * 4;
+};
+template <typename MAP> constexpr bool lz_map_ok() {
+  return MAP::kU1 - MAP::kUField <= 65535u && MAP::kU0 >= MAP::kUField && MAP::kX1 - MAP::kXField <= 65535u && MAP::kX0 >= MAP::kXField &&
+         MAP::kUField + 8u * (MAP::kMaxStates - 1) <= 65535u && MAP::kXField + 4u * (MAP::kMaxPdfs - 1) <= 65535u &&
+         MAP::kBytes <= 160u * 1024u;
+}
+static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzWide<5>>() && lz_map_ok<LzWide<2>>(), "ds_read offset fields are 16 bits");
+constexpr uint32_t kLzBytes = LzNarrow::kBytes;
 
 typedef float lz_v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const lz_v2f lz_lds_cv2f;
@@ -47,7 +70,7 @@ __device__ __forceinline__ lz_v2f lz_ld2(uint32_t byte_addr) { return *(lz_lds_c
 __device__ __forceinline__ void lz_st1(uint32_t byte_addr, float v) { *(lz_lds_float*)(byte_addr) = v; }
 #pragma clang diagnostic pop
 
-template <int R>
+template <int R, typename MAP>
 struct LazyArcs {
   uint32_t pk[R];
   float p[R];
@@ -56,7 +79,7 @@ struct LazyArcs {
     for (int s = 0; s < R; s++) {
       uint2 a = make_uint2(0u, 0u);                    // rows past the plan: p = 0, harmless addresses
       if (s < nslot_rows) a = wave_slots[s * 64];
-      pk[s] = ((a.x & 0xffffu) << 3) | ((kLzXField + ((a.x >> 16) << 2)) << 16);
+      pk[s] = (MAP::kUField + ((a.x & 0xffffu) << 3)) | ((MAP::kXField + ((a.x >> 16) << 2)) << 16);
       p[s] = __uint_as_float(a.y);
     }
   }
@@ -87,15 +110,17 @@ __device__ __forceinline__ void lazy_group_end(const LazyWave& w, lz_v2f acc, ui
   lz_st1(lds_dst, val);
 }
 
-// One frame of a recursion tile, lazy form: gathers from state buffer UOFF and nnet-output buffer VOFF,
-// writes the new values into state buffer UNEXT (byte offset).  Same software pipeline as tile_rows.
-template <int R, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook>
-__device__ __forceinline__ void lazy_tile(LazyArcs<R>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers) {
+// One frame of a recursion tile, lazy form: gathers from the state buffer at ds_read offset UOFF and the nnet-output
+// buffer at VOFF, writes the new values into the state buffer at absolute address UNEXT.  Same software pipeline as
+// tile_rows; up to 96 slot-rows per wave (three words of group-end bits).
+template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook>
+__device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers) {
   constexpr int kChunk = 4;
-  static_assert(R % kChunk == 0 && R <= 64 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
+  static_assert(R % kChunk == 0 && R <= 96 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
-  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), cm = gr.chunkmask;
-  asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
+  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), m_2 = gr.endmask2, cm = gr.chunkmask;
+  if constexpr (R > 64) asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(m_2), "+s"(cm));
+  else asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
   lz_v2f acc = {0.f, 0.f};
   lz_v2f ub[2][kChunk];
   float vb[2][kChunk];
@@ -130,10 +155,13 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R>& ar, const GroupRegs& gr, 
         const int sidx = c * kChunk + k;
         const float wk = ar.p[sidx] * vb[cb][k];
         nacc = __builtin_elementwise_fma(lz_v2f{wk, wk}, ub[cb][k], nacc);
-        if (((sidx < 32 ? m_lo : m_hi) >> (sidx & 31)) & 1u) {
-          const uint32_t lo_before = sidx < 32 ? (m_lo & ((1u << (sidx & 31)) - 1u)) : m_lo;
-          const uint32_t hi_before = sidx < 32 ? 0u : (m_hi & ((1u << (sidx & 31)) - 1u));
-          const int g = __builtin_popcount(lo_before) + __builtin_popcount(hi_before);
+        const uint32_t mword = sidx < 32 ? m_lo : (sidx < 64 ? m_hi : m_2);
+        if ((mword >> (sidx & 31)) & 1u) {
+          const uint32_t below = (1u << (sidx & 31)) - 1u;
+          const uint32_t lo_before = sidx < 32 ? (m_lo & below) : m_lo;
+          const uint32_t hi_before = sidx < 32 ? 0u : (sidx < 64 ? (m_hi & below) : m_hi);
+          int g = __builtin_popcount(lo_before) + __builtin_popcount(hi_before);
+          if constexpr (R > 64) if (sidx >= 64) g += __builtin_popcount(m_2 & below);
           const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
           lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
           nacc = lz_v2f{0.f, 0.f};
@@ -147,8 +175,9 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R>& ar, const GroupRegs& gr, 
 // One (sequence, direction).  The direction is a template parameter and the kernel branches ONCE, at its
 // top: with both directions in one body the register allocator keeps a second copy of every arc register
 // across the (uniform) direction branches.
-template <int R, bool fwd>
+template <int R, typename MAP, bool fwd>
 __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b) {
+  constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,21 +186,21 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const int Hp = a.Hp, D = a.D;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
-  const TilePlan tp = fwd ? hd->alpha : hd->beta;
+  const TilePlan tp = NW == 16 ? (fwd ? hd->alpha : hd->beta) : (fwd ? hd->alpha8 : hd->beta8);
   const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
 
-  float* U0 = reinterpret_cast<float*>(smem_raw);                  // float2[4096]; buffer 1 at + kLzU1 bytes
-  float* X0 = reinterpret_cast<float*>(smem_raw + kLzX0);
-  float* red = reinterpret_cast<float*>(smem_raw + kLzRed);        // [parity][which][64]
+  float* red = reinterpret_cast<float*>(smem_raw + MAP::kRed);     // [parity][which][64]
+  // bit 0: not ok (a total or normaliser that is not finite-positive, a bad length); bit 1: a NaN network output was
+  // staged (kept apart: it also turns the log-probability into NaN, and a later "not ok" must not hide it)
   int bad = lds_addr(smem_raw) != 0u ? 1 : 0;                      // the packed arc addresses are absolute
-  if (fwd && seq_len_bad(a.lengths, b, a.T)) bad = 1;
+  if (fwd && seq_len_bad(a.lengths, b, a.T)) bad |= 1;
 
   GroupRegs groups;
   groups.load<R>(we, gtab, lane);
   const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
-  LazyArcs<R> arcs;
+  LazyArcs<R, MAP> arcs;
   arcs.load(groups.nslots, wave_slots);
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
@@ -185,39 +214,42 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 
   LazyWave w;
   // group g of this wave: rows base_g .. base_g + 63 (lane l owns row base_g + l)
-  int gbase[kLzMaxGroups];
+  int gbase[MG];
 #pragma unroll
-  for (int g = 0; g < kLzMaxGroups; g++) gbase[g] = g < groups.ngroups ? __builtin_amdgcn_readlane(groups.base, g) : 0;
-  float* LK = reinterpret_cast<float*>(smem_raw + kLzLk);
-  if (groups.ngroups > kLzMaxGroups || groups.nslots > R) bad = 1;   // the host checks the plan before choosing this kernel
+  for (int g = 0; g < MG; g++) gbase[g] = g < groups.ngroups ? __builtin_amdgcn_readlane(groups.base, g) : 0;
+  if (groups.ngroups > MG || groups.nslots > R) bad |= 1;   // the host checks the plan before choosing this kernel
 
   // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
-  XRow<kNT, 4, 1> xq;
+  XRow<NT, 4, MAP::kXch> xq;
   {
     float p0 = 0.f, p1 = 0.f;
-    for (int i = tid; i < 4096; i += kNT) {
+    for (int i = tid; i < (int)MAP::kMaxStates; i += NT) {
       float s = 0.f, second = fwd ? 0.f : 1.f, l = 0.f;
       if (i < Hp) { s = start_g[i]; l = leaky_g[i]; if (fwd) second = coef * l; }
-      *reinterpret_cast<lz_v2f*>(U0 + 2 * i) = lz_v2f{s, second};
-      *reinterpret_cast<lz_v2f*>(U0 + kLzU1 / 4 + 2 * i) = lz_v2f{0.f, second};
-      if (!fwd) LK[i] = l;
+      *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{s, second};
+      *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, second};
+      if (!fwd) *reinterpret_cast<float*>(smem_raw + MAP::kLk + 4 * i) = l;
       p0 += s; p1 += s * l;
     }
     const int t0 = fwd ? 0 : L - 1;
     xq.load(xseq + (size_t)t0 * D, D, tid);
-    if (fwd && xq.has_nan()) bad = 2;
-    xq.store(X0, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    if (fwd && xq.has_nan()) bad |= 2;
+    xq.store(reinterpret_cast<float*>(smem_raw + MAP::kX0), xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
     p0 = wave_sum(p0); p1 = wave_sum(p1);
+    if (NW < 16) {                                     // partial sums of waves that do not exist: zero, once
+      if (tid < 256) red[tid] = 0.f;
+      __syncthreads();
+    }
     if (lane == 0) { red[wave] = p0; red[64 + wave] = p1; }
-    if (tid >= 16 && tid < 64) { red[tid] = 0.f; red[64 + tid] = 0.f; }
+    if (tid >= NW && tid < 64) { red[tid] = 0.f; red[64 + tid] = 0.f; }
     __syncthreads();
     const float tot = wave_sum(red[lane]), wtot = wave_sum(red[64 + lane]);
     w.inv = __builtin_amdgcn_rcpf(tot);
     w.c = coef * wtot;
-    if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;
+    if (!(tot > 0.f) || !(w.inv > 0.f)) bad |= 1;
     w.sprev = fwd ? tot : w.c;                         // the start row (alpha row 0 / beta row L) goes out at the end of frame 0
     if (tid == 0) totv[fwd ? 0 : L] = tot;
-    __syncthreads();                                                 // red is rewritten by the first frame
+    __syncthreads();                                                 // red is rewritten by the first frame (its first 4 NW entries per sum)
   }
 
   float last_tot = 1.f;
@@ -248,7 +280,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   do {                                                                                                      \
     const float tot = wave_sum(red[(PARP) * 128 + (LQ)]);                                                   \
     w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
-    if (!(tot > 0.f) || !(w.inv > 0.f)) bad = 1;                                                            \
+    if (!(tot > 0.f) || !(w.inv > 0.f)) bad |= 1;                                                           \
     if (FWDC) w.sprev = tot;                                                                                \
     else { w.c = coef * wave_sum(red[(PARP) * 128 + 64 + (LQ)]); w.sprev = w.c; }                           \
     if ((TQ) == 0) totv[(FWDC) ? (JP) + 1 : L - 1 - (JP)] = tot;                                            \
@@ -263,22 +295,23 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     int tq = tid;                                                                                           \
     asm volatile("" : "+v"(tq));                                                                            \
     const int lq = tq & 63;                                                                                 \
-    constexpr uint32_t UOFF = (PAR) ? kLzU1 : 0u, UNEXT = (PAR) ? 0u : kLzU1;                               \
-    constexpr uint32_t VOFF = (PAR) ? 32768u : 16384u;       /* kLzXField + VOFF = nnet-output buffer PAR */ \
+    constexpr uint32_t UCUR = (PAR) ? MAP::kU1 : MAP::kU0, UNEXT = (PAR) ? MAP::kU0 : MAP::kU1;             \
+    constexpr uint32_t UOFF = UCUR - MAP::kUField;                                                          \
+    constexpr uint32_t VOFF = ((PAR) ? MAP::kX1 : MAP::kX0) - MAP::kXField;   /* nnet-output buffer PAR */   \
     const int tn = (FWDC) ? j + 1 : L - 2 - j;               /* nnet-output row of the NEXT step */          \
     const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
     LZ_PH0();                                                                                               \
     if (have_next) xq.load_row(xbuf, tn, D, tq);             /* in flight during the arc work */             \
-    lazy_tile<R, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, [&]() {                                     \
+    lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, [&]() {                                \
       if (j > 0) PYCHAIN_LZ_TOTALS((PAR) ^ 1, j - 1, (FWDC), lq, tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) - it sits in the buffer this */ \
       /* frame gathers from - is completed and leaves for HBM, also behind the first gathers */              \
       const int trow = (FWDC) ? j : L - j;                                                                  \
       const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
       const int lane4 = lq * 4, lane8 = lq * 8;              /* one VGPR of addresses, the group in the SGPR offset */ \
-      _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++)                                              \
+      _Pragma("unroll") for (int g = 0; g < MG; g++)                                                        \
         if (g < groups.ngroups) {                                                                           \
-          const lz_v2f prow = lz_ld2(UOFF + gbase[g] * 8 + lane8);                                          \
+          const lz_v2f prow = lz_ld2(UCUR + gbase[g] * 8 + lane8);                                          \
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow.y, prow.x)), sbuf, lane4, \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
         }                                                                                                   \
@@ -286,26 +319,30 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     LZ_PH(0);                                                /* arc phase */                                 \
     /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
     /* lane's rows (and, beta, their leaky probs) for the totals */                                         \
-    float val[kLzMaxGroups], lkv[kLzMaxGroups];                                                             \
+    float val[MG], lkv[MG];                                                                                 \
     {                                                                                                       \
       const int lane8 = lq * 8;                                                                             \
-      _Pragma("unroll") for (int g = 0; g < kLzMaxGroups; g++) {                                            \
+      _Pragma("unroll") for (int g = 0; g < MG; g++) {                                                      \
         val[g] = 0.f; lkv[g] = 0.f;                                                                         \
         if (g < groups.ngroups) {                                                                           \
           val[g] = lds_abs(UNEXT + gbase[g] * 8 + lane8);                                                   \
-          if (!(FWDC)) lkv[g] = lds_abs(kLzLk + gbase[g] * 4 + (lane8 >> 1));                               \
+          if (!(FWDC)) lkv[g] = lds_abs(MAP::kLk + gbase[g] * 4 + (lane8 >> 1));                            \
         }                                                                                                   \
       }                                                                                                     \
     }                                                                                                       \
     /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
     if (have_next) {                                                                                        \
-      if ((FWDC) && xq.has_nan()) bad = 2;                   /* a NaN network output: not ok, NaN log-probability */ \
-      xq.store(X0 + ((PAR) ? 0 : 4096), xseq, D, tq, a.input_is_exp);                                       \
+      if ((FWDC) && xq.has_nan()) bad |= 2;                  /* a NaN network output: not ok, NaN log-probability */ \
+      xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \
     }                                                                                                       \
     LZ_PH(1);                                                /* LDS re-reads issued, nnet-output row clamped / exp'd / stored */ \
-    float s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                       \
-    float s1 = 0.f;                                                                                         \
-    if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
+    float s0 = 0.f, s1 = 0.f;                                                                               \
+    if constexpr (MG == 4) {                                                                                \
+      s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                           \
+      if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
+    } else {                                                                                                \
+      _Pragma("unroll") for (int g = 0; g < MG; g++) { s0 += val[g]; if (!(FWDC)) s1 = __builtin_fmaf(val[g], lkv[g], s1); } \
+    }                                                                                                       \
     /* totals: four row sums per wave before the barrier, the rest of the reduction after it */             \
     {                                                                                                       \
       const float r0 = dpp_row_sum(s0);                                                                     \
@@ -326,11 +363,11 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   if (nsteps > 0) PYCHAIN_LZ_TOTALS((nsteps - 1) & 1, nsteps - 1, fwd, lane, tid);   // the last step's
   if constexpr (!fwd) {
     // the last beta row (row L - nsteps: row 1, or the start row if the sequence has one frame) never saw a next frame
-    const float* UL = U0 + ((nsteps & 1) ? kLzU1 / 4 : 0);
+    const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
     const int row_off = (L - nsteps) * Hp * 4;
-    for (int g = 0; g < kLzMaxGroups; g++)
+    for (int g = 0; g < MG; g++)
       if (g < groups.ngroups) {
-        const lz_v2f u = *reinterpret_cast<const lz_v2f*>(UL + 2 * (gbase[g] + lane));
+        const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * (gbase[g] + lane));
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, u.y, u.x)), sbuf, lane * 4,
                                               row_off + gbase[g] * 4, kStoreDeviceScope);
       }
@@ -353,32 +390,33 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i a'(L,i) final(i) + sum_{t<L} log tot(t),
     // a'(L,i) = a(L,i) + tot(L) cl(i); the vector of step L-1 sits in buffer (L & 1)
     const float* fin = reinterpret_cast<const float*>(plan + hd->off_final_a);
-    const float* UL = U0 + ((nsteps & 1) ? kLzU1 / 4 : 0);
+    const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
     float f = 0.f;
-    for (int i = tid; i < Hp; i += kNT) {
-      const lz_v2f u = *reinterpret_cast<const lz_v2f*>(UL + 2 * i);
+    for (int i = tid; i < Hp; i += NT) {
+      const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * i);
       f += __builtin_fmaf(last_tot, u.y, u.x) * fin[i];
     }
     f = wave_sum(f);
     __syncthreads();
-    if (lane == 0) red[wave] = f;
-    if (tid >= 16 && tid < 64) red[tid] = 0.f;
-    if (tid == 0) red[64] = 0.f;
+    if (tid < 64) red[tid] = 0.f;
+    if (tid == 64) red[64] = 0.f;
     __syncthreads();
-    if (bad == 2) red[64] = 1.f;                      // somebody staged a NaN network output
+    if (lane == 0) red[wave] = f;
+    __syncthreads();
+    if (bad & 2) red[64] = 1.f;                       // somebody staged a NaN network output
     __syncthreads();
     const float fs = wave_sum(red[lane]);
     if (tid == 0) {
       a.fin_dot[b] = red[64] != 0.f ? __builtin_nanf("") : fs;       // den_finish_kernel: objf = sum_t log tot(t) + log of this
-      if (!(fs > 0.f)) bad = 1;
+      if (!(fs > 0.f)) bad |= 1;
     }
   }
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
-template <int R>
-__global__ __launch_bounds__(kNT) void den_recursion_lazy_kernel(const DenArgs a) {
+template <int R, typename MAP>
+__global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, true>(a, smem_raw, blockIdx.x);
-  else lazy_recursion<R, false>(a, smem_raw, blockIdx.x - a.B);
+  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true>(a, smem_raw, blockIdx.x);
+  else lazy_recursion<R, MAP, false>(a, smem_raw, blockIdx.x - a.B);
 }

@@ -176,7 +176,8 @@ struct XRow {
       }
     }
   }
-  __device__ __forceinline__ void store(float* lds, const float* __restrict__ row, int D, int tid, int is_exp) {
+  // returns true if the register-less form (XCH == 0) met a NaN element (the register forms are asked with has_nan())
+  __device__ __forceinline__ bool store(float* lds, const float* __restrict__ row, int D, int tid, int is_exp) {
     if constexpr (XCH > 0) {
       if (is_exp == kXExpClamp) store_mode<kXExpClamp>(lds, D, tid);
       else if (is_exp == kXIdentity) store_mode<kXIdentity>(lds, D, tid);
@@ -195,8 +196,15 @@ struct XRow {
             }
         }
       }
+      return false;
     } else {  // any D: no register staging
-      for (int e = tid; e < D; e += NT) { const float r = row[e]; lds[e] = (is_exp == kXClamp && r != r) ? r : clamp_exp(r, is_exp); }
+      bool nan = false;
+      for (int e = tid; e < D; e += NT) {
+        const float r = row[e];
+        nan = nan || r != r;
+        lds[e] = (is_exp == kXClamp && r != r) ? r : clamp_exp(r, is_exp);
+      }
+      return nan;
     }
   }
 };

@@ -38,11 +38,18 @@ struct NumArgs {
   // workgroups watch every element of every row and turn the loss into NaN, and the row-staging waves, whose
   // instruction count sets the pace of a numerator step, skip the check (num_fb 8 % faster).
   int watch_nan;
+  int no_staging_waves;      // option num_no_staging_waves (this call's snapshot, common.h:CallKnobs)
+  // option debug_corrupt_row "num,b,t,scale": log(scale) is added to the stored alpha(t,.) of utterance b between the
+  // recursions and the occupancy pass, so that the 5 % invariant can be seen to fire; corrupt_b < 0: off
+  int corrupt_b, corrupt_t;
+  float corrupt_log;
 };
 
 size_t num_fb_lds_bytes(int H, int K, int D);
 // forward and backward recursions (launch 1, 2B workgroups): reads x + graphs, writes objf, logp_ws, alpha_ws, beta_ws
 hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why);
+// option debug_corrupt_row (NumArgs::corrupt_b)
+hipError_t launch_num_corrupt(const NumArgs& a, hipStream_t st);
 // distinct pdf-ids per sequence (upd_ws, ucount_ws): needed before a compact occupancy launch
 hipError_t launch_num_prep(const NumArgs& a, hipStream_t st, const char** why);
 // occupancies -> gradient rows (launch 2): reads alpha_ws, beta_ws, logp_ws, x; writes/accumulates grad

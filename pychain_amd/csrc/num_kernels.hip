@@ -606,7 +606,7 @@ hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
   }
   const int D = a.D;
   if (D % 4 == 0) {
-    if (!option("num_no_staging_waves")) {                     // test / tuning option
+    if (!a.no_staging_waves) {                                 // test / tuning option
       if (D <= 4 * 4 * kFbLd) return launch_fb<4, 4, kFbLd>(a, lds, st);
       if (D <= 4 * 8 * kFbLd) return launch_fb<4, 8, kFbLd>(a, lds, st);
     }
@@ -616,6 +616,17 @@ hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
     return launch_fb<1, 8>(a, lds, st);
   }
   return launch_fb<1, 0>(a, lds, st);
+}
+
+namespace {
+__global__ void num_corrupt_kernel(double* row, int n, double add) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) row[i] += add;
+}
+}  // namespace
+hipError_t launch_num_corrupt(const NumArgs& a, hipStream_t st) {
+  double* row = a.alpha_ws + ((size_t)a.corrupt_b * (a.T + 1) + a.corrupt_t) * a.H;
+  hipLaunchKernelGGL(num_corrupt_kernel, dim3(1), dim3(256), 0, st, row, a.H, (double)a.corrupt_log);
+  return hipGetLastError();
 }
 
 hipError_t launch_num_prep(const NumArgs& a, hipStream_t st, const char** why) {

@@ -326,13 +326,29 @@ int max_wave_rows(const std::vector<int>& gsl, int nwaves) {
   return mx;
 }
 
-// Deal the groups of a tile to `nwaves` waves and lay the slot stream out in wave order.
-BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, int nwaves) {
+// The waves of a dealing joined in pairs (heaviest with lightest): half as many waves, none with more than twice
+// the slot-rows or groups of the heaviest wave before.  Groups in descending slot count inside a wave.
+std::vector<std::vector<int>> pair_waves(const std::vector<std::vector<int>>& deal, const std::vector<int>& gsl) {
+  const int n = (int)deal.size();
+  std::vector<int> load(n, 0), by_load(n);
+  for (int w = 0; w < n; w++) for (int g : deal[w]) load[w] += gsl[g];
+  std::iota(by_load.begin(), by_load.end(), 0);
+  std::stable_sort(by_load.begin(), by_load.end(), [&](int a, int b) { return load[a] > load[b]; });
+  std::vector<std::vector<int>> out((n + 1) / 2);
+  for (int i = 0; i < (n + 1) / 2; i++) {
+    out[i] = deal[by_load[i]];
+    if (n - 1 - i != i) out[i].insert(out[i].end(), deal[by_load[n - 1 - i]].begin(), deal[by_load[n - 1 - i]].end());
+    std::stable_sort(out[i].begin(), out[i].end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
+  }
+  return out;
+}
+
+// Lay the slot stream of a tile out in wave order for a given dealing of its groups to waves.
+BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, const std::vector<std::vector<int>>& per_wave) {
   BuiltTile o;
   o.nrows = (int)t.order.size();
-  const int ngroups = t.npos / 64;
   const std::vector<int>& gsl = t.gsl;
-  std::vector<std::vector<int>> per_wave = deal_groups(gsl, nwaves);
+  const int nwaves = (int)per_wave.size();
   o.waves.resize(nwaves);
   int row_cursor = 0;
   for (int w = 0; w < nwaves; w++) {
@@ -544,10 +560,14 @@ extern "C" int64_t pychain_hip_den_plan_build(
             (double)so_b.cycles / std::max(1L, so_b.columns.load()), (double)so_g.cycles / std::max(1L, so_g.columns.load()),
             so_a.columns.load(), so_b.columns.load(), so_g.columns.load());
 
-  BuiltTile ta = emit_tile(tiles[0], so_a, lay, PLAN_REC_WAVES);
-  BuiltTile tb = emit_tile(tiles[1], so_b, lay, PLAN_REC_WAVES);
-  BuiltTile tg = emit_tile(tiles[2], so_g, lay, PLAN_GAM_WAVES);
-  BuiltTile tg2 = emit_tile(tiles[2], so_g, lay, PLAN_GAM2_WAVES);
+  const auto deal_a = deal_groups(tiles[0].gsl, PLAN_REC_WAVES), deal_b = deal_groups(tiles[1].gsl, PLAN_REC_WAVES);
+  static_assert(PLAN_REC8_WAVES * 2 == PLAN_REC_WAVES || PLAN_REC_WAVES != 16, "the 8-wave dealing joins the 16 waves in pairs");
+  BuiltTile ta = emit_tile(tiles[0], so_a, lay, deal_a);
+  BuiltTile tb = emit_tile(tiles[1], so_b, lay, deal_b);
+  BuiltTile tg = emit_tile(tiles[2], so_g, lay, deal_groups(tiles[2].gsl, PLAN_GAM_WAVES));
+  BuiltTile tg2 = emit_tile(tiles[2], so_g, lay, deal_groups(tiles[2].gsl, PLAN_GAM2_WAVES));
+  BuiltTile ta8 = emit_tile(tiles[0], so_a, lay, PLAN_REC_WAVES == 16 ? pair_waves(deal_a, tiles[0].gsl) : deal_groups(tiles[0].gsl, PLAN_REC8_WAVES));
+  BuiltTile tb8 = emit_tile(tiles[1], so_b, lay, PLAN_REC_WAVES == 16 ? pair_waves(deal_b, tiles[1].gsl) : deal_groups(tiles[1].gsl, PLAN_REC8_WAVES));
 
   // ---- lay the blob out
   size_t off = align16(sizeof(PlanHeader));
@@ -557,6 +577,8 @@ extern "C" int64_t pychain_hip_den_plan_build(
   hd.H = H; hd.K = K; hd.D = D; hd.Hp = Hp;
   for (const BuiltTile* t : {&ta, &tb})
     for (const WaveEntry& we : t->waves) hd.rec_max_wave_groups = std::max(hd.rec_max_wave_groups, we.ngroups);
+  for (const BuiltTile* t : {&ta8, &tb8})
+    for (const WaveEntry& we : t->waves) hd.rec8_max_wave_groups = std::max(hd.rec8_max_wave_groups, we.ngroups);
   auto place_tile = [&](TilePlan& tp, const BuiltTile& t) {
     tp.ngroups = (int)t.groups.size(); tp.nwaves = (int)t.waves.size();
     tp.total_slot_rows = t.total_slot_rows; tp.max_wave_slot_rows = t.max_wave; tp.nrows = t.nrows;
@@ -565,6 +587,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
     tp.off_slots = (int32_t)off; off = align16(off + std::max<size_t>(1, t.slots.size()) * 4);
   };
   place_tile(hd.alpha, ta); place_tile(hd.beta, tb); place_tile(hd.gamma, tg); place_tile(hd.gamma2, tg2);
+  place_tile(hd.alpha8, ta8); place_tile(hd.beta8, tb8);
   auto place_vec = [&](int32_t& o, size_t n) { o = (int32_t)off; off = align16(off + n * 4); };
   place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
@@ -583,6 +606,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
     memcpy(base + tp.off_slots, t.slots.data(), t.slots.size() * 4);
   };
   write_tile(hd.alpha, ta); write_tile(hd.beta, tb); write_tile(hd.gamma, tg); write_tile(hd.gamma2, tg2);
+  write_tile(hd.alpha8, ta8); write_tile(hd.beta8, tb8);
   float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);
@@ -592,5 +616,8 @@ extern "C" int64_t pychain_hip_den_plan_build(
     leaky_b[pb] = leaky[h]; final_b[pb] = final_[h];
   }
   for (int i = 0; i < gpos; i++) row_pdf[i] = i < (int)tiles[2].order.size() ? tiles[2].order[i] : -1;
+  // integrity of everything behind the header: the kernels follow the blob's offsets and packed LDS addresses
+  // unchecked, so a plan that comes back from a cache file is verified first (pychain_hip_den_plan_info)
+  reinterpret_cast<PlanHeader*>(base)->payload_hash = (int32_t)pychain_hip::plan_payload_hash(base, off);
   return (int64_t)off;
 }

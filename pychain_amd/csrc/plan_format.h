@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 7
+#define PLAN_VERSION 8
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -40,6 +40,8 @@
 #define PLAN_RESIDENT_2 40
 #define PLAN_RESIDENT_FIT 36   // between the last two: reached with per-group slack fitted to the wave budget (plan.cpp: fit_slack)
 #define PLAN_GAM2_WAVES 8      // the gamma plan again, scheduled for the two-frame occupancy kernel (8 waves x 256 VGPRs)
+#define PLAN_REC8_WAVES 8      // the alpha / beta plans again, for the 8-wave ("wide") lazy recursion: the waves of the 16-wave
+                               // dealing joined in pairs, so a wave owns at most twice the slot-rows and groups
 
 struct TilePlan {              // all offsets are bytes from the start of the blob
   int32_t ngroups;
@@ -78,6 +80,23 @@ struct PlanHeader {
   int32_t off_row_pdf;         // int32[gamma.ngroups*64] natural pdf-id of each gamma row, -1 = padding
   int32_t reserved1[2];
   TilePlan gamma2;             // same rows as `gamma` (row_pdf applies), dealt to PLAN_GAM2_WAVES waves
+  TilePlan alpha8, beta8;      // same rows and slot order as `alpha` / `beta`, dealt to PLAN_REC8_WAVES waves
+  int32_t rec8_max_wave_groups;
+  int32_t payload_hash;        // FNV-1a over bytes [sizeof(PlanHeader), total_bytes): checked by pychain_hip_den_plan_info
+  int32_t reserved2[2];
 };
+
+#ifdef __cplusplus
+#include <stddef.h>
+namespace pychain_hip {
+// FNV-1a (32 bit) over the blob behind its header
+inline uint32_t plan_payload_hash(const void* blob, size_t total_bytes) {
+  const unsigned char* p = (const unsigned char*)blob;
+  uint32_t h = 2166136261u;
+  for (size_t i = sizeof(PlanHeader); i < total_bytes; i++) { h ^= p[i]; h *= 16777619u; }
+  return h;
+}
+}  // namespace pychain_hip
+#endif
 
 #endif

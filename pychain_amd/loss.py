@@ -45,13 +45,17 @@ class ChainFunction(torch.autograd.Function):
             if graphs.shared_graph is not None:
                 plan = _plan.graph_plan(graphs.shared_graph, D, x.device)
             else:
-                key = ("den_plans", str(x.device), D)
+                names = ("forward_transitions", "forward_transition_indices", "forward_transition_probs",
+                         "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+                         "leaky_probs", "initial_probs", "final_probs")
+                # keyed like graph_plan / device_tensors: an in-place edit or a replaced tensor re-compiles
+                key = ("den_plans", str(x.device), D) + tuple(
+                    (getattr(graphs, n).data_ptr(), getattr(graphs, n)._version) for n in names)
                 hit = graphs._device_cache.get(key)
                 if hit is None:
-                    hit = _plan.batch_plans({n: getattr(graphs, n) for n in (
-                        "forward_transitions", "forward_transition_indices", "forward_transition_probs",
-                        "backward_transitions", "backward_transition_indices", "backward_transition_probs",
-                        "leaky_probs", "initial_probs", "final_probs")}, D, x.device)
+                    for k in [k for k in graphs._device_cache if k[:1] == ("den_plans",)]:
+                        del graphs._device_cache[k]
+                    hit = _plan.batch_plans({n: getattr(graphs, n) for n in names}, D, x.device)
                     graphs._device_cache[key] = hit
                 plan = hit
             objf, input_grad, bad = native.den_forward_backward(
@@ -76,7 +80,8 @@ class ChainFunction(torch.autograd.Function):
             ctx.save_for_backward(input_grad)
         else:
             ctx.grad_buf = input_grad
-            ctx.again = lambda: ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient)[1]
+            ctx.again = _recompute(x, lambda: ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient),
+                                   lambda r: (r[1], r[2]))
         ctx.in_dtype = input.dtype   # fp16 / bf16 inputs are evaluated in fp32; the gradient goes back in their dtype
         ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
         ChainFunction.last_bad_count = bad
@@ -92,8 +97,25 @@ class ChainFunction(torch.autograd.Function):
             return torch.mul(input_grad, objf_grad).to(ctx.in_dtype), None, None, None
         grad = _take_grad_buffer(ctx, "grad_buf")
         if grad is None:
-            grad = ctx.again()               # second backward over a retained graph: evaluate again
+            grad, ChainFunction.last_bad_count = ctx.again()   # second backward over a retained graph: evaluate again
         return native.rescale_(grad, objf_grad).to(ctx.in_dtype), None, None, None
+
+
+def _recompute(x, evaluate, pick):
+    """The closure a second backward over a retained graph calls: evaluates again from the inputs kept by reference.
+    autograd's version check only guards tensors saved with save_for_backward, so it is restated here: an in-place
+    edit of the network output between the two backward calls would silently change the gradient (the reference
+    saved the gradient itself, loss.py:79)."""
+    version = x._version
+
+    def again():
+        if x._version != version:
+            raise RuntimeError(
+                "one of the variables needed for gradient computation has been modified by an inplace operation: "
+                "the network output given to the LF-MMI loss is at version %d; expected version %d (second backward "
+                "over a retained graph re-evaluates the loss from it)" % (x._version, version))
+        return pick(evaluate())
+    return again
 
 
 def _take_grad_buffer(ctx, attr):
@@ -147,9 +169,9 @@ class ChainLossFunction(torch.autograd.Function):
         ctx.state = state
         # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
         spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)
-        ctx.again = lambda: native.chain_loss_forward(
+        ctx.again = _recompute(x, lambda: native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
-            with_grad=spec, grad_scale=hscale)[3]
+            with_grad=spec, grad_scale=hscale), lambda r: (r[3], r[2]))
         ctx.in_dtype = input.dtype
         ChainFunction.last_bad_count = bad       # int32[2]: denominator, numerator; never synced here
         return objf
@@ -161,7 +183,7 @@ class ChainLossFunction(torch.autograd.Function):
         g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
         state = _take_grad_buffer(ctx, "state")
         if state is None:
-            state = ctx.again()
+            state, ChainFunction.last_bad_count = ctx.again()
         if ctx.speculative:
             grad = native.rescale_(state.grad, g)
         else:

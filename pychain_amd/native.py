@@ -10,7 +10,8 @@ import torch
 
 from . import _lib, _plan
 
-_ws_cache = {}
+_ws_cache = {}          # (device, stream, tag) -> uint8 tensor, most recently used last
+_WS_CACHE_ENTRIES = 8   # a training process uses 2 (den, num) per stream; more are streams that came and went
 
 
 def _require_device(t, what):
@@ -26,10 +27,13 @@ def _workspace(nbytes, device, tag="a"):
     two streams of one device run concurrently and must not share it.  (A replaced buffer goes back to the
     caching allocator, which hands it out again only in the stream order of its allocation.)"""
     key = (str(device), _stream(device), tag)
-    ws = _ws_cache.get(key)
+    ws = _ws_cache.pop(key, None)
     if ws is None or ws.numel() < nbytes:
+        ws = None                      # (the old buffer goes back to the allocator before the larger one is asked for)
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
+    _ws_cache[key] = ws                # (re-)inserted last = most recently used
+    while len(_ws_cache) > _WS_CACHE_ENTRIES:
+        _ws_cache.pop(next(iter(_ws_cache)))       # least recently used: multi-GB buffers of streams no longer in use
     return ws
 
 

@@ -48,3 +48,28 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     d = np.abs(a - b).max()
     return d / max(np.abs(b).max(), 1e-30)
+
+
+class OracleChainLoss(torch.nn.Module):
+    """ChainLoss(avg=False) evaluated by the CPU oracle, with autograd: the TEST stand-in for the per-rank loss where
+    there is no GPU (tests/test_parallel.py, examples/train_tdnn.py --loss-cls helpers:OracleChainLoss).  What is
+    under test there is the collective / DDP wiring around it."""
+
+    def __init__(self, den_graph, leaky, avg=False):
+        super().__init__()
+        self.den_graph, self.leaky = den_graph, leaky
+
+    def forward(self, x, lengths, num_graphs):
+        import oracle as orc
+
+        class F(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, xx):
+                loss, grad = orc.chain_loss(xx, lengths, self.den_graph, num_graphs, self.leaky, avg=False)
+                ctx.save_for_backward(torch.from_numpy(np.asarray(grad, dtype=np.float32)))
+                return torch.tensor(float(loss))
+
+            @staticmethod
+            def backward(ctx, g):
+                return ctx.saved_tensors[0] * g
+        return F.apply(x)

@@ -27,27 +27,7 @@ def test_shard_indices_balanced_and_sorted():
         assert bool((ls[:-1] >= ls[1:]).all())
 
 
-class _OracleLoss(torch.nn.Module):
-    """ChainLoss(avg=False) evaluated by the CPU oracle, with autograd (test stand-in)."""
-
-    def __init__(self, den_graph, leaky, avg=False):
-        super().__init__()
-        self.den_graph, self.leaky = den_graph, leaky
-
-    def forward(self, x, lengths, num_graphs):
-        import oracle as orc
-
-        class F(torch.autograd.Function):
-            @staticmethod
-            def forward(ctx, xx):
-                loss, grad = orc.chain_loss(xx, lengths, self.den_graph, num_graphs, self.leaky, avg=False)
-                ctx.save_for_backward(torch.from_numpy(np.asarray(grad, dtype=np.float32)))
-                return torch.tensor(float(loss))
-
-            @staticmethod
-            def backward(ctx, g):
-                return ctx.saved_tensors[0] * g
-        return F.apply(x)
+from helpers import OracleChainLoss as _OracleLoss  # noqa: E402  (ChainLoss(avg=False) by the CPU oracle, with autograd)
 
 
 def _worker(rank, world, port, out):
@@ -88,3 +68,30 @@ def test_sharded_loss_matches_single_process():
         # every rank holds the whole gradient after the optional slab all-reduce
         np.testing.assert_allclose(slab, ref_grad, atol=1e-6)
         np.testing.assert_allclose(st, [2.0, 1.0])
+
+
+def test_training_example_two_ranks_ddp_on_gloo():
+    """examples/train_tdnn.py as a launcher would start it, 2 ranks, no GPU: DistributedDataParallel around the model,
+    ShardedChainLoss (ONE 3-float all-reduce per step), clip, optimizer step - the wiring of SURVEY.md §8(f)4 - with the
+    per-rank loss evaluated by the CPU oracle stand-in.  The loss falls, and both ranks report the same GLOBAL loss."""
+    import re
+    import socket
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(repo, "tests"), os.path.join(repo, "oracle"), env.get("PYTHONPATH", "")])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(repo, "examples", "train_tdnn.py"),
+           "--backend", "gloo", "--device", "cpu", "--loss-cls", "helpers:OracleChainLoss",
+           "--steps", "8", "--batch", "3", "--frames", "40", "--pdfs", "40", "--states", "20", "--arcs", "60",
+           "--hidden", "32", "--max-num-states", "8", "--lr", "0.01"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    seen = dict((int(m.group(1)), (float(m.group(2)), float(m.group(3))))
+                for m in re.finditer(r"rank (\d) of 2: global loss (\S+) -> (\S+)", r.stdout))
+    assert sorted(seen) == [0, 1], r.stdout
+    assert seen[0] == seen[1]                         # the value every rank holds is the global one
+    assert seen[0][1] < seen[0][0]                    # and it fell

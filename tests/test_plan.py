@@ -35,6 +35,31 @@ def test_plan_structure():
     assert set(hd["row_pdf"][hd["row_pdf"] >= 0].tolist()) == set(g.forward_transitions[:, 2].tolist())
 
 
+def test_plan_eight_wave_dealing_and_checksum():
+    """The 8-wave dealing of the recursion tiles (den_recursion_lazy_kernel<wide>) joins the 16 waves in pairs: same
+    slot-rows, at most twice the rows and groups per wave, the same sums; and a plan whose payload was damaged on its
+    way through the disk cache is refused by pychain_hip_den_plan_info."""
+    g = syn.make_den_graph(1200, 12000, 2000, seed=4)
+    blob = _blob(g, 2000)
+    hd = emu.parse(blob)
+    rng = np.random.default_rng(0)
+    for name in ("alpha", "beta"):
+        t16, t8 = hd[name], hd[name + "8"]
+        assert t8["nwaves"] == 8 and t16["nwaves"] == 16
+        assert t8["total_slot_rows"] == t16["total_slot_rows"] and t8["ngroups"] == t16["ngroups"]
+        assert t8["max_wave_slot_rows"] <= 2 * t16["max_wave_slot_rows"] <= 80
+        assert t8["waves"][:, 1].max() <= 2 * t16["waves"][:, 1].max()
+        U, V = rng.random(hd["Hp"]), rng.random(2000)
+        assert np.array_equal(emu.tile_rows(t16, U, V, hd["Hp"], np.float64), emu.tile_rows(t8, U, V, hd["Hp"], np.float64))
+    assert hd["rec8_max_wave_groups"] <= 2 * hd["rec_max_wave_groups"]
+    assert _plan.plan_info(blob)["num_states"] == 1200
+    bad = blob.copy()
+    bad[len(bad) // 2] ^= 0x40
+    info = np.zeros(8, dtype=np.int32)
+    rc = _lib.lib().pychain_hip_den_plan_info(bad.ctypes.data_as(ctypes.c_void_p), bad.nbytes, info.ctypes.data_as(ctypes.c_void_p))
+    assert rc < 0 and b"checksum" in _lib.lib().pychain_hip_last_error()
+
+
 def _lds_cycles(t):
     """Modelled LDS cycles per half slot-row of a tile: a wave64 ds_read_b32 is served as two 32-lane
     halves over 32 banks, a half costs as many cycles as its fullest bank (equal addresses broadcast)."""
@@ -179,6 +204,21 @@ def test_plan_disk_cache_round_trip(tmp_path, monkeypatch):
     den.final_probs.mul_(2.0)
     d = _plan.build_plan_blob(*[getattr(den, n) for n in _plan._NAMES], 512)
     assert (a == d).all() and os.path.getsize(path) == a.nbytes
+    # ... and so is a file of the right size and header whose payload was damaged (the kernels would follow its
+    # offsets and packed LDS addresses unchecked)
+    with open(path, "r+b") as f:
+        f.seek(a.nbytes // 2)
+        byte = f.read(1)
+        f.seek(a.nbytes // 2)
+        f.write(bytes([byte[0] ^ 0x01]))
+    e = _plan.build_plan_blob(*[getattr(den, n) for n in _plan._NAMES], 512)
+    assert (a == e).all()
+    with open(path, "rb") as f:
+        assert f.read() == a.tobytes()                  # rewritten with the good bytes
+    # the key carries the library build: a rebuilt plan compiler does not get its predecessor's plans
+    monkeypatch.setattr(_plan, "_BUILD_ID", "another build")
+    _plan.build_plan_blob(*[getattr(den, n) for n in _plan._NAMES], 512)
+    assert len(os.listdir(tmp_path)) == 4
 
 
 def test_graph_plan_follows_in_place_edits():
