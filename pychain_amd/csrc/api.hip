@@ -308,11 +308,11 @@ bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
   // CUs the one-sequence workgroups leave enough of the chip to the occupancy launches and their chain is shorter
   return 8 * a.B >= 3 * device_cu_count();
 }
-// the 8-wave shape of the lazy recursion: where the 16-wave shape does not fit (D > 4096); option den_wide: "1" wherever
-// the shape allows (measurements, tests), "0" never
+// the 8-wave shape of the lazy recursion: only on request (option den_wide = "1", wherever the shape allows).  MEASURED
+// SLOWER than both alternatives - C3 5.02 ms against 3.43 ms for the 16-wave shape, C4 7.64 ms against 5.96 ms for
+// den_recursion_kernel (profiles/r03_a_time_matrix.txt): two waves per SIMD keep too few gathers in flight for the LDS.
 bool den_call_is_wide(const DenArgs& a, int resident_slot_rows) {
-  if (!den_wide_eligible(a, resident_slot_rows) || a.knobs.den_wide == 0) return false;
-  return a.knobs.den_wide > 0 || !den_lazy_eligible(a, resident_slot_rows);
+  return a.knobs.den_wide > 0 && den_wide_eligible(a, resident_slot_rows);
 }
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
   return a.knobs.den_lazy && !a.knobs.den_relaunch && !den_call_is_pair(a, resident_slot_rows) &&

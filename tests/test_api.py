@@ -144,3 +144,30 @@ def test_no_cpu_fallback():
         for fn in files:
             if fn.endswith((".py", ".hip", ".cpp", ".h")):
                 assert not pat.search(open(os.path.join(root, fn)).read()), fn
+
+
+def test_options_are_per_thread_and_restored():
+    """A validation thread at verbose level 1 does not change what a training thread's calls see; the context manager puts
+    back what was there (also a process-wide default taken from the environment at load time)."""
+    import threading
+    L_ = _lib.lib()
+    L_.pychain_hip_set_option(b"den_segments", b"3")            # process-wide default (as PYCHAIN_DEN_SEGMENTS=3 would)
+    try:
+        assert _lib.get_option("den_segments") == "3"
+        with _lib.option("den_segments", 5):
+            assert _lib.get_option("den_segments") == "5"
+            seen = []
+            t = threading.Thread(target=lambda: seen.append(_lib.get_option("den_segments")))
+            t.start(); t.join()
+            assert seen == ["3"]                                 # the other thread sees the default, not this override
+            with _lib.option("den_segments", ""):
+                assert _lib.get_option("den_segments") is None   # "" = unset for this thread
+            assert _lib.get_option("den_segments") == "5"
+        assert _lib.get_option("den_segments") == "3"            # not lost
+    finally:
+        L_.pychain_hip_set_option(b"den_segments", None)
+    assert _lib.get_option("den_segments") is None
+    from pychain_amd import native
+    native.set_verbose_level(2)
+    assert L_.pychain_hip_get_verbose_level() == 2 and _lib.get_option("verbose") == "2"
+    native.set_verbose_level(0)

@@ -1,0 +1,72 @@
+"""BASELINE.json's full-size configurations against the ORACLE, every utterance: the bench batch of C3 (64 utterances,
+fused ChainLoss, the gradient a trainer consumes: gamma_den - gamma_num) and C4 (32 utterances, denominator only).
+The oracle (0.5 - 1 s per utterance and flavour) is fanned out over the host cores of the GPU box; each worker compares
+its utterances with the HIP gradient in shared memory.  Reference: pychain/loss.py:27-105 over
+chain-computation.cc:92-330 and chain-log-domain-computation.cc:84-271."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_fanout, record_parity
+from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, _lib, _plan, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _summary(rows, fl, what="max_diff"):
+    diff = max(r[fl][what] for r in rows)
+    ref = max(r[fl]["max_ref"] for r in rows)
+    per_utt = max(r[fl][what] / r[fl]["max_ref"] for r in rows)
+    return diff / ref, per_utt
+
+
+def test_full_size_c3_vs_oracle():
+    """All 64 utterances of the bench batch (76 684 frames), fused loss: loss within 1e-4 of the fp32 and of the fp64
+    evaluation; FUSED gradient within 1e-5 of the fp64 evaluation of the reference's equations.  Against the fp32
+    restatement of the reference the bound is the triangle inequality, nothing looser: the reference's own distance from
+    fp64 on this batch (its fp32 log-domain numerator: measured 8.6e-4 over the 64 utterances, 2.1e-4 on the four of
+    profiles/r02_parity_c3.txt) plus the 1e-5 of the line above, and a literal 1.5e-3 on top."""
+    w = syn.make_workload("C3", device=DEV)
+    x = w["x"].clone().requires_grad_(True)
+    loss = ChainLoss(w["den_graph"], 1e-5, avg=False)(x, w["lengths"], w["num_graphs"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert ChainFunction.last_bad_count.tolist() == [0, 0]
+    rows = oracle_fanout(w["x"], w["lengths"], w["den_graph"], w["num_graphs"], x.grad)
+    assert len(rows) == 64 and all(r["tail_zero"] for r in rows)
+    got = float(loss.detach())
+    for fl in ("f32", "f64"):
+        ref = sum(r[fl]["den_objf"] - r[fl]["num_objf"] for r in rows)
+        assert abs(got - ref) <= 1e-4 * abs(ref), (fl, got, ref)
+    e64, e64u = _summary(rows, "f64")
+    e32, e32u = _summary(rows, "f32")
+    own, ownu = _summary(rows, "f32", "own_diff")
+    record_parity("full_size_c3_fused", grad_vs_f64=e64, grad_vs_f64_worst_utterance=e64u, grad_vs_f32=e32,
+                  grad_vs_f32_worst_utterance=e32u, f32_reference_vs_f64=own, f32_reference_vs_f64_worst_utterance=ownu,
+                  loss=got)
+    assert e64 <= 1e-5 and e64u <= 2e-5, (e64, e64u)
+    assert e32 <= own + 1e-5 and e32 <= 1.5e-3, (e32, own)
+
+
+def test_full_size_c4_vs_oracle():
+    """All 32 utterances of C4 (T = 2000, 8408 pdfs), denominator only: objf and gradient within 1e-4 of the fp32
+    restatement, 1e-5 of the fp64 evaluation."""
+    w = syn.make_workload("C4", device=DEV)
+    cfg = w["cfg"]
+    x = w["x"].clone().requires_grad_(True)
+    o = ChainFunction.apply(x, w["lengths"], ChainGraphBatch(w["den_graph"], cfg["B"]), 1e-5)
+    o.backward()
+    torch.cuda.synchronize()
+    assert int(ChainFunction.last_bad_count.sum()) == 0
+    rows = oracle_fanout(w["x"], w["lengths"], w["den_graph"], None, x.grad)
+    assert len(rows) == 32
+    got = float(o.detach())
+    for fl in ("f32", "f64"):
+        ref = sum(r[fl]["den_objf"] for r in rows)
+        assert abs(got - ref) <= 1e-4 * abs(ref), (fl, got, ref)
+    e64, _ = _summary(rows, "f64")
+    e32, _ = _summary(rows, "f32")
+    own, _ = _summary(rows, "f32", "own_diff")
+    record_parity("full_size_c4_den", grad_vs_f64=e64, grad_vs_f32=e32, f32_reference_vs_f64=own, objf=got)
+    assert e64 <= 1e-5 and e32 <= 1e-4, (e64, e32)

@@ -153,3 +153,84 @@ def test_ok_is_the_third_return_value_of_the_pychain_C_surface():
     bad_x[0, 0, 0] = float("nan")
     objf, grad, ok = native.forward_backward(*args(bad_x))
     assert not bool(ok.all())
+
+
+# ---- the 5 % invariant itself (chain-computation.cc:363-390, chain-log-domain-computation.cc:289-303) -----------------
+# Every test above trips a non-finite branch.  Here the data stay finite and healthy-looking: ONE stored alpha row is scaled
+# (option debug_corrupt_row) between the recursions and the occupancy pass, which is exactly what the reference's check is
+# there to notice - alpha.beta of that frame no longer equals the sequence's probability.
+
+
+def _den_with(x, L, den, corrupt=None, verbose=0, **opts):
+    ctx = [_lib.option(k, v) for k, v in opts.items()]
+    if corrupt:
+        ctx.append(_lib.option("debug_corrupt_row", corrupt))
+    ctx.append(_lib.option("verbose", verbose))
+    for c in ctx:
+        c.__enter__()
+    try:
+        return _den(x, L, den)
+    finally:
+        for c in reversed(ctx):
+            c.__exit__()
+
+
+@pytest.mark.parametrize("form", ["lazy", "two_barrier", "pair", "wide"])
+def test_five_percent_invariant_fires_denominator(form):
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([90, 77, 64, 90])
+    x = syn.make_input(4, 90, cfg["D"], seed=43, device=DEV)
+    opts = {"lazy": {}, "two_barrier": {"den_lazy": 0}, "pair": {"den_pair": 1}, "wide": {"den_wide": 1}}[form]
+    o0, g0, bad = _den_with(x, L, den, **opts)
+    assert bad == 0
+    # frame 0 is checked always (as in the reference)
+    o, g, bad = _den_with(x, L, den, corrupt="den,1,0,1.2", **opts)
+    assert bad > 0 and o == o0                       # the log-probability comes from the recursions: untouched
+    # 4 % is inside the tolerance
+    o, g, bad = _den_with(x, L, den, corrupt="den,1,0,1.04", **opts)
+    assert bad == 0
+    # another frame: seen only when every frame is checked (verbose level >= 1, chain-computation.cc:337-338)
+    o, g, bad = _den_with(x, L, den, corrupt="den,2,37,1.2", **opts)
+    assert bad == 0
+    o, g, bad = _den_with(x, L, den, corrupt="den,2,37,1.2", verbose=1, **opts)
+    assert bad > 0
+    o, g, bad = _den_with(x, L, den, corrupt="den,2,37,0.8", verbose=1, **opts)
+    assert bad > 0
+    o, g, bad = _den_with(x, L, den, verbose=1, **opts)
+    assert bad == 0 and o == o0 and torch.equal(g, g0)
+
+
+def test_five_percent_invariant_fires_numerator():
+    cfg = syn.CONFIGS["C3"]
+    L = torch.tensor([120, 96, 80])
+    x = syn.make_input(3, 120, cfg["D"], seed=47, device=DEV)
+    numg = syn.make_num_graphs(L.tolist(), cfg["D"], seed=700)
+
+    def run(corrupt=None, verbose=0):
+        ctx = [_lib.option("verbose", verbose)] + ([_lib.option("debug_corrupt_row", corrupt)] if corrupt else [])
+        for c in ctx:
+            c.__enter__()
+        try:
+            return _num(x, L, numg)
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+    o0, g0, bad = run()
+    assert bad == 0
+    o, g, bad = run("num,0,0,1.2")
+    assert bad > 0 and o == o0
+    o, g, bad = run("num,0,0,1.04")
+    assert bad == 0
+    o, g, bad = run("num,1,50,1.2")
+    assert bad == 0
+    o, g, bad = run("num,1,50,1.2", verbose=1)
+    assert bad > 0
+    # the fused loss reports it in its numerator word
+    xx = x.clone().requires_grad_(True)
+    den = syn.make_den_graph(200, 2000, cfg["D"], seed=2)
+    with _lib.option("debug_corrupt_row", "num,2,0,1.3"):
+        ChainLoss(den, 1e-5)(xx, L, numg).backward()
+    torch.cuda.synchronize()
+    bc = ChainFunction.last_bad_count.tolist()
+    assert bc[0] == 0 and bc[1] > 0

@@ -1,0 +1,108 @@
+"""The 8-wave shape of the lazy-normalisation recursion (den_lazy.inc.h: LzWide; nnet-output rows of up to 9216 pdfs,
+the C4 path) and the choice of kernel per shape.  Replaces chain-computation.cc:113-194,247-330 at D > 4096."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from helpers import rel_err
+from pychain_amd import ChainFunction, ChainGraphBatch, _lib, _plan, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _den(x, L, den, **opts):
+    xx = x.clone().requires_grad_(True)
+    gb = ChainGraphBatch(den, x.size(0))
+    ctx = [_lib.option(k, v) for k, v in opts.items()]
+    for c in ctx:
+        c.__enter__()
+    try:
+        o = ChainFunction.apply(xx, L, gb, 1e-5)
+        o.backward()
+        torch.cuda.synchronize()
+    finally:
+        for c in reversed(ctx):
+            c.__exit__()
+    assert int(ChainFunction.last_bad_count.sum()) == 0
+    return float(o.detach()), xx.grad
+
+
+def _names(den, D, B, **opts):
+    plan = _plan.graph_plan(den, D, torch.device(DEV))
+    ctx = [_lib.option(k, v) for k, v in opts.items()]
+    for c in ctx:
+        c.__enter__()
+    try:
+        return _lib.den_kernel_names(plan.slot_rows, den.num_states, D, B)
+    finally:
+        for c in reversed(ctx):
+            c.__exit__()
+
+
+def test_wide_recursion_on_the_c3_graph_vs_its_sixteen_wave_form_and_the_oracle():
+    """Forced onto the C3 graph (where the 16-wave shape is the default): same results to rounding as the 16-wave form,
+    bit-identical to itself over every occupancy schedule, and within 1e-4 of the oracle; ragged lengths, a one-frame
+    sequence."""
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([301, 288, 130, 1])
+    x = syn.make_input(4, 301, cfg["D"], seed=21, device=DEV)
+    assert _names(den, cfg["D"], 4)[0] == "den_recursion_lazy_kernel"
+    assert _names(den, cfg["D"], 4, den_wide=1)[0] == "den_recursion_lazy_kernel<wide>"
+    o16, g16 = _den(x, L, den)
+    o8, g8 = _den(x, L, den, den_wide=1)
+    assert abs(o8 - o16) <= 1e-6 * abs(o16) and rel_err(g8.cpu().numpy(), g16.cpu().numpy()) <= 1e-5
+    for nseg in (1, 3):
+        o, g = _den(x, L, den, den_wide=1, den_segments=nseg)
+        assert o == o8 and torch.equal(g, g8)
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 4), 1e-5)
+    assert abs(o8 - ro) <= 1e-4 * abs(ro) and rel_err(g8.cpu().numpy(), rg) <= 1e-4
+    assert bool((g8[2, 130:] == 0).all()) and bool((g8[3, 1:] == 0).all())
+
+
+@pytest.mark.parametrize("H,K,D", [(40, 300, 4100), (700, 6000, 8408), (3000, 30000, 9216)])
+def test_wide_rows_vs_oracle(H, K, D):
+    """4096 < D <= 9216 through the 8-wave recursion (small, medium and C4-size graphs: 32-, 64- and 80-row loops):
+    against the oracle."""
+    den = syn.make_den_graph(H, K, D, seed=3)
+    L = torch.tensor([97, 64, 5])
+    x = syn.make_input(3, 97, D, seed=33, device=DEV)
+    assert _names(den, D, 3, den_wide=1)[0] == "den_recursion_lazy_kernel<wide>"
+    o, g = _den(x, L, den, den_wide=1)
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 3), 1e-5)
+    assert abs(o - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4
+    o2, g2 = _den(x, L, den, den_wide=0)                     # the two-barrier kernel: second opinion
+    assert abs(o - o2) <= 1e-6 * abs(o2) and rel_err(g.cpu().numpy(), g2.cpu().numpy()) <= 1e-5
+
+
+def test_wide_recursion_nan_and_bad_lengths():
+    den = syn.make_den_graph(60, 400, 5000, seed=5)
+    x = syn.make_input(2, 40, 5000, seed=7, device=DEV)
+    x[1, 17, 4999] = float("nan")
+    xx = x.clone().requires_grad_(True)
+    with _lib.option("den_wide", 1):
+        o = ChainFunction.apply(xx, torch.tensor([40, 33]), ChainGraphBatch(den, 2), 1e-5)
+    torch.cuda.synchronize()
+    assert int(ChainFunction.last_bad_count.sum()) > 0 and np.isnan(float(o.detach()))
+
+
+def test_which_kernel_each_shape_gets():
+    """The kernel a shape selects is pinned (a silent drop to a slower kernel is a performance bug nobody sees):
+    pychain_hip_den_kernel_names answers from the same predicates the launcher uses."""
+    cases = [
+        # H, K, D, B -> recursion, occupancy
+        (3000, 30000, 3456, 64, "den_recursion_lazy_kernel", "den_gamma2_kernel"),          # C3
+        (3000, 30000, 3456, 128, "den_recursion_pair_kernel", "den_gamma2_kernel"),         # B >= 96: two sequences per workgroup
+        (200, 2000, 1000, 64, "den_recursion_lazy_kernel", "den_gamma2_kernel"),            # C2
+        (20, 60, 40, 2, "den_recursion_lazy_kernel", "den_gamma2_kernel"),                  # C1
+        (3000, 30000, 8408, 32, "den_recursion_kernel", "den_gamma_kernel"),                # C4
+        (300, 3000, 4100, 8, "den_recursion_kernel", "den_gamma_kernel"),
+    ]
+    for H, K, D, B, rec, occ in cases:
+        den = syn.make_den_graph(H, K, D, seed=1)
+        got = _names(den, D, B)
+        assert got[0] == rec, (H, K, D, B, got)
+        if occ is not None:
+            assert got[1] == occ, (H, K, D, B, got)
