@@ -28,7 +28,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves",
-                                     "den_pair", "den_wide", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
+                                     "den_pair", "den_wide", "den_dma", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
                                      "den_lazy", "debug_corrupt_row"};
 bool known_option(const char* name) {
   if (!name) return false;
@@ -69,6 +69,7 @@ CallKnobs call_knobs() {
   k.num_no_staging_waves = option_set("num_no_staging_waves");
   k.den_pair = option_int("den_pair", -1);
   k.den_wide = option_int("den_wide", -1);
+  k.den_dma = option_int("den_dma", -1);
   k.gamma_tiled = option_int("gamma_tiled", -1);
   k.force_general = option_int("force_general", 0) ? 1 : 0;
   std::string v;
@@ -127,6 +128,7 @@ namespace {
 bool den_call_is_pair(const DenArgs& a, int resident_slot_rows);
 bool den_call_is_wide(const DenArgs& a, int resident_slot_rows);
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows);
+int den_call_shape(const DenArgs& a, int resident_slot_rows);
 }  // namespace
 extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D, int B, int plans_shared,
                                             char* buf, size_t buf_bytes) {
@@ -138,7 +140,7 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
   a.plan_stride = plans_shared ? 0 : 256;
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
-  a.wide = a.lazy && den_call_is_wide(a, resident_slot_rows) ? 1 : 0;
+  a.wide = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   snprintf(buf, buf_bytes, "%s,%s", den_recursion_kernel_name(a, resident_slot_rows),
            den_occupancy_kernel_name(a, (D + 63) / 64, resident_slot_rows));
   return PYCHAIN_HIP_OK;
@@ -314,9 +316,19 @@ bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
 bool den_call_is_wide(const DenArgs& a, int resident_slot_rows) {
   return a.knobs.den_wide > 0 && den_wide_eligible(a, resident_slot_rows);
 }
+// the 16-wave shape with LDS-direct nnet-output rows: where the plain 16-wave shape does not fit (4096 < D <= 9216: C4);
+// option den_dma: "1" / "2" wherever the shape allows, "0" never
+bool den_call_is_dma(const DenArgs& a, int resident_slot_rows) {
+  if (a.knobs.den_dma == 0 || !den_dma_eligible(a, resident_slot_rows)) return false;
+  return a.knobs.den_dma > 0 || !den_lazy_eligible(a, resident_slot_rows);
+}
+int den_call_shape(const DenArgs& a, int resident_slot_rows) {     // DenArgs::wide
+  if (den_call_is_wide(a, resident_slot_rows)) return 1;
+  return den_call_is_dma(a, resident_slot_rows) ? 2 : 0;
+}
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
   return a.knobs.den_lazy && !a.knobs.den_relaunch && !den_call_is_pair(a, resident_slot_rows) &&
-         (den_lazy_eligible(a, resident_slot_rows) || den_call_is_wide(a, resident_slot_rows));
+         (den_lazy_eligible(a, resident_slot_rows) || den_call_is_wide(a, resident_slot_rows) || den_call_is_dma(a, resident_slot_rows));
 }
 
 // option debug_corrupt_row: row[0..n) *= scale, between the recursion and the occupancy launches
@@ -339,7 +351,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt) ? den_segments(a) : 1;
   // the lazy-normalisation recursion runs a whole sequence in one launch: not with the relaunch schedule
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
-  a.wide = a.lazy && den_call_is_wide(a, resident_slot_rows) ? 1 : 0;
+  a.wide = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   // two sequences per workgroup once the 2B one-sequence workgroups would fill the chip (option den_pair: 1 always
   // where the shape allows, 0 never); rows in den_recursion_kernel's form
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
@@ -648,7 +660,7 @@ int chain_loss_backward_impl(
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
   da.lazy = den_call_is_lazy(da, resident_slot_rows) ? 1 : 0;
-  da.wide = da.lazy && den_call_is_wide(da, resident_slot_rows) ? 1 : 0;
+  da.wide = da.lazy ? den_call_shape(da, resident_slot_rows) : 0;
   NumArgs na;
   // the occupancy launch reads only the forward transitions / indices / log-probs of the graphs
   rc = fill_num_args(na, ft, fi, fp, ft, fi, fp, fp, fp,

@@ -26,7 +26,8 @@ struct DenArgs {
   // 1: the recursions run as den_recursion_pair_kernel (den_pair.inc.h): two sequences per workgroup, ceil(B/2)
   // workgroups per direction; rows as den_recursion_kernel stores them (lazy = 0).  Shared plan only.
   int pair;
-  // 1: the lazy recursions run in their 8-wave shape (den_lazy.inc.h: LzWide - nnet-output rows of up to 9216 pdfs)
+  // which shape the lazy recursions run in (den_lazy.inc.h): 0 = LzNarrow (16 waves, D <= 4096), 1 = LzWide (8 waves),
+  // 2 = LzDma (16 waves, nnet-output rows of up to 9216 pdfs brought in by LDS-direct loads)
   int wide;
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
@@ -76,6 +77,7 @@ struct DenArgs {
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows);
 // ... in its 8-wave shape (DenArgs::wide); checked before den_lazy_eligible, which is the 16-wave shape
 bool den_wide_eligible(const DenArgs& a, int resident_slot_rows);
+bool den_dma_eligible(const DenArgs& a, int resident_slot_rows);
 // names of the kernels launch_den would run for this call: recursion, occupancy (measurement tools and the
 // kernel-selection test label by them)
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows);

@@ -1365,6 +1365,24 @@ hipError_t launch_wide_x(const DenArgs& a, int rows, hipStream_t st) {
   if (rows <= 32) return launch_one(den_recursion_lazy_kernel<64, M>, a, grid, M::kBytes, st, M::kWaves * 64);
   return launch_one(den_recursion_lazy_kernel<80, M>, a, grid, M::kBytes, st, M::kWaves * 64);
 }
+// the 16-wave shape with LDS-direct nnet-output rows (LzDma): D <= 9216, Hp <= 3072
+inline bool dma_shape_ok(const DenArgs& a, int hint) {
+  const int rows = hint & 1023;
+  return ((hint >> 30) & 1) && a.D % 4 == 0 && a.D <= (int)LzDma::kMaxPdfs && a.Hp <= (int)LzDma::kMaxStates && rows > 0 &&
+         rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
+}
+template <typename M>
+hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
+  const dim3 grid(2 * a.B);
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M>, a, grid, M::kBytes, st);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M>, a, grid, M::kBytes, st);
+  return launch_one(den_recursion_lazy_kernel<kMaxResident, M>, a, grid, M::kBytes, st);
+}
+hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
+  // (option den_dma = 2: the narrow map with LDS-direct rows, where the shape fits it - an experiment on C3)
+  if (a.knobs.den_dma == 2 && lazy_shape_ok(a, hint)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
+  return launch_dma_m<LzDma>(a, hint & 1023, st);
+}
 hipError_t launch_wide(const DenArgs& a, int hint, hipStream_t st) {
   const int rows = hint & 1023;
   return a.D <= (int)LzWide<2>::kMaxPdfs ? launch_wide_x<2>(a, rows, st) : launch_wide_x<5>(a, rows, st);
@@ -1392,7 +1410,7 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
     e = launch_pair(a, hint, st);
     if (e != hipSuccess) return e;
   } else if ((a.phase_mask & 1) && a.lazy) {
-    e = a.wide ? launch_wide(a, hint, st) : launch_lazy(a, hint, st);
+    e = a.wide == 1 ? launch_wide(a, hint, st) : (a.wide == 2 ? launch_dma(a, hint, st) : launch_lazy(a, hint, st));
     if (e != hipSuccess) return e;
   } else if (a.phase_mask & 1) {
     const dim3 grid(2 * a.B);
@@ -1452,10 +1470,11 @@ hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hi
 
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows); }
 bool den_wide_eligible(const DenArgs& a, int resident_slot_rows) { return wide_shape_ok(a, resident_slot_rows); }
+bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return dma_shape_ok(a, resident_slot_rows); }
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
   (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";
-  if (a.lazy) return a.wide ? "den_recursion_lazy_kernel<wide>" : "den_recursion_lazy_kernel";
+  if (a.lazy) return a.wide == 1 ? "den_recursion_lazy_kernel<wide>" : (a.wide == 2 ? "den_recursion_lazy_kernel<dma>" : "den_recursion_lazy_kernel");
   return "den_recursion_kernel";
 }
 const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {

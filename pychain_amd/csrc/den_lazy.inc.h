@@ -39,18 +39,33 @@ struct LzNarrow {
   //   [64K, 80K)  nnet-output buffer 0 (exp'd row)      [80K, 96K)  nnet-output buffer 1
   //   [96K, ...)  partial sums, beta's leaky probs
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 1;
+  static constexpr bool kDma = false;
   static constexpr uint32_t kU0 = 0, kU1 = 32768, kX0 = 65536, kX1 = 81920, kUField = 0, kXField = 49152;
   static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
   static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
 };
+// the same map with the nnet-output rows brought in by LDS-direct loads (lazy_recursion: kDma): an experiment on C3
+struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static constexpr int kXch = 0; };
 template <int XCH>
 struct LzWide {
   //   [0, 36K)    nnet-output buffer 0: float[<= 9216]  [36K, 72K)  nnet-output buffer 1
   //   [72K, 96K)  state buffer 0: float2[<= 3072]       [96K, 120K) state buffer 1
   //   [120K, ...) beta's leaky probs, partial sums
   static constexpr int kWaves = 8, kMaxGroups = 8, kXch = XCH;
+  static constexpr bool kDma = false;
   static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = XCH * 4 * 8 * 64 < 9216 ? XCH * 4 * 8 * 64 : 9216;
+  static constexpr uint32_t kLk = 122880, kRed = kLk + kMaxStates * 4, kBytes = kRed + 2 * 2 * 64 * 4;
+};
+// 16 waves x 128 VGPRs AND nnet-output rows of up to 9216 pdfs (C4): the rows never pass through registers.  Every wave
+// requests its 1 KiB chunks of the NEXT step's raw row with `buffer_load_dwordx4 ... lds` (lane l's 16 bytes land at
+// chunk base + 16 l: tools/ubench/ldsdma.hip) at the start of a frame, straight into the buffer the next frame gathers
+// from, and clamps / exp's its own chunks IN PLACE at the end of the frame.
+struct LzDma {
+  static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
+  static constexpr bool kDma = true;
+  static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
+  static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 9216;
   static constexpr uint32_t kLk = 122880, kRed = kLk + kMaxStates * 4, kBytes = kRed + 2 * 2 * 64 * 4;
 };
 template <typename MAP> constexpr bool lz_map_ok() {
@@ -58,7 +73,7 @@ template <typename MAP> constexpr bool lz_map_ok() {
          MAP::kUField + 8u * (MAP::kMaxStates - 1) <= 65535u && MAP::kXField + 4u * (MAP::kMaxPdfs - 1) <= 65535u &&
          MAP::kBytes <= 160u * 1024u;
 }
-static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzWide<5>>() && lz_map_ok<LzWide<2>>(), "ds_read offset fields are 16 bits");
+static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzWide<5>>() && lz_map_ok<LzWide<2>>() && lz_map_ok<LzDma>(), "ds_read offset fields are 16 bits");
 constexpr uint32_t kLzBytes = LzNarrow::kBytes;
 
 typedef float lz_v2f __attribute__((ext_vector_type(2)));
@@ -68,6 +83,48 @@ typedef __attribute__((address_space(3))) float lz_lds_float;
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 __device__ __forceinline__ lz_v2f lz_ld2(uint32_t byte_addr) { return *(lz_lds_cv2f*)(byte_addr); }
 __device__ __forceinline__ void lz_st1(uint32_t byte_addr, float v) { *(lz_lds_float*)(byte_addr) = v; }
+#pragma clang diagnostic pop
+
+// ---- nnet-output rows by LDS-direct loads (MAP::kDma) -----------------------------------------------------------
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+typedef __attribute__((address_space(3))) void lz_lds_void;
+typedef float lz_v4 __attribute__((ext_vector_type(4)));
+#define PYCHAIN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)     /* vmcnt(0) only (gfx9 encoding) */
+// row t of the sequence behind `buf` -> LDS at byte address xbase, 1 KiB chunks dealt to the NW waves; lanes past the
+// row's end re-read its last 16 bytes (a chunk may run past the end of the whole slab otherwise)
+template <int NW, int NCH>
+__device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int lane, uint32_t xbase) {
+  const int row_bytes = D * 4;
+  const int soff = __builtin_amdgcn_readfirstlane(t * row_bytes);
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int ch = wave + c * NW;                       // (uniform)
+    if (ch * 1024 < row_bytes) {
+      const int voff = min(lane * 16, row_bytes - 16 - ch * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(buf, (lz_lds_void*)(xbase + (uint32_t)ch * 1024u), 16, voff,
+                                               soff + ch * 1024, 0, 0);
+    }
+  }
+}
+// this wave's chunks of the row at xbase: raw -> clamp / exp, in place; returns true if a NaN was seen
+template <int NW, int NCH>
+__device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_t xbase, int is_exp) {
+  bool nan = false;
+  PYCHAIN_WAIT_VM0();                                   // this wave's loads have landed
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    const int ch = wave + c * NW;
+    if (ch * 1024 < D * 4) {
+      const uint32_t addr = xbase + (uint32_t)ch * 1024u + (uint32_t)lane * 16u;
+      lz_v4 q = *(const __attribute__((address_space(3))) lz_v4*)(addr);
+      nan = nan || __builtin_isunordered(q.x, q.y) || __builtin_isunordered(q.z, q.w);
+      if (is_exp == kXExpClamp) q = lz_v4{clamp_exp(q.x, kXExpClamp), clamp_exp(q.y, kXExpClamp), clamp_exp(q.z, kXExpClamp), clamp_exp(q.w, kXExpClamp)};
+      *(__attribute__((address_space(3))) lz_v4*)(addr) = q;
+    }
+  }
+  return nan;
+}
 #pragma clang diagnostic pop
 
 template <int R, typename MAP>
@@ -221,6 +278,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 
   // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
   XRow<NT, 4, MAP::kXch> xq;
+  constexpr int kDmaCh = ((int)MAP::kMaxPdfs / 256 + NW - 1) / NW;   // 1 KiB chunks of a row one wave may own
   {
     float p0 = 0.f, p1 = 0.f;
     for (int i = tid; i < (int)MAP::kMaxStates; i += NT) {
@@ -232,9 +290,14 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       p0 += s; p1 += s * l;
     }
     const int t0 = fwd ? 0 : L - 1;
-    xq.load(xseq + (size_t)t0 * D, D, tid);
-    if (fwd && xq.has_nan()) bad |= 2;
-    xq.store(reinterpret_cast<float*>(smem_raw + MAP::kX0), xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    if constexpr (MAP::kDma) {
+      lz_dma_row<NW, kDmaCh>(xbuf, t0, D, wave, lane, MAP::kX0);
+      if (lz_dma_finish<NW, kDmaCh>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
+    } else {
+      xq.load(xseq + (size_t)t0 * D, D, tid);
+      if (fwd && xq.has_nan()) bad |= 2;
+      xq.store(reinterpret_cast<float*>(smem_raw + MAP::kX0), xseq + (size_t)t0 * D, D, tid, a.input_is_exp);
+    }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     if (NW < 16) {                                     // partial sums of waves that do not exist: zero, once
       if (tid < 256) red[tid] = 0.f;
@@ -301,7 +364,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const int tn = (FWDC) ? j + 1 : L - 2 - j;               /* nnet-output row of the NEXT step */          \
     const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
     LZ_PH0();                                                                                               \
-    if (have_next) xq.load_row(xbuf, tn, D, tq);             /* in flight during the arc work */             \
+    if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
+      if (have_next) lz_dma_row<NW, kDmaCh>(xbuf, tn, D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1);            \
+    } else if (have_next) xq.load_row(xbuf, tn, D, tq);      /* in flight during the arc work */             \
     lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, [&]() {                                \
       if (j > 0) PYCHAIN_LZ_TOTALS((PAR) ^ 1, j - 1, (FWDC), lq, tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) - it sits in the buffer this */ \
@@ -331,7 +396,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       }                                                                                                     \
     }                                                                                                       \
     /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
-    if (have_next) {                                                                                        \
+    if constexpr (MAP::kDma) {                                                                              \
+      if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
+    } else if (have_next) {                                                                                 \
       if ((FWDC) && xq.has_nan()) bad |= 2;                  /* a NaN network output: not ok, NaN log-probability */ \
       xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \
     }                                                                                                       \

@@ -74,6 +74,8 @@ struct Balancer {
   std::vector<std::vector<int>> pos_of_row;          // [tile][row id] -> row position
   struct Occ { int tile, row, op; };
   std::vector<std::vector<Occ>> occ[2];              // [layout A / B][state]: arcs that gather this state
+  std::vector<std::vector<int>> gmax;                // [tile][group]: arc count of the group's longest row (fixed: it sets the slot-rows)
+  bool free_moves = true;                            // PYCHAIN_PLAN_FREE=0: only rows of equal arc count trade places, across half-groups
   Lcg rng{0x2545F491u};
 
   Balancer(std::vector<Tile>& t, Layouts& l) : tiles(t), lay(l) {
@@ -86,8 +88,11 @@ struct Balancer {
     hist.assign((size_t)n * 64, 0);
     occ[0].resize(lay.pos[kLayA].size()); occ[1].resize(lay.pos[kLayB].size());
     pos_of_row.resize(tiles.size());
+    gmax.resize(tiles.size());
     for (size_t ti = 0; ti < tiles.size(); ti++) {
       const Tile& tl = tiles[ti];
+      gmax[ti].assign(tl.npos / 64 + 1, 0);
+      for (size_t i = 0; i < tl.order.size(); i++) gmax[ti][i / 64] = std::max(gmax[ti][i / 64], (int)(*tl.rows)[tl.order[i]].size());
       pos_of_row[ti].assign(tl.rows->size(), -1);
       for (size_t i = 0; i < tl.order.size(); i++) pos_of_row[ti][tl.order[i]] = (int)i;
       for (int row : tl.order)
@@ -144,15 +149,27 @@ struct Balancer {
       const int n = (int)tl.order.size();
       if (n <= 32) continue;
       const int p1 = rng.next() % n;
-      const int span = 1 + rng.next() % 512;           // rows are sorted by arc count: equal counts are neighbours
-      const int p2 = p1 + ((rng.next() & 1) ? span : -span);
-      if (p2 < 0 || p2 >= n || p2 / 32 == p1 / 32) continue;
+      // rows are sorted by arc count: equal counts are neighbours.  Half of the moves stay inside p1's group of 64
+      // (every permutation of a group's rows is free: its slot-row count is that of its longest row, whichever lane owns it)
+      int p2;
+      if (free_moves && (rng.next() & 1)) {
+        p2 = (p1 & ~63) + (int)(rng.next() & 63);
+      } else {
+        const int span = 1 + rng.next() % 512;
+        p2 = p1 + ((rng.next() & 1) ? span : -span);
+      }
+      if (p2 < 0 || p2 >= n || p2 == p1) continue;
       const int r1 = tl.order[p1], r2 = tl.order[p2];
-      if ((*tl.rows)[r1].size() != (*tl.rows)[r2].size()) continue;
+      const int d1 = (int)(*tl.rows)[r1].size(), d2 = (int)(*tl.rows)[r2].size();
+      if (d1 != d2) {
+        // rows of different arc counts may trade places where neither group's longest row grows
+        if (!free_moves || d1 > gmax[ti][p2 / 64] || d2 > gmax[ti][p1 / 64]) continue;
+      } else if (!free_moves && p2 / 32 == p1 / 32) continue;
       const int h1 = hg0[ti] + p1 / 32, h2 = hg0[ti] + p2 / 32;
       const int L = tl.own_layout;
+      if (h1 == h2 && L < 0) continue;                  // nothing changes
       // apply, evaluate, undo on rejection (all updates are exact inverses of each other)
-      long d = move_row(ti, r1, h1, h2) + move_row(ti, r2, h2, h1);
+      long d = h1 == h2 ? 0 : move_row(ti, r1, h1, h2) + move_row(ti, r2, h2, h1);
       pos_of_row[ti][r1] = p2; pos_of_row[ti][r2] = p1;
       if (L >= 0) {
         d += rebank(L, r1, p1 & 31, p2 & 31); lay.pos[L][r1] = p2;
@@ -166,7 +183,7 @@ struct Balancer {
           rebank(L, r1, p2 & 31, p1 & 31); lay.pos[L][r1] = p1;
         }
         pos_of_row[ti][r1] = p1; pos_of_row[ti][r2] = p2;
-        move_row(ti, r2, h1, h2); move_row(ti, r1, h2, h1);
+        if (h1 != h2) { move_row(ti, r2, h1, h2); move_row(ti, r1, h2, h1); }
       }
     }
   }
@@ -180,90 +197,123 @@ struct SlotOrder {
   const Tile& t;
   const Layouts& lay;
   std::vector<int> cell_off, cell;
-  std::atomic<long> cycles{0}, columns{0};           // modelled LDS cycles / half slot-rows (statistics)
+  std::atomic<long> cycles{0}, columns{0};           // sum over half slot-rows and operands of the fullest bank / half slot-rows (statistics)
+  std::atomic<long> cycles_op[2] = {{0}, {0}};       // ... per operand
+  std::atomic<long> cost_tenths{0}, slot_rows{0};    // modelled extra LDS cycles (x 10) of the conflicts / slot-rows
+  // What a gather with a fullest bank of L lanes (the larger of its two 32-lane halves: they are served side by side)
+  // costs beyond a conflict-free one, in tenths of a cycle, measured on gfx950 (tools/ubench/ldsbanks.hip,
+  // profiles/r03_ubench_ldsbanks.txt): ds_read_b32  L=2 +0.6, L=4 +2.8, L=8 +7.0;  ds_read_b64  L=2 +0.2, L=4 +2.8, L=8 +7.1.
+  // (A conflict-free wave64 gather occupies the LDS for 2.0 / 2.3 cycles - an all-padding slot-row costs that too.)
+  int wide_op[2] = {0, 0};                           // operand gathered with ds_read_b64 (state vectors of the lazy recursions)
+  int extra_tenths(int op, int L) const {
+    if (L <= 1) return 0;
+    if (L == 2) return wide_op[op] ? 2 : 6;
+    if (L == 3) return 18;
+    return 10 * L - 12;
+  }
 
-  SlotOrder(const Tile& tile, const Layouts& l) : t(tile), lay(l) {
+  SlotOrder(const Tile& tile, const Layouts& l, bool op0_wide, bool op1_wide) : t(tile), lay(l) {
+    wide_op[0] = op0_wide; wide_op[1] = op1_wide;
+    cost_model = (int)env_long("PYCHAIN_PLAN_COST", 1);
     int off = 0;
     for (int g : t.gsl) { cell_off.push_back(off); off += 64 * g; }
     cell.assign(off, -1);
   }
-  struct Col { int cnt[2][32]; int nm[2][34]; int mx[2]; };
-  static constexpr int kLambda = 12;
-  static int col_add(Col& c, int op, int b, int d) {   // returns the energy change
-    int& x = c.cnt[op][b];
-    const int before = kLambda * c.mx[op] + x * x;
-    c.nm[op][x]--; x += d; c.nm[op][x]++;
-    if (d > 0) { if (x > c.mx[op]) c.mx[op] = x; }
-    else { while (c.mx[op] > 0 && c.nm[op][c.mx[op]] == 0) c.mx[op]--; }
-    return kLambda * c.mx[op] + x * x - before;
+  // one slot-row (column) of a group: bank loads of both halves and both operands
+  struct Col { int cnt[2][2][32]; int nm[2][2][34]; int mx[2][2]; };
+  static constexpr int kScale = 4;                   // energy = kScale * extra tenths + sum of squared bank loads
+  int cost_model = 1;                                // 0: 12 * (fullest bank of half 0 + of half 1) (both operands alike: the model of rounds 1-2)
+  int col_energy_op(const Col& c, int op) const {
+    if (cost_model == 0) return 12 * (c.mx[0][op] + c.mx[1][op]);
+    return kScale * extra_tenths(op, std::max(c.mx[0][op], c.mx[1][op]));
   }
-  void half(int g, int hh, long moves_per_cell) {
-    Lcg rng{0x9E3779B9u ^ (uint32_t)((g * 2 + hh) * 2654435761u)};   // per half-group: results do not depend on the thread count
+  int col_add(Col& c, int hh, int op, int b, int d) const {   // returns the energy change
+    int& x = c.cnt[hh][op][b];
+    const int before = col_energy_op(c, op) + x * x;
+    c.nm[hh][op][x]--; x += d; c.nm[hh][op][x]++;
+    if (d > 0) { if (x > c.mx[hh][op]) c.mx[hh][op] = x; }
+    else { while (c.mx[hh][op] > 0 && c.nm[hh][op][c.mx[hh][op]] == 0) c.mx[hh][op]--; }
+    return col_energy_op(c, op) + x * x - before;
+  }
+  void group(int g, long moves_per_cell) {
+    Lcg rng{0x9E3779B9u ^ (uint32_t)((g * 2) * 2654435761u)};   // per group: results do not depend on the thread count
     const int A = t.gsl[g];
     int nr = 0;
-    for (int r = 0; r < 32; r++) if (g * 64 + hh * 32 + r < (int)t.order.size()) nr = r + 1;
+    for (int r = 0; r < 64; r++) if (g * 64 + r < (int)t.order.size()) nr = r + 1;
     if (A == 0 || nr == 0) return;
-    int* cl = &cell[cell_off[g] + hh * 32 * A];      // [row][slot]
+    int* cl = &cell[cell_off[g]];                    // [row][slot]
     std::vector<Col> cs(A);
-    for (auto& c : cs) { memset(&c, 0, sizeof(c)); c.nm[0][0] = c.nm[1][0] = 32; }
+    for (auto& c : cs) { memset(&c, 0, sizeof(c)); for (int hh = 0; hh < 2; hh++) c.nm[hh][0][0] = c.nm[hh][1][0] = 32; }
     std::vector<int> b0(nr * A, -1), b1(nr * A, -1);
-    // greedy: rows with most arcs first; each arc goes to the free slot of its row with fewest collisions
+    // greedy: rows with most arcs first; each arc goes to the free slot of its row with fewest collisions in its half
     std::vector<int> rorder(nr);
     std::iota(rorder.begin(), rorder.end(), 0);
-    auto arcs_of = [&](int r) -> const std::vector<Arc>& { return (*t.rows)[t.order[g * 64 + hh * 32 + r]]; };
+    auto arcs_of = [&](int r) -> const std::vector<Arc>& { return (*t.rows)[t.order[g * 64 + r]]; };
     std::stable_sort(rorder.begin(), rorder.end(), [&](int x, int y) { return arcs_of(x).size() > arcs_of(y).size(); });
     for (int r : rorder) {
       const auto& arcs = arcs_of(r);
+      const int hh = r >> 5;
       for (int a = 0; a < (int)arcs.size(); a++) {
         const int x0 = lay.bank(t.lay[0], arcs[a].e0), x1 = lay.bank(t.lay[1], arcs[a].e1);
         int best = -1, bc = 0;
         for (int j = 0; j < A; j++) {
           if (cl[r * A + j] >= 0) continue;
-          const int cst = cs[j].cnt[0][x0] + cs[j].cnt[1][x1];
+          const int cst = cs[j].cnt[hh][0][x0] + cs[j].cnt[hh][1][x1];
           if (best < 0 || cst < bc) { best = j; bc = cst; }
         }
         cl[r * A + best] = a; b0[r * A + best] = x0; b1[r * A + best] = x1;
-        col_add(cs[best], 0, x0, +1); col_add(cs[best], 1, x1, +1);
+        col_add(cs[best], hh, 0, x0, +1); col_add(cs[best], hh, 1, x1, +1);
       }
     }
     if (A >= 2) {
       const long iters = moves_per_cell * nr * A;
-      const double t0 = 8.0, t1 = 0.2, cool = iters > 1 ? pow(t1 / t0, 1.0 / (double)iters) : 1.0;
+      const double t0 = 0.01 * (double)env_long("PYCHAIN_PLAN_T0", 300), t1 = 0.01 * (double)env_long("PYCHAIN_PLAN_T1", 3);
+      const double cool = iters > 1 ? pow(t1 / t0, 1.0 / (double)iters) : 1.0;
       double T = t0;
       for (long it = 0; it < iters; it++, T *= cool) {
         const int r = rng.next() % nr, j1 = rng.next() % A;
         int j2 = rng.next() % (A - 1); if (j2 >= j1) j2++;
-        const int i1 = r * A + j1, i2 = r * A + j2;
+        const int i1 = r * A + j1, i2 = r * A + j2, hh = r >> 5;
         if (b0[i1] < 0 && b0[i2] < 0) continue;
         int dE = 0;
-        if (b0[i1] >= 0) dE += col_add(cs[j1], 0, b0[i1], -1) + col_add(cs[j1], 1, b1[i1], -1);
-        if (b0[i2] >= 0) dE += col_add(cs[j2], 0, b0[i2], -1) + col_add(cs[j2], 1, b1[i2], -1);
-        if (b0[i1] >= 0) dE += col_add(cs[j2], 0, b0[i1], +1) + col_add(cs[j2], 1, b1[i1], +1);
-        if (b0[i2] >= 0) dE += col_add(cs[j1], 0, b0[i2], +1) + col_add(cs[j1], 1, b1[i2], +1);
+        if (b0[i1] >= 0) dE += col_add(cs[j1], hh, 0, b0[i1], -1) + col_add(cs[j1], hh, 1, b1[i1], -1);
+        if (b0[i2] >= 0) dE += col_add(cs[j2], hh, 0, b0[i2], -1) + col_add(cs[j2], hh, 1, b1[i2], -1);
+        if (b0[i1] >= 0) dE += col_add(cs[j2], hh, 0, b0[i1], +1) + col_add(cs[j2], hh, 1, b1[i1], +1);
+        if (b0[i2] >= 0) dE += col_add(cs[j1], hh, 0, b0[i2], +1) + col_add(cs[j1], hh, 1, b1[i2], +1);
         if (dE <= 0 || rng.unit() < exp(-(double)dE / T)) {
           std::swap(cl[i1], cl[i2]); std::swap(b0[i1], b0[i2]); std::swap(b1[i1], b1[i2]);
         } else {
-          if (b0[i2] >= 0) { col_add(cs[j1], 0, b0[i2], -1); col_add(cs[j1], 1, b1[i2], -1); }
-          if (b0[i1] >= 0) { col_add(cs[j2], 0, b0[i1], -1); col_add(cs[j2], 1, b1[i1], -1); }
-          if (b0[i2] >= 0) { col_add(cs[j2], 0, b0[i2], +1); col_add(cs[j2], 1, b1[i2], +1); }
-          if (b0[i1] >= 0) { col_add(cs[j1], 0, b0[i1], +1); col_add(cs[j1], 1, b1[i1], +1); }
+          if (b0[i2] >= 0) { col_add(cs[j1], hh, 0, b0[i2], -1); col_add(cs[j1], hh, 1, b1[i2], -1); }
+          if (b0[i1] >= 0) { col_add(cs[j2], hh, 0, b0[i1], -1); col_add(cs[j2], hh, 1, b1[i1], -1); }
+          if (b0[i2] >= 0) { col_add(cs[j2], hh, 0, b0[i2], +1); col_add(cs[j2], hh, 1, b1[i2], +1); }
+          if (b0[i1] >= 0) { col_add(cs[j1], hh, 0, b0[i1], +1); col_add(cs[j1], hh, 1, b1[i1], +1); }
         }
       }
     }
-    long cyc = 0;
-    for (int j = 0; j < A; j++) cyc += std::max(cs[j].mx[0], 1) + std::max(cs[j].mx[1], 1);
-    cycles += cyc; columns += A;
+    long cyc0 = 0, cyc1 = 0, extra = 0;
+    for (int j = 0; j < A; j++) {
+      for (int hh = 0; hh < 2; hh++) { cyc0 += std::max(cs[j].mx[hh][0], 1); cyc1 += std::max(cs[j].mx[hh][1], 1); }
+      for (int op = 0; op < 2; op++) extra += extra_tenths(op, std::max(cs[j].mx[0][op], cs[j].mx[1][op]));
+    }
+    cycles += cyc0 + cyc1; columns += 2 * A;
+    cycles_op[0] += cyc0; cycles_op[1] += cyc1;
+    cost_tenths += extra; slot_rows += A;
   }
-  // half-groups are independent: annealed on up to 8 host threads
+  // groups are independent: annealed on up to 8 host threads
   void run(long moves_per_cell) {
-    const int n = 2 * (int)t.gsl.size();
+    const int n = (int)t.gsl.size();
     std::atomic<int> next{0};
-    auto work = [&]() { for (int i; (i = next++) < n;) half(i >> 1, i & 1, moves_per_cell); };
+    auto work = [&]() { for (int i; (i = next++) < n;) group(i, moves_per_cell); };
     const int nthreads = (int)std::min<long>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (long)n);
     std::vector<std::thread> pool;
     for (int i = 1; i < nthreads; i++) pool.emplace_back(work);
     work();
     for (auto& th : pool) th.join();
+  }
+  // modelled LDS-busy cycles of the tile per frame: every slot-row issues one gather per operand
+  double lds_cycles() const {
+    const double base = (wide_op[0] ? 2.3 : 2.0) + (wide_op[1] ? 2.3 : 2.0);
+    return base * (double)slot_rows.load() + 0.1 * (double)cost_tenths.load();
   }
 };
 
@@ -375,9 +425,13 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, cons
           probs[l] = arc.p; real[l] = true;
           if (!fill[l >> 5]) fill[l >> 5] = words[l];
         }
+        // PYCHAIN_PLAN_LINEAR=1 (timing experiments only - WRONG RESULTS): every gather lane-linear, i.e. conflict-free
+        static const bool linear = env_long("PYCHAIN_PLAN_LINEAR", 0) != 0;
         for (int l = 0; l < 64; l++) {
           uint32_t pb; memcpy(&pb, &probs[l], 4);
-          o.slots.push_back(real[l] ? words[l] : fill[l >> 5]); o.slots.push_back(pb);
+          uint32_t wd = real[l] ? words[l] : fill[l >> 5];
+          if (linear) wd = (uint32_t)(l + 64 * (j & 7)) | ((uint32_t)(l + 64 * (j & 7)) << 16);
+          o.slots.push_back(wd); o.slots.push_back(pb);
         }
       }
       n += gsl[g];
@@ -461,11 +515,9 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
   // modelled LDS cycles per half slot-row run 3.64 ms (3.57 with 2.5x the annealing) against 3.52 ms for 40 rows
   // at 2.15 - the frame follows the LDS cycles (+5 %), not the instruction count (-10 %).
   const long fit_target = env_long("PYCHAIN_PLAN_FIT", 0);
-  if (fit_target > kResident[1] && fit_target < kResident[2] && base <= fit_target) {
-    std::vector<int> fitted = fit_slack(t.gsl, nwaves, (int)fit_target);
-    long spare = 0, ngr = 0;
-    for (size_t g = 0; g < fitted.size(); g++) if (t.gsl[g] >= 4) { spare += fitted[g] - t.gsl[g]; ngr++; }
-    if (ngr > 0 && 4 * spare >= 7 * ngr) { t.gsl = fitted; return; }   // >= 1.75 spare rows per group on average
+  if (fit_target >= kResident[1] && fit_target < kResident[2] && base <= fit_target) {
+    t.gsl = fit_slack(t.gsl, nwaves, (int)fit_target);
+    return;
   }
   int chosen = 0;
   for (int ri = 0; ri < 3 && chosen == 0; ri++) {
@@ -548,17 +600,28 @@ extern "C" int64_t pychain_hip_den_plan_build(
   std::iota(lay.pos[kLayX].begin(), lay.pos[kLayX].end(), 0);
   {
     Balancer bal(tiles, lay);
+    bal.free_moves = env_long("PYCHAIN_PLAN_FREE", 1) != 0;
     const long before = stats ? bal.overload() : 0;
     bal.run(balance_moves * K, 40.0, 0.5);
     if (stats) fprintf(stderr, "[plan] row placement: bank overload %ld -> %ld (of %ld arc operands)\n", before, bal.overload(), 6L * K);
   }
-  SlotOrder so_a(tiles[0], lay), so_b(tiles[1], lay), so_g(tiles[2], lay);
+  // (the state vectors of the recursion tiles are float2 in the lazy kernels: ds_read_b64; the occupancy tiles are
+  // gathered with one width for both operands)
+  SlotOrder so_a(tiles[0], lay, true, false), so_b(tiles[1], lay, true, false), so_g(tiles[2], lay, true, true);
   so_a.run(anneal_moves); so_b.run(anneal_moves); so_g.run(anneal_moves);
   if (stats)
     fprintf(stderr, "[plan] modelled LDS cycles per half slot-row (2.0 = conflict-free): alpha %.3f beta %.3f gamma %.3f; "
                     "half slot-rows %ld %ld %ld\n", (double)so_a.cycles / std::max(1L, so_a.columns.load()),
             (double)so_b.cycles / std::max(1L, so_b.columns.load()), (double)so_g.cycles / std::max(1L, so_g.columns.load()),
             so_a.columns.load(), so_b.columns.load(), so_g.columns.load());
+  if (stats)
+    fprintf(stderr, "[plan] modelled LDS-busy cycles per frame (gfx950 gather costs): alpha %.0f (%ld slot-rows, conflicts %.0f) beta %.0f (%ld, %.0f)\n",
+            so_a.lds_cycles(), so_a.slot_rows.load(), 0.1 * so_a.cost_tenths.load(), so_b.lds_cycles(), so_b.slot_rows.load(),
+            0.1 * so_b.cost_tenths.load());
+  if (stats)
+    fprintf(stderr, "[plan] ... per operand (1.0 = conflict-free): alpha state %.3f nnet-output %.3f; beta state %.3f nnet-output %.3f\n",
+            (double)so_a.cycles_op[0] / std::max(1L, so_a.columns.load()), (double)so_a.cycles_op[1] / std::max(1L, so_a.columns.load()),
+            (double)so_b.cycles_op[0] / std::max(1L, so_b.columns.load()), (double)so_b.cycles_op[1] / std::max(1L, so_b.columns.load()));
 
   const auto deal_a = deal_groups(tiles[0].gsl, PLAN_REC_WAVES), deal_b = deal_groups(tiles[1].gsl, PLAN_REC_WAVES);
   static_assert(PLAN_REC8_WAVES * 2 == PLAN_REC_WAVES || PLAN_REC_WAVES != 16, "the 8-wave dealing joins the 16 waves in pairs");

@@ -73,8 +73,48 @@ def test_wide_rows_vs_oracle(H, K, D):
     o, g = _den(x, L, den, den_wide=1)
     ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 3), 1e-5)
     assert abs(o - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4
-    o2, g2 = _den(x, L, den, den_wide=0)                     # the two-barrier kernel: second opinion
+    o2, g2 = _den(x, L, den, den_wide=0, den_dma=0)          # the two-barrier kernel: second opinion
     assert abs(o - o2) <= 1e-6 * abs(o2) and rel_err(g.cpu().numpy(), g2.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("H,K,D", [(40, 300, 4100), (700, 6000, 8408), (3000, 30000, 9216), (3000, 30000, 8408)])
+def test_dma_rows_vs_oracle(H, K, D):
+    """4096 < D <= 9216 takes the 16-wave lazy recursion with LDS-direct nnet-output rows (LzDma) by default: small,
+    medium and C4-size graphs (16-, 32- and 40-row loops), a row whose last 1 KiB chunk is partial, ragged lengths,
+    against the oracle and against the two-barrier kernel."""
+    den = syn.make_den_graph(H, K, D, seed=3)
+    L = torch.tensor([97, 64, 5, 1])
+    x = syn.make_input(4, 97, D, seed=33, device=DEV)
+    assert _names(den, D, 4)[0] == "den_recursion_lazy_kernel<dma>"
+    o, g = _den(x, L, den)
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 4), 1e-5)
+    assert abs(o - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4
+    o2, g2 = _den(x, L, den, den_dma=0)                      # the two-barrier kernel: second opinion
+    assert _names(den, D, 4, den_dma=0)[0] == "den_recursion_kernel"
+    assert abs(o - o2) <= 1e-6 * abs(o2) and rel_err(g.cpu().numpy(), g2.cpu().numpy()) <= 1e-5
+    for nseg in (1, 3):
+        o3, g3 = _den(x, L, den, den_segments=nseg)
+        assert o3 == o and torch.equal(g3, g)
+
+
+def test_dma_rows_on_the_narrow_map_match_the_register_path_bit_for_bit():
+    """The same recursion with its rows through registers (default on C3) and through LDS-direct loads (option
+    den_dma = 2): the arithmetic is the same operation for operation."""
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([301, 288, 130, 1])
+    x = syn.make_input(4, 301, cfg["D"], seed=21, device=DEV)
+    o, g = _den(x, L, den)
+    o2, g2 = _den(x, L, den, den_dma=2)
+    assert _names(den, cfg["D"], 4, den_dma=2)[0] == "den_recursion_lazy_kernel<dma>"
+    assert o == o2 and torch.equal(g, g2)
+    xn = x.clone()
+    xn[1, 200, 77] = float("nan")
+    xx = xn.requires_grad_(True)
+    with _lib.option("den_dma", 2):
+        o = ChainFunction.apply(xx, L, ChainGraphBatch(den, 4), 1e-5)
+    torch.cuda.synchronize()
+    assert int(ChainFunction.last_bad_count.sum()) > 0 and np.isnan(float(o.detach()))
 
 
 def test_wide_recursion_nan_and_bad_lengths():
@@ -97,8 +137,10 @@ def test_which_kernel_each_shape_gets():
         (3000, 30000, 3456, 128, "den_recursion_pair_kernel", "den_gamma2_kernel"),         # B >= 96: two sequences per workgroup
         (200, 2000, 1000, 64, "den_recursion_lazy_kernel", "den_gamma2_kernel"),            # C2
         (20, 60, 40, 2, "den_recursion_lazy_kernel", "den_gamma2_kernel"),                  # C1
-        (3000, 30000, 8408, 32, "den_recursion_kernel", "den_gamma_kernel"),                # C4
-        (300, 3000, 4100, 8, "den_recursion_kernel", "den_gamma_kernel"),
+        (3000, 30000, 8408, 32, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),      # C4
+        (300, 3000, 4100, 8, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),
+        (300, 3000, 9220, 8, "den_recursion_kernel", "den_gamma_kernel"),                   # rows beyond the LDS map
+        (300, 3000, 4098, 8, "den_recursion_kernel", "den_gamma_kernel"),                   # D % 4 != 0
     ]
     for H, K, D, B, rec, occ in cases:
         den = syn.make_den_graph(H, K, D, seed=1)

@@ -10,8 +10,6 @@ if [ "$1" = "run" ]; then
   PYCHAIN_HIP_LIB=$ROOT/tools/variants/phases.so TIME_DEN_ONLY=recursion PYCHAIN_DEN_SEGMENTS=1 python $ROOT/tools/time_den.py C3 2>&1 | grep -E "^lazy dir|^pair dir|recursion ms" | sort | uniq -c | sort -k3,3n -k5,5n
 else
   mkdir -p $ROOT/tools/variants
-  cd $ROOT/pychain_amd/csrc
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -fno-slp-vectorize -DPYCHAIN_PROFILE_PHASES -I $ROOT/include \
-    plan.cpp fst.cpp den_kernels.hip num_kernels.hip api.hip -o $ROOT/tools/variants/phases.so
-  echo built $ROOT/tools/variants/phases.so
+  cd $ROOT
+  python -c "from pychain_amd import build_ext; print('built', build_ext.build(extra_flags=['-DPYCHAIN_PROFILE_PHASES'], lib='$ROOT/tools/variants/phases.so'))"
 fi

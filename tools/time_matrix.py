@@ -1,6 +1,6 @@
 """Time the fused step (or the denominator-only step for workloads without numerators) for a list of
 (workload, options) cells in ONE process: tools/time_matrix.py "C3" "C3:den_wide=1" "C4" "C4:den_wide=0" "C3@128" ...
-A cell is  WORKLOAD[@B][:opt=value[,opt=value...]] ; prints one line per cell (median of 5 groups of 6 steps) and, with
+A cell is  WORKLOAD[@B][:opt=value[;opt=value...]] ; prints one line per cell (median of 5 groups of 6 steps) and, with
 --parts, the recursion / occupancy launches in isolation."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,8 +14,12 @@ cells = [a for a in sys.argv[1:] if not a.startswith("--")]
 cache = {}
 
 
-def workload(name, B):
-    key = (name, B)
+def workload(name, B, plan_env=()):
+    key = (name, B, tuple(plan_env))
+    for k in [k for k in os.environ if k.startswith("PYCHAIN_PLAN_") and k != "PYCHAIN_PLAN_CACHE_DIR"]:
+        del os.environ[k]
+    for k, v in plan_env:                              # plan compiler knobs are read when the plan is built
+        os.environ["PYCHAIN_" + k] = v
     if key not in cache:
         cache.clear()
         torch.cuda.empty_cache()
@@ -49,8 +53,10 @@ def timed(fn, groups=5, per=6):
 for cell in cells:
     head, _, optstr = cell.partition(":")
     name, _, bstr = head.partition("@")
-    opts = dict(o.split("=", 1) for o in optstr.split(",") if o)
-    w = workload(name, int(bstr) if bstr else None)
+    opts = dict(o.split("=", 1) for o in optstr.split(";") if o)
+    plan_env = sorted((k, v) for k, v in opts.items() if k.startswith("PLAN_"))
+    opts = {k: v for k, v in opts.items() if not k.startswith("PLAN_")}
+    w = workload(name, int(bstr) if bstr else None, plan_env)
     cfg = w["cfg"]
     x = w["x"].requires_grad_(True)
     crit = ChainLoss(w["den_graph"], 1e-5, avg=False)
