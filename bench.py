@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=48, help="utterances in the CPU baseline sample")
     ap.add_argument("--dry-run", action="store_true",
                     help="harness check without a GPU: gloo, no-op steps (tests/test_bench_launch.py)")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short runs of the other BASELINE.json configurations reported beside the metric (N = 1)")
+    ap.add_argument("--rooflines", action="store_true",
+                    help="N > 1: measure the per-kernel rooflines on rank 0 as well (the other ranks wait in a barrier)")
+    ap.add_argument("--no-fresh-num-graphs", action="store_true",
+                    help="skip the host-side leg: a fresh numerator ChainGraphBatch per step, as a trainer builds it")
     return ap.parse_args()
 
 
@@ -104,9 +110,8 @@ def kernel_rooflines(w, dev, iters):
     bytes_rec = (8 * D + 4 * (H + 1)) * frames
     bytes_gam = (4 * D + 4 * (H + 1)) * frames
     ms_rec, ms_gam = out["den_recursion_kernel"], out["den_gamma_kernel"]
-    two_frame = D % 4 == 0 and D <= 4096 and H <= 4032 and not os.environ.get("PYCHAIN_GAMMA16")
-    occ_name = "den_gamma2_kernel" if two_frame else "den_gamma_kernel"
-    rec_name = "den_recursion_lazy_kernel" if L.pychain_hip_den_recursion_is_lazy(plan.slot_rows, H, D) else "den_recursion_kernel"
+    # the kernels this shape runs, as the library's own launcher decides (include/pychain_hip.h: pychain_hip_den_kernel_names)
+    rec_name, occ_name = _lib.den_kernel_names(plan.slot_rows, H, D, cfg["B"])
     # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, summary committed under
     # profiles/ by tools/profile_round.sh): the newest file measured on this very workload and kernel
     traffic, traffic_source = None, None
@@ -150,6 +155,108 @@ def kernel_rooflines(w, dev, iters):
     except Exception:
         roof["d2d_copy_GBps"] = None
     return roof
+
+
+def _adhoc_workload(name, B, dev):
+    """BASELINE config `name`, optionally at another batch size (same graph, ragged lengths drawn for B)."""
+    from pychain_amd import synthetic as syn
+    if B is None:
+        w = syn.make_workload(name, device=dev)
+    else:
+        cfg = dict(syn.CONFIGS[name])
+        cfg["B"] = B
+        lengths = syn.make_lengths(B, cfg["T"], cfg["lengths"], seed=2)
+        w = dict(cfg=cfg, lengths=lengths, den_graph=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0),
+                 num_graphs=syn.make_num_graphs(lengths.tolist(), cfg["D"], seed=100) if cfg["num"] else None,
+                 x=syn.make_input(B, cfg["T"], cfg["D"], seed=1, device=dev))
+    w["lengths_dev"] = w["lengths"].to(dev)
+    return w
+
+
+def other_workloads(dev, steps=6, warmup=3):
+    """The other single-GPU configurations of BASELINE.json and the bench shape at larger batches, a few steps each:
+    reported BESIDE the metric (`other_workloads`), never in `value`.  C4 is BASELINE.json's "HBM-roofline run"."""
+    from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, _lib, _plan, native
+    out = {}
+    for label, name, B in (("C4", "C4", None), ("C2", "C2", None), ("C3@B=128", "C3", 128), ("C3@B=256", "C3", 256)):
+        try:
+            w = _adhoc_workload(name, B, dev)
+            cfg = w["cfg"]
+            x = w["x"].requires_grad_(True)
+            crit = ChainLoss(w["den_graph"], 1e-5, avg=False)
+            gb = ChainGraphBatch(w["den_graph"], cfg["B"])
+
+            def step():
+                x.grad = None
+                if w["num_graphs"] is not None:
+                    crit(x, w["lengths_dev"], w["num_graphs"]).backward()
+                else:
+                    ChainFunction.apply(x, w["lengths_dev"], gb, 1e-5).backward()
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            frames = int(w["lengths"].sum())
+            plan = _plan.graph_plan(w["den_graph"], cfg["D"], dev)
+            rec, occ = _lib.den_kernel_names(plan.slot_rows, cfg["H"], cfg["D"], cfg["B"])
+            stream = torch.cuda.current_stream(dev)
+            call = lambda: native.den_forward_backward(plan, w["x"].detach(), w["lengths_dev"], 1e-5)
+            parts = {}
+            for key, mask in (("recursion_ms", 1), ("occupancy_ms", 2), ("den_ms", 3)):
+                with _lib.option("den_phase_mask", mask):
+                    call(); torch.cuda.synchronize()
+                    parts[key] = event_time_ms(call, 3, stream)
+            den_bytes = (12 * cfg["D"] + 8 * (cfg["H"] + 1)) * frames
+            out[label] = {
+                "workload": "%s: B=%d T<=%d (%d frames), %d pdfs, den %d states/%d arcs%s"
+                            % (name, cfg["B"], cfg["T"], frames, cfg["D"], cfg["H"], cfg["K"], " + numerators" if cfg["num"] else ", denominator only"),
+                "ms_per_step": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1), "steps": steps,
+                "recursion_kernel": rec, "occupancy_kernel": occ,
+                "recursion_ms": round(parts["recursion_ms"], 4), "occupancy_ms": round(parts["occupancy_ms"], 4),
+                "den_forward_backward": {"algorithmic_bytes": den_bytes, "ms": round(parts["den_ms"], 4),
+                                         "frac": round(den_bytes / (parts["den_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "n_bad": int(ChainFunction.last_bad_count.sum()),
+            }
+            del w, x, crit, gb
+        except Exception as e:          # context figures: never lose the bench line to them
+            out[label] = {"error": str(e)[:200]}
+        native.release_workspaces()
+        torch.cuda.empty_cache()
+    return out
+
+
+def fresh_num_graphs(w, dev, reps=5):
+    """Host work the metric does not see: a drop-in trainer builds a NEW numerator ChainGraphBatch from its list of
+    per-utterance ChainGraph objects every step (pychain/graph.py:122-175) and the loss uploads it.  Timed on the bench
+    batch: constructor (one native pack into a pinned staging buffer) + upload (ONE H2D copy) + on-device reorder."""
+    from pychain_amd import ChainGraph, ChainGraphBatch, synthetic as syn
+    lengths = w["lengths"].tolist()
+    D = w["cfg"]["D"]
+    graphs = [ChainGraph(syn.make_num_fst(int(min(max(round(Tb / 4.0), 4), 400, Tb)), D, 100 + b), log_domain=True)
+              for b, Tb in enumerate(lengths)]
+    mk, mh = max(g.num_transitions for g in graphs), max(g.num_states for g in graphs)
+    order = torch.randperm(len(graphs), generator=torch.Generator().manual_seed(3))
+    t_build = t_up = t_re = 0.0
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        gb = ChainGraphBatch(graphs, max_num_transitions=mk, max_num_states=mh)
+        t1 = time.perf_counter()
+        gb.device_tensors(dev)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        gb.reorder(order)
+        gb.device_tensors(dev)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        if _ > 0:
+            t_build += t1 - t0; t_up += t2 - t1; t_re += t3 - t2
+    return {"utterances": len(graphs), "construct_ms": round(t_build / reps * 1e3, 3), "upload_ms": round(t_up / reps * 1e3, 3),
+            "reorder_and_restage_ms": round(t_re / reps * 1e3, 3),
+            "note": "per step on the launching thread; NOT in `value` (the reference pays the same work in Python: graph.py:122-194)"}
 
 
 def grad_slab_allreduce(x, world, rank, dev, iters=2):
@@ -308,7 +415,14 @@ def dry_run(args, rank, world):
         stats = allreduce_stats(torch.tensor(-1.0), float(local_frames), None)
     if world > 1:
         dist.barrier()
-    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dt = time.perf_counter() - t0
+    mine = torch.tensor([dt, float(local_frames)], dtype=torch.float64)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    tmax = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -317,6 +431,8 @@ def dry_run(args, rank, world):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax) / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
             "dry_run": True, "frames_per_step_all_ranks": float(stats[1]),
+            "per_rank": {"ms_per_step": [round(float(p[0]) / args.steps * 1e3, 4) for p in per_rank],
+                         "frames": [int(p[1]) for p in per_rank]},
             "config": {"workload": "dry run (no kernels)", "parallelism": "utterance-sharded dp%d" % world,
                        "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"}}))
     if world > 1:
@@ -381,6 +497,14 @@ def main():
         stats = step()
     fence()
     dt = time.perf_counter() - t0
+    # per-rank view (imbalance between the shards is the only thing that can cost the scaling): each rank's own
+    # time for the K steps and its frame count, gathered once after the timed region
+    mine = torch.tensor([dt, float(local_frames)], device=dev, dtype=torch.float64)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -395,7 +519,8 @@ def main():
             slab = {"error": str(e)[:200]}
 
     if rank == 0:
-        roof = kernel_rooflines(w, dev, max(3, min(args.steps, 10)))
+        # (N > 1: the other ranks would idle in a barrier behind these ~30 launches: on request only)
+        roof = kernel_rooflines(w, dev, max(3, min(args.steps, 10))) if (world == 1 or args.rooflines) else None
         out = {
             "metric": "LF-MMI frames/sec (fwd+bwd)", "value": round(total_frames * args.steps / dt, 1),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -407,9 +532,30 @@ def main():
                        "global_batch": cfg["B"] * world, "parallelism": "utterance-sharded dp%d" % world,
                        "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"},
             "n_bad": n_bad, "roofline": roof,
+            "per_rank": {"ms_per_step": [round(float(p[0]) / args.steps * 1e3, 4) for p in per_rank],
+                         "frames": [int(p[1]) for p in per_rank],
+                         "ms_per_step_min": round(min(float(p[0]) for p in per_rank) / args.steps * 1e3, 4),
+                         "ms_per_step_max": round(max(float(p[0]) for p in per_rank) / args.steps * 1e3, 4)},
         }
+        if roof is None:
+            out["roofline_note"] = "per-kernel rooflines are measured at N = 1 (or with --rooflines)"
         if slab is not None:
             out["grad_slab_allreduce"] = slab
+        if world == 1 and cfg["num"] and not args.no_fresh_num_graphs:
+            try:
+                out["host_graph_batch"] = fresh_num_graphs(w, dev)
+            except Exception as e:
+                out["host_graph_batch"] = {"error": str(e)[:200]}
+        if world == 1 and not args.no_other_workloads and args.workload == "C3":
+            keep = {k: w[k] for k in ("cfg", "lengths", "den_graph", "num_graphs")}
+            x_cpu = w["x"].detach().float().cpu() if not args.no_cpu_baseline else None
+            del x
+            w.pop("x")
+            torch.cuda.empty_cache()
+            out["other_workloads"] = other_workloads(dev)
+            if x_cpu is not None:
+                keep["x"] = x_cpu
+            w = keep
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
         print(json.dumps(out))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 9
+#define PYCHAIN_HIP_ABI_VERSION 10
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -293,6 +293,30 @@ int pychain_hip_chain_loss_backward(
     float* grad, int32_t* bad_count,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
+
+/* ------------------------------------------------------------------------
+ * Batch containers (replaces the Python collation of pychain/graph.py:122-194).
+ * The ten tensors of a ChainGraphBatch built from a list of graphs live in ONE buffer, fields in the order
+ *   forward_transitions [B,K,3] i32, forward_transition_indices [B,H,2] i32, forward_transition_probs [B,K] f32,
+ *   backward_transitions, backward_transition_indices, backward_transition_probs (same shapes),
+ *   final_probs [B,H] f32, initial_probs [B,H] f32, leaky_probs [B,H] f32 (absent in the log domain), start_state [B] i64,
+ * each field 64-byte aligned: _layout gives their byte offsets / bytes per utterance and returns the buffer size.
+ *   _pack        host: rec[b] = {num_transitions, num_states, start_state, then the host addresses of the graph's nine
+ *                tensors in field order (leaky = 0 in the log domain)}; pads as the reference does (zeros; -inf for
+ *                initial / final probs in the log domain, graph.py:140-145).  Pack into pinned memory and the whole
+ *                batch reaches the device with ONE copy.
+ *   _reorder     host: out[b] = in[order[b]] for every field (index_select along the batch: graph.py:177-194; B_out may
+ *                differ from B_in - sharding selects a subset)
+ *   _reorder_dev the same gather between two DEVICE buffers, one launch on `stream`; order_dev: dev int64[B_out]. */
+#define PYCHAIN_HIP_BATCH_FIELDS 10
+#define PYCHAIN_HIP_BATCH_REC_WORDS 12
+int64_t pychain_hip_batch_layout(int B, int K, int H, int log_domain, int64_t offsets[PYCHAIN_HIP_BATCH_FIELDS],
+                                 int64_t row_bytes[PYCHAIN_HIP_BATCH_FIELDS]);
+int     pychain_hip_batch_pack(int B, int K, int H, int log_domain, const uint64_t* rec, void* out, size_t out_bytes);
+int     pychain_hip_batch_reorder(int B_in, int B_out, int K, int H, int log_domain, const void* in, void* out,
+                                  const int64_t* order);
+int     pychain_hip_batch_reorder_dev(int B_in, int B_out, int K, int H, int log_domain, const void* in_dev, void* out_dev,
+                                      const int64_t* order_dev, void* stream);
 
 /* ------------------------------------------------------------------------
  * Graph ingestion without OpenFST (host only, one-time per graph): what the reference's

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -47,6 +47,10 @@ _SIGNATURES = {
     "pychain_hip_rescale": (_i, [_vp, _sz, _vp, _vp]),
     "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i,
                                              _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "pychain_hip_batch_layout": (_i64, [_i, _i, _i, _i, _vp, _vp]),
+    "pychain_hip_batch_pack": (_i, [_i, _i, _i, _i, _vp, _vp, _sz]),
+    "pychain_hip_batch_reorder": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pychain_hip_batch_reorder_dev": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pychain_hip_fst_read": (_vp, [ctypes.c_char_p, _i64]),
     "pychain_hip_fst_from_arcs": (_vp, [ctypes.c_int32, ctypes.c_int32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pychain_hip_fst_free": (None, [_vp]),

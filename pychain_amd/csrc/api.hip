@@ -316,11 +316,13 @@ bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
 bool den_call_is_wide(const DenArgs& a, int resident_slot_rows) {
   return a.knobs.den_wide > 0 && den_wide_eligible(a, resident_slot_rows);
 }
-// the 16-wave shape with LDS-direct nnet-output rows: where the plain 16-wave shape does not fit (4096 < D <= 9216: C4);
-// option den_dma: "1" / "2" wherever the shape allows, "0" never
+// the nnet-output rows of the lazy recursions come in by LDS-direct loads (default wherever a lazy shape fits: on the
+// 16-wave map of C1-C3 it is 2 % faster than rows through registers and bit-identical, and it is what makes rows of
+// 4096 < D <= 9216 pdfs - C4 - fit a 128-VGPR wave at all); option den_dma = "0": rows through registers, i.e. the
+// 16-wave map for D <= 4096 and den_recursion_kernel beyond
 bool den_call_is_dma(const DenArgs& a, int resident_slot_rows) {
-  if (a.knobs.den_dma == 0 || !den_dma_eligible(a, resident_slot_rows)) return false;
-  return a.knobs.den_dma > 0 || !den_lazy_eligible(a, resident_slot_rows);
+  if (a.knobs.den_dma == 0) return false;
+  return den_lazy_eligible(a, resident_slot_rows) || den_dma_eligible(a, resident_slot_rows);
 }
 int den_call_shape(const DenArgs& a, int resident_slot_rows) {     // DenArgs::wide
   if (den_call_is_wide(a, resident_slot_rows)) return 1;
@@ -704,4 +706,32 @@ extern "C" int pychain_hip_chain_loss_forward_backward(
                                         bi, bp, initial, final_, graph_batch_stride, num_H, num_K, nnet_output,
                                         seq_lengths, B, T, D, den_objf, num_objf, grad, grad_scale, bad_count, den_ws,
                                         den_ws_bytes, num_ws, num_ws_bytes, stream);
+}
+
+// ---- on-device reorder of a staged batch (include/pychain_hip.h: batch containers) ------------------------------------
+namespace {
+struct GatherArgs { int64_t in_off[PYCHAIN_HIP_BATCH_FIELDS], out_off[PYCHAIN_HIP_BATCH_FIELDS], row_bytes[PYCHAIN_HIP_BATCH_FIELDS]; };
+__global__ void batch_gather_kernel(const char* in, char* out, const int64_t* order, int B_in, GatherArgs g) {
+  const int b = blockIdx.x, f = blockIdx.y;
+  const int64_t rb = g.row_bytes[f];
+  if (rb == 0) return;
+  int64_t src = order[b];
+  if (src < 0 || src >= B_in) src = 0;                                    // (validated on the host where the order lives there)
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(in + g.in_off[f] + rb * src);
+  uint32_t* d = reinterpret_cast<uint32_t*>(out + g.out_off[f] + rb * b);
+  for (int64_t i = threadIdx.x; i < rb / 4; i += blockDim.x) d[i] = s[i];
+}
+}  // namespace
+extern "C" int pychain_hip_batch_reorder_dev(int B_in, int B_out, int K, int H, int log_domain, const void* in_dev, void* out_dev,
+                                             const int64_t* order_dev, void* stream) {
+  GatherArgs g;
+  if (pychain_hip_batch_layout(B_in, K, H, log_domain, g.in_off, g.row_bytes) < 0 ||
+      pychain_hip_batch_layout(B_out, K, H, log_domain, g.out_off, g.row_bytes) < 0)
+    return PYCHAIN_HIP_EINVAL;
+  if (!in_dev || !out_dev || !order_dev) return fail(PYCHAIN_HIP_EINVAL, "batch_reorder_dev: null pointer");
+  hipLaunchKernelGGL(batch_gather_kernel, dim3(B_out, PYCHAIN_HIP_BATCH_FIELDS), dim3(256), 0, (hipStream_t)stream,
+                     (const char*)in_dev, (char*)out_dev, order_dev, B_in, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PYCHAIN_HIP_ELAUNCH, "batch_reorder_dev: %s", hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
 }

@@ -23,7 +23,7 @@ struct CallKnobs {
   int den_relaunch, no_fold, gamma16, num_no_staging_waves;
   int den_pair;               // -1 automatic, 0 never, 1 wherever the shape allows
   int den_wide;               // -1 automatic, 0 never, 1 wherever the shape allows (8-wave lazy recursion)
-  int den_dma;                // -1 automatic, 0 never, 1 wherever the shape allows (16-wave lazy recursion, LDS-direct rows), 2 = on the narrow map
+  int den_dma;                // 0: nnet-output rows of the lazy recursions through registers, else (default) by LDS-direct loads
   int gamma_tiled;            // -1 automatic, 0 never, 1 wherever the shape allows (two-frame occupancy kernel tiled over pdfs)
   int force_general;          // 1: the streamed general kernels even where a fast one fits (tests)
   int nbounds;

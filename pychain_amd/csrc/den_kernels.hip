@@ -1379,8 +1379,8 @@ hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
   return launch_one(den_recursion_lazy_kernel<kMaxResident, M>, a, grid, M::kBytes, st);
 }
 hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
-  // (option den_dma = 2: the narrow map with LDS-direct rows, where the shape fits it - an experiment on C3)
-  if (a.knobs.den_dma == 2 && lazy_shape_ok(a, hint)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
+  // the map of C1-C3 where the shape fits it, else the one for rows of up to 9216 pdfs
+  if (lazy_shape_ok(a, hint)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
   return launch_dma_m<LzDma>(a, hint & 1023, st);
 }
 hipError_t launch_wide(const DenArgs& a, int hint, hipStream_t st) {

@@ -205,6 +205,15 @@ struct SlotOrder {
   // profiles/r03_ubench_ldsbanks.txt): ds_read_b32  L=2 +0.6, L=4 +2.8, L=8 +7.0;  ds_read_b64  L=2 +0.2, L=4 +2.8, L=8 +7.1.
   // (A conflict-free wave64 gather occupies the LDS for 2.0 / 2.3 cycles - an all-padding slot-row costs that too.)
   int wide_op[2] = {0, 0};                           // operand gathered with ds_read_b64 (state vectors of the lazy recursions)
+  // Two copies of operand 1 in LDS (the nnet-output row, the second one skewed by 16 banks): every arc reads the copy the
+  // compiler picks for it (bit 15 of its operand-1 index), which all but removes the conflicts of that operand - the
+  // expensive ones - and leaves the slot order free to serve operand 0.  0 = one copy.
+  int v_choice = 0, u_choice = 0;                    // operand 1 / operand 0 have a second copy
+  static constexpr int kChoiceBit = 0x8000, kChoiceBit0 = 0x4000;   // in a cell: operand 1 / operand 0 read their second copy
+  // bank of element n in the second copy: its 32-element block is rotated by 4 ((n >> 5) & 7) elements (whole float4s
+  // stay together: the kernels write a row 16 bytes at a time), so that the two candidate banks of an arc are not tied to
+  // each other the way a fixed skew would tie them
+  static int second_bank(int n) { return (n + 4 * ((n >> 5) & 7)) & 31; }
   int extra_tenths(int op, int L) const {
     if (L <= 1) return 0;
     if (L == 2) return wide_op[op] ? 2 : 6;
@@ -212,8 +221,8 @@ struct SlotOrder {
     return 10 * L - 12;
   }
 
-  SlotOrder(const Tile& tile, const Layouts& l, bool op0_wide, bool op1_wide) : t(tile), lay(l) {
-    wide_op[0] = op0_wide; wide_op[1] = op1_wide;
+  SlotOrder(const Tile& tile, const Layouts& l, bool op0_wide, bool op1_wide, bool choice = false, bool choice0 = false) : t(tile), lay(l) {
+    wide_op[0] = op0_wide; wide_op[1] = op1_wide; v_choice = choice ? 1 : 0; u_choice = choice0 ? 1 : 0;
     cost_model = (int)env_long("PYCHAIN_PLAN_COST", 1);
     int off = 0;
     for (int g : t.gsl) { cell_off.push_back(off); off += 64 * g; }
@@ -244,7 +253,7 @@ struct SlotOrder {
     int* cl = &cell[cell_off[g]];                    // [row][slot]
     std::vector<Col> cs(A);
     for (auto& c : cs) { memset(&c, 0, sizeof(c)); for (int hh = 0; hh < 2; hh++) c.nm[hh][0][0] = c.nm[hh][1][0] = 32; }
-    std::vector<int> b0(nr * A, -1), b1(nr * A, -1);
+    std::vector<int> b0(nr * A, -1), b1(nr * A, -1), alt(nr * A, -1), alt0(nr * A, -1);   // banks of a cell's arc; alt / alt0 = operand 1 / 0 in its other copy
     // greedy: rows with most arcs first; each arc goes to the free slot of its row with fewest collisions in its half
     std::vector<int> rorder(nr);
     std::iota(rorder.begin(), rorder.end(), 0);
@@ -254,14 +263,20 @@ struct SlotOrder {
       const auto& arcs = arcs_of(r);
       const int hh = r >> 5;
       for (int a = 0; a < (int)arcs.size(); a++) {
-        const int x0 = lay.bank(t.lay[0], arcs[a].e0), x1 = lay.bank(t.lay[1], arcs[a].e1);
-        int best = -1, bc = 0;
+        const int uc[2] = {lay.bank(t.lay[0], arcs[a].e0), second_bank(lay.pos[t.lay[0]][arcs[a].e0])};
+        const int xc[2] = {lay.bank(t.lay[1], arcs[a].e1), second_bank(lay.pos[t.lay[1]][arcs[a].e1])};
+        int best = -1, bc = 0, bch = 0, bch0 = 0;
         for (int j = 0; j < A; j++) {
           if (cl[r * A + j] >= 0) continue;
-          const int cst = cs[j].cnt[hh][0][x0] + cs[j].cnt[hh][1][x1];
-          if (best < 0 || cst < bc) { best = j; bc = cst; }
+          for (int ch0 = 0; ch0 <= u_choice; ch0++)
+            for (int ch = 0; ch <= v_choice; ch++) {
+              const int cst = cs[j].cnt[hh][0][uc[ch0]] + cs[j].cnt[hh][1][xc[ch]];
+              if (best < 0 || cst < bc) { best = j; bc = cst; bch = ch; bch0 = ch0; }
+            }
         }
-        cl[r * A + best] = a; b0[r * A + best] = x0; b1[r * A + best] = x1;
+        const int x0 = uc[bch0], x1 = xc[bch];
+        alt[r * A + best] = xc[bch ^ 1]; alt0[r * A + best] = uc[bch0 ^ 1];
+        cl[r * A + best] = a | (bch ? kChoiceBit : 0) | (bch0 ? kChoiceBit0 : 0); b0[r * A + best] = x0; b1[r * A + best] = x1;
         col_add(cs[best], hh, 0, x0, +1); col_add(cs[best], hh, 1, x1, +1);
       }
     }
@@ -272,6 +287,18 @@ struct SlotOrder {
       double T = t0;
       for (long it = 0; it < iters; it++, T *= cool) {
         const int r = rng.next() % nr, j1 = rng.next() % A;
+        if ((v_choice || u_choice) && (rng.next() & 3) == 0) {   // a quarter of the moves: one arc reads the other copy of an operand
+          const int i = r * A + j1, hh = r >> 5;
+          if (b0[i] < 0) continue;
+          const int op = (u_choice && (!v_choice || (rng.next() & 1))) ? 0 : 1;
+          std::vector<int>& cur = op ? b1 : b0;
+          std::vector<int>& other = op ? alt : alt0;
+          const int nb = other[i];
+          const int dE = col_add(cs[j1], hh, op, cur[i], -1) + col_add(cs[j1], hh, op, nb, +1);
+          if (dE <= 0 || rng.unit() < exp(-(double)dE / T)) { cl[i] ^= op ? kChoiceBit : kChoiceBit0; other[i] = cur[i]; cur[i] = nb; }
+          else { col_add(cs[j1], hh, op, nb, -1); col_add(cs[j1], hh, op, cur[i], +1); }
+          continue;
+        }
         int j2 = rng.next() % (A - 1); if (j2 >= j1) j2++;
         const int i1 = r * A + j1, i2 = r * A + j2, hh = r >> 5;
         if (b0[i1] < 0 && b0[i2] < 0) continue;
@@ -281,7 +308,7 @@ struct SlotOrder {
         if (b0[i1] >= 0) dE += col_add(cs[j2], hh, 0, b0[i1], +1) + col_add(cs[j2], hh, 1, b1[i1], +1);
         if (b0[i2] >= 0) dE += col_add(cs[j1], hh, 0, b0[i2], +1) + col_add(cs[j1], hh, 1, b1[i2], +1);
         if (dE <= 0 || rng.unit() < exp(-(double)dE / T)) {
-          std::swap(cl[i1], cl[i2]); std::swap(b0[i1], b0[i2]); std::swap(b1[i1], b1[i2]);
+          std::swap(cl[i1], cl[i2]); std::swap(b0[i1], b0[i2]); std::swap(b1[i1], b1[i2]); std::swap(alt[i1], alt[i2]); std::swap(alt0[i1], alt0[i2]);
         } else {
           if (b0[i2] >= 0) { col_add(cs[j1], hh, 0, b0[i2], -1); col_add(cs[j1], hh, 1, b1[i2], -1); }
           if (b0[i1] >= 0) { col_add(cs[j2], hh, 0, b0[i1], -1); col_add(cs[j2], hh, 1, b1[i1], -1); }
@@ -418,10 +445,13 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, cons
           real[l] = false; probs[l] = 0.f; words[l] = 0u;
           const int pos = g * 64 + l;
           if (pos >= (int)t.order.size()) continue;
-          const int a = so.cell[so.cell_off[g] + l * A + j];
-          if (a < 0) continue;
+          const int ac = so.cell[so.cell_off[g] + l * A + j];
+          if (ac < 0) continue;
+          const int a = ac & ~(SlotOrder::kChoiceBit | SlotOrder::kChoiceBit0);
           const Arc& arc = (*t.rows)[t.order[pos]][a];
-          words[l] = (uint32_t)lay.pos[t.lay[0]][arc.e0] | ((uint32_t)lay.pos[t.lay[1]][arc.e1] << 16);
+          // (bit 15 of an index = "read the second copy of this operand": PlanHeader::choices)
+          words[l] = ((uint32_t)lay.pos[t.lay[0]][arc.e0] | ((ac & SlotOrder::kChoiceBit0) ? 0x8000u : 0u)) |
+                     (((uint32_t)lay.pos[t.lay[1]][arc.e1] | ((ac & SlotOrder::kChoiceBit) ? 0x8000u : 0u)) << 16);
           probs[l] = arc.p; real[l] = true;
           if (!fill[l >> 5]) fill[l >> 5] = words[l];
         }
@@ -607,7 +637,13 @@ extern "C" int64_t pychain_hip_den_plan_build(
   }
   // (the state vectors of the recursion tiles are float2 in the lazy kernels: ds_read_b64; the occupancy tiles are
   // gathered with one width for both operands)
-  SlotOrder so_a(tiles[0], lay, true, false), so_b(tiles[1], lay, true, false), so_g(tiles[2], lay, true, true);
+  // PYCHAIN_PLAN_CHOICE: the recursion tiles may pick one of two LDS copies of an operand per arc (bit 15 of its index in
+  // the slot word; needs num_pdfs / num_states <= 32768)
+  // MODEL ONLY (default 0: no kernel keeps second copies): with both operands doubled the C3 graph still compiles to
+  // ~130-180 modelled conflict cycles per frame at 32 slot-rows per wave - not built further
+  const long choice_knob = env_long("PYCHAIN_PLAN_CHOICE", 0);          // bit 0: nnet-output row, bit 1: state vector
+  const bool choice = (choice_knob & 1) && D <= 32768, choice0 = (choice_knob & 2) && H <= 32768;
+  SlotOrder so_a(tiles[0], lay, true, false, choice, choice0), so_b(tiles[1], lay, true, false, choice, choice0), so_g(tiles[2], lay, true, true);
   so_a.run(anneal_moves); so_b.run(anneal_moves); so_g.run(anneal_moves);
   if (stats)
     fprintf(stderr, "[plan] modelled LDS cycles per half slot-row (2.0 = conflict-free): alpha %.3f beta %.3f gamma %.3f; "

@@ -15,6 +15,9 @@ path:
 
 All tensors live on the CPU exactly as in the reference.
 """
+import ctypes
+
+import numpy as np
 import torch
 
 from . import simplefst
@@ -92,6 +95,77 @@ _TENSORS = ("forward_transitions", "forward_transition_indices", "forward_transi
             "backward_transitions", "backward_transition_indices", "backward_transition_probs",
             "final_probs", "leaky_probs", "initial_probs", "start_state")
 
+# ---- one buffer per batch (include/pychain_hip.h: batch containers) -------------------------------------------
+# field order of pychain_hip_batch_layout, with the shape of a row and the dtype of each field
+_PACKED = (("forward_transitions", lambda K, H: (K, 3), torch.int32),
+           ("forward_transition_indices", lambda K, H: (H, 2), torch.int32),
+           ("forward_transition_probs", lambda K, H: (K,), torch.float32),
+           ("backward_transitions", lambda K, H: (K, 3), torch.int32),
+           ("backward_transition_indices", lambda K, H: (H, 2), torch.int32),
+           ("backward_transition_probs", lambda K, H: (K,), torch.float32),
+           ("final_probs", lambda K, H: (H,), torch.float32),
+           ("initial_probs", lambda K, H: (H,), torch.float32),
+           ("leaky_probs", lambda K, H: (H,), torch.float32),
+           ("start_state", lambda K, H: (), torch.int64))
+
+
+def _native():
+    """The C library, or None where it is not built (the containers then collate in Python, as the reference does)."""
+    try:
+        from . import _lib
+        return _lib.lib()
+    except (ImportError, OSError):
+        return None
+
+
+def _layout(L, B, K, H, log_domain):
+    offs = np.zeros(10, dtype=np.int64)
+    rows = np.zeros(10, dtype=np.int64)
+    total = L.pychain_hip_batch_layout(B, K, H, int(log_domain), offs.ctypes.data_as(ctypes.c_void_p),
+                                       rows.ctypes.data_as(ctypes.c_void_p))
+    if total < 0:
+        raise ValueError("bad batch sizes B=%d K=%d H=%d" % (B, K, H))
+    return int(total), offs, rows
+
+
+_REC_NAMES = tuple(name for name, _s, _d in _PACKED[:9])
+
+
+def _pack_record(g):
+    """(num_transitions, num_states, start_state, addresses of the nine tensors in _PACKED order), or None if a
+    tensor is not a contiguous CPU int32 / float32 tensor of the expected size.  Remembered on the graph for as long
+    as it keeps the very same tensor objects (a trainer collates the same ChainGraph objects step after step)."""
+    d = g.__dict__
+    c = d.get("_pack_cache")
+    if c is not None and c[1] == (g.num_transitions, g.num_states, g.start_state):
+        ts = c[0]
+        for i in range(9):
+            if d[_REC_NAMES[i]] is not ts[i]:
+                break
+        else:
+            return c[2]
+    rec = _pack_record_uncached(g)
+    d["_pack_cache"] = (tuple(d[n] for n in _REC_NAMES), (g.num_transitions, g.num_states, g.start_state), rec)
+    return rec
+
+
+def _pack_record_uncached(g):
+    rec = [g.num_transitions, g.num_states, int(g.start_state)]
+    k, h = g.num_transitions, g.num_states
+    want = ((k * 3, torch.int32), (h * 2, torch.int32), (k, torch.float32), (k * 3, torch.int32), (h * 2, torch.int32),
+            (k, torch.float32), (h, torch.float32), (h, torch.float32), (h, torch.float32))
+    for (name, _shape, _dt), (n, dt) in zip(_PACKED[:9], want):
+        t = getattr(g, name)
+        if t is None:
+            if name != "leaky_probs":
+                return None
+            rec.append(0)
+            continue
+        if t.dtype != dt or t.device.type != "cpu" or not t.is_contiguous() or t.numel() != n:
+            return None
+        rec.append(t.data_ptr())
+    return rec
+
 
 class ChainGraphBatch(object):
     """B graphs as batched tensors (pychain/graph.py:73-194)."""
@@ -99,6 +173,7 @@ class ChainGraphBatch(object):
     def __init__(self, graphs, batch_size=None, max_num_transitions=None, max_num_states=None):
         self.shared_graph = None     # set when every row is the same ChainGraph
         self._device_cache = {}
+        self._staging = None         # the one buffer behind a batch built from a list (initialized_by_list)
         if isinstance(graphs, ChainGraph):
             if not batch_size:
                 raise ValueError("batch size should be specified to expand a single graph")
@@ -140,7 +215,49 @@ class ChainGraphBatch(object):
         self.start_state = graph.start_state * torch.ones(B, dtype=torch.long)
         self.shared_graph = graph
 
+    def _install(self, staging, offs, rows, B, K, H):
+        """The batch tensors as views of the ONE buffer `staging` (uint8, pinned where a GPU is present)."""
+        self._staging, self._shape = staging, (B, K, H)
+        self._offs, self._rows = offs, rows
+        for i, (name, shape, dt) in enumerate(_PACKED):
+            if rows[i] == 0:
+                setattr(self, name, None)
+                continue
+            flat = staging[int(offs[i]):int(offs[i]) + int(rows[i]) * B].view(dt)
+            setattr(self, name, flat.view((B,) + shape(K, H)))
+
+    def _packed_consistent(self):
+        """True while every batch tensor still IS its view of the staging buffer (nobody replaced an attribute)."""
+        st = getattr(self, "_staging", None)
+        if st is None:
+            return False
+        base = st.data_ptr()
+        for i, (name, _shape, _dt) in enumerate(_PACKED):
+            t = getattr(self, name)
+            if (t is None) != (self._rows[i] == 0):
+                return False
+            if t is not None and t.data_ptr() != base + int(self._offs[i]):
+                return False
+        return True
+
     def initialized_by_list(self, graphs, max_num_transitions, max_num_states):
+        # One native pack into one (pinned) buffer instead of ~9 small tensor copies per utterance in Python
+        # (graph.py:122-175: 3.3 ms for a 64-utterance batch, on the thread that launches the loss, every step)
+        self._staging = None
+        L = _native()
+        recs = [_pack_record(g) for g in graphs] if L is not None else [None]
+        if L is not None and all(r is not None for r in recs) and all(g.log_domain == graphs[0].log_domain for g in graphs):
+            B, K, H = self.batch_size, int(max_num_transitions), int(max_num_states)
+            self.log_domain = graphs[0].log_domain
+            self.num_states, self.num_transitions = H, K
+            total, offs, rows = _layout(L, B, K, H, self.log_domain)
+            staging = torch.empty(total, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            rec = np.array(recs, dtype=np.uint64)
+            from . import _lib
+            _lib.check(L.pychain_hip_batch_pack(B, K, H, int(self.log_domain), rec.ctypes.data_as(ctypes.c_void_p),
+                                                staging.data_ptr(), total), "pychain_hip_batch_pack")
+            self._install(staging, offs, rows, B, K, H)
+            return
         ttype = graphs[0].forward_transitions.dtype
         ptype = graphs[0].forward_transition_probs.dtype
         B, K, H = self.batch_size, max_num_transitions, max_num_states
@@ -177,18 +294,69 @@ class ChainGraphBatch(object):
             self.start_state[i] = g.start_state
 
     def reorder(self, new_order):
-        """Permute the batch (pychain/graph.py:177-194)."""
+        """Permute (or select from) the batch (pychain/graph.py:177-194).  A batch built from a list is re-gathered
+        natively in its one buffer, and a copy already staged on a device is re-gathered THERE by one launch instead of
+        being dropped and uploaded again."""
+        if self.shared_graph is None and self._packed_consistent():
+            L = _native()
+            from . import _lib
+            order = torch.as_tensor(new_order, dtype=torch.int64).cpu().contiguous()
+            B_in, K, H = self._shape
+            B_out = int(order.numel())
+            total, offs, rows = _layout(L, B_out, K, H, self.log_domain)
+            old, old_cache = self._staging, self._device_cache
+            staging = torch.empty(total, dtype=torch.uint8, pin_memory=old.is_pinned())
+            _lib.check(L.pychain_hip_batch_reorder(B_in, B_out, K, H, int(self.log_domain), old.data_ptr(), staging.data_ptr(),
+                                                   order.data_ptr()), "pychain_hip_batch_reorder")
+            old_key = self._device_key_packed()
+            self._install(staging, offs, rows, B_out, K, H)
+            self.batch_size = B_out
+            self._device_cache = {}
+            for key, hit in old_cache.items():
+                if key[1:] != old_key or "_buffer" not in hit:
+                    continue                               # stale (an in-place edit since it was staged): upload afresh
+                dbuf = hit["_buffer"]
+                with torch.cuda.device(dbuf.device):
+                    out = torch.empty(total, dtype=torch.uint8, device=dbuf.device)
+                    od = order.to(dbuf.device, non_blocking=True)
+                    _lib.check(L.pychain_hip_batch_reorder_dev(B_in, B_out, K, H, int(self.log_domain), dbuf.data_ptr(),
+                                                               out.data_ptr(), od.data_ptr(),
+                                                               torch.cuda.current_stream(dbuf.device).cuda_stream),
+                               "pychain_hip_batch_reorder_dev")
+                self._device_cache[(key[0],) + self._device_key_packed()] = self._device_views(out)
+            return
         for name in _TENSORS:
             t = getattr(self, name)
             if t is not None:
                 setattr(self, name, t.index_select(0, new_order))
+        self._staging = None
         self._device_cache = {}
         # every row of a shared batch is the same graph: still shared
 
     # ---- device staging for the HIP path (not in the reference API) -------
+    def _device_key_packed(self):
+        return (self._staging.data_ptr(), self._staging._version)
+
+    def _device_views(self, dbuf):
+        B, K, H = self._shape
+        hit = {"_buffer": dbuf}
+        for i, (name, shape, dt) in enumerate(_PACKED[:-1]):
+            if self._rows[i]:
+                flat = dbuf[int(self._offs[i]):int(self._offs[i]) + int(self._rows[i]) * B].view(dt)
+                hit[name] = flat.view((B,) + shape(K, H))
+        return hit
+
     def device_tensors(self, device):
         """Contiguous device copies of the per-sequence tensors, cached until
         `reorder`.  Replaces the per-call `.cuda()` of chain-computation.cc:77-89."""
+        if self.shared_graph is None and self._packed_consistent():
+            # ONE copy of the one (pinned) buffer; an in-place edit of any tensor bumps the buffer's version
+            key = (str(device),) + self._device_key_packed()
+            hit = self._device_cache.get(key)
+            if hit is None:
+                hit = self._device_views(self._staging.to(device, non_blocking=True))
+                self._device_cache = {key: hit}
+            return hit
         # (data_ptr, _version) of every tensor: an in-place edit or a replaced attribute re-stages
         key = (str(device),) + tuple((getattr(self, n).data_ptr(), getattr(self, n)._version)
                                      for n in _TENSORS[:-1] if getattr(self, n) is not None)

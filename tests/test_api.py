@@ -171,3 +171,51 @@ def test_options_are_per_thread_and_restored():
     native.set_verbose_level(2)
     assert L_.pychain_hip_get_verbose_level() == 2 and _lib.get_option("verbose") == "2"
     native.set_verbose_level(0)
+
+
+def _same_batch(a, b):
+    from pychain_amd.graph import _TENSORS
+    for n in _TENSORS:
+        x, y = getattr(a, n), getattr(b, n)
+        assert (x is None) == (y is None), n
+        if x is not None:
+            assert x.dtype == y.dtype and x.shape == y.shape, n
+            assert np.array_equal(x.numpy(), y.numpy(), equal_nan=True), n      # (-inf == -inf)
+    assert a.num_states == b.num_states and a.batch_size == b.batch_size and a.log_domain == b.log_domain
+
+
+def test_native_batch_pack_matches_the_python_collation(monkeypatch):
+    """ChainGraphBatch(list) packs natively into ONE buffer (pychain_hip_batch_pack) and `reorder` re-gathers that buffer
+    (pychain_hip_batch_reorder): bit-equal to the statement-by-statement Python collation of pychain/graph.py:122-194 kept
+    as the fallback - log domain and probability domain, padding in K and H, a reorder that selects a subset, an attribute
+    replaced by hand (the batch then stops trusting its buffer)."""
+    import pychain_amd.graph as G
+    num = [ChainGraph(syn.make_num_fst(h, 40, seed=20 + h), log_domain=True) for h in (5, 9, 3, 12)]
+    den = [syn.make_den_graph(h, 4 * h, 40, seed=h) for h in (6, 11, 8)]
+    for graphs in (num, den):
+        mk, mh = max(g.num_transitions for g in graphs) + 3, max(g.num_states for g in graphs) + 2
+        native = ChainGraphBatch(graphs, max_num_transitions=mk, max_num_states=mh)
+        assert native._staging is not None and native._packed_consistent()
+        with monkeypatch.context() as m:
+            m.setattr(G, "_native", lambda: None)
+            python = ChainGraphBatch(graphs, max_num_transitions=mk, max_num_states=mh)
+        assert python._staging is None
+        _same_batch(native, python)
+        for order in (torch.tensor([2, 0, 1]), torch.tensor([1, 1]), torch.tensor([0])):
+            a, b = ChainGraphBatch(graphs, max_num_transitions=mk, max_num_states=mh), None
+            with monkeypatch.context() as m:
+                m.setattr(G, "_native", lambda: None)
+                b = ChainGraphBatch(graphs, max_num_transitions=mk, max_num_states=mh)
+                b.reorder(order)
+            a.reorder(order)
+            b.batch_size = int(order.numel())              # (the reference leaves that to the caller)
+            assert a._packed_consistent()
+            _same_batch(a, b)
+        # a replaced attribute: the buffer is no longer the truth
+        c = ChainGraphBatch(graphs, max_num_transitions=mk, max_num_states=mh)
+        c.final_probs = c.final_probs.clone()
+        assert not c._packed_consistent()
+        c.reorder(torch.tensor([1, 0, 2]))
+        assert torch.equal(c.final_probs[0], native.final_probs[1]) and c._staging is None
+    with pytest.raises(_lib.PychainHipError):
+        ChainGraphBatch(num, max_num_transitions=2, max_num_states=50)     # a graph larger than the batch allows

@@ -58,3 +58,15 @@ def test_rank_count_must_match_the_flag():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-run"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
+
+
+def test_eight_ranks_as_the_scaling_run_will_start_them():
+    """--gpus 8 (the driver's widest scaling point): eight ranks, every one counted once by the ONE all-reduce, per-rank
+    times and frame counts in the line (imbalance is the only thing that can cost the scaling)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 8 and j["config"]["parallelism"].endswith("dp8")
+    assert j["frames_per_step_all_ranks"] == sum(1000 + k for k in range(8))
+    assert j["per_rank"]["frames"] == [1000 + k for k in range(8)] and len(j["per_rank"]["ms_per_step"]) == 8

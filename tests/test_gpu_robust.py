@@ -133,3 +133,51 @@ def test_unknown_option_is_an_error():
     with pytest.raises(_lib.PychainHipError, match="unknown option"):
         with _lib.option("no_such_option"):
             pass
+
+
+def test_batch_is_staged_with_one_copy_and_reordered_on_the_device():
+    """A numerator batch built from a list reaches the device as ONE buffer (one H2D copy of the pinned staging buffer),
+    and `reorder` re-gathers the staged copy on the device (pychain_hip_batch_reorder_dev) instead of dropping it; an
+    in-place edit of a host tensor re-stages.  Reference: pychain/graph.py:122-194."""
+    from pychain_amd.graph import _PACKED
+    L = [50, 37, 44, 21]
+    gb = syn.make_num_graphs(L, 40, seed=100, max_states=12)
+    assert gb._staging is not None and gb._staging.is_pinned()
+    dev = torch.device(DEV)
+    dt = gb.device_tensors(dev)
+    base = dt["_buffer"]
+    for name, _s, _d in _PACKED[:-1]:
+        if getattr(gb, name) is not None:
+            assert torch.equal(dt[name].cpu(), getattr(gb, name)), name
+            assert base.data_ptr() <= dt[name].data_ptr() < base.data_ptr() + base.numel()
+    assert gb.device_tensors(dev) is dt                                   # cached
+    order = torch.tensor([2, 0, 3])
+    gb.reorder(order)                                                     # a subset: sharding does this
+    dt2 = gb.device_tensors(dev)
+    assert dt2 is not dt and gb.batch_size == 3
+    torch.cuda.synchronize()
+    for name, _s, _d in _PACKED[:-1]:
+        if getattr(gb, name) is not None:
+            assert torch.equal(dt2[name].cpu(), getattr(gb, name)), name
+    gb.final_probs[0, 0] = -1.0                                           # in-place edit: staged copy is stale
+    dt3 = gb.device_tensors(dev)
+    assert dt3 is not dt2 and float(dt3["final_probs"][0, 0]) == -1.0
+    # and the loss computed from the re-gathered batch is the loss of the re-gathered utterances
+    x = syn.make_input(4, 50, 40, seed=5, device=DEV)
+    gb2 = syn.make_num_graphs(L, 40, seed=100, max_states=12)
+    gb2.device_tensors(dev)
+    gb2.reorder(order)
+    got = ChainFunction.apply(x[order.to(DEV)].contiguous(), torch.tensor(L)[order], gb2)
+    # ... against the same graphs re-indexed on the host, tensor by tensor, and uploaded afresh
+    gb3 = syn.make_num_graphs(L, 40, seed=100, max_states=12)
+    with torch.no_grad():
+        host = ChainGraphBatch.__new__(ChainGraphBatch)
+        host.__dict__.update(gb3.__dict__)
+        host._device_cache = {}
+        host._staging = None
+        for n in ("forward_transitions", "forward_transition_indices", "forward_transition_probs", "backward_transitions",
+                  "backward_transition_indices", "backward_transition_probs", "final_probs", "initial_probs", "start_state"):
+            setattr(host, n, getattr(gb3, n).index_select(0, order))
+        host.batch_size = 3
+    want = ChainFunction.apply(x[order.to(DEV)].contiguous(), torch.tensor(L)[order], host)
+    assert float(got) == float(want)

@@ -49,9 +49,9 @@ def test_wide_recursion_on_the_c3_graph_vs_its_sixteen_wave_form_and_the_oracle(
     den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
     L = torch.tensor([301, 288, 130, 1])
     x = syn.make_input(4, 301, cfg["D"], seed=21, device=DEV)
-    assert _names(den, cfg["D"], 4)[0] == "den_recursion_lazy_kernel"
+    assert _names(den, cfg["D"], 4, den_dma=0)[0] == "den_recursion_lazy_kernel"
     assert _names(den, cfg["D"], 4, den_wide=1)[0] == "den_recursion_lazy_kernel<wide>"
-    o16, g16 = _den(x, L, den)
+    o16, g16 = _den(x, L, den, den_dma=0)
     o8, g8 = _den(x, L, den, den_wide=1)
     assert abs(o8 - o16) <= 1e-6 * abs(o16) and rel_err(g8.cpu().numpy(), g16.cpu().numpy()) <= 1e-5
     for nseg in (1, 3):
@@ -98,21 +98,20 @@ def test_dma_rows_vs_oracle(H, K, D):
 
 
 def test_dma_rows_on_the_narrow_map_match_the_register_path_bit_for_bit():
-    """The same recursion with its rows through registers (default on C3) and through LDS-direct loads (option
-    den_dma = 2): the arithmetic is the same operation for operation."""
+    """The same recursion with its rows through LDS-direct loads (default) and through registers (option den_dma = 0):
+    the arithmetic is the same operation for operation."""
     cfg = syn.CONFIGS["C3"]
     den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
     L = torch.tensor([301, 288, 130, 1])
     x = syn.make_input(4, 301, cfg["D"], seed=21, device=DEV)
-    o, g = _den(x, L, den)
-    o2, g2 = _den(x, L, den, den_dma=2)
-    assert _names(den, cfg["D"], 4, den_dma=2)[0] == "den_recursion_lazy_kernel<dma>"
+    o, g = _den(x, L, den, den_dma=0)
+    o2, g2 = _den(x, L, den)
+    assert _names(den, cfg["D"], 4)[0] == "den_recursion_lazy_kernel<dma>"
     assert o == o2 and torch.equal(g, g2)
     xn = x.clone()
     xn[1, 200, 77] = float("nan")
     xx = xn.requires_grad_(True)
-    with _lib.option("den_dma", 2):
-        o = ChainFunction.apply(xx, L, ChainGraphBatch(den, 4), 1e-5)
+    o = ChainFunction.apply(xx, L, ChainGraphBatch(den, 4), 1e-5)
     torch.cuda.synchronize()
     assert int(ChainFunction.last_bad_count.sum()) > 0 and np.isnan(float(o.detach()))
 
@@ -133,10 +132,10 @@ def test_which_kernel_each_shape_gets():
     pychain_hip_den_kernel_names answers from the same predicates the launcher uses."""
     cases = [
         # H, K, D, B -> recursion, occupancy
-        (3000, 30000, 3456, 64, "den_recursion_lazy_kernel", "den_gamma2_kernel"),          # C3
+        (3000, 30000, 3456, 64, "den_recursion_lazy_kernel<dma>", "den_gamma2_kernel"),     # C3
         (3000, 30000, 3456, 128, "den_recursion_pair_kernel", "den_gamma2_kernel"),         # B >= 96: two sequences per workgroup
-        (200, 2000, 1000, 64, "den_recursion_lazy_kernel", "den_gamma2_kernel"),            # C2
-        (20, 60, 40, 2, "den_recursion_lazy_kernel", "den_gamma2_kernel"),                  # C1
+        (200, 2000, 1000, 64, "den_recursion_lazy_kernel<dma>", "den_gamma2_kernel"),       # C2
+        (20, 60, 40, 2, "den_recursion_lazy_kernel<dma>", "den_gamma2_kernel"),             # C1
         (3000, 30000, 8408, 32, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),      # C4
         (300, 3000, 4100, 8, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),
         (300, 3000, 9220, 8, "den_recursion_kernel", "den_gamma_kernel"),                   # rows beyond the LDS map
