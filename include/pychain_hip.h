@@ -117,6 +117,12 @@ int         pychain_hip_get_option(const char* name, char* buf, size_t buf_bytes
  *                         scatter, chain-kernels.cu:53-87,230-240)
  * plus the permuted leaky / initial / final vectors.
  *
+ * Graphs the tile kernels do not take - more than 65 535 states or pdfs (packed 16-bit arc addresses), or a state
+ * vector + nnet-output row beyond the 160 KiB LDS of one CU - are compiled into a GENERAL format instead (the reference
+ * layout plus the arcs grouped by pdf-id); pychain_hip_den_plan_info then reports the launch hint
+ * PYCHAIN_HIP_HINT_GENERAL and the denominator runs on kernels that gather from global memory: slow, but complete,
+ * like the reference's CPU path (chain-computation.cc:113-176,247-311 has no size limit).
+ *
  * Returns the number of bytes the plan needs (> 0).  If `blob` is NULL or
  * `blob_bytes` is too small nothing is written (call once to size, once to
  * fill).  The filled blob is position independent: copy it to the device with
@@ -196,6 +202,7 @@ int pychain_hip_den_forward_backward(
  *                           pdfs only (fused ChainLoss: pass grad_scale < 0 to
  *                           subtract the numerator from the denominator grad)
  */
+#define PYCHAIN_HIP_HINT_GENERAL ((int)0x80000000)   /* launch hint of a plan in the general format (pychain_hip_den_plan_info) */
 #define PYCHAIN_HIP_GRAD_LOG    0
 #define PYCHAIN_HIP_GRAD_LINEAR 1
 #define PYCHAIN_HIP_GRAD_ACCUM  2

@@ -14,6 +14,8 @@ import torch
 
 from . import _lib
 
+HINT_GENERAL = -(1 << 31)      # PYCHAIN_HIP_HINT_GENERAL: a plan in the general format (any H, K, D; den_general.hip)
+
 _NAMES = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
           "backward_transitions", "backward_transition_indices", "backward_transition_probs",
           "leaky_probs", "initial_probs", "final_probs"]
@@ -92,7 +94,7 @@ def plan_info(blob):
 # ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans, created 0700; "0" / "off" disables).  Writes are
 # atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.  A file is only
 # believed if its header matches the request AND its payload matches the checksum in the header.
-_KNOBS = ("PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_FREE",
+_KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_FREE",
           "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_CHOICE")
 
 
@@ -177,9 +179,14 @@ def batch_plans(tensors, num_pdfs, device):
     rows = [0] if same else range(B)
     blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
     hints = [plan_info(b)["slot_rows"] for b in blobs]
-    slot_rows = sum(max((h >> sh) & 1023 for h in hints) << sh for sh in (0, 10, 20))
-    if all((h >> 30) & 1 for h in hints):      # every plan fits the lazy-normalisation recursion (<= 4 groups per wave)
-        slot_rows |= 1 << 30
+    if any(h == HINT_GENERAL for h in hints):
+        # the format follows from the sizes (and PYCHAIN_PLAN_GENERAL): all plans of one batch are alike
+        assert all(h == HINT_GENERAL for h in hints)
+        slot_rows = HINT_GENERAL
+    else:
+        slot_rows = sum(max((h >> sh) & 1023 for h in hints) << sh for sh in (0, 10, 20))
+        if all((h >> 30) & 1 for h in hints):      # every plan fits the lazy-normalisation recursion (<= 4 groups per wave)
+            slot_rows |= 1 << 30
     if same:
         return DevicePlan(torch.from_numpy(blobs[0]).to(device), 0, slot_rows, H)
     stride = (max(b.nbytes for b in blobs) + 255) // 256 * 256

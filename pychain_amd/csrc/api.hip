@@ -138,6 +138,10 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
   a.knobs = call_knobs();
   a.H = H; a.Hp = roundup64(H); a.D = D; a.B = B; a.frames_per_block = 32;
   a.plan_stride = plans_shared ? 0 : 256;
+  if (resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) {
+    snprintf(buf, buf_bytes, "den_general_recursion_kernel,den_general_gamma_kernel");
+    return PYCHAIN_HIP_OK;
+  }
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   a.wide = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
@@ -149,6 +153,19 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
 extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]) {
   if (!host_blob || !info || blob_bytes < sizeof(PlanHeader))
     return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: null or truncated blob");
+  if (((const int32_t*)host_blob)[0] == PLAN_MAGIC_GENERAL) {
+    const GeneralPlanHeader* gh = (const GeneralPlanHeader*)host_blob;
+    if (blob_bytes < sizeof(GeneralPlanHeader) || gh->version != PLAN_VERSION || (size_t)gh->total_bytes > blob_bytes ||
+        (size_t)gh->total_bytes < sizeof(GeneralPlanHeader))
+      return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: not a plan of this library version");
+    if ((int32_t)general_payload_hash(host_blob, (size_t)gh->total_bytes) != gh->payload_hash)
+      return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: plan payload does not match its checksum (corrupted or foreign file)");
+    memset(info, 0, 8 * sizeof(int32_t));
+    info[0] = gh->H; info[1] = gh->K; info[2] = gh->D;
+    info[3] = gh->total_bytes > 0x7fffffff ? 0x7fffffff : (int32_t)gh->total_bytes;
+    info[4] = PYCHAIN_HIP_HINT_GENERAL;          // launch hint: the general kernels (den_general.hip)
+    return PYCHAIN_HIP_OK;
+  }
   const PlanHeader* hd = (const PlanHeader*)host_blob;
   if (hd->magic != PLAN_MAGIC || hd->version != PLAN_VERSION || (size_t)hd->total_bytes > blob_bytes ||
       (size_t)hd->total_bytes < sizeof(PlanHeader))
@@ -182,7 +199,7 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
 }
 
 namespace {
-int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, int H, int D,
+int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, int hint, int H, int D,
                   const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
                   int B, int T, float leaky_hmm_coefficient, float grad_scale,
                   float* objf_per_seq, float* grad, int32_t* bad_count,
@@ -191,8 +208,9 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
     return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
   if (B <= 0 || T <= 0 || H <= 0 || D <= 0)
     return fail(PYCHAIN_HIP_EINVAL, "%s: bad sizes B=%d T=%d H=%d D=%d", who, B, T, H, D);
-  if (H > 65535 || D > 65535)
-    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: num_states and num_pdfs must be <= 65535", who);
+  if ((H > 65535 || D > 65535) && hint != PYCHAIN_HIP_HINT_GENERAL)
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: more than 65535 states or pdfs need a plan in the general format (build it with "
+                "pychain_hip_den_plan_build and pass the launch hint pychain_hip_den_plan_info reports)", who);
   // chain-computation.cc:68 asserts 0 < coefficient < 1 (compiled out under NDEBUG); here it is an error
   if (!(leaky_hmm_coefficient > 0.f && leaky_hmm_coefficient < 1.f))
     return fail(PYCHAIN_HIP_EINVAL, "%s: leaky_hmm_coefficient must be in (0,1), got %g", who,
@@ -321,8 +339,7 @@ bool den_call_is_wide(const DenArgs& a, int resident_slot_rows) {
 // 4096 < D <= 9216 pdfs - C4 - fit a 128-VGPR wave at all); option den_dma = "0": rows through registers, i.e. the
 // 16-wave map for D <= 4096 and den_recursion_kernel beyond
 bool den_call_is_dma(const DenArgs& a, int resident_slot_rows) {
-  if (a.knobs.den_dma == 0) return false;
-  return den_lazy_eligible(a, resident_slot_rows) || den_dma_eligible(a, resident_slot_rows);
+  return a.knobs.den_dma != 0 && den_dma_eligible(a, resident_slot_rows);
 }
 int den_call_shape(const DenArgs& a, int resident_slot_rows) {     // DenArgs::wide
   if (den_call_is_wide(a, resident_slot_rows)) return 1;
@@ -348,6 +365,21 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
                             hipEvent_t gamma_wait) {
   const int gmax = (a.D + 63) / 64;
   const int user_mask = a.phase_mask;
+  if (resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) {
+    // a plan in the general format: den_general.hip, no overlap (rows in den_recursion_kernel's normalised form)
+    a.lazy = 0; a.pair = 0; a.wide = 0;
+    a.check = (occupancy && user_mask == 3) ? 1 : 0;
+    const bool corrupt_g = a.knobs.corrupt_what == 1 && a.knobs.corrupt_b < a.B && a.knobs.corrupt_t < a.T;
+    a.phase_mask = user_mask & 1;
+    hipError_t eg = a.phase_mask ? launch_den_general(a, st) : hipSuccess;
+    if (eg == hipSuccess && corrupt_g && a.phase_mask)
+      eg = launch_scale_row(a.alpha_store + ((size_t)a.knobs.corrupt_b * a.T + a.knobs.corrupt_t) * a.Hp, a.Hp, a.knobs.corrupt_scale, st);
+    if (eg == hipSuccess && gamma_wait) eg = hipStreamWaitEvent(st, gamma_wait, 0);
+    a.phase_mask = occupancy ? (user_mask & 2) : 0;
+    if (eg == hipSuccess && a.phase_mask) eg = launch_den_general(a, st);
+    a.phase_mask = user_mask;
+    return eg;
+  }
   // (a corrupted row - option debug_corrupt_row - is written between the recursion and the occupancy launches: no overlap)
   const bool corrupt = a.knobs.corrupt_what == 1 && a.knobs.corrupt_b < a.B && a.knobs.corrupt_t < a.T;
   const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt) ? den_segments(a) : 1;
@@ -461,7 +493,7 @@ extern "C" int pychain_hip_den_forward_backward(
     float* objf_per_seq, float* grad, int32_t* bad_count,
     void* workspace, size_t workspace_bytes, void* stream) {
   DenArgs a;
-  int rc = fill_den_args(a, plans_dev, plan_stride_bytes, H, D, nnet_output, input_is_exp, seq_lengths, B, T,
+  int rc = fill_den_args(a, plans_dev, plan_stride_bytes, resident_slot_rows, H, D, nnet_output, input_is_exp, seq_lengths, B, T,
                          leaky_hmm_coefficient, grad_scale, objf_per_seq, grad, bad_count, workspace,
                          workspace_bytes, "den_forward_backward");
   if (rc != PYCHAIN_HIP_OK) return rc;
@@ -580,7 +612,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (!bad_count) return fail(PYCHAIN_HIP_EINVAL, "%s: null bad_count", who);
   DenArgs da;
   // without `grad` only the recursions run; any non-null aligned pointer then passes the checks
-  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, leaky,
+  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, resident_slot_rows, den_H, D, nnet_output, 0, seq_lengths, B, T, leaky,
                          grad_scale, den_objf, grad ? grad : (float*)den_ws, bad_count, den_ws, den_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   NumArgs na;
@@ -598,7 +630,8 @@ extern "C" int pychain_hip_chain_loss_forward(
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
   const bool no_fold = da.knobs.no_fold != 0;                             // test / tuning option
-  const bool fold = grad && !no_fold && den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
+  const bool fold = grad && !no_fold && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL &&
+                    den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
   if (fold) {
     da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
     da.fold_scale = -grad_scale;
@@ -657,7 +690,7 @@ int chain_loss_backward_impl(
   if (!bad_count || !ft || !fi || !fp) return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
   DenArgs da;
   float dummy_coef = 0.5f;       // the occupancy launch does not use the leaky coefficient
-  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, den_H, D, nnet_output, 0, seq_lengths, B, T, dummy_coef,
+  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, resident_slot_rows, den_H, D, nnet_output, 0, seq_lengths, B, T, dummy_coef,
                          grad_scale, (float*)den_ws, grad, bad_count, den_ws, den_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
@@ -674,7 +707,8 @@ int chain_loss_backward_impl(
   const char* why = nullptr;
   hipError_t e = zero_bad ? hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st) : hipSuccess;
   da.phase_mask = 2;
-  if (e == hipSuccess) e = launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
+  if (e == hipSuccess)
+    e = resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL ? launch_den_general(da, st) : launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
   if (e == hipSuccess) e = launch_num_occ(na, false, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));

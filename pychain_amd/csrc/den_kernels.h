@@ -98,6 +98,9 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
 int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, const int* seg_bound, int seg,
                          int* out, int out_len);
 
+// The kernels for plans in the general format (den_general.hip): the launches a.phase_mask selects, on `st`.
+hipError_t launch_den_general(const DenArgs& a, hipStream_t st);
+
 // After the last launch of a call: objf from the stored totals + the invariant check (DenArgs::tot_a).
 // One workgroup per sequence.
 hipError_t launch_den_finish(const DenArgs& a, hipStream_t st);

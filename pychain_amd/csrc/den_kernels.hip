@@ -1337,9 +1337,10 @@ inline int pick_r(const DenArgs& a, int rows, int lds_words) {
 // The lazy-normalisation recursion (den_lazy.inc.h) in its 16-wave shape serves the shape the benchmarks run: nnet-output
 // row and state vector within its fixed LDS map, every arc of a wave in registers, at most LzNarrow::kMaxGroups groups
 // per wave (bit 30 of the plan hint), the whole sequence in one launch.
-inline bool lazy_shape_ok(const DenArgs& a, int hint) {
+// (`dma`: rows by LDS-direct loads, which take any row length; rows through registers are float4 loads: D % 4 == 0)
+inline bool lazy_shape_ok(const DenArgs& a, int hint, bool dma = false) {
   const int rows = hint & 1023;
-  return ((hint >> 30) & 1) && a.D % 4 == 0 && a.D <= (int)LzNarrow::kMaxPdfs && a.Hp <= (int)LzNarrow::kMaxStates && rows > 0 &&
+  return ((hint >> 30) & 1) && (dma || a.D % 4 == 0) && a.D <= (int)LzNarrow::kMaxPdfs && a.Hp <= (int)LzNarrow::kMaxStates && rows > 0 &&
          rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
 }
 hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
@@ -1368,7 +1369,7 @@ hipError_t launch_wide_x(const DenArgs& a, int rows, hipStream_t st) {
 // the 16-wave shape with LDS-direct nnet-output rows (LzDma): D <= 9216, Hp <= 3072
 inline bool dma_shape_ok(const DenArgs& a, int hint) {
   const int rows = hint & 1023;
-  return ((hint >> 30) & 1) && a.D % 4 == 0 && a.D <= (int)LzDma::kMaxPdfs && a.Hp <= (int)LzDma::kMaxStates && rows > 0 &&
+  return ((hint >> 30) & 1) && a.D <= (int)LzDma::kMaxPdfs && a.Hp <= (int)LzDma::kMaxStates && rows > 0 &&
          rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
 }
 template <typename M>
@@ -1380,7 +1381,7 @@ hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
 }
 hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
   // the map of C1-C3 where the shape fits it, else the one for rows of up to 9216 pdfs
-  if (lazy_shape_ok(a, hint)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
+  if (lazy_shape_ok(a, hint, true)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
   return launch_dma_m<LzDma>(a, hint & 1023, st);
 }
 hipError_t launch_wide(const DenArgs& a, int hint, hipStream_t st) {
@@ -1470,7 +1471,7 @@ hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hi
 
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows); }
 bool den_wide_eligible(const DenArgs& a, int resident_slot_rows) { return wide_shape_ok(a, resident_slot_rows); }
-bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return dma_shape_ok(a, resident_slot_rows); }
+bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) || dma_shape_ok(a, resident_slot_rows); }
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
   (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";

@@ -101,7 +101,10 @@ __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int
   for (int c = 0; c < NCH; c++) {
     const int ch = wave + c * NW;                       // (uniform)
     if (ch * 1024 < row_bytes) {
-      const int voff = min(lane * 16, row_bytes - 16 - ch * 1024);
+      // a lane that starts inside the row reads its 16 bytes as they are (D % 4 != 0: the last one runs a few floats
+      // into the next row or, at the end of the slab, into the zeros of the buffer's range check); one that starts past
+      // the row's end re-reads the row's last 16 bytes
+      const int voff = ch * 1024 + lane * 16 < row_bytes ? lane * 16 : max(0, row_bytes - 16 - ch * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(buf, (lz_lds_void*)(xbase + (uint32_t)ch * 1024u), 16, voff,
                                                soff + ch * 1024, 0, 0);
     }
@@ -118,7 +121,12 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
     if (ch * 1024 < D * 4) {
       const uint32_t addr = xbase + (uint32_t)ch * 1024u + (uint32_t)lane * 16u;
       lz_v4 q = *(const __attribute__((address_space(3))) lz_v4*)(addr);
-      nan = nan || __builtin_isunordered(q.x, q.y) || __builtin_isunordered(q.z, q.w);
+      if ((D & 3) == 0) {
+        nan = nan || __builtin_isunordered(q.x, q.y) || __builtin_isunordered(q.z, q.w);
+      } else {                                          // (elements past the row's end belong to the next frame, or to nobody)
+        const int e = ch * 256 + lane * 4;
+        nan = nan || (e < D && q.x != q.x) || (e + 1 < D && q.y != q.y) || (e + 2 < D && q.z != q.z) || (e + 3 < D && q.w != q.w);
+      }
       if (is_exp == kXExpClamp) q = lz_v4{clamp_exp(q.x, kXExpClamp), clamp_exp(q.y, kXExpClamp), clamp_exp(q.z, kXExpClamp), clamp_exp(q.w, kXExpClamp)};
       *(__attribute__((address_space(3))) lz_v4*)(addr) = q;
     }

@@ -560,6 +560,55 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
 
 size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 
+// The general format (plan_format.h: GeneralPlanHeader): the reference layout, plus the arcs grouped by pdf-id in the
+// (state, arc) order the reference accumulates in (chain-computation.cc:293-305)
+int64_t build_general(const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
+                      const float* leaky, const float* initial, const float* final_, int H, int K, int D, int Hp,
+                      void* blob, size_t blob_bytes) {
+  for (int h = 0; h < H; h++) {
+    for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++)
+      if (bt[3 * k + 1] != h)
+        return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: backward transition %d is not grouped under its destination", k);
+    for (int k = fi[2 * h]; k < fi[2 * h + 1]; k++)
+      if (ft[3 * k] != h)
+        return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: forward transition %d is not grouped under its source", k);
+  }
+  GeneralPlanHeader hd;
+  memset(&hd, 0, sizeof(hd));
+  hd.magic = PLAN_MAGIC_GENERAL; hd.version = PLAN_VERSION; hd.H = H; hd.K = K; hd.D = D; hd.Hp = Hp;
+  size_t off = align16(sizeof(hd));
+  auto place = [&](int64_t& o, size_t bytes) { o = (int64_t)off; off = align16(off + bytes); };
+  place(hd.off_a_idx, (size_t)H * 8); place(hd.off_a_arc, (size_t)K * 8); place(hd.off_a_p, (size_t)K * 4);
+  place(hd.off_b_idx, (size_t)H * 8); place(hd.off_b_arc, (size_t)K * 8); place(hd.off_b_p, (size_t)K * 4);
+  place(hd.off_g_idx, ((size_t)D + 1) * 4); place(hd.off_g_arc, (size_t)K * 8); place(hd.off_g_p, (size_t)K * 4);
+  place(hd.off_leaky, (size_t)Hp * 4); place(hd.off_init, (size_t)Hp * 4); place(hd.off_final, (size_t)Hp * 4);
+  hd.total_bytes = (int64_t)off;
+  if (!blob || blob_bytes < off) return (int64_t)off;
+  char* base = (char*)blob;
+  memset(base, 0, off);
+  memcpy(base + hd.off_a_idx, bi, (size_t)H * 8); memcpy(base + hd.off_b_idx, fi, (size_t)H * 8);
+  int32_t* a_arc = (int32_t*)(base + hd.off_a_arc); int32_t* b_arc = (int32_t*)(base + hd.off_b_arc);
+  for (int k = 0; k < K; k++) {
+    a_arc[2 * k] = bt[3 * k]; a_arc[2 * k + 1] = bt[3 * k + 2];           // {src, pdf}, grouped by destination
+    b_arc[2 * k] = ft[3 * k + 1]; b_arc[2 * k + 1] = ft[3 * k + 2];       // {dst, pdf}, grouped by source
+  }
+  memcpy(base + hd.off_a_p, bp, (size_t)K * 4); memcpy(base + hd.off_b_p, fp, (size_t)K * 4);
+  int32_t* g_idx = (int32_t*)(base + hd.off_g_idx); int32_t* g_arc = (int32_t*)(base + hd.off_g_arc); float* g_p = (float*)(base + hd.off_g_p);
+  std::vector<int32_t> fill(D + 1, 0);
+  for (int k = 0; k < K; k++) fill[ft[3 * k + 2] + 1]++;
+  for (int n = 0; n < D; n++) fill[n + 1] += fill[n];
+  memcpy(g_idx, fill.data(), ((size_t)D + 1) * 4);
+  for (int k = 0; k < K; k++) {                                             // counting sort: stable in (state, arc) order
+    const int32_t slot = fill[ft[3 * k + 2]]++;
+    g_arc[2 * slot] = ft[3 * k]; g_arc[2 * slot + 1] = ft[3 * k + 1]; g_p[slot] = fp[k];
+  }
+  memcpy(base + hd.off_leaky, leaky, (size_t)H * 4); memcpy(base + hd.off_init, initial, (size_t)H * 4);
+  memcpy(base + hd.off_final, final_, (size_t)H * 4);
+  hd.payload_hash = (int32_t)pychain_hip::general_payload_hash(base, off);
+  memcpy(base, &hd, sizeof(hd));
+  return (int64_t)off;
+}
+
 }  // namespace
 
 extern "C" int64_t pychain_hip_den_plan_build(
@@ -571,10 +620,6 @@ extern "C" int64_t pychain_hip_den_plan_build(
     return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: null graph pointer");
   if (H <= 0 || K <= 0 || D <= 0)
     return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: empty graph (H=%d K=%d D=%d)", H, K, D);
-  if (H > 65535 || D > 65535)
-    return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED,
-                             "den_plan_build: packed arc format needs num_states and num_pdfs <= 65535 "
-                             "(got H=%d D=%d)", H, D);
   for (int h = 0; h < H; h++) {
     if (fi[2 * h] < 0 || fi[2 * h + 1] < fi[2 * h] || fi[2 * h + 1] > K ||
         bi[2 * h] < 0 || bi[2 * h + 1] < bi[2 * h] || bi[2 * h + 1] > K)
@@ -587,6 +632,9 @@ extern "C" int64_t pychain_hip_den_plan_build(
       return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: transition %d has a state or pdf out of range", k);
   }
   const int Hp = (H + 63) / 64 * 64;
+  // graphs the tile-plan kernels do not take (or PYCHAIN_PLAN_GENERAL=1: the tests): the general format
+  if (!pychain_hip::plan_fits_fast_kernels(H, D) || env_long("PYCHAIN_PLAN_GENERAL", 0) != 0)
+    return build_general(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, Hp, blob, blob_bytes);
   std::vector<int> indeg(H), outdeg(H), ids(H);
   std::iota(ids.begin(), ids.end(), 0);
   for (int h = 0; h < H; h++) { indeg[h] = bi[2 * h + 1] - bi[2 * h]; outdeg[h] = fi[2 * h + 1] - fi[2 * h]; }

@@ -86,9 +86,39 @@ struct PlanHeader {
   int32_t reserved2[2];
 };
 
+// ---- the GENERAL format: graphs the compiled tile plans do not take (more than 65 535 states or pdfs, or vectors that
+// do not fit the LDS of one CU).  The reference layout as it is (fstext.cc:49-116), plus the arcs grouped by pdf-id for
+// an atomics-free occupancy pass; read by den_general.hip straight from global memory.
+#define PLAN_MAGIC_GENERAL 0x47504843  // "CHPG"
+struct GeneralPlanHeader {
+  int32_t magic, version;
+  int32_t H, K, D, Hp;
+  int64_t total_bytes;
+  int64_t off_a_idx, off_a_arc, off_a_p;   // arcs by destination: int32[H][2] begin/end, int32[K][2] {src, pdf}, float[K]
+  int64_t off_b_idx, off_b_arc, off_b_p;   // arcs by source:      int32[H][2],           int32[K][2] {dst, pdf}, float[K]
+  int64_t off_g_idx, off_g_arc, off_g_p;   // arcs by pdf-id:      int32[D + 1],          int32[K][2] {src, dst}, float[K]
+  int64_t off_leaky, off_init, off_final;  // float[Hp], natural state order
+  int32_t payload_hash, reserved[3];
+};
+
 #ifdef __cplusplus
 #include <stddef.h>
 namespace pychain_hip {
+inline uint32_t general_payload_hash(const void* blob, size_t total_bytes) {
+  const unsigned char* p = (const unsigned char*)blob;
+  uint32_t h = 2166136261u;
+  for (size_t i = sizeof(GeneralPlanHeader); i < total_bytes; i++) { h ^= p[i]; h *= 16777619u; }
+  return h;
+}
+// Does a graph of these sizes fit the compiled-plan kernels (packed 16-bit LDS addresses; state vector + nnet-output row
+// in the 160 KiB LDS of one CU, as launch_den checks)?  Else the plan is built in the general format.
+inline bool plan_fits_fast_kernels(int H, int D) {
+  if (H > 65535 || D > 65535) return false;
+  const size_t Hp = (size_t)(H + 63) / 64 * 64, Dp = (size_t)(D + 3) & ~(size_t)3, gmax = (size_t)(D + 63) / 64;
+  const bool db = D % 4 == 0 && D <= 4096;
+  const size_t lds_rec = 4 * (3 * Hp + (db ? 8192 : Dp) + 32), lds_gam = 4 * (2 * Hp + 2 * Dp + gmax * 64 + 16);
+  return lds_rec <= 160 * 1024 && lds_gam <= 160 * 1024;
+}
 // FNV-1a (32 bit) over the blob behind its header
 inline uint32_t plan_payload_hash(const void* blob, size_t total_bytes) {
   const unsigned char* p = (const unsigned char*)blob;

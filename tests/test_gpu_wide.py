@@ -77,20 +77,25 @@ def test_wide_rows_vs_oracle(H, K, D):
     assert abs(o - o2) <= 1e-6 * abs(o2) and rel_err(g.cpu().numpy(), g2.cpu().numpy()) <= 1e-5
 
 
-@pytest.mark.parametrize("H,K,D", [(40, 300, 4100), (700, 6000, 8408), (3000, 30000, 9216), (3000, 30000, 8408)])
+@pytest.mark.parametrize("H,K,D", [(40, 300, 4100), (700, 6000, 8408), (3000, 30000, 9216), (3000, 30000, 8408),
+                                   (40, 300, 3457), (200, 2000, 1001), (300, 3000, 4098), (64, 500, 7)])
 def test_dma_rows_vs_oracle(H, K, D):
-    """4096 < D <= 9216 takes the 16-wave lazy recursion with LDS-direct nnet-output rows (LzDma) by default: small,
-    medium and C4-size graphs (16-, 32- and 40-row loops), a row whose last 1 KiB chunk is partial, ragged lengths,
+    """The 16-wave lazy recursion with LDS-direct nnet-output rows is the default wherever a lazy shape fits: rows of
+    4096 < D <= 9216 pdfs (small, medium and C4-size graphs: 16-, 32- and 40-row loops), a row whose last 1 KiB chunk is
+    partial, and row lengths that are NOT a multiple of four floats (rows then start at any 4-byte address: the last lane
+    of a row reads a few floats of the next one, which must not leak - not even as a false NaN alarm); ragged lengths;
     against the oracle and against the two-barrier kernel."""
     den = syn.make_den_graph(H, K, D, seed=3)
     L = torch.tensor([97, 64, 5, 1])
     x = syn.make_input(4, 97, D, seed=33, device=DEV)
+    x[1, 64:] = float("nan")                                 # padding frames may hold anything
+    x[2, 5:] = float("nan")
     assert _names(den, D, 4)[0] == "den_recursion_lazy_kernel<dma>"
     o, g = _den(x, L, den)
-    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 4), 1e-5)
+    ro, rg = orc.chain_function(torch.nan_to_num(x.cpu(), nan=0.0), L, ChainGraphBatch(den, 4), 1e-5)
     assert abs(o - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4
-    o2, g2 = _den(x, L, den, den_dma=0)                      # the two-barrier kernel: second opinion
-    assert _names(den, D, 4, den_dma=0)[0] == "den_recursion_kernel"
+    o2, g2 = _den(x, L, den, den_dma=0, den_lazy=0)          # the two-barrier kernel: second opinion
+    assert _names(den, D, 4, den_dma=0, den_lazy=0)[0] == "den_recursion_kernel"
     assert abs(o - o2) <= 1e-6 * abs(o2) and rel_err(g.cpu().numpy(), g2.cpu().numpy()) <= 1e-5
     for nseg in (1, 3):
         o3, g3 = _den(x, L, den, den_segments=nseg)
@@ -139,7 +144,9 @@ def test_which_kernel_each_shape_gets():
         (3000, 30000, 8408, 32, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),      # C4
         (300, 3000, 4100, 8, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),
         (300, 3000, 9220, 8, "den_recursion_kernel", "den_gamma_kernel"),                   # rows beyond the LDS map
-        (300, 3000, 4098, 8, "den_recursion_kernel", "den_gamma_kernel"),                   # D % 4 != 0
+        (300, 3000, 4098, 8, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),         # D % 4 != 0: rows by LDS-direct loads
+        (3000, 30000, 3457, 64, "den_recursion_lazy_kernel<dma>", "den_gamma_kernel"),      # one pdf more than C3: no cliff in the recursion
+        (5000, 20000, 3456, 8, "den_recursion_kernel", "den_gamma_kernel"),                 # more states than the lazy LDS maps hold
     ]
     for H, K, D, B, rec, occ in cases:
         den = syn.make_den_graph(H, K, D, seed=1)

@@ -231,3 +231,35 @@ def test_graph_plan_follows_in_place_edits():
     den.final_probs.fill_(0.25)
     p2 = _plan.graph_plan(den, 64, torch.device("cpu"))
     assert p2 is not p1 and not torch.equal(p1.blob, p2.blob)
+
+
+def test_general_plan_format(monkeypatch):
+    """Graphs beyond the tile kernels (here: forced, and a genuine one with more than 65 535 pdfs) compile to the general
+    format: the reference layout + the arcs grouped by pdf-id, checksummed, launch hint PYCHAIN_HIP_HINT_GENERAL."""
+    import struct
+    g = syn.make_den_graph(50, 400, 70000, seed=9)                  # D > 65535: no packed 16-bit addresses
+    blob = _blob(g, 70000)
+    info = _plan.plan_info(blob)
+    assert info["slot_rows"] == _plan.HINT_GENERAL and (info["num_states"], info["num_transitions"], info["num_pdfs"]) == (50, 400, 70000)
+    magic, version, H, K, D, Hp, total = struct.unpack_from("6iq", blob.tobytes(), 0)
+    assert magic == 0x47504843 and total == blob.nbytes and Hp == 64
+    offs = struct.unpack_from("12q", blob.tobytes(), 32)
+    g_idx = np.frombuffer(blob.tobytes(), dtype=np.int32, count=D + 1, offset=offs[6])
+    g_arc = np.frombuffer(blob.tobytes(), dtype=np.int32, count=2 * K, offset=offs[7]).reshape(K, 2)
+    ft = g.forward_transitions.numpy()
+    assert g_idx[0] == 0 and g_idx[-1] == K and np.all(np.diff(g_idx) >= 0)
+    for n in np.unique(ft[:, 2])[:50]:
+        want = ft[ft[:, 2] == n][:, :2]                              # (state, arc) order of the reference
+        assert np.array_equal(g_arc[g_idx[n]:g_idx[n + 1]], want)
+    bad = blob.copy()
+    bad[-5] ^= 1
+    i8 = np.zeros(8, dtype=np.int32)
+    assert _lib.lib().pychain_hip_den_plan_info(bad.ctypes.data_as(ctypes.c_void_p), bad.nbytes, i8.ctypes.data_as(ctypes.c_void_p)) < 0
+    # a graph the tile kernels take, forced: same format
+    monkeypatch.setenv("PYCHAIN_PLAN_GENERAL", "1")
+    small = syn.make_den_graph(20, 60, 40, seed=0)
+    assert _plan.plan_info(_blob(small, 40))["slot_rows"] == _plan.HINT_GENERAL
+    monkeypatch.delenv("PYCHAIN_PLAN_GENERAL")
+    assert _plan.plan_info(_blob(small, 40))["slot_rows"] != _plan.HINT_GENERAL
+    # state vector + nnet-output row beyond the LDS of one CU: general too
+    assert _plan.plan_info(_blob(syn.make_den_graph(300, 1200, 40000, seed=1), 40000))["slot_rows"] == _plan.HINT_GENERAL
