@@ -28,7 +28,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves",
-                                     "den_pair", "den_wide", "den_dma", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
+                                     "den_pair", "den_wide", "den_dma", "den_stream", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
                                      "den_lazy", "debug_corrupt_row"};
 bool known_option(const char* name) {
   if (!name) return false;
@@ -70,6 +70,7 @@ CallKnobs call_knobs() {
   k.den_pair = option_int("den_pair", -1);
   k.den_wide = option_int("den_wide", -1);
   k.den_dma = option_int("den_dma", -1);
+  k.den_stream = option_int("den_stream", -1);
   k.gamma_tiled = option_int("gamma_tiled", -1);
   k.force_general = option_int("force_general", 0) ? 1 : 0;
   std::string v;
@@ -234,8 +235,10 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   char* ws = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   a.alpha_store = (float*)ws;
   a.beta_store = (float*)(ws + align256(4 * (size_t)B * T * a.Hp));
-  a.logsum_ws = (double*)(ws + align256(4 * (size_t)B * T * a.Hp) + align256(4 * (size_t)B * (T + 1) * a.Hp));
-  a.progress = (int32_t*)((char*)a.logsum_ws + align256(8 * (size_t)B));
+  a.seq_progress = (int32_t*)(ws + align256(4 * (size_t)B * T * a.Hp) + align256(4 * (size_t)B * (T + 1) * a.Hp));   // [2][B]
+  a.progress = (int32_t*)((char*)a.seq_progress + align256(8 * (size_t)B));
+  a.stream_next = a.progress + 32;
+  a.stream = 0;
   a.tot_a = (float*)((char*)a.progress + 256);
   a.tot_b = (float*)((char*)a.tot_a + align256(4 * (size_t)B * (T + 2)));
   a.gtot = (float*)((char*)a.tot_b + align256(4 * (size_t)B * (T + 2)));
@@ -420,6 +423,28 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   }
   for (int s = 0; s < a.knobs.nbounds && s < nseg - 1; s++)   // option den_bounds: ends of all segments but the last, as fractions of T
     a.seg_bound[s] = std::min(a.T, ((int)(std::max(a.knobs.bounds[s], 0.5) * a.T) + 31) / 32 * 32);   // nothing is computable before T/2
+  if (!a.knobs.den_relaunch && a.knobs.den_stream != 0 && den_stream_eligible(a, gmax, resident_slot_rows)) {
+    // Streamed schedule (DenArgs::stream, den_kernels.hip: stream_take): ONE recursion launch whose workgroups report
+    // per-sequence progress, ONE persistent occupancy launch on the side stream - released when every recursion
+    // workgroup has passed T/2 (nothing is computable before; the numerator has the idle CUs until then) - that draws
+    // rings of frames from a queue in the order in which they become computable.  No segment granularity, no exposed last
+    // launch: what is left when the recursions end is the last ring of every sequence.
+    a.stream = 1; a.sig_n = 1; a.stream_blocks = device_cu_count();
+    a.seg_bound[0] = std::min(a.T, (a.T / 2 + 31) / 32 * 32);
+    e = hipMemsetAsync(a.seq_progress, 0, align256(8 * (size_t)a.B) + 256, st);    // per-sequence progress, gate counters, queue head
+    if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
+    a.phase_mask = 1; a.seg_begin = 0; a.seg_end = 0x7fffffff;
+    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
+    if (e == hipSuccess) e = launch_den_gate(a.progress, den_recursion_blocks(a), a.bad, side->stream2);
+    if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
+    a.phase_mask = 2; a.gam_nseg = 0; a.gam_seg = 0; a.stream = 3;
+    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
+    if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
+    a.phase_mask = user_mask; a.sig_n = 0; a.stream = 0;
+    return e;
+  }
   if (!a.knobs.den_relaunch) {
     // Gated schedule: ONE recursion launch; its workgroups count themselves into progress[s] when their
     // steps below seg_bound[s] are done, and a one-wave gate kernel in front of occupancy launch s (side

@@ -54,7 +54,15 @@ struct DenArgs {
   int seg_begin, seg_end;
   int gam_seg, gam_nseg;
   int seg_bound[16];         // recursion segment s covers steps [seg_bound[s-1], seg_bound[s]) (seg_bound[-1] = 0)
-  double* logsum_ws;         // [B] running sum of log tot-alpha carried across recursion segments
+  // Streamed occupancy pass (`stream` = 1): the recursion workgroup of (direction, sequence) publishes in
+  // seq_progress[dir * B + b] how many of its rows are complete and visible device-wide - alpha rows 0 .. P-1, beta rows
+  // L .. L-P+1 - every kStreamWidth steps and when it ends; ONE persistent occupancy launch takes the frames in rings of
+  // kStreamWidth by the step count that makes them computable (max(t, L-1-t)) from the queue counter stream_next and
+  // waits for exactly the two counters a ring needs.  Frame t needs alpha row t and beta row t+1: Pa >= t+1, Pb >= L-t.
+  int32_t* seq_progress;     // [2][B], zeroed before the recursion launch
+  int32_t* stream_next;      // [1], zeroed before the recursion launch
+  int stream;                // bit 0: the recursions report progress; bit 1: this occupancy launch is the streamed one
+  int stream_blocks;         // its grid (the CU count: the workgroups that do not fit beside the recursions start as those end)
   // Progress signalling (the gated schedule): a recursion workgroup adds 1 to progress[s] once its steps
   // [0, seg_bound[s]) are done and their rows are visible device-wide, s < sig_n; the occupancy launch of
   // segment s is released by den_gate_kernel when progress[s] reaches 2B.  sig_n = 0: no signalling.
@@ -78,6 +86,9 @@ bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows);
 // ... in its 8-wave shape (DenArgs::wide); checked before den_lazy_eligible, which is the 16-wave shape
 bool den_wide_eligible(const DenArgs& a, int resident_slot_rows);
 bool den_dma_eligible(const DenArgs& a, int resident_slot_rows);
+// true if the occupancy pass of this call can run as ONE persistent launch beside the recursion (DenArgs::stream): the
+// recursion kernel of the call reports per-sequence progress (lazy and pair forms), one plan for all sequences
+bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
 // names of the kernels launch_den would run for this call: recursion, occupancy (measurement tools and the
 // kernel-selection test label by them)
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows);
@@ -104,6 +115,8 @@ hipError_t launch_den_general(const DenArgs& a, hipStream_t st);
 // After the last launch of a call: objf from the stored totals + the invariant check (DenArgs::tot_a).
 // One workgroup per sequence.
 hipError_t launch_den_finish(const DenArgs& a, hipStream_t st);
+
+constexpr int kStreamWidth = 16;      // frames per ring of the streamed occupancy pass = steps between two progress reports
 
 // One wave that waits until *progress >= target (set by the recursion workgroups), so that what follows
 // it in stream order starts then; gives up after ~20 s and counts that in *bad.

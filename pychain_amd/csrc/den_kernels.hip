@@ -715,42 +715,89 @@ int den_compact_grid_x(const DenArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------
+// streamed occupancy pass: the queue of frame ranges (DenArgs::stream)
+// ------------------------------------------------------------------------------------
+// Frame t of a length-L sequence becomes computable when the alpha recursion has stored row t and the beta recursion row
+// t+1, i.e. after max(t, L-1-t) steps: nothing before L/2, then ever faster, from the middle outwards.  The queue hands
+// out, per sequence, rings of kStreamWidth frames on either side of the middle in that order - item id = padding of
+// sequence id (id < B), else ((ring * B + b) * 2 + side) - so that ids are drawn in the order in which they become ready,
+// whatever the lengths (which live on the device).  A workgroup draws an id, skips it if it holds no frame, waits until
+// the two recursion workgroups of the sequence have reported the rows it needs (DenArgs::seq_progress) and evaluates it.
+// No deadlock: the recursion workgroups were all resident before this kernel was released (its gate waits for every one
+// of them to pass T/2), they wait for nobody, and every item only waits for them.
+struct StreamItem { int b, lo, hi, L, pad; };
+__device__ __forceinline__ bool stream_take(const DenArgs& a, int* slot, StreamItem& it) {
+  __syncthreads();                                      // the previous item (and its slot) is done with
+  if (threadIdx.x == 0) {
+    const int B = a.B, W = kStreamWidth, total = B + ((a.T + W - 1) / W) * 2 * B;
+    int b = -1, lo = 0, hi = 0, L = 0, pad = 0;
+    for (;;) {
+      const int id = atomicAdd(a.stream_next, 1);
+      if (id >= total) { b = -1; break; }
+      if (id < B) {                                     // frames past the sequence's end: exact zeros
+        b = id; L = seq_len(a.lengths, b, a.T); lo = L; hi = a.T; pad = 1;
+        if (lo < hi) break;
+        continue;
+      }
+      const int q = id - B, r = q / (2 * B), rem = q - r * 2 * B, side = rem & 1;
+      b = rem >> 1; L = seq_len(a.lengths, b, a.T); pad = 0;
+      const int half = L / 2;
+      if (side) { lo = max(W * r, half); hi = min(W * r + W, L); }          // right of the middle: computable after t steps
+      else { lo = max(0, L - W * r - W); hi = min(half, L - W * r); }       // left: after L - 1 - t steps
+      if (lo >= hi) continue;
+      // alpha rows lo .. hi-1 and beta rows lo+1 .. hi
+      const int need_a = hi, need_b = L - lo;
+      const unsigned long long t0 = wall_clock64();     // 100 MHz
+      while (__hip_atomic_load(a.seq_progress + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_a ||
+             __hip_atomic_load(a.seq_progress + B + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need_b) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 2000000000ull) { atomicAdd(a.bad, 1); lo = hi; break; }   // 20 s: the recursion died
+      }
+      if (lo < hi) break;
+    }
+    slot[0] = b; slot[1] = lo; slot[2] = hi; slot[3] = L; slot[4] = pad;
+  }
+  __syncthreads();
+  it.b = slot[0]; it.lo = slot[1]; it.hi = slot[2]; it.L = slot[3]; it.pad = slot[4];
+  return it.b >= 0;
+}
+constexpr int kLoadDeviceScope = 16;     // cache-policy operand of a buffer load: sc1 (rows another XCD wrote while this kernel runs)
+
+// ------------------------------------------------------------------------------------
 // launch 2: occupancies (time-parallel)
 // ------------------------------------------------------------------------------------
-template <int VEC, int XCH, int R>
+// STREAM = false: one workgroup per (chunk of frames_per_block frames, sequence), the frames of occupancy launch gam_seg.
+// STREAM = true:  persistent workgroups drawing frame ranges from the queue above (one plan for all sequences).
+template <int VEC, int XCH, int R, bool STREAM>
 __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-#ifdef PYCHAIN_PROFILE_PHASES
-  const unsigned long long gk0 = PH_T();
-  unsigned long long gph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define GPH(i) do { const unsigned long long n_ = PH_T(); gph[i] += n_ - gpt; gpt = n_; } while (0)
-#else
-#define GPH(i) (void)0
-#endif
+  __shared__ int stream_slot[8];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y;
-  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int Hp = a.Hp, D = a.D, Dp = (D + 3) & ~3;
-  const int chunk = den_chunk_of_block(blockIdx.x, L, a);
-  if (chunk < 0) return;
-  const int t_begin = chunk * a.frames_per_block;
-  const int t_end = min(t_begin + a.frames_per_block, a.T);
-  float* gseq = a.grad + (size_t)b * a.T * D;
+  int b = STREAM ? 0 : blockIdx.y;
+  int L = STREAM ? 1 : __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
+  int t_first = 0, t_live_end = 0;
   const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
-  if (t_begin >= L) {                               // whole chunk is padding: exact zeros (zeros_like, :58)
-    if (first_launch)
-      for (size_t i = (size_t)t_begin * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
-    return;
-  }
-  const int t_live_end = min(t_end, L);
   const LaunchFrames lf(a);
-  const int t_first = den_next_frame(t_begin, t_live_end, L, lf);
-  if (t_first >= t_live_end) {                      // none of this chunk's frames belongs to this launch
+  if constexpr (!STREAM) {
+    const int chunk = den_chunk_of_block(blockIdx.x, L, a);
+    if (chunk < 0) return;
+    const int t_begin = chunk * a.frames_per_block;
+    const int t_end = min(t_begin + a.frames_per_block, a.T);
+    float* gseq0 = a.grad + (size_t)b * a.T * D;
+    if (t_begin >= L) {                               // whole chunk is padding: exact zeros (zeros_like, :58)
+      if (first_launch)
+        for (size_t i = (size_t)t_begin * D + tid; i < (size_t)t_end * D; i += kNT) gseq0[i] = 0.f;
+      return;
+    }
+    t_live_end = min(t_end, L);
+    // padded tail of a chunk that straddles the sequence end
     if (first_launch && t_live_end < t_end)
-      for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
-    return;
+      for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq0[i] = 0.f;
+    t_first = den_next_frame(t_begin, t_live_end, L, lf);
+    if (t_first >= t_live_end) return;                // none of this chunk's frames belongs to this launch
   }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
@@ -775,23 +822,38 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   arcs.load(groups.nslots, wave_slots, lds0, lds0 + 4u * (uint32_t)Hp);
   const uint2* tail_slots = wave_slots + (size_t)R * 64;
 
-  const float* xseq = a.x + (size_t)b * a.T * D;
-  const float* aseq = a.alpha_store + (size_t)b * a.T * Hp;
-  const float* bseq = a.beta_store + (size_t)b * (a.T + 1) * Hp;
-
   if (tid < 16) red[tid] = 0.f;
   for (int i = tid; i < Dp; i += kNT) q[i] = 0.f;   // pdfs without arcs stay zero forever
   for (int i = tid; i < tp.ngroups * 64; i += kNT) rmap[i] = row_pdf[i];
   int bad = 0;
   const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
-  // Software pipeline over frames: the global loads of frame t+1 (alpha', beta, nnet-output
-  // rows) are issued into registers before frame t is evaluated and committed to LDS after
-  // the last LDS read of frame t, so HBM latency is off the per-frame critical path.
   XRow<kNT, VEC, XCH> xq;
   constexpr int kUV = 1;                             // float4 chunks of U and of V per thread (Hp <= 4*kNT fast path)
   float4 ureg[kUV], vreg[kUV];
   const bool uv_in_regs = Hp <= kUV * 4 * kNT;
-  // (macros, not lambdas: by-reference captures would put the staging registers on the stack)
+
+  for (;;) {                                         // STREAM: one pass per item of the queue; else exactly one pass
+    if constexpr (STREAM) {
+      StreamItem it;
+      if (!stream_take(a, stream_slot, it)) break;
+      b = it.b; L = it.L;
+      if (it.pad) {
+        float* gz = a.grad + (size_t)b * a.T * D;
+        for (size_t i = (size_t)it.lo * D + tid; i < (size_t)it.hi * D; i += kNT) gz[i] = 0.f;
+        continue;
+      }
+      t_first = it.lo; t_live_end = it.hi;
+    }
+    float* gseq = a.grad + (size_t)b * a.T * D;
+    const float* xseq = a.x + (size_t)b * a.T * D;
+    const float* aseq = a.alpha_store + (size_t)b * a.T * Hp;
+    const float* bseq = a.beta_store + (size_t)b * (a.T + 1) * Hp;
+    const XBuf abuf = make_xbuf(aseq, (size_t)a.T * Hp * sizeof(float)), bbuf = make_xbuf(bseq, (size_t)(a.T + 1) * Hp * sizeof(float));
+    // Software pipeline over frames: the global loads of frame t+1 (alpha', beta, nnet-output
+    // rows) are issued into registers before frame t is evaluated and committed to LDS after
+    // the last LDS read of frame t, so HBM latency is off the per-frame critical path.
+    // (macros, not lambdas: by-reference captures would put the staging registers on the stack;
+    //  STREAM: the state rows may have been written by another XCD while this kernel runs: device-scope loads)
 #define GAMMA_PREFETCH(t)                                                                     \
   do {                                                                                        \
     xq.load(xseq + (size_t)(t) * D, D, tid);                                                  \
@@ -800,8 +862,17 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
       const float* br_ = bseq + (size_t)((t) + 1) * Hp;                                       \
       _Pragma("unroll") for (int c = 0; c < kUV; c++) {                                       \
         const int i = (c * kNT + tid) * 4;                                                    \
-        if (i < Hp) { ureg[c] = *reinterpret_cast<const float4*>(ar_ + i);                    \
-                      vreg[c] = *reinterpret_cast<const float4*>(br_ + i); }                  \
+        if (i < Hp) {                                                                         \
+          if constexpr (STREAM) {                                                             \
+            const u32x4 ua_ = __builtin_amdgcn_raw_buffer_load_b128(abuf, i * 4, (t) * Hp * 4, kLoadDeviceScope);        \
+            const u32x4 va_ = __builtin_amdgcn_raw_buffer_load_b128(bbuf, i * 4, ((t) + 1) * Hp * 4, kLoadDeviceScope);  \
+            ureg[c] = make_float4(__uint_as_float(ua_.x), __uint_as_float(ua_.y), __uint_as_float(ua_.z), __uint_as_float(ua_.w)); \
+            vreg[c] = make_float4(__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z), __uint_as_float(va_.w)); \
+          } else {                                                                            \
+            ureg[c] = *reinterpret_cast<const float4*>(ar_ + i);                              \
+            vreg[c] = *reinterpret_cast<const float4*>(br_ + i);                              \
+          }                                                                                   \
+        }                                                                                     \
       }                                                                                       \
     }                                                                                         \
   } while (0)
@@ -815,101 +886,71 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
                       *reinterpret_cast<float4*>(V + i) = vreg[c]; }                          \
       }                                                                                       \
     } else {                                                                                  \
-      const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
-      const float* br_ = bseq + (size_t)((t) + 1) * Hp;                                       \
       for (int i = tid * 4; i < Hp; i += kNT * 4) {                                           \
-        *reinterpret_cast<float4*>(U + i) = *reinterpret_cast<const float4*>(ar_ + i);        \
-        *reinterpret_cast<float4*>(V + i) = *reinterpret_cast<const float4*>(br_ + i);        \
+        const u32x4 ua_ = __builtin_amdgcn_raw_buffer_load_b128(abuf, i * 4, (t) * Hp * 4, STREAM ? kLoadDeviceScope : 0);        \
+        const u32x4 va_ = __builtin_amdgcn_raw_buffer_load_b128(bbuf, i * 4, ((t) + 1) * Hp * 4, STREAM ? kLoadDeviceScope : 0);  \
+        *reinterpret_cast<float4*>(U + i) = make_float4(__uint_as_float(ua_.x), __uint_as_float(ua_.y), __uint_as_float(ua_.z), __uint_as_float(ua_.w)); \
+        *reinterpret_cast<float4*>(V + i) = make_float4(__uint_as_float(va_.x), __uint_as_float(va_.y), __uint_as_float(va_.z), __uint_as_float(va_.w)); \
       }                                                                                       \
     }                                                                                         \
   } while (0)
-  GAMMA_PREFETCH(t_first);
-  GAMMA_COMMIT(t_first);
-  __syncthreads();
-#ifdef PYCHAIN_PROFILE_PHASES
-  unsigned long long gpt = PH_T();
-  const unsigned long long gsetup = gpt - gk0;
-  int gframes = 0;
-#endif
-  for (int t = t_first; t < t_live_end;) {
-#ifdef PYCHAIN_PROFILE_PHASES
-    gframes++;
-#endif
-    float* grow = gseq + (size_t)t * D;
-    const int t_next = den_next_frame(t + 1, t_live_end, L, lf);
-    const bool have_next = t_next < t_live_end;
-#ifndef PYCHAIN_EXPG_NO_LOAD
-    if (have_next) GAMMA_PREFETCH(t_next);
-#endif
-    float s0 = 0.f, s1 = 0.f;
-#ifndef PYCHAIN_EXPG_NO_ARCS     // (PYCHAIN_EXPG_*: ablation builds for timing only - results are wrong)
-    GPH(0);
-    tile_rows<R, 1>(arcs, groups, tail_slots, lane, U, V, q, rmap, nullptr, s0, s1);
-#endif
-    GPH(1);
+    GAMMA_PREFETCH(t_first);
+    GAMMA_COMMIT(t_first);
     __syncthreads();
-    GPH(2);
-    float g[(VEC * XCH) > 0 ? (VEC * XCH) : 1];
-    float part = 0.f;
-    if constexpr (XCH > 0) {
+    for (int t = t_first; t < t_live_end;) {
+      float* grow = gseq + (size_t)t * D;
+      const int t_next = STREAM ? t + 1 : den_next_frame(t + 1, t_live_end, L, lf);
+      const bool have_next = t_next < t_live_end;
+      if (have_next) GAMMA_PREFETCH(t_next);
+      float s0 = 0.f, s1 = 0.f;
+      tile_rows<R, 1>(arcs, groups, tail_slots, lane, U, V, q, rmap, nullptr, s0, s1);
+      __syncthreads();
+      float g[(VEC * XCH) > 0 ? (VEC * XCH) : 1];
+      float part = 0.f;
+      if constexpr (XCH > 0) {
 #pragma unroll
-      for (int c = 0; c < XCH; c++)
+        for (int c = 0; c < XCH; c++)
 #pragma unroll
-        for (int k = 0; k < VEC; k++) {
-          const int e = (c * kNT + tid) * VEC + k;
-          g[c * VEC + k] = e < D ? product_into_sum(xr[e], q[e], part) : 0.f;
-        }
-    } else {
-      for (int e = tid; e < D; e += kNT) part += xr[e] * q[e];
-    }
-    part = wave_sum(part);
-    if (lane == 0) red[wave] = part;
-    GPH(3);
-    __syncthreads();                                   // also: every read of U/V/xr of this frame is done
-    GPH(4);
-    const float tot = block_total(red, lane);
-    const float sc = gscale / tot;
-    if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
-    if (a.check && (t == 0 || a.check_all) && tid == 0) den_record_frame_total(a, b, t, tot);
-    if constexpr (XCH > 0) {
+          for (int k = 0; k < VEC; k++) {
+            const int e = (c * kNT + tid) * VEC + k;
+            g[c * VEC + k] = e < D ? product_into_sum(xr[e], q[e], part) : 0.f;
+          }
+      } else {
+        for (int e = tid; e < D; e += kNT) part += xr[e] * q[e];
+      }
+      part = wave_sum(part);
+      if (lane == 0) red[wave] = part;
+      __syncthreads();                                   // also: every read of U/V/xr of this frame is done
+      const float tot = block_total(red, lane);
+      const float sc = gscale / tot;
+      if (!(tot > 0.f) || !(sc - sc == 0.f)) bad = 1;
+      if (a.check && (t == 0 || a.check_all) && tid == 0) den_record_frame_total(a, b, t, tot);
+      if constexpr (XCH > 0) {
 #pragma unroll
-      for (int c = 0; c < XCH; c++) {
-        const int e = (c * kNT + tid) * VEC;
-#ifdef PYCHAIN_EXPG_NO_STORE
-        if (e < D && sc == 12345.f) {
-#else
-        if (e < D) {
-#endif
-          if constexpr (VEC == 4) {
-            *reinterpret_cast<float4*>(grow + e) =
-                make_float4(g[c * 4] * sc, g[c * 4 + 1] * sc, g[c * 4 + 2] * sc, g[c * 4 + 3] * sc);
-          } else {
-            grow[e] = g[c] * sc;
+        for (int c = 0; c < XCH; c++) {
+          const int e = (c * kNT + tid) * VEC;
+          if (e < D) {
+            if constexpr (VEC == 4) {
+              *reinterpret_cast<float4*>(grow + e) =
+                  make_float4(g[c * 4] * sc, g[c * 4 + 1] * sc, g[c * 4 + 2] * sc, g[c * 4 + 3] * sc);
+            } else {
+              grow[e] = g[c] * sc;
+            }
           }
         }
+        if (have_next) GAMMA_COMMIT(t_next);
+      } else {
+        for (int e = tid; e < D; e += kNT) grow[e] = xr[e] * q[e] * sc;
+        __syncthreads();                                 // generic-D path re-reads xr/q above
+        if (have_next) GAMMA_COMMIT(t_next);
       }
-#ifndef PYCHAIN_EXPG_NO_LOAD
-      if (have_next) GAMMA_COMMIT(t_next);
-#endif
-    } else {
-      for (int e = tid; e < D; e += kNT) grow[e] = xr[e] * q[e] * sc;
-      __syncthreads();                                 // generic-D path re-reads xr/q above
-      if (have_next) GAMMA_COMMIT(t_next);
+      __syncthreads();   // next frame's operands are in place; q is rewritten by the next frame
+      t = t_next;
     }
-    GPH(5);
-    __syncthreads();   // next frame's operands are in place; q is rewritten by the next frame
-    GPH(6);
-    t = t_next;
+#undef GAMMA_PREFETCH
+#undef GAMMA_COMMIT
+    if constexpr (!STREAM) break;
   }
-#ifdef PYCHAIN_PROFILE_PHASES
-  if (lane == 0 && b == 0 && blockIdx.x == 3 && (wave == 0 || wave == kNW - 1))
-    printf("gamma wave %d frames %d setup %llu cycles/frame: prefetch %llu arcs %llu bar1 %llu prod %llu bar2 %llu write+commit %llu bar3 %llu\n",
-           wave, gframes, gsetup, gph[0] / gframes, gph[1] / gframes, gph[2] / gframes, gph[3] / gframes,
-           gph[4] / gframes, gph[5] / gframes, gph[6] / gframes);
-#endif
-  // padded tail of a chunk that straddles the sequence end
-  if (first_launch && t_live_end < t_end)
-    for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq[i] = 0.f;
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
@@ -1046,31 +1087,35 @@ __device__ __forceinline__ bool den_frame_in_launch(int t, int t_live_end, int L
   return t < t_live_end && lf.has(t, L);
 }
 
-template <int XCH, int R>
+// STREAM as in den_gamma_kernel: persistent workgroups drawing frame ranges from the queue (one plan for all sequences).
+template <int XCH, int R, bool STREAM>
 __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ int stream_slot[8];
   constexpr int UVC = 2;                              // float4 chunks of a state row per thread: Hp <= 4 * UVC * kNT2
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y;
-  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int Hp = a.Hp, D = a.D, T = a.T, Dp = (D + 3) & ~3;
-  const int chunk = den_chunk_of_block(blockIdx.x, L, a);
-  if (chunk < 0) return;
-  const int t_begin = chunk * a.frames_per_block;               // frames_per_block is even
-  const int t_end = min(t_begin + a.frames_per_block, T);
-  float* gseq = a.grad + (size_t)b * T * D;
+  int b = STREAM ? 0 : blockIdx.y;
+  int L = STREAM ? 1 : __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
-  const int t_live_end = min(t_end, L);
-  // pairs (t0, t0+1), t0 even, with at least one frame of this launch
   const LaunchFrames lf(a);
-  int t0 = t_begin;
-  while (t0 < t_live_end && !den_frame_in_launch(t0, t_live_end, L, lf) && !den_frame_in_launch(t0 + 1, t_live_end, L, lf)) t0 += 2;
-  if (t0 >= t_live_end) {                             // nothing to evaluate: padding of the first launch is exact zeros
-    if (first_launch)
-      for (size_t i = (size_t)max(t_begin, min(t_live_end, t_end)) * D + tid; i < (size_t)t_end * D; i += kNT2) gseq[i] = 0.f;
-    return;
+  int t0 = 0, t_live_end = 0, t_lo = 0;               // frames [t_lo, t_live_end) of this pass, t0 = first pair (even)
+  if constexpr (!STREAM) {
+    const int chunk = den_chunk_of_block(blockIdx.x, L, a);
+    if (chunk < 0) return;
+    const int t_begin = chunk * a.frames_per_block;               // frames_per_block is even
+    const int t_end = min(t_begin + a.frames_per_block, T);
+    float* gseq0 = a.grad + (size_t)b * T * D;
+    t_live_end = min(t_end, L);
+    // pairs (t0, t0+1), t0 even, with at least one frame of this launch
+    t0 = t_begin;
+    while (t0 < t_live_end && !den_frame_in_launch(t0, t_live_end, L, lf) && !den_frame_in_launch(t0 + 1, t_live_end, L, lf)) t0 += 2;
+    // padding of the first launch is exact zeros: a whole chunk past the end, or the tail of one that straddles it
+    if (first_launch && max(t_begin, t_live_end) < t_end)
+      for (size_t i = (size_t)max(t_begin, t_live_end) * D + tid; i < (size_t)t_end * D; i += kNT2) gseq0[i] = 0.f;
+    if (t0 >= t_live_end) return;                     // nothing to evaluate
   }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
@@ -1095,45 +1140,81 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   arcs.load(groups.nslots, wave_slots, lds0, lds0 + 8u * (uint32_t)Hp);
   const uint2* tail_slots = wave_slots + (size_t)R * 64;
 
-  const float* xseq = a.x + (size_t)b * T * D;
-  const float* aseq = a.alpha_store + (size_t)b * T * Hp;
-  const float* bseq = a.beta_store + (size_t)b * (T + 1) * Hp;
-
   if (tid < 32) red[tid] = 0.f;
   for (int i = tid; i < 2 * Dp; i += kNT2) q2[i] = 0.f;          // pdfs without arcs stay zero forever
   for (int i = tid; i < tp.ngroups * 64; i += kNT2) rmap[i] = row_pdf[i];
   int bad = 0;
   const float gscale = a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale;
-  // numerator fold: thread u (and u + kNT2) owns the u-th distinct pdf of the sequence; the set of
-  // touched pdfs is the same in every frame, so n2 needs no clearing between pairs
   const bool fold = a.fold_rows != nullptr;
   const float nscale = a.grad_scale_dev ? a.fold_scale * *a.grad_scale_dev : a.fold_scale;
-  const int U = fold ? a.fold_ucount[b] : 0;
-  const int32_t* upd = a.fold_upd + (size_t)b * a.fold_K;
-  const float* frows = a.fold_rows + (size_t)b * T * a.fold_K;
-  int pd0 = -1, pd1 = -1;
-  if (fold) {
-    for (int i = tid; i < 4 * Dp; i += kNT2) n2[i] = 0.f;
-    if (tid < U) pd0 = upd[tid];
-    if (tid + kNT2 < U) pd1 = upd[tid + kNT2];
-  }
-
+  int prev_U = 0, prev_b = -1;
   // state rows of a pair: global -> registers (one pair ahead) -> LDS, interleaved
   float4 ua[UVC], ub[UVC], va[UVC], vb[UVC];
-#define GAMMA2_PREFETCH(t)                                                                       \
-  do {                                                                                           \
-    const float* a0_ = aseq + (size_t)(t) * Hp;                                                  \
-    const float* a1_ = aseq + (size_t)min((t) + 1, T - 1) * Hp;                                  \
-    const float* b0_ = bseq + (size_t)((t) + 1) * Hp;                                            \
-    const float* b1_ = bseq + (size_t)min((t) + 2, T) * Hp;                                      \
-    _Pragma("unroll") for (int c = 0; c < UVC; c++) {                                            \
-      const int i = (c * kNT2 + tid) * 4;                                                        \
-      if (i < Hp) {                                                                              \
-        ua[c] = *reinterpret_cast<const float4*>(a0_ + i); ub[c] = *reinterpret_cast<const float4*>(a1_ + i); \
-        va[c] = *reinterpret_cast<const float4*>(b0_ + i); vb[c] = *reinterpret_cast<const float4*>(b1_ + i); \
-      }                                                                                          \
-    }                                                                                            \
-  } while (0)
+  XRow<kNT2, 4, XCH> x0, x1;
+#ifdef PYCHAIN_PROFILE_PHASES
+  unsigned long long g2ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g2t = PH_T();
+  int g2pairs = 0;
+#define G2PH(i) do { const unsigned long long n_ = PH_T(); g2ph[i] += n_ - g2t; g2t = n_; } while (0)
+#else
+#define G2PH(i) (void)0
+#endif
+
+  for (;;) {                                          // STREAM: one pass per item of the queue; else exactly one pass
+    if constexpr (STREAM) {
+      StreamItem it;
+      if (!stream_take(a, stream_slot, it)) break;
+      b = it.b; L = it.L;
+      if (it.pad) {
+        float* gz = a.grad + (size_t)b * T * D;
+        for (size_t i = (size_t)it.lo * D + tid; i < (size_t)it.hi * D; i += kNT2) gz[i] = 0.f;
+        continue;
+      }
+      t_lo = it.lo; t_live_end = it.hi; t0 = t_lo & ~1;
+    }
+    float* gseq = a.grad + (size_t)b * T * D;
+    const float* xseq = a.x + (size_t)b * T * D;
+    const float* aseq = a.alpha_store + (size_t)b * T * Hp;
+    const float* bseq = a.beta_store + (size_t)b * (T + 1) * Hp;
+    const XBuf abuf = make_xbuf(aseq, (size_t)T * Hp * sizeof(float)), bbuf = make_xbuf(bseq, (size_t)(T + 1) * Hp * sizeof(float));
+    // which frames of [t0, ..) this pass evaluates
+    auto wanted = [&](int t) { return STREAM ? (t >= t_lo && t < t_live_end) : den_frame_in_launch(t, t_live_end, L, lf); };
+    // numerator fold: thread u (and u + kNT2) owns the u-th distinct pdf of the sequence; the set of
+    // touched pdfs is the same in every frame, so n2 needs no clearing between pairs (only between sequences)
+    const int U = fold ? a.fold_ucount[b] : 0;
+    const int32_t* upd = a.fold_upd + (size_t)b * a.fold_K;
+    const float* frows = a.fold_rows + (size_t)b * T * a.fold_K;
+    int pd0 = -1, pd1 = -1;
+    if (fold) {
+      if (b != prev_b) {
+        if (!STREAM || prev_b < 0) { for (int i = tid; i < 4 * Dp; i += kNT2) n2[i] = 0.f; }
+        else {
+          // the previous sequence's pdfs back to zero (the entries it touched, not the whole table)
+          const int32_t* pupd = a.fold_upd + (size_t)prev_b * a.fold_K;
+          for (int u = tid; u < prev_U; u += kNT2) { const int n = pupd[u]; n2[2 * n] = 0.f; n2[2 * n + 1] = 0.f; n2[2 * Dp + 2 * n] = 0.f; n2[2 * Dp + 2 * n + 1] = 0.f; }
+        }
+        prev_b = b; prev_U = U;
+        __syncthreads();
+      }
+      if (tid < U) pd0 = upd[tid];
+      if (tid + kNT2 < U) pd1 = upd[tid + kNT2];
+    }
+    // load number n of a pair's state rows: n = 4 * c + {0: alpha'(t), 1: alpha'(t+1), 2: beta(t+1), 3: beta(t+2)}
+    // (STREAM: device-scope loads - another XCD may have written the rows while this kernel runs)
+    auto row_load = [&](XBuf buf, int row, int i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(buf, i * 4, row * Hp * 4, STREAM ? kLoadDeviceScope : 0);
+      return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    };
+    auto prefetch_one = [&](int n, int t) {
+      const int c = n >> 2, i = (c * kNT2 + tid) * 4;
+      if (c < UVC && i < Hp) {
+        switch (n & 3) {
+          case 0: ua[c] = row_load(abuf, t, i); break;
+          case 1: ub[c] = row_load(abuf, min(t + 1, T - 1), i); break;
+          case 2: va[c] = row_load(bbuf, t + 1, i); break;
+          default: vb[c] = row_load(bbuf, min(t + 2, T), i); break;
+        }
+      }
+    };
 #define GAMMA2_COMMIT()                                                                          \
   do {                                                                                           \
     _Pragma("unroll") for (int c = 0; c < UVC; c++) {                                            \
@@ -1146,146 +1227,113 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       }                                                                                          \
     }                                                                                            \
   } while (0)
-  // load number n of a pair's state rows: n = 4 * c + {0: alpha'(t), 1: alpha'(t+1), 2: beta(t+1), 3: beta(t+2)}
-  auto prefetch_one = [&](int n, int t) {
-    const int c = n >> 2, i = (c * kNT2 + tid) * 4;
-    if (c < UVC && i < Hp) {
-      switch (n & 3) {
-        case 0: ua[c] = *reinterpret_cast<const float4*>(aseq + (size_t)t * Hp + i); break;
-        case 1: ub[c] = *reinterpret_cast<const float4*>(aseq + (size_t)min(t + 1, T - 1) * Hp + i); break;
-        case 2: va[c] = *reinterpret_cast<const float4*>(bseq + (size_t)(t + 1) * Hp + i); break;
-        default: vb[c] = *reinterpret_cast<const float4*>(bseq + (size_t)min(t + 2, T) * Hp + i); break;
+    for (int n = 0; n < 4 * UVC; n++) prefetch_one(n, t0);
+    GAMMA2_COMMIT();
+    __syncthreads();
+    int npar = 0;
+    while (t0 < t_live_end) {
+#ifdef PYCHAIN_PROFILE_PHASES
+      g2pairs++;
+#endif
+      const bool valid0 = wanted(t0), valid1 = wanted(t0 + 1);
+      int tn = t0 + 2;
+      while (tn < t_live_end && !wanted(tn) && !wanted(tn + 1)) tn += 2;
+      const bool have_next = tn < t_live_end;
+      // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
+      x0.load(xseq + (size_t)t0 * D, D, tid);
+      x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
+      float r00 = 0.f, r01 = 0.f, r10 = 0.f, r11 = 0.f;  // numerator rows of this pair (in flight during the arc work)
+      const float* fr0 = frows + (size_t)t0 * a.fold_K;
+      const float* fr1 = frows + (size_t)min(t0 + 1, T - 1) * a.fold_K;
+      if (pd0 >= 0) { r00 = fr0[tid]; r10 = fr1[tid]; }
+      if (pd1 >= 0) { r01 = fr0[tid + kNT2]; r11 = fr1[tid + kNT2]; }
+      G2PH(0);
+      // the next pair's state rows are requested inside the arc loop, one load per chunk (a pair that is the
+      // last of its pass re-reads its own rows: no branch per chunk)
+      const int tpre = have_next ? tn : t0;
+      tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap, [&](int c) {
+        constexpr int NC = R / 4 > 0 ? R / 4 : 1;
+        // spread over the first chunks, two chunks apart where the loop is long enough
+        constexpr int kStep = NC >= 16 ? 2 : 1;
+        if (c % kStep == 0 && c / kStep < 4 * UVC) prefetch_one(c / kStep, tpre);
+      });
+      if (R / 4 < 4 * UVC * (R / 4 >= 16 ? 2 : 1))          // arc loop shorter than the list of loads: the rest here
+        for (int n = (R / 4) / (R / 4 >= 16 ? 2 : 1); n < 4 * UVC; n++) prefetch_one(n, tpre);
+      G2PH(1);
+      float* n2p = n2 + (npar ? 2 * Dp : 0);             // this buffer was last read two pairs ago
+      if (fold) {
+        if (pd0 >= 0) *reinterpret_cast<v2f*>(n2p + 2 * pd0) = v2f{r00, r10};
+        if (pd1 >= 0) *reinterpret_cast<v2f*>(n2p + 2 * pd1) = v2f{r01, r11};
+        for (int u = tid + 2 * kNT2; u < U; u += kNT2) *reinterpret_cast<v2f*>(n2p + 2 * upd[u]) = v2f{fr0[u], fr1[u]};
       }
-    }
-  };
-  GAMMA2_PREFETCH(t0);
-  GAMMA2_COMMIT();
-  __syncthreads();
-  XRow<kNT2, 4, XCH> x0, x1;
-  int npar = 0;
-#ifdef PYCHAIN_PROFILE_PHASES
-  unsigned long long g2ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g2t = PH_T();
-  int g2pairs = 0;
-#define G2PH(i) do { const unsigned long long n_ = PH_T(); g2ph[i] += n_ - g2t; g2t = n_; } while (0)
-#else
-#define G2PH(i) (void)0
-#endif
-  while (t0 < t_live_end) {
-#ifdef PYCHAIN_PROFILE_PHASES
-    g2pairs++;
-#endif
-    const bool valid0 = den_frame_in_launch(t0, t_live_end, L, lf), valid1 = den_frame_in_launch(t0 + 1, t_live_end, L, lf);
-    int tn = t0 + 2;
-    while (tn < t_live_end && !den_frame_in_launch(tn, t_live_end, L, lf) && !den_frame_in_launch(tn + 1, t_live_end, L, lf)) tn += 2;
-    const bool have_next = tn < t_live_end;
-    // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
-    x0.load(xseq + (size_t)t0 * D, D, tid);
-    x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
-    float r00 = 0.f, r01 = 0.f, r10 = 0.f, r11 = 0.f;  // numerator rows of this pair (in flight during the arc work)
-    const float* fr0 = frows + (size_t)t0 * a.fold_K;
-    const float* fr1 = frows + (size_t)min(t0 + 1, T - 1) * a.fold_K;
-    if (pd0 >= 0) { r00 = fr0[tid]; r10 = fr1[tid]; }
-    if (pd1 >= 0) { r01 = fr0[tid + kNT2]; r11 = fr1[tid + kNT2]; }
-    G2PH(0);
-#ifndef PYCHAIN_EXPG_NO_ARCS
-    // the next pair's state rows are requested inside the arc loop, one load per chunk (a pair that is the
-    // last of its block re-reads its own rows: no branch per chunk)
-    const int tpre = have_next ? tn : t0;
-    tile_rows2<R>(arcs, groups, tail_slots, lane, U2, V2, q2, rmap, [&](int c) {
-#ifndef PYCHAIN_EXPG_NO_LOAD
-      constexpr int NC = R / 4 > 0 ? R / 4 : 1;
-      // spread over the first chunks, two chunks apart where the loop is long enough
-      constexpr int kStep = NC >= 16 ? 2 : 1;
-      if (c % kStep == 0 && c / kStep < 4 * UVC) prefetch_one(c / kStep, tpre);
-#endif
-    });
-#else
-    const int tpre = have_next ? tn : t0;
-    for (int n = 0; n < 4 * UVC; n++) prefetch_one(n, tpre);
-#endif
-    if (R / 4 < 4 * UVC * (R / 4 >= 16 ? 2 : 1))          // arc loop shorter than the list of loads: the rest here
-      for (int n = (R / 4) / (R / 4 >= 16 ? 2 : 1); n < 4 * UVC; n++) prefetch_one(n, tpre);
-    G2PH(1);
-    float* n2p = n2 + (npar ? 2 * Dp : 0);             // this buffer was last read two pairs ago
-    if (fold) {
-      if (pd0 >= 0) *reinterpret_cast<v2f*>(n2p + 2 * pd0) = v2f{r00, r10};
-      if (pd1 >= 0) *reinterpret_cast<v2f*>(n2p + 2 * pd1) = v2f{r01, r11};
-      for (int u = tid + 2 * kNT2; u < U; u += kNT2) *reinterpret_cast<v2f*>(n2p + 2 * upd[u]) = v2f{fr0[u], fr1[u]};
-    }
-    npar ^= 1;
-    G2PH(2);
-    __syncthreads();                                   // q2 (and n2) complete; every gather of this pair is done
-    G2PH(3);
-    float g0[4 * XCH], g1[4 * XCH];
-    float part0 = 0.f, part1 = 0.f;
-    auto products = [&](auto mode) {                   // (the mode is uniform: one branch, not a select per element)
+      npar ^= 1;
+      G2PH(2);
+      __syncthreads();                                   // q2 (and n2) complete; every gather of this pair is done
+      G2PH(3);
+      float g0[4 * XCH], g1[4 * XCH];
+      float part0 = 0.f, part1 = 0.f;
+      auto products = [&](auto mode) {                   // (the mode is uniform: one branch, not a select per element)
+#pragma unroll
+        for (int c = 0; c < XCH; c++) {
+          const int e = (c * kNT2 + tid) * 4;
+          float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+          if (e < D) { qa = *reinterpret_cast<const float4*>(q2 + 2 * e); qb = *reinterpret_cast<const float4*>(q2 + 2 * e + 4); }
+          const float qf0[4] = {qa.x, qa.z, qb.x, qb.z}, qf1[4] = {qa.y, qa.w, qb.y, qb.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            g0[c * 4 + k] = e < D ? product_into_sum(clamp_exp(x0.v[c * 4 + k], decltype(mode)::value), qf0[k], part0) : 0.f;
+            g1[c * 4 + k] = e < D ? product_into_sum(clamp_exp(x1.v[c * 4 + k], decltype(mode)::value), qf1[k], part1) : 0.f;
+          }
+        }
+      };
+      if (a.input_is_exp == kXExpClamp) products(std::integral_constant<int, kXExpClamp>{});
+      else if (a.input_is_exp == kXIdentity) products(std::integral_constant<int, kXIdentity>{});
+      else products(std::integral_constant<int, kXClamp>{});
+      part0 = wave_sum(part0); part1 = wave_sum(part1);
+      if (lane == 0) { red[wave] = part0; red[16 + wave] = part1; }
+      G2PH(4);
+      if (have_next) GAMMA2_COMMIT();                    // U2/V2 are free since the barrier above
+      G2PH(5);
+      __syncthreads();                                   // totals visible; next operands in place; q2 read
+      G2PH(6);
+      const float tot0 = block_total(red, lane), tot1 = block_total(red + 16, lane);
+      const float sc0 = gscale / tot0, sc1 = gscale / tot1;
+      if (valid0 && (!(tot0 > 0.f) || !(sc0 - sc0 == 0.f))) bad = 1;
+      if (valid1 && (!(tot1 > 0.f) || !(sc1 - sc1 == 0.f))) bad = 1;
+      if (a.check && tid == 0) {
+        if (valid0 && (t0 == 0 || a.check_all)) den_record_frame_total(a, b, t0, tot0);
+        if (valid1 && a.check_all) den_record_frame_total(a, b, t0 + 1, tot1);
+      }
+      float* grow0 = gseq + (size_t)t0 * D;
+      float* grow1 = grow0 + D;
 #pragma unroll
       for (int c = 0; c < XCH; c++) {
         const int e = (c * kNT2 + tid) * 4;
-        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
-        if (e < D) { qa = *reinterpret_cast<const float4*>(q2 + 2 * e); qb = *reinterpret_cast<const float4*>(q2 + 2 * e + 4); }
-        const float qf0[4] = {qa.x, qa.z, qb.x, qb.z}, qf1[4] = {qa.y, qa.w, qb.y, qb.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          g0[c * 4 + k] = e < D ? product_into_sum(clamp_exp(x0.v[c * 4 + k], decltype(mode)::value), qf0[k], part0) : 0.f;
-          g1[c * 4 + k] = e < D ? product_into_sum(clamp_exp(x1.v[c * 4 + k], decltype(mode)::value), qf1[k], part1) : 0.f;
+        if (e < D) {
+          float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;     // numerator occupancies {f0,f1} x 4 pdfs
+          if (fold) { na = *reinterpret_cast<const float4*>(n2p + 2 * e); nb = *reinterpret_cast<const float4*>(n2p + 2 * e + 4); }
+          // (g * sc) rounded, then + numerator: bit-identical to the unfused order (occupancy pass, then
+          // the numerator accumulated into the stored gradient)
+#define G2(gv, scv, nv) mul_add_mul_rn((gv), (scv), (nv), nscale)
+          if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(G2(g0[c * 4], sc0, na.x), G2(g0[c * 4 + 1], sc0, na.z),
+                                                                             G2(g0[c * 4 + 2], sc0, nb.x), G2(g0[c * 4 + 3], sc0, nb.z));
+          if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(G2(g1[c * 4], sc1, na.y), G2(g1[c * 4 + 1], sc1, na.w),
+                                                                             G2(g1[c * 4 + 2], sc1, nb.y), G2(g1[c * 4 + 3], sc1, nb.w));
+#undef G2
         }
       }
-    };
-    if (a.input_is_exp == kXExpClamp) products(std::integral_constant<int, kXExpClamp>{});
-    else if (a.input_is_exp == kXIdentity) products(std::integral_constant<int, kXIdentity>{});
-    else products(std::integral_constant<int, kXClamp>{});
-    part0 = wave_sum(part0); part1 = wave_sum(part1);
-    if (lane == 0) { red[wave] = part0; red[16 + wave] = part1; }
-    G2PH(4);
-#ifndef PYCHAIN_EXPG_NO_LOAD
-    if (have_next) GAMMA2_COMMIT();                    // U2/V2 are free since the barrier above
-#endif
-    G2PH(5);
-    __syncthreads();                                   // totals visible; next operands in place; q2 read
-    G2PH(6);
-    const float tot0 = block_total(red, lane), tot1 = block_total(red + 16, lane);
-    const float sc0 = gscale / tot0, sc1 = gscale / tot1;
-    if (valid0 && (!(tot0 > 0.f) || !(sc0 - sc0 == 0.f))) bad = 1;
-    if (valid1 && (!(tot1 > 0.f) || !(sc1 - sc1 == 0.f))) bad = 1;
-    if (a.check && tid == 0) {
-      if (valid0 && (t0 == 0 || a.check_all)) den_record_frame_total(a, b, t0, tot0);
-      if (valid1 && a.check_all) den_record_frame_total(a, b, t0 + 1, tot1);
+      t0 = tn;
+      G2PH(7);
     }
-    float* grow0 = gseq + (size_t)t0 * D;
-    float* grow1 = grow0 + D;
-#pragma unroll
-    for (int c = 0; c < XCH; c++) {
-      const int e = (c * kNT2 + tid) * 4;
-#ifdef PYCHAIN_EXPG_NO_STORE
-      if (e < D && sc0 == 12345.f) {
-#else
-      if (e < D) {
-#endif
-        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;     // numerator occupancies {f0,f1} x 4 pdfs
-        if (fold) { na = *reinterpret_cast<const float4*>(n2p + 2 * e); nb = *reinterpret_cast<const float4*>(n2p + 2 * e + 4); }
-        // (g * sc) rounded, then + numerator: bit-identical to the unfused order (occupancy pass, then
-        // the numerator accumulated into the stored gradient)
-#define G2(gv, scv, nv) mul_add_mul_rn((gv), (scv), (nv), nscale)
-        if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(G2(g0[c * 4], sc0, na.x), G2(g0[c * 4 + 1], sc0, na.z),
-                                                                           G2(g0[c * 4 + 2], sc0, nb.x), G2(g0[c * 4 + 3], sc0, nb.z));
-        if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(G2(g1[c * 4], sc1, na.y), G2(g1[c * 4 + 1], sc1, na.w),
-                                                                           G2(g1[c * 4 + 2], sc1, nb.y), G2(g1[c * 4 + 3], sc1, nb.w));
-#undef G2
-      }
-    }
-    t0 = tn;
-    G2PH(7);
+#undef GAMMA2_COMMIT
+    if constexpr (!STREAM) break;
   }
 #ifdef PYCHAIN_PROFILE_PHASES
-  if (lane == 0 && b == 0 && chunk == 20 && (wave == 0 || wave == 7))
+  if (lane == 0 && b == 0 && (wave == 0 || wave == 7) && g2pairs > 0 && blockIdx.x == 20)
     printf("gamma2 wave %d pairs %d cycles/pair: issue-loads %llu arcs %llu fold %llu bar1 %llu products %llu commit %llu bar2 %llu scale+store %llu\n",
            wave, g2pairs, g2ph[0] / g2pairs, g2ph[1] / g2pairs, g2ph[2] / g2pairs, g2ph[3] / g2pairs, g2ph[4] / g2pairs,
            g2ph[5] / g2pairs, g2ph[6] / g2pairs, g2ph[7] / g2pairs);
 #endif
-  // padded tail of a chunk that straddles the sequence end
-  if (first_launch && t_live_end < t_end)
-    for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT2) gseq[i] = 0.f;
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
@@ -1317,13 +1365,6 @@ inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
   return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
          a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) <= 160 * 1024;
 }
-template <int XCH>
-hipError_t launch_gamma2(const DenArgs& a, int rows2, size_t lds, dim3 grid, hipStream_t st) {
-  if (rows2 <= 16) return launch_one(den_gamma2_kernel<XCH, 16>, a, grid, lds, st, kNT2);
-  if (rows2 <= 32) return launch_one(den_gamma2_kernel<XCH, 32>, a, grid, lds, st, kNT2);
-  return launch_one(den_gamma2_kernel<XCH, 64>, a, grid, lds, st, kNT2);
-}
-
 // rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
 // than kMaxResident keep the first kMaxResident rows in registers and stream their tail.
 inline int pick_r(const DenArgs& a, int rows, int lds_words) {
@@ -1332,6 +1373,26 @@ inline int pick_r(const DenArgs& a, int rows, int lds_words) {
   if (rows <= 32) return 32;
   if (rows <= PLAN_RESIDENT_FIT && kMaxResident > PLAN_RESIDENT_FIT) return PLAN_RESIDENT_FIT;
   return kMaxResident;
+}
+
+template <int XCH, bool STREAM>
+hipError_t launch_gamma2(const DenArgs& a, int rows2, size_t lds, dim3 grid, hipStream_t st) {
+  if (rows2 <= 16) return launch_one(den_gamma2_kernel<XCH, 16, STREAM>, a, grid, lds, st, kNT2);
+  if (rows2 <= 32) return launch_one(den_gamma2_kernel<XCH, 32, STREAM>, a, grid, lds, st, kNT2);
+  return launch_one(den_gamma2_kernel<XCH, 64, STREAM>, a, grid, lds, st, kNT2);
+}
+// the streamed form of the one-frame kernel: float4 rows, every arc of a wave in registers
+template <int XCH>
+hipError_t launch_gamma_stream(const DenArgs& a, int r, size_t lds, dim3 grid, hipStream_t st) {
+  if (r <= 16) return launch_one(den_gamma_kernel<4, XCH, 16, true>, a, grid, lds, st);
+  if (r <= 32) return launch_one(den_gamma_kernel<4, XCH, 32, true>, a, grid, lds, st);
+  return launch_one(den_gamma_kernel<4, XCH, kMaxResident, true>, a, grid, lds, st);
+}
+inline bool gamma_stream_shape_ok(const DenArgs& a, int hint, int gamma_max_groups) {
+  if (a.plan_stride != 0) return false;
+  if (gamma2_eligible(a, (hint >> 20) & 1023, gamma_max_groups)) return true;
+  const int r = pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
+  return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && r > 0;
 }
 
 // The lazy-normalisation recursion (den_lazy.inc.h) in its 16-wave shape serves the shape the benchmarks run: nnet-output
@@ -1427,17 +1488,24 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
     if (e != hipSuccess) return e;
   }
   if (a.phase_mask & 2) {
-    const dim3 grid(gx, a.B);
+    const bool stream = (a.stream & 2) != 0;            // ONE persistent launch over the whole queue (DenArgs::stream)
+    const dim3 grid = stream ? dim3(a.stream_blocks) : dim3(gx, a.B);
     if (gamma2_eligible(a, (hint >> 20) & 1023, gamma_max_groups)) {
       const size_t lds2 = gamma2_lds_bytes(a, gamma_max_groups);
-      return a.D <= 4 * kNT2 ? launch_gamma2<1>(a, (hint >> 20) & 1023, lds2, grid, st)
-                             : launch_gamma2<2>(a, (hint >> 20) & 1023, lds2, grid, st);
+      const int r2 = (hint >> 20) & 1023;
+      if (stream) return a.D <= 4 * kNT2 ? launch_gamma2<1, true>(a, r2, lds2, grid, st) : launch_gamma2<2, true>(a, r2, lds2, grid, st);
+      return a.D <= 4 * kNT2 ? launch_gamma2<1, false>(a, r2, lds2, grid, st) : launch_gamma2<2, false>(a, r2, lds2, grid, st);
     }
-    switch (pick_r(a, (hint >> 10) & 1023, 2 * a.Hp)) {
-      case 0: e = launch_one(den_gamma_kernel<VEC, XCH, 0>, a, grid, lds_gam, st); break;
-      case 16: e = launch_one(den_gamma_kernel<VEC, XCH, 16>, a, grid, lds_gam, st); break;
-      case 32: e = launch_one(den_gamma_kernel<VEC, XCH, 32>, a, grid, lds_gam, st); break;
-      default: e = launch_one(den_gamma_kernel<VEC, XCH, kMaxResident>, a, grid, lds_gam, st); break;
+    const int r = pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
+    if (stream) {
+      if constexpr (VEC == 4 && XCH > 0) return launch_gamma_stream<XCH>(a, r, lds_gam, grid, st);
+      else return hipErrorInvalidValue;                 // (den_stream_eligible said no)
+    }
+    switch (r) {
+      case 0: e = launch_one(den_gamma_kernel<VEC, XCH, 0, false>, a, grid, lds_gam, st); break;
+      case 16: e = launch_one(den_gamma_kernel<VEC, XCH, 16, false>, a, grid, lds_gam, st); break;
+      case 32: e = launch_one(den_gamma_kernel<VEC, XCH, 32, false>, a, grid, lds_gam, st); break;
+      default: e = launch_one(den_gamma_kernel<VEC, XCH, kMaxResident, false>, a, grid, lds_gam, st); break;
     }
   }
   return e;
@@ -1470,6 +1538,9 @@ hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hi
 }
 
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows); }
+bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
+  return (a.lazy || a.pair) && gamma_stream_shape_ok(a, resident_slot_rows, gamma_max_groups);
+}
 bool den_wide_eligible(const DenArgs& a, int resident_slot_rows) { return wide_shape_ok(a, resident_slot_rows); }
 bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) || dma_shape_ok(a, resident_slot_rows); }
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {

@@ -430,10 +430,20 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* (this frame's totals: reduced by the next step behind its first gathers, or after the loop) */       \
   } while (0)
 
+  // progress report of the streamed occupancy pass (DenArgs::seq_progress): P rows complete and visible device-wide
+  int32_t* my_progress = a.seq_progress + (fwd ? 0 : a.B) + b;
+#define PYCHAIN_LZ_REPORT(P)                                                                                \
+  do {                                                                                                      \
+    __builtin_amdgcn_s_waitcnt(0);                     /* this wave's row stores are acknowledged */          \
+    __syncthreads();                                                                                        \
+    if (tid == 0) __hip_atomic_store(my_progress, (P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         \
+  } while (0)
   for (int jj = 0; jj < nsteps; jj += 2) {
     PYCHAIN_LZ_STEP(jj, 0, fwd);
     if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
     PYCHAIN_LZ_SIGNAL(jj + 1);                                // (rows lag one step: after jj + 2 steps the rows of steps < jj + 1 are out)
+    // step j stores the row of the frame before it (alpha row j, beta row L - j): after steps 0 .. jj + 1, jj + 2 rows
+    if (a.stream && ((jj + 2) & (kStreamWidth - 1)) == 0 && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
   }
   if (nsteps > 0) PYCHAIN_LZ_TOTALS((nsteps - 1) & 1, nsteps - 1, fwd, lane, tid);   // the last step's
   if constexpr (!fwd) {
@@ -448,6 +458,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       }
   }
   PYCHAIN_LZ_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // a sequence shorter than a bound is done with it now
+  if (a.stream) PYCHAIN_LZ_REPORT(L);                       // every row this direction owes the occupancy pass: alpha 0 .. L-1, beta L .. 1
+#undef PYCHAIN_LZ_REPORT
 #undef PYCHAIN_LZ_SIGNAL
 #undef PYCHAIN_LZ_STEP
 #undef PYCHAIN_LZ_TOTALS

@@ -365,12 +365,28 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     if (fwd && (j + 1 == nA || j + 1 == nB)) final_dot(j + 1 == nA, haveB && j + 1 == nB);                  \
   } while (0)
 
+  // progress reports of the streamed occupancy pass (DenArgs::seq_progress), one counter per sequence: step j stores row
+  // j + 1 (alpha; row 0 went out before the loop) / row L - 1 - j (beta; row L before the loop): j + 2 rows after step j
+  int32_t* progA = a.seq_progress + (fwd ? 0 : a.B) + bA;
+  int32_t* progB = a.seq_progress + (fwd ? 0 : a.B) + bB;
+#define PYCHAIN_PR_REPORT(DONE)                                                                             \
+  do {                                                                                                      \
+    __builtin_amdgcn_s_waitcnt(0);                                                                          \
+    __syncthreads();                                                                                        \
+    if (tid == 0) {                                                                                         \
+      __hip_atomic_store(progA, min((DONE) + 1, LA), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
+      if (haveB) __hip_atomic_store(progB, min((DONE) + 1, LB), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    }                                                                                                       \
+  } while (0)
   for (int jj = 0; jj < nmax; jj += 2) {
     PYCHAIN_PR_STEP(jj, 0u);
     if (jj + 1 < nmax) PYCHAIN_PR_STEP(jj + 1, kPrX1 - kPrX0);
     PYCHAIN_PR_SIGNAL(jj + 2);                         // bounds are even
+    if (a.stream && ((jj + 2) & (kStreamWidth - 1)) == 0 && jj + 2 < nmax) PYCHAIN_PR_REPORT(jj + 2);
   }
   PYCHAIN_PR_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // sequences shorter than a bound are done with it now
+  if (a.stream) PYCHAIN_PR_REPORT(0x3fffffff);
+#undef PYCHAIN_PR_REPORT
 #undef PYCHAIN_PR_SIGNAL
 #undef PYCHAIN_PR_STEP
 #ifdef PYCHAIN_PROFILE_PHASES
