@@ -120,8 +120,9 @@ def kernel_rooflines(w, dev, iters):
         try:
             with open(path) as f:
                 tj = json.load(f)
-            if tj.get("workload") == cfg.get("name") and tj.get("frames") == frames and rec_name in tj:
-                traffic = tj[rec_name]["hbm_bytes_per_launch"]
+            base = rec_name.split("<")[0]           # (the lazy recursion's shapes share their counters' kernel name)
+            if tj.get("workload") == cfg.get("name") and tj.get("frames") == frames and base in tj:
+                traffic = tj[base]["hbm_bytes_per_launch"]
                 traffic_source = "profiles/" + os.path.basename(path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch; not re-measured in this run)"
                 break
         except Exception:

@@ -24,7 +24,8 @@ def per_kernel(path, counter):
 
 
 def short(k):
-    for n in ("den_recursion_lazy_kernel", "den_recursion_kernel", "den_gamma2_kernel", "den_gamma_kernel", "den_finish_kernel"):
+    for n in ("den_recursion_lazy_kernel", "den_recursion_pair_kernel", "den_recursion_kernel", "den_gamma2_kernel", "den_gamma_kernel",
+              "den_finish_kernel"):
         if n in k:
             return n
     return None
