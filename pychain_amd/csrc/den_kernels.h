@@ -116,7 +116,26 @@ hipError_t launch_den_general(const DenArgs& a, hipStream_t st);
 // One workgroup per sequence.
 hipError_t launch_den_finish(const DenArgs& a, hipStream_t st);
 
-constexpr int kStreamWidth = 16;      // frames per ring of the streamed occupancy pass = steps between two progress reports
+// Rings of the streamed occupancy pass by the step count `need` = max(t, L-1-t) that makes a frame computable:
+// kStreamWidth frames wide (= steps between two progress reports of a recursion) up to kStreamFineSpan steps before the end
+// of the longest possible sequence (T), kStreamFineWidth from there on - what is left to evaluate when the recursions end
+// is the last ring of the longest sequences, so those rings are thin.
+constexpr int kStreamWidth = 16, kStreamFineWidth = 4, kStreamFineSpan = 64;
+__host__ __device__ inline int stream_fine_begin(int T) { const int f = (T - kStreamFineSpan) / kStreamWidth * kStreamWidth; return f > 0 ? f : 0; }
+__host__ __device__ inline int stream_ring_count(int T) {
+  const int f = stream_fine_begin(T);
+  return f / kStreamWidth + (T - f + kStreamFineWidth - 1) / kStreamFineWidth;
+}
+// ring r covers need in [lo, hi)
+__host__ __device__ inline void stream_ring(int T, int r, int& lo, int& hi) {
+  const int f = stream_fine_begin(T), nc = f / kStreamWidth;
+  if (r < nc) { lo = r * kStreamWidth; hi = lo + kStreamWidth; }
+  else { lo = f + (r - nc) * kStreamFineWidth; hi = lo + kStreamFineWidth; }
+}
+// a recursion reports after `done` steps if that is a ring boundary
+__host__ __device__ inline bool stream_report_due(int T, int done) {
+  return done < stream_fine_begin(T) ? (done & (kStreamWidth - 1)) == 0 : (done & (kStreamFineWidth - 1)) == 0;
+}
 
 // One wave that waits until *progress >= target (set by the recursion workgroups), so that what follows
 // it in stream order starts then; gives up after ~20 s and counts that in *bad.

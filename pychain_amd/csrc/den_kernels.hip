@@ -729,7 +729,7 @@ struct StreamItem { int b, lo, hi, L, pad; };
 __device__ __forceinline__ bool stream_take(const DenArgs& a, int* slot, StreamItem& it) {
   __syncthreads();                                      // the previous item (and its slot) is done with
   if (threadIdx.x == 0) {
-    const int B = a.B, W = kStreamWidth, total = B + ((a.T + W - 1) / W) * 2 * B;
+    const int B = a.B, total = B + stream_ring_count(a.T) * 2 * B;
     int b = -1, lo = 0, hi = 0, L = 0, pad = 0;
     for (;;) {
       const int id = atomicAdd(a.stream_next, 1);
@@ -742,8 +742,10 @@ __device__ __forceinline__ bool stream_take(const DenArgs& a, int* slot, StreamI
       const int q = id - B, r = q / (2 * B), rem = q - r * 2 * B, side = rem & 1;
       b = rem >> 1; L = seq_len(a.lengths, b, a.T); pad = 0;
       const int half = L / 2;
-      if (side) { lo = max(W * r, half); hi = min(W * r + W, L); }          // right of the middle: computable after t steps
-      else { lo = max(0, L - W * r - W); hi = min(half, L - W * r); }       // left: after L - 1 - t steps
+      int n0, n1;                                                           // the ring: need in [n0, n1)
+      stream_ring(a.T, r, n0, n1);
+      if (side) { lo = max(n0, half); hi = min(n1, L); }                    // right of the middle: computable after t steps
+      else { lo = max(0, L - n1); hi = min(half, L - n0); }                 // left: after L - 1 - t steps
       if (lo >= hi) continue;
       // alpha rows lo .. hi-1 and beta rows lo+1 .. hi
       const int need_a = hi, need_b = L - lo;

@@ -443,7 +443,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
     PYCHAIN_LZ_SIGNAL(jj + 1);                                // (rows lag one step: after jj + 2 steps the rows of steps < jj + 1 are out)
     // step j stores the row of the frame before it (alpha row j, beta row L - j): after steps 0 .. jj + 1, jj + 2 rows
-    if (a.stream && ((jj + 2) & (kStreamWidth - 1)) == 0 && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
+    if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
   }
   if (nsteps > 0) PYCHAIN_LZ_TOTALS((nsteps - 1) & 1, nsteps - 1, fwd, lane, tid);   // the last step's
   if constexpr (!fwd) {

@@ -382,7 +382,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     PYCHAIN_PR_STEP(jj, 0u);
     if (jj + 1 < nmax) PYCHAIN_PR_STEP(jj + 1, kPrX1 - kPrX0);
     PYCHAIN_PR_SIGNAL(jj + 2);                         // bounds are even
-    if (a.stream && ((jj + 2) & (kStreamWidth - 1)) == 0 && jj + 2 < nmax) PYCHAIN_PR_REPORT(jj + 2);
+    if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nmax) PYCHAIN_PR_REPORT(jj + 2);
   }
   PYCHAIN_PR_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // sequences shorter than a bound are done with it now
   if (a.stream) PYCHAIN_PR_REPORT(0x3fffffff);
