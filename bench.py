@@ -348,10 +348,18 @@ def cpu_baseline(w, nsample, all_cores=True):
     (i) one thread - the faithful counterpart of the reference, whose loops over sequences, states and
     arcs are serial (chain-computation.cc:113-176); (ii) all host cores, utterances dealt to one
     single-threaded worker process per core."""
+    import copy
     torch.set_num_threads(1)
     n = min(nsample, w["cfg"]["B"])
-    w = {k: w[k] for k in ("cfg", "lengths", "den_graph", "num_graphs")} | {
-        "x_cpu": w["x"].detach().float().cpu().contiguous().share_memory_()}
+    # (the worker processes get the graphs WITHOUT what the GPU run cached on them: device-resident plans and uploads)
+    den_graph = copy.copy(w["den_graph"])
+    den_graph._plan_cache = {}
+    num_graphs = w["num_graphs"]
+    if num_graphs is not None:
+        num_graphs = copy.copy(num_graphs)
+        num_graphs._device_cache = {}
+    w = {"cfg": w["cfg"], "lengths": w["lengths"], "den_graph": den_graph, "num_graphs": num_graphs,
+         "x_cpu": w["x"].detach().float().cpu().contiguous().share_memory_()}
     order = torch.argsort(w["lengths"], descending=True, stable=True)      # (already sorted in C1-C4)
     sample = _cpu_sample(w, order[:n])
     frames = int(sample[1].sum())
