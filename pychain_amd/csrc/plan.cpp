@@ -564,7 +564,7 @@ size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 // (state, arc) order the reference accumulates in (chain-computation.cc:293-305)
 int64_t build_general(const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
                       const float* leaky, const float* initial, const float* final_, int H, int K, int D, int Hp,
-                      void* blob, size_t blob_bytes) {
+                      void* blob, size_t blob_bytes, std::vector<char>* grow) {
   for (int h = 0; h < H; h++) {
     for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++)
       if (bt[3 * k + 1] != h)
@@ -583,6 +583,7 @@ int64_t build_general(const int32_t* ft, const int32_t* fi, const float* fp, con
   place(hd.off_g_idx, ((size_t)D + 1) * 4); place(hd.off_g_arc, (size_t)K * 8); place(hd.off_g_p, (size_t)K * 4);
   place(hd.off_leaky, (size_t)Hp * 4); place(hd.off_init, (size_t)Hp * 4); place(hd.off_final, (size_t)Hp * 4);
   hd.total_bytes = (int64_t)off;
+  if (grow) { grow->resize(off); blob = grow->data(); blob_bytes = off; }
   if (!blob || blob_bytes < off) return (int64_t)off;
   char* base = (char*)blob;
   memset(base, 0, off);
@@ -611,11 +612,64 @@ int64_t build_general(const int32_t* ft, const int32_t* fi, const float* fp, con
 
 }  // namespace
 
+namespace {
+// (`grow`: the blob is written into this vector, sized as needed - one compile instead of size + fill)
+int64_t plan_build_impl(const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
+                        const float* leaky, const float* initial, const float* final_, int H, int K, int D, void* blob, size_t blob_bytes,
+                        std::vector<char>* grow = nullptr);
+// The contract is "call once to size, once to fill": both calls would compile the plan (seconds of annealing for a
+// C3-size graph).  The sizing call keeps what it built, keyed by a hash of every input byte and the knobs; the fill call
+// with the same inputs copies it.  One entry per host thread.
+struct LastPlan { uint64_t key = 0; std::vector<char> blob; };
+uint64_t fnv64(uint64_t h, const void* p, size_t n) {
+  const unsigned char* c = (const unsigned char*)p;
+  for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; }
+  return h;
+}
+}  // namespace
+
 extern "C" int64_t pychain_hip_den_plan_build(
     const int32_t* ft, const int32_t* fi, const float* fp,
     const int32_t* bt, const int32_t* bi, const float* bp,
     const float* leaky, const float* initial, const float* final_,
     int H, int K, int D, void* blob, size_t blob_bytes) {
+  if (!ft || !fi || !fp || !bt || !bi || !bp || !leaky || !initial || !final_ || H <= 0 || K <= 0 || D <= 0)
+    return plan_build_impl(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, blob, blob_bytes);   // (reports the error)
+  static thread_local LastPlan last;
+  uint64_t key = 14695981039346656037ull;
+  const int dims[3] = {H, K, D};
+  key = fnv64(key, dims, sizeof(dims));
+  key = fnv64(key, ft, (size_t)K * 12); key = fnv64(key, fi, (size_t)H * 8); key = fnv64(key, fp, (size_t)K * 4);
+  key = fnv64(key, bt, (size_t)K * 12); key = fnv64(key, bi, (size_t)H * 8); key = fnv64(key, bp, (size_t)K * 4);
+  key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
+  for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
+                           "PYCHAIN_PLAN_FREE", "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR",
+                           "PYCHAIN_PLAN_CHOICE"}) {
+    const char* v = getenv(knob);
+    key = fnv64(key, knob, strlen(knob));
+    if (v) key = fnv64(key, v, strlen(v));
+  }
+  if (last.key != key || last.blob.empty()) {
+    std::vector<char> fresh;
+    const int64_t rc = plan_build_impl(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, nullptr, 0, &fresh);
+    if (rc < 0) return rc;
+    last.key = key; last.blob.swap(fresh);
+  }
+  const int64_t need = (int64_t)last.blob.size();
+  if (blob && blob_bytes >= (size_t)need) {
+    memcpy(blob, last.blob.data(), (size_t)need);
+    LastPlan().blob.swap(last.blob);                   // handed over: the (possibly large) copy is not kept
+    last.key = 0;
+  }
+  return need;
+}
+
+namespace {
+int64_t plan_build_impl(
+    const int32_t* ft, const int32_t* fi, const float* fp,
+    const int32_t* bt, const int32_t* bi, const float* bp,
+    const float* leaky, const float* initial, const float* final_,
+    int H, int K, int D, void* blob, size_t blob_bytes, std::vector<char>* grow) {
   if (!ft || !fi || !fp || !bt || !bi || !bp || !leaky || !initial || !final_)
     return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: null graph pointer");
   if (H <= 0 || K <= 0 || D <= 0)
@@ -634,7 +688,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   const int Hp = (H + 63) / 64 * 64;
   // graphs the tile-plan kernels do not take (or PYCHAIN_PLAN_GENERAL=1: the tests): the general format
   if (!pychain_hip::plan_fits_fast_kernels(H, D) || env_long("PYCHAIN_PLAN_GENERAL", 0) != 0)
-    return build_general(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, Hp, blob, blob_bytes);
+    return build_general(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, Hp, blob, blob_bytes, grow);
   std::vector<int> indeg(H), outdeg(H), ids(H);
   std::iota(ids.begin(), ids.end(), 0);
   for (int h = 0; h < H; h++) { indeg[h] = bi[2 * h + 1] - bi[2 * h]; outdeg[h] = fi[2 * h + 1] - fi[2 * h]; }
@@ -742,6 +796,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   if (off > (size_t)INT32_MAX)
     return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED, "den_plan_build: plan larger than 2 GiB");
   hd.total_bytes = (int32_t)off;
+  if (grow) { grow->resize(off); blob = grow->data(); blob_bytes = off; }
   if (!blob || blob_bytes < off) return (int64_t)off;
 
   char* base = (char*)blob;
@@ -768,3 +823,4 @@ extern "C" int64_t pychain_hip_den_plan_build(
   reinterpret_cast<PlanHeader*>(base)->payload_hash = (int32_t)pychain_hip::plan_payload_hash(base, off);
   return (int64_t)off;
 }
+}  // namespace

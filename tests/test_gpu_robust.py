@@ -181,3 +181,57 @@ def test_batch_is_staged_with_one_copy_and_reordered_on_the_device():
         host.batch_size = 3
     want = ChainFunction.apply(x[order.to(DEV)].contiguous(), torch.tensor(L)[order], host)
     assert float(got) == float(want)
+
+
+def test_streamed_and_gated_schedules_with_a_second_process_on_the_gpu():
+    """The persistent occupancy launch and the gate kernels spin on counters the recursion workgroups advance: another
+    process keeping the same GPU busy (compute-bound kernels with many workgroups, as a second job, a profiler or a
+    debugger would) must only slow them down - same bits, ok, no time-out into `bad`."""
+    import os
+    import subprocess
+    import sys
+    import time
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([600, 590, 400, 333, 150, 7])
+    x = syn.make_input(6, 600, cfg["D"], seed=91, device=DEV)
+    numg = syn.make_num_graphs(L.tolist(), cfg["D"], seed=900)
+    crit = ChainLoss(den, 1e-5)
+
+    def step():
+        xx = x.clone().requires_grad_(True)
+        loss = crit(xx, L, numg)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), xx.grad, ChainFunction.last_bad_count.tolist()
+    quiet = step()
+    hog = subprocess.Popen([sys.executable, "-c", (
+        "import torch, time\n"
+        "a = torch.randn(8192, 8192, device='cuda:0'); b = torch.randn(8192, 8192, device='cuda:0')\n"
+        "torch.cuda.synchronize(); print('up', flush=True)\n"
+        "t0 = time.time()\n"
+        "while time.time() - t0 < 12:\n"
+        "    for _ in range(20): c = a @ b\n"
+        "    torch.cuda.synchronize()\n")], stdout=subprocess.PIPE, text=True,
+        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    try:
+        assert hog.stdout.readline().strip() == "up"
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < 6 and hog.poll() is None:
+            for opts in ({}, {"den_stream": 0}):
+                ctx = [_lib.option(k, v) for k, v in opts.items()]
+                for c in ctx:
+                    c.__enter__()
+                try:
+                    got = step()
+                finally:
+                    for c in reversed(ctx):
+                        c.__exit__()
+                assert got[2] == [0, 0], (opts, got[2])
+                assert torch.equal(got[0], quiet[0]) and torch.equal(got[1], quiet[1]), opts
+                n += 1
+        assert n >= 4
+    finally:
+        hog.kill()                                   # (our own child, by handle)
+        hog.wait()
