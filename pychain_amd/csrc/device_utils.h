@@ -51,16 +51,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
-// exp(c) for |c| <= 30 in 5 VALU ops: v_exp_f32 on c*log2(e) with the rounding error of
-// that product fed back, exp(c) = 2^t * (1 + r ln2).  Relative error ~2e-7 (v_exp ulp + the
-// dropped low part of log2 e, |c|*1.9e-8*ln2 <= 4e-7); the generic expf spends ~25
-// instructions on range handling this input range never needs.
+// exp(c) for |c| <= 30.  PYCHAIN_EXP_OPS == 5 (rounds 1-2): v_exp_f32 on c*log2(e) with the rounding error of that product
+// fed back, exp(c) = 2^t * (1 + r ln2): relative error ~2e-7 whatever |c|.  PYCHAIN_EXP_OPS == 2 (round 3, default): v_exp_f32
+// on the rounded product alone: the error of t = c*log2(e) in fp32 is |t| * 6e-8, i.e. a relative error of |c| * 6e-8 in the
+// result - 2e-7 at |c| = 3 (network outputs are O(1)), 1.8e-6 at the clamp (|c| = 30) - against a parity bar of 1e-4 and an
+// oracle whose own expf is 1 ulp.  The clamp / exp of a row sits in the serial tail of every recursion frame, where the four
+// waves of a SIMD issue it one after another: three instructions less per element are ~150 cycles per frame.
+#ifndef PYCHAIN_EXP_OPS
+#define PYCHAIN_EXP_OPS 2
+#endif
 __device__ __forceinline__ float exp_bounded(float c) {
   const float kL2E = 1.44269502162933349609375f;       // fp32(log2 e)
   const float t = c * kL2E;
+#if PYCHAIN_EXP_OPS == 2
+  return __builtin_amdgcn_exp2f(t);
+#else
   const float r = fmaf(c, kL2E, -t);
   const float e = __builtin_amdgcn_exp2f(t);
   return fmaf(e, r * 0.693147182464599609375f, e);
+#endif
 }
 
 // How a raw nnet-output element enters LDS (pychain/loss.py:30,43):
