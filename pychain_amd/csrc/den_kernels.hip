@@ -763,6 +763,7 @@ __device__ __forceinline__ bool stream_take(const DenArgs& a, int* slot, StreamI
   it.b = slot[0]; it.lo = slot[1]; it.hi = slot[2]; it.L = slot[3]; it.pad = slot[4];
   return it.b >= 0;
 }
+constexpr size_t kStaticLds = 64;       // the occupancy kernels' own static LDS (the queue slot) beside their dynamic segment
 constexpr int kLoadDeviceScope = 16;     // cache-policy operand of a buffer load: sc1 (rows another XCD wrote while this kernel runs)
 
 // ------------------------------------------------------------------------------------
@@ -1365,7 +1366,7 @@ inline size_t gamma2_lds_bytes(const DenArgs& a, int gamma_max_groups) {
 inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
   const bool off = a.knobs.gamma16 != 0;                               // test / tuning option: force the one-frame kernel
   return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
-         a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) <= 160 * 1024;
+         a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) + kStaticLds <= 160 * 1024;
 }
 // rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
 // than kMaxResident keep the first kMaxResident rows in registers and stream their tail.
@@ -1567,7 +1568,7 @@ hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_
   const bool db = a.D % 4 == 0 && a.D <= 4 * kNT;        // the <4, 1> instantiation: two 16 KiB nnet-output buffers
   const size_t lds_rec = sizeof(float) * (3 * (size_t)a.Hp + (db ? 2 * (size_t)(kXOff / 4) : (size_t)Dp) + 32);
   const size_t lds_gam = sizeof(float) * (2 * (size_t)a.Hp + 2 * (size_t)Dp + (size_t)gamma_max_groups * 64 + 16);
-  if (lds_rec > 160 * 1024 || lds_gam > 160 * 1024) {
+  if (lds_rec > 160 * 1024 || lds_gam + kStaticLds > 160 * 1024) {
     *why = "state vector + nnet-output row do not fit the 160 KiB LDS of one CU";
     return hipErrorInvalidValue;
   }

@@ -117,7 +117,7 @@ inline bool plan_fits_fast_kernels(int H, int D) {
   const size_t Hp = (size_t)(H + 63) / 64 * 64, Dp = (size_t)(D + 3) & ~(size_t)3, gmax = (size_t)(D + 63) / 64;
   const bool db = D % 4 == 0 && D <= 4096;
   const size_t lds_rec = 4 * (3 * Hp + (db ? 8192 : Dp) + 32), lds_gam = 4 * (2 * Hp + 2 * Dp + gmax * 64 + 16);
-  return lds_rec <= 160 * 1024 && lds_gam <= 160 * 1024;
+  return lds_rec <= 160 * 1024 && lds_gam + 64 <= 160 * 1024;     // (+ 64: the occupancy kernels' static LDS)
 }
 // FNV-1a (32 bit) over the blob behind its header
 inline uint32_t plan_payload_hash(const void* blob, size_t total_bytes) {
