@@ -52,8 +52,9 @@ def parse():
                     help="harness check without a GPU: gloo, no-op steps (tests/test_bench_launch.py)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short runs of the other BASELINE.json configurations reported beside the metric (N = 1)")
-    ap.add_argument("--rooflines", action="store_true",
-                    help="N > 1: measure the per-kernel rooflines on rank 0 as well (the other ranks wait in a barrier)")
+    ap.add_argument("--no-rooflines", action="store_true",
+                    help="skip the per-kernel roofline measurement on rank 0 (at N > 1 it is a short one: 3 launches per kernel, "
+                         "no d2d copy probe - the other ranks wait for it in a barrier)")
     ap.add_argument("--no-fresh-num-graphs", action="store_true",
                     help="skip the host-side leg: a fresh numerator ChainGraphBatch per step, as a trainer builds it")
     return ap.parse_args()
@@ -85,7 +86,7 @@ def event_time_ms(fn, iters, stream):
     return sum(s.elapsed_time(e) for s, e in zip(start, stop)) / iters
 
 
-def kernel_rooflines(w, dev, iters):
+def kernel_rooflines(w, dev, iters, d2d=True):
     """Per-kernel launch time of the denominator, each launch isolated with the phase mask."""
     from pychain_amd import _lib, _plan, native
     L = _lib.lib()
@@ -146,6 +147,8 @@ def kernel_rooflines(w, dev, iters):
             "frac": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
     }
     # context: what a plain device-to-device copy reaches on this box
+    if not d2d:
+        return roof
     try:
         src = torch.empty(256 << 20, dtype=torch.float32, device=dev)      # 1 GiB
         dst = torch.empty_like(src)
@@ -528,8 +531,8 @@ def main():
             slab = {"error": str(e)[:200]}
 
     if rank == 0:
-        # (N > 1: the other ranks would idle in a barrier behind these ~30 launches: on request only)
-        roof = kernel_rooflines(w, dev, max(3, min(args.steps, 10))) if (world == 1 or args.rooflines) else None
+        # (N > 1: the other ranks idle in a barrier behind this: 3 launches per kernel there, ~50 ms)
+        roof = None if args.no_rooflines else kernel_rooflines(w, dev, 3 if world > 1 else max(3, min(args.steps, 10)), d2d=world == 1)
         out = {
             "metric": "LF-MMI frames/sec (fwd+bwd)", "value": round(total_frames * args.steps / dt, 1),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -547,7 +550,7 @@ def main():
                          "ms_per_step_max": round(max(float(p[0]) for p in per_rank) / args.steps * 1e3, 4)},
         }
         if roof is None:
-            out["roofline_note"] = "per-kernel rooflines are measured at N = 1 (or with --rooflines)"
+            out["roofline_note"] = "per-kernel rooflines skipped (--no-rooflines)"
         if slab is not None:
             out["grad_slab_allreduce"] = slab
         if world == 1 and cfg["num"] and not args.no_fresh_num_graphs:
