@@ -94,8 +94,8 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "gamma16" (one-frame occupancy kernel), "num_no_staging_waves",
  *   "den_pair" ("1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of
  *   the CU count in sequences on, i.e. B >= 96 on 256 CUs - results are bit-identical to den_recursion_kernel's),
- *   "den_wide" ("1": the 8-wave lazy recursion wherever the shape allows, "0": never; default: where the 16-wave one
- *   does not fit, i.e. 4096 < D <= 9216), "gamma_tiled", "force_general" (the streamed general kernels even where a
+ *   "den_wide" ("1": the 8-wave lazy recursion wherever the shape allows, "2": the 12-wave one - on plans compiled
+ *   under PYCHAIN_PLAN_TWELVE=1, else ok = false; default "0": both measured slower than the 16-wave kernel), "gamma_tiled", "force_general" (the streamed general kernels even where a
  *   fast one fits),
  *   "debug_corrupt_row" ("den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the
  *   recursions and the occupancy pass, so that the 5 % invariant of chain-computation.cc:363-390 /

@@ -1450,6 +1450,8 @@ hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
 }
 hipError_t launch_wide(const DenArgs& a, int hint, hipStream_t st) {
   const int rows = hint & 1023;
+  if (a.knobs.den_wide == 2 && lazy_shape_ok(a, hint, true))       // experiment: twelve waves (rows of a wave <= 56, checked by the kernel)
+    return launch_one(den_recursion_lazy_kernel<56, LzNarrowDma12>, a, dim3(2 * a.B), LzNarrowDma12::kBytes, st, 12 * 64);
   return a.D <= (int)LzWide<2>::kMaxPdfs ? launch_wide_x<2>(a, rows, st) : launch_wide_x<5>(a, rows, st);
 }
 
@@ -1549,6 +1551,7 @@ bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_sh
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
   (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";
+  if (a.lazy && a.wide == 1 && a.knobs.den_wide == 2) return "den_recursion_lazy_kernel<12 waves>";
   if (a.lazy) return a.wide == 1 ? "den_recursion_lazy_kernel<wide>" : (a.wide == 2 ? "den_recursion_lazy_kernel<dma>" : "den_recursion_lazy_kernel");
   return "den_recursion_kernel";
 }

@@ -44,8 +44,11 @@ struct LzNarrow {
   static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
   static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
 };
-// the same map with the nnet-output rows brought in by LDS-direct loads (lazy_recursion: kDma): an experiment on C3
+// the same map with the nnet-output rows brought in by LDS-direct loads (lazy_recursion: kDma): the default of C1-C3
 struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static constexpr int kXch = 0; };
+// ... with TWELVE waves (168 VGPRs each, <= 56 slot-rows per wave over the plan's 12-wave dealing): option den_wide = 2, an
+// experiment
+struct LzNarrowDma12 : LzNarrowDma { static constexpr int kWaves = 12; };
 template <int XCH>
 struct LzWide {
   //   [0, 36K)    nnet-output buffer 0: float[<= 9216]  [36K, 72K)  nnet-output buffer 1
@@ -251,8 +254,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const int Hp = a.Hp, D = a.D;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
-  const TilePlan tp = NW == 16 ? (fwd ? hd->alpha : hd->beta) : (fwd ? hd->alpha8 : hd->beta8);
-  const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
+  const TilePlan tp = NW == 16 ? (fwd ? hd->alpha : hd->beta) : (NW == 12 ? (fwd ? hd->alpha12 : hd->beta12) : (fwd ? hd->alpha8 : hd->beta8));
+  const bool have_tile = tp.nwaves == NW;                         // (the 12-wave dealing is in the plan on request only)
+  const WaveEntry we = have_tile ? reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave] : WaveEntry{};
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
 
@@ -260,7 +264,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // bit 0: not ok (a total or normaliser that is not finite-positive, a bad length); bit 1: a NaN network output was
   // staged (kept apart: it also turns the log-probability into NaN, and a later "not ok" must not hide it)
   int bad = lds_addr(smem_raw) != 0u ? 1 : 0;                      // the packed arc addresses are absolute
-  if (fwd && seq_len_bad(a.lengths, b, a.T)) bad |= 1;
+  if ((fwd && seq_len_bad(a.lengths, b, a.T)) || !have_tile) bad |= 1;
 
   GroupRegs groups;
   groups.load<R>(we, gtab, lane);

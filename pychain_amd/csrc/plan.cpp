@@ -644,7 +644,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
   for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
                            "PYCHAIN_PLAN_FREE", "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR",
-                           "PYCHAIN_PLAN_CHOICE"}) {
+                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE"}) {
     const char* v = getenv(knob);
     key = fnv64(key, knob, strlen(knob));
     if (v) key = fnv64(key, v, strlen(v));
@@ -769,6 +769,14 @@ int64_t plan_build_impl(
   BuiltTile tg2 = emit_tile(tiles[2], so_g, lay, deal_groups(tiles[2].gsl, PLAN_GAM2_WAVES));
   BuiltTile ta8 = emit_tile(tiles[0], so_a, lay, PLAN_REC_WAVES == 16 ? pair_waves(deal_a, tiles[0].gsl) : deal_groups(tiles[0].gsl, PLAN_REC8_WAVES));
   BuiltTile tb8 = emit_tile(tiles[1], so_b, lay, PLAN_REC_WAVES == 16 ? pair_waves(deal_b, tiles[1].gsl) : deal_groups(tiles[1].gsl, PLAN_REC8_WAVES));
+  // the 12-wave dealing of the recursion tiles: only on request (PYCHAIN_PLAN_TWELVE=1; the kernel that reads it - option
+  // den_wide = 2 - measured 15 % slower than the 16-wave one on C3: DESIGN.md S4 "Round 3")
+  const bool twelve = env_long("PYCHAIN_PLAN_TWELVE", 0) != 0;
+  BuiltTile ta12, tb12;
+  if (twelve) {
+    ta12 = emit_tile(tiles[0], so_a, lay, deal_groups(tiles[0].gsl, 12));
+    tb12 = emit_tile(tiles[1], so_b, lay, deal_groups(tiles[1].gsl, 12));
+  }
 
   // ---- lay the blob out
   size_t off = align16(sizeof(PlanHeader));
@@ -780,6 +788,10 @@ int64_t plan_build_impl(
     for (const WaveEntry& we : t->waves) hd.rec_max_wave_groups = std::max(hd.rec_max_wave_groups, we.ngroups);
   for (const BuiltTile* t : {&ta8, &tb8})
     for (const WaveEntry& we : t->waves) hd.rec8_max_wave_groups = std::max(hd.rec8_max_wave_groups, we.ngroups);
+  if (twelve) for (const BuiltTile* t : {&ta12, &tb12}) {
+    for (const WaveEntry& we : t->waves) hd.rec12_max_wave_groups = std::max(hd.rec12_max_wave_groups, we.ngroups);
+    hd.rec12_max_wave_slot_rows = std::max(hd.rec12_max_wave_slot_rows, t->max_wave);
+  }
   auto place_tile = [&](TilePlan& tp, const BuiltTile& t) {
     tp.ngroups = (int)t.groups.size(); tp.nwaves = (int)t.waves.size();
     tp.total_slot_rows = t.total_slot_rows; tp.max_wave_slot_rows = t.max_wave; tp.nrows = t.nrows;
@@ -789,6 +801,7 @@ int64_t plan_build_impl(
   };
   place_tile(hd.alpha, ta); place_tile(hd.beta, tb); place_tile(hd.gamma, tg); place_tile(hd.gamma2, tg2);
   place_tile(hd.alpha8, ta8); place_tile(hd.beta8, tb8);
+  if (twelve) { place_tile(hd.alpha12, ta12); place_tile(hd.beta12, tb12); }
   auto place_vec = [&](int32_t& o, size_t n) { o = (int32_t)off; off = align16(off + n * 4); };
   place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
@@ -809,6 +822,7 @@ int64_t plan_build_impl(
   };
   write_tile(hd.alpha, ta); write_tile(hd.beta, tb); write_tile(hd.gamma, tg); write_tile(hd.gamma2, tg2);
   write_tile(hd.alpha8, ta8); write_tile(hd.beta8, tb8);
+  if (twelve) { write_tile(hd.alpha12, ta12); write_tile(hd.beta12, tb12); }
   float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);

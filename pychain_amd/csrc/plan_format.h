@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 8
+#define PLAN_VERSION 9
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -83,7 +83,8 @@ struct PlanHeader {
   TilePlan alpha8, beta8;      // same rows and slot order as `alpha` / `beta`, dealt to PLAN_REC8_WAVES waves
   int32_t rec8_max_wave_groups;
   int32_t payload_hash;        // FNV-1a over bytes [sizeof(PlanHeader), total_bytes): checked by pychain_hip_den_plan_info
-  int32_t reserved2[2];
+  int32_t rec12_max_wave_groups, rec12_max_wave_slot_rows;
+  TilePlan alpha12, beta12;    // ... dealt to 12 waves (experiment: option den_wide = 2; DESIGN.md S4 "Round 3")
 };
 
 // ---- the GENERAL format: graphs the compiled tile plans do not take (more than 65 535 states or pdfs, or vectors that

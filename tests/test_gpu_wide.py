@@ -62,6 +62,30 @@ def test_wide_recursion_on_the_c3_graph_vs_its_sixteen_wave_form_and_the_oracle(
     assert bool((g8[2, 130:] == 0).all()) and bool((g8[3, 1:] == 0).all())
 
 
+def test_twelve_wave_experiment_on_the_c3_graph(monkeypatch):
+    """den_wide = 2: the 12-wave dealing (in the plan only under PYCHAIN_PLAN_TWELVE=1), 56-row loops, 163 VGPRs.  Measured
+    15 % slower than the 16-wave kernel (profiles/r03_g_twelve_waves.txt) - kept as a reproducible experiment: same
+    results to rounding, within 1e-4 of the oracle; on a plan without the dealing the kernel refuses (ok = False)."""
+    cfg = syn.CONFIGS["C3"]
+    L = torch.tensor([301, 288, 130, 1])
+    x = syn.make_input(4, 301, cfg["D"], seed=21, device=DEV)
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    o16, g16 = _den(x, L, den)
+    xx = x.clone().requires_grad_(True)
+    with _lib.option("den_wide", 2):
+        ChainFunction.apply(xx, L, ChainGraphBatch(den, 4), 1e-5)
+    torch.cuda.synchronize()
+    assert int(ChainFunction.last_bad_count.sum()) > 0
+    monkeypatch.setenv("PYCHAIN_PLAN_TWELVE", "1")
+    monkeypatch.setenv("PYCHAIN_PLAN_CACHE_DIR", "off")
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    assert _names(den, cfg["D"], 4, den_wide=2)[0] == "den_recursion_lazy_kernel<12 waves>"
+    o12, g12 = _den(x, L, den, den_wide=2)
+    assert abs(o12 - o16) <= 1e-6 * abs(o16) and rel_err(g12.cpu().numpy(), g16.cpu().numpy()) <= 1e-5
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 4), 1e-5)
+    assert abs(o12 - ro) <= 1e-4 * abs(ro) and rel_err(g12.cpu().numpy(), rg) <= 1e-4
+
+
 @pytest.mark.parametrize("H,K,D", [(40, 300, 4100), (700, 6000, 8408), (3000, 30000, 9216)])
 def test_wide_rows_vs_oracle(H, K, D):
     """4096 < D <= 9216 through the 8-wave recursion (small, medium and C4-size graphs: 32-, 64- and 80-row loops):

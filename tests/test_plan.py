@@ -60,6 +60,23 @@ def test_plan_eight_wave_dealing_and_checksum():
     assert rc < 0 and b"checksum" in _lib.lib().pychain_hip_last_error()
 
 
+def test_plan_twelve_wave_dealing_on_request(monkeypatch):
+    """PYCHAIN_PLAN_TWELVE=1 adds the recursion tiles dealt to 12 waves (the den_wide = 2 experiment): the same groups
+    and sums, C3's rows within the kernel's 56-row / 4-group loops; absent otherwise."""
+    cfg = syn.CONFIGS["C3"]
+    g = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    assert emu.parse(_blob(g, cfg["D"]))["alpha12"]["nwaves"] == 0
+    monkeypatch.setenv("PYCHAIN_PLAN_TWELVE", "1")
+    hd = emu.parse(_blob(g, cfg["D"]))
+    rng = np.random.default_rng(1)
+    for name in ("alpha", "beta"):
+        t16, t12 = hd[name], hd[name + "12"]
+        assert t12["nwaves"] == 12 and t12["total_slot_rows"] == t16["total_slot_rows"] and t12["ngroups"] == t16["ngroups"]
+        assert t12["max_wave_slot_rows"] <= 56 and t12["waves"][:, 1].max() <= 4
+        U, V = rng.random(hd["Hp"]), rng.random(cfg["D"])
+        assert np.array_equal(emu.tile_rows(t16, U, V, hd["Hp"], np.float64), emu.tile_rows(t12, U, V, hd["Hp"], np.float64))
+
+
 def _lds_cycles(t):
     """Modelled LDS cycles per half slot-row of a tile: a wave64 ds_read_b32 is served as two 32-lane
     halves over 32 banks, a half costs as many cycles as its fullest bank (equal addresses broadcast)."""
