@@ -161,6 +161,45 @@ struct LazyArcs {
   }
 };
 
+// The same arcs in 2.5 registers each instead of 2 (loops of <= 32 slot-rows: 80 VGPRs, what 40 packed rows take): the
+// state address has a register of its own, two rows share one for their nnet-output addresses and hold their
+// probabilities as a pair.  Per pair of rows a frame then issues 2 unpacking instructions, ONE v_pk_mul_f32 and 2
+// v_pk_fma_f32 - 2.5 VALU instructions per arc against 4 (v_and, v_lshrrev, v_mul, v_pk_fma) for the packed form.  The
+// arithmetic and its order are the same: bit-identical results.
+template <int R, typename MAP>
+struct LazyArcsSplit {
+  static_assert(R % 4 == 0 && R <= 32, "2.5 registers per arc fit for loops of up to 32 slot-rows");
+  uint32_t ua[R];               // state (b64) address
+  uint32_t xp[R / 2];           // nnet-output (b32) addresses of rows 2i | 2i + 1 << 16
+  lz_v2f pp[R / 2];
+  __device__ __forceinline__ void load(int nslot_rows, const uint2* __restrict__ wave_slots) {
+#pragma unroll
+    for (int s = 0; s < R; s += 2) {
+      uint2 a = make_uint2(0u, 0u), b = make_uint2(0u, 0u);
+      if (s < nslot_rows) a = wave_slots[s * 64];
+      if (s + 1 < nslot_rows) b = wave_slots[(s + 1) * 64];
+      ua[s] = MAP::kUField + ((a.x & 0xffffu) << 3);
+      ua[s + 1] = MAP::kUField + ((b.x & 0xffffu) << 3);
+      xp[s / 2] = (MAP::kXField + ((a.x >> 16) << 2)) | ((MAP::kXField + ((b.x >> 16) << 2)) << 16);
+      pp[s / 2] = lz_v2f{__uint_as_float(a.y), __uint_as_float(b.y)};
+    }
+  }
+  __device__ __forceinline__ void opaque4(int s) { asm volatile("" : "+v"(xp[s / 2]), "+v"(xp[s / 2 + 1])); }
+  // rows s, s + 1 (s even)
+  template <uint32_t UOFF, uint32_t VOFF>
+  __device__ __forceinline__ void gather2(int s, lz_v2f& u0, lz_v2f& u1, lz_v2f& v) {
+    u0 = lz_ld2(ua[s] + UOFF);
+    v.x = lds_abs((xp[s / 2] & 0xffffu) + VOFF);
+    u1 = lz_ld2(ua[s + 1] + UOFF);
+    v.y = lds_abs((xp[s / 2] >> 16) + VOFF);
+  }
+};
+template <int R, typename MAP> struct LazyArcsOf { typedef LazyArcs<R, MAP> type; };
+#ifndef PYCHAIN_NO_SPLIT_ARCS
+template <typename MAP> struct LazyArcsOf<16, MAP> { typedef LazyArcsSplit<16, MAP> type; };
+template <typename MAP> struct LazyArcsOf<32, MAP> { typedef LazyArcsSplit<32, MAP> type; };
+#endif
+
 // what a wave carries from frame to frame besides its arcs
 struct LazyWave {
   float inv, c;                 // 1 / total of the previous frame; beta: coef * leaky-weighted sum of the previous frame
@@ -240,6 +279,62 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
   }
 }
 
+// ... and over arcs in the split form (LazyArcsSplit): rows in pairs
+template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook>
+__device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers) {
+  constexpr int kChunk = 4;
+  static_assert(PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
+  constexpr int NC = R / kChunk;
+  uint32_t m_lo = (uint32_t)gr.endmask, cm = gr.chunkmask;
+  asm volatile("" : "+s"(m_lo), "+s"(cm));
+  lz_v2f acc = {0.f, 0.f};
+  lz_v2f ub[2][kChunk];
+  lz_v2f vb[2][kChunk / 2];
+  ar.opaque4(0);
+#pragma unroll
+  for (int k = 0; k < kChunk; k += 2) ar.template gather2<UOFF, VOFF>(k, ub[0][k], ub[0][k + 1], vb[0][k / 2]);
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int cb = c & 1;
+    wave_priority_by_progress<NC>(c);
+    if (c + 1 < NC) {
+      ar.opaque4((c + 1) * kChunk);
+#pragma unroll
+      for (int k = 0; k < kChunk; k += 2)
+        ar.template gather2<UOFF, VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k], ub[cb ^ 1][k + 1], vb[cb ^ 1][k / 2]);
+    }
+    if (c == 0) after_first_gathers();
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    lz_v2f wk[kChunk / 2];
+#pragma unroll
+    for (int k = 0; k < kChunk / 2; k++) wk[k] = ar.pp[c * (kChunk / 2) + k] * vb[cb][k];
+    lz_v2f nacc = acc;
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) {
+      const float x = (k & 1) ? wk[k / 2].y : wk[k / 2].x;
+      nacc = __builtin_elementwise_fma(lz_v2f{x, x}, ub[cb][k], nacc);
+    }
+    if (__builtin_expect(((cm >> c) & 1u) != 0u, 0)) {         // a chunk with a group end (a few per frame) redoes it
+      nacc = acc;
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) {
+        const int sidx = c * kChunk + k;
+        const float x = (k & 1) ? wk[k / 2].y : wk[k / 2].x;
+        nacc = __builtin_elementwise_fma(lz_v2f{x, x}, ub[cb][k], nacc);
+        if ((m_lo >> sidx) & 1u) {
+          const int g = __builtin_popcount(m_lo & ((1u << sidx) - 1u));
+          const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
+          lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
+          nacc = lz_v2f{0.f, 0.f};
+        }
+      }
+    }
+    acc = nacc;
+  }
+}
+
 // One (sequence, direction).  The direction is a template parameter and the kernel branches ONCE, at its
 // top: with both directions in one body the register allocator keeps a second copy of every arc register
 // across the (uniform) direction branches.
@@ -269,7 +364,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   GroupRegs groups;
   groups.load<R>(we, gtab, lane);
   const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
-  LazyArcs<R, MAP> arcs;
+  typename LazyArcsOf<R, MAP>::type arcs;
   arcs.load(groups.nslots, wave_slots);
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));

@@ -48,6 +48,7 @@ struct Tile {
   int own_layout = -1;               // the layout whose positions ARE this tile's row positions (-1: none)
   int weight = 1;                    // weight of this tile's LDS cycles in the objective
   std::vector<int> gsl;              // slot-rows per group
+  bool fitted = false;               // gsl was fitted to a 32-row loop (init_tile): little slack, worth a longer annealing
 };
 
 struct Layouts {
@@ -223,7 +224,8 @@ struct SlotOrder {
 
   SlotOrder(const Tile& tile, const Layouts& l, bool op0_wide, bool op1_wide, bool choice = false, bool choice0 = false) : t(tile), lay(l) {
     wide_op[0] = op0_wide; wide_op[1] = op1_wide; v_choice = choice ? 1 : 0; u_choice = choice0 ? 1 : 0;
-    cost_model = (int)env_long("PYCHAIN_PLAN_COST", 1);
+    cost_model = (int)env_long("PYCHAIN_PLAN_COST", 0);
+    w_op[0] = (int)env_long("PYCHAIN_PLAN_W0", 12); w_op[1] = (int)env_long("PYCHAIN_PLAN_W1", 12);
     int off = 0;
     for (int g : t.gsl) { cell_off.push_back(off); off += 64 * g; }
     cell.assign(off, -1);
@@ -231,9 +233,13 @@ struct SlotOrder {
   // one slot-row (column) of a group: bank loads of both halves and both operands
   struct Col { int cnt[2][2][32]; int nm[2][2][34]; int mx[2][2]; };
   static constexpr int kScale = 4;                   // energy = kScale * extra tenths + sum of squared bank loads
-  int cost_model = 1;                                // 0: 12 * (fullest bank of half 0 + of half 1) (both operands alike: the model of rounds 1-2)
+  int w_op[2] = {12, 12};
+  // cost model 0 (default): w * (fullest bank of half 0 + of half 1), both operands alike - the model of rounds 1-2, and the
+  // one the frame follows in situ (C3, 32-row loops: 1313 -> 878 of these units = 3.27 -> 3.09 ms); 1: the isolated gather costs
+  // of tools/ubench/ldsbanks.hip (halves side by side, a two-way conflict nearly free) - plans that look better and run slower
+  int cost_model = 0;
   int col_energy_op(const Col& c, int op) const {
-    if (cost_model == 0) return 12 * (c.mx[0][op] + c.mx[1][op]);
+    if (cost_model == 0) return w_op[op] * (c.mx[0][op] + c.mx[1][op]);
     return kScale * extra_tenths(op, std::max(c.mx[0][op], c.mx[1][op]));
   }
   int col_add(Col& c, int hh, int op, int b, int d) const {   // returns the energy change
@@ -456,7 +462,7 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, cons
           if (!fill[l >> 5]) fill[l >> 5] = words[l];
         }
         // PYCHAIN_PLAN_LINEAR=1 (timing experiments only - WRONG RESULTS): every gather lane-linear, i.e. conflict-free
-        static const bool linear = env_long("PYCHAIN_PLAN_LINEAR", 0) != 0;
+        const bool linear = env_long("PYCHAIN_PLAN_LINEAR", 0) != 0;
         for (int l = 0; l < 64; l++) {
           uint32_t pb; memcpy(&pb, &probs[l], 4);
           uint32_t wd = real[l] ? words[l] : fill[l >> 5];
@@ -538,16 +544,25 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
   static const int kResident[3] = {PLAN_RESIDENT_0, PLAN_RESIDENT_1, PLAN_RESIDENT_2};
   const int base = max_wave_rows(t.gsl, nwaves);
   if (base > kResident[2]) return;                                  // the tail is streamed anyway
-  // A loop of PLAN_RESIDENT_FIT rows instead of PLAN_RESIDENT_2 saves a tenth of the arc instructions (every
-  // wave walks all resident rows every frame) if about two spare rows per group still fit: uniform slack does
-  // not land on the wave budget (C3: slack 2 -> 576 rows = 36 x 16, but whole groups deal to 37), a fitted one
-  // does.  MEASURED SLOWER at C3 and therefore off by default (PYCHAIN_PLAN_FIT=36 enables it): 36 rows at 2.44
-  // modelled LDS cycles per half slot-row run 3.64 ms (3.57 with 2.5x the annealing) against 3.52 ms for 40 rows
-  // at 2.15 - the frame follows the LDS cycles (+5 %), not the instruction count (-10 %).
+  // PYCHAIN_PLAN_FIT=n (32 <= n < 40): per-group slack fitted to an n-row wave budget (fit_slack) instead of uniform
+  // slack; -1: never.  Default (0): fitted to the 32-row loop where uniform slack >= 2 does not land there but about one
+  // spare row per two groups does - the 32-row loops keep their arcs in 2.5 registers each (den_lazy.inc.h: LazyArcsSplit),
+  // 2.5 VALU instructions per arc instead of 4, and then the frame follows the bank conflicts that are left:
+  // C3 623 -> 512 slot-rows, recursion 3.33 -> 3.08 ms (profiles/r03_h_split_arcs.txt).  [Rounds 1-2, all arcs packed:
+  // 36 and 32 fitted rows measured no faster than 40 with slack.]
   const long fit_target = env_long("PYCHAIN_PLAN_FIT", 0);
   if (fit_target >= kResident[1] && fit_target < kResident[2] && base <= fit_target) {
     t.gsl = fit_slack(t.gsl, nwaves, (int)fit_target);
+    t.fitted = true;
     return;
+  }
+  if (fit_target == 0 && own_layout >= 0 && base <= kResident[1] && base > kResident[0] &&
+      max_wave_rows(with_slack(2), nwaves) > kResident[1]) {
+    const std::vector<int> fit = fit_slack(t.gsl, nwaves, kResident[1]);
+    long spare = 0, elig = 0;
+    for (int g = 0; g < ng; g++) { spare += fit[g] - t.gsl[g]; if (t.gsl[g] >= 4) elig++; }
+    if (getenv("PYCHAIN_PLAN_STATS")) fprintf(stderr, "[plan] fit: base %d, fitted max %d, spare %ld, eligible %ld\n", base, max_wave_rows(fit, nwaves), spare, elig);
+    if (max_wave_rows(fit, nwaves) <= kResident[1] && 2 * spare >= elig) { t.gsl = fit; t.fitted = true; return; }
   }
   int chosen = 0;
   for (int ri = 0; ri < 3 && chosen == 0; ri++) {
@@ -644,7 +659,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
   for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
                            "PYCHAIN_PLAN_FREE", "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR",
-                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE"}) {
+                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1"}) {
     const char* v = getenv(knob);
     key = fnv64(key, knob, strlen(knob));
     if (v) key = fnv64(key, v, strlen(v));
@@ -717,7 +732,7 @@ int64_t plan_build_impl(
   // row-placement moves per transition (0 = rows stay in degree order), PYCHAIN_PLAN_ANNEAL slot moves per cell
   const int slack = (int)env_long("PYCHAIN_PLAN_SLACK", -1);
   const long balance_moves = env_long("PYCHAIN_PLAN_BALANCE", 170);
-  const long anneal_moves = env_long("PYCHAIN_PLAN_ANNEAL", 200);
+  const long anneal_knob = env_long("PYCHAIN_PLAN_ANNEAL", -1);        // < 0: 200, and 3000 for a recursion tile fitted to the 32-row loop
   const bool stats = env_long("PYCHAIN_PLAN_STATS", 0) != 0;
 
   // The occupancy tiles take no slack: their kernels are not bound by gather cycles and the two-frame
@@ -746,7 +761,8 @@ int64_t plan_build_impl(
   const long choice_knob = env_long("PYCHAIN_PLAN_CHOICE", 0);          // bit 0: nnet-output row, bit 1: state vector
   const bool choice = (choice_knob & 1) && D <= 32768, choice0 = (choice_knob & 2) && H <= 32768;
   SlotOrder so_a(tiles[0], lay, true, false, choice, choice0), so_b(tiles[1], lay, true, false, choice, choice0), so_g(tiles[2], lay, true, true);
-  so_a.run(anneal_moves); so_b.run(anneal_moves); so_g.run(anneal_moves);
+  auto moves = [&](const Tile& t) { return anneal_knob >= 0 ? anneal_knob : (t.fitted ? 3000L : 200L); };
+  so_a.run(moves(tiles[0])); so_b.run(moves(tiles[1])); so_g.run(moves(tiles[2]));
   if (stats)
     fprintf(stderr, "[plan] modelled LDS cycles per half slot-row (2.0 = conflict-free): alpha %.3f beta %.3f gamma %.3f; "
                     "half slot-rows %ld %ld %ld\n", (double)so_a.cycles / std::max(1L, so_a.columns.load()),
