@@ -95,7 +95,7 @@ def plan_info(blob):
 # atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.  A file is only
 # believed if its header matches the request AND its payload matches the checksum in the header.
 _KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_FREE",
-          "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1")
+          "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED")
 
 
 def _cache_dir():
@@ -184,9 +184,10 @@ def batch_plans(tensors, num_pdfs, device):
         assert all(h == HINT_GENERAL for h in hints)
         slot_rows = HINT_GENERAL
     else:
-        slot_rows = sum(max((h >> sh) & 1023 for h in hints) << sh for sh in (0, 10, 20))
-        if all((h >> 30) & 1 for h in hints):      # every plan fits the lazy-normalisation recursion (<= 4 groups per wave)
-            slot_rows |= 1 << 30
+        slot_rows = sum(max((h >> sh) & mask for h in hints) << sh for sh, mask in ((0, 1023), (10, 1023), (20, 511)))
+        for bit in (29, 30):                       # every plan holds two-copy tiles / fits the lazy recursion (<= 4 groups per wave)
+            if all((h >> bit) & 1 for h in hints):
+                slot_rows |= 1 << bit
     if same:
         return DevicePlan(torch.from_numpy(blobs[0]).to(device), 0, slot_rows, H)
     stride = (max(b.nbytes for b in blobs) + 255) // 256 * 256

@@ -28,7 +28,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves",
-                                     "den_pair", "den_wide", "den_dma", "den_stream", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
+                                     "den_pair", "den_wide", "den_dma", "den_two_copy", "den_stream", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
                                      "den_lazy", "debug_corrupt_row"};
 bool known_option(const char* name) {
   if (!name) return false;
@@ -70,6 +70,7 @@ CallKnobs call_knobs() {
   k.den_pair = option_int("den_pair", -1);
   k.den_wide = option_int("den_wide", -1);
   k.den_dma = option_int("den_dma", -1);
+  k.den_two_copy = option_int("den_two_copy", -1);
   k.den_stream = option_int("den_stream", -1);
   k.gamma_tiled = option_int("gamma_tiled", -1);
   k.force_general = option_int("force_general", 0) ? 1 : 0;
@@ -183,8 +184,11 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (m > 1023) m = 1023;
   if (gmm > 1023) gmm = 1023;
   if (gm2 > 1023) gm2 = 1023;
-  // launch hint, 10 bits each: recursion rows | occupancy rows (16 waves) << 10 | occupancy rows (8 waves) << 20
+  // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (10 bits) << 10 | occupancy rows, 8 waves (9 bits) << 20
+  if (gm2 > 511) gm2 = 511;
   info[4] = m | (gmm << 10) | (gm2 << 20);
+  // bit 29: the plan holds the two-copy recursion tiles (alpha_c / beta_c)
+  if (hd->alpha_c.nwaves == PLAN_REC_WAVES && hd->beta_c.nwaves == PLAN_REC_WAVES) info[4] |= 1 << 29;
   // bit 30: every recursion wave owns at most 4 groups (what den_recursion_lazy_kernel keeps in registers)
   if (hd->rec_max_wave_groups >= 1 && hd->rec_max_wave_groups <= 4) info[4] |= 1 << 30;
   return PYCHAIN_HIP_OK;

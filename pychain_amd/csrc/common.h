@@ -24,6 +24,7 @@ struct CallKnobs {
   int den_pair;               // -1 automatic, 0 never, 1 wherever the shape allows
   int den_wide;               // -1 automatic, 0 never, 1 wherever the shape allows (8-wave lazy recursion)
   int den_dma;                // 0: nnet-output rows of the lazy recursions through registers, else (default) by LDS-direct loads
+  int den_two_copy;           // 0: never the two-copy recursion (LzNarrowDma2), else (default) wherever the plan holds its tiles and the shape fits
   int den_stream;             // 0: the occupancy pass in gated segments (rounds 1-2), else (default) as one persistent launch
   int gamma_tiled;            // -1 automatic, 0 never, 1 wherever the shape allows (two-frame occupancy kernel tiled over pdfs)
   int force_general;          // 1: the streamed general kernels even where a fast one fits (tests)

@@ -1393,7 +1393,7 @@ hipError_t launch_gamma_stream(const DenArgs& a, int r, size_t lds, dim3 grid, h
 }
 inline bool gamma_stream_shape_ok(const DenArgs& a, int hint, int gamma_max_groups) {
   if (a.plan_stride != 0) return false;
-  if (gamma2_eligible(a, (hint >> 20) & 1023, gamma_max_groups)) return true;
+  if (gamma2_eligible(a, (hint >> 20) & 511, gamma_max_groups)) return true;
   const int r = pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
   return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && r > 0;
 }
@@ -1443,7 +1443,17 @@ hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
   if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M>, a, grid, M::kBytes, st);
   return launch_one(den_recursion_lazy_kernel<kMaxResident, M>, a, grid, M::kBytes, st);
 }
+// the plan holds two-copy tiles (hint bit 29) and the shape fits the two-copy map: 32-row loops, rows of up to 4096 pdfs
+inline bool two_copy_shape_ok(const DenArgs& a, int hint) {
+  return ((hint >> 29) & 1) && a.knobs.den_two_copy != 0 && lazy_shape_ok(a, hint, true) && (hint & 1023) <= 32 &&
+         a.D <= (int)LzNarrowDma2::kMaxPdfs && a.Hp <= (int)LzNarrowDma2::kMaxStates;
+}
 hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
+  if (two_copy_shape_ok(a, hint)) {
+    const dim3 grid(2 * a.B);
+    if ((hint & 1023) <= 16) return launch_one(den_recursion_lazy_kernel<16, LzNarrowDma2>, a, grid, LzNarrowDma2::kBytes, st);
+    return launch_one(den_recursion_lazy_kernel<32, LzNarrowDma2>, a, grid, LzNarrowDma2::kBytes, st);
+  }
   // the map of C1-C3 where the shape fits it, else the one for rows of up to 9216 pdfs
   if (lazy_shape_ok(a, hint, true)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
   return launch_dma_m<LzDma>(a, hint & 1023, st);
@@ -1495,9 +1505,9 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
   if (a.phase_mask & 2) {
     const bool stream = (a.stream & 2) != 0;            // ONE persistent launch over the whole queue (DenArgs::stream)
     const dim3 grid = stream ? dim3(a.stream_blocks) : dim3(gx, a.B);
-    if (gamma2_eligible(a, (hint >> 20) & 1023, gamma_max_groups)) {
+    if (gamma2_eligible(a, (hint >> 20) & 511, gamma_max_groups)) {
       const size_t lds2 = gamma2_lds_bytes(a, gamma_max_groups);
-      const int r2 = (hint >> 20) & 1023;
+      const int r2 = (hint >> 20) & 511;
       if (stream) return a.D <= 4 * kNT2 ? launch_gamma2<1, true>(a, r2, lds2, grid, st) : launch_gamma2<2, true>(a, r2, lds2, grid, st);
       return a.D <= 4 * kNT2 ? launch_gamma2<1, false>(a, r2, lds2, grid, st) : launch_gamma2<2, false>(a, r2, lds2, grid, st);
     }
@@ -1549,20 +1559,20 @@ bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_sl
 bool den_wide_eligible(const DenArgs& a, int resident_slot_rows) { return wide_shape_ok(a, resident_slot_rows); }
 bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) || dma_shape_ok(a, resident_slot_rows); }
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
-  (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";
   if (a.lazy && a.wide == 1 && a.knobs.den_wide == 2) return "den_recursion_lazy_kernel<12 waves>";
+  if (a.lazy && a.wide == 2 && two_copy_shape_ok(a, resident_slot_rows)) return "den_recursion_lazy_kernel<two copies>";
   if (a.lazy) return a.wide == 1 ? "den_recursion_lazy_kernel<wide>" : (a.wide == 2 ? "den_recursion_lazy_kernel<dma>" : "den_recursion_lazy_kernel");
   return "den_recursion_kernel";
 }
 const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  return gamma2_eligible(a, (resident_slot_rows >> 20) & 1023, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
 }
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows) { return pair_shape_ok(a, resident_slot_rows); }
 int den_recursion_blocks(const DenArgs& a) { return a.pair ? 2 * ((a.B + 1) / 2) : 2 * a.B; }
 
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  return gamma2_eligible(a, (resident_slot_rows >> 20) & 1023, gamma_max_groups);
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups);
 }
 
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,

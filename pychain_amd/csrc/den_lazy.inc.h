@@ -40,6 +40,7 @@ struct LzNarrow {
   //   [96K, ...)  partial sums, beta's leaky probs
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 1;
   static constexpr bool kDma = false;
+  static constexpr uint32_t kXCopy = 0;               // byte offset of a second copy of the nnet-output row (0: one copy)
   static constexpr uint32_t kU0 = 0, kU1 = 32768, kX0 = 65536, kX1 = 81920, kUField = 0, kXField = 49152;
   static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
   static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
@@ -49,12 +50,30 @@ struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static conste
 // ... with TWELVE waves (168 VGPRs each, <= 56 slot-rows per wave over the plan's 12-wave dealing): option den_wide = 2, an
 // experiment
 struct LzNarrowDma12 : LzNarrowDma { static constexpr int kWaves = 12; };
+// ... and with TWO copies of the nnet-output row, the second one with its 32-element blocks rotated (PLAN_SECOND_POS): the
+// plan's two-copy tiles (alpha_c / beta_c) say per arc which copy to read - a free binary choice per arc for the plan
+// compiler, which removes most bank conflicts of that operand at 32 slot-rows per wave.  The row is loaded once; the wave
+// that clamps / exp's a chunk in place writes the rotated copy too.  Arcs in the split form only (loops of <= 32 rows).
+//   [0, 16K) row 0   [16K, 32K) row 0, rotated   [32K, 48K) row 1   [48K, 64K) row 1, rotated
+//   [64K, 96K) state buffer 0   [96K, 128K) state buffer 1   [128K, ...) partial sums, beta's leaky probs
+struct LzNarrowDma2 {
+  static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
+  static constexpr bool kDma = true;
+  static constexpr uint32_t kXCopy = 16384;
+  static constexpr uint32_t kX0 = 0, kX1 = 32768, kU0 = 65536, kU1 = 98304, kUField = 65536, kXField = 0;
+  static constexpr uint32_t kRed = 131072, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
+  static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
+};
+static_assert(LzNarrowDma2::kX1 + LzNarrowDma2::kXCopy + 4 * LzNarrowDma2::kMaxPdfs <= LzNarrowDma2::kU0 && LzNarrowDma2::kBytes <= 160u * 1024u &&
+              LzNarrowDma2::kXField + LzNarrowDma2::kXCopy + 4 * (LzNarrowDma2::kMaxPdfs - 1) <= 65535u && LzNarrowDma2::kX1 - LzNarrowDma2::kXField <= 65535u &&
+              LzNarrowDma2::kU1 - LzNarrowDma2::kUField <= 65535u, "two-copy map");
 template <int XCH>
 struct LzWide {
   //   [0, 36K)    nnet-output buffer 0: float[<= 9216]  [36K, 72K)  nnet-output buffer 1
   //   [72K, 96K)  state buffer 0: float2[<= 3072]       [96K, 120K) state buffer 1
   //   [120K, ...) beta's leaky probs, partial sums
   static constexpr int kWaves = 8, kMaxGroups = 8, kXch = XCH;
+  static constexpr uint32_t kXCopy = 0;
   static constexpr bool kDma = false;
   static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = XCH * 4 * 8 * 64 < 9216 ? XCH * 4 * 8 * 64 : 9216;
@@ -66,6 +85,7 @@ struct LzWide {
 // from, and clamps / exp's its own chunks IN PLACE at the end of the frame.
 struct LzDma {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
+  static constexpr uint32_t kXCopy = 0;
   static constexpr bool kDma = true;
   static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 9216;
@@ -92,6 +112,9 @@ __device__ __forceinline__ void lz_st1(uint32_t byte_addr, float v) { *(lz_lds_f
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 typedef __attribute__((address_space(3))) void lz_lds_void;
+#ifndef PYCHAIN_LATE_FINISH
+#define PYCHAIN_LATE_FINISH 1                          /* 0: the in-place clamp / exp of an LDS-direct row after the arc phase (ablation) */
+#endif
 typedef float lz_v4 __attribute__((ext_vector_type(4)));
 #define PYCHAIN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)     /* vmcnt(0) only (gfx9 encoding) */
 // row t of the sequence behind `buf` -> LDS at byte address xbase, 1 KiB chunks dealt to the NW waves; lanes past the
@@ -114,7 +137,8 @@ __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int
   }
 }
 // this wave's chunks of the row at xbase: raw -> clamp / exp, in place; returns true if a NaN was seen
-template <int NW, int NCH>
+// (XCOPY != 0: ... and once more, block-rotated, at xbase + XCOPY)
+template <int NW, int NCH, uint32_t XCOPY = 0>
 __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_t xbase, int is_exp) {
   bool nan = false;
   PYCHAIN_WAIT_VM0();                                   // this wave's loads have landed
@@ -132,6 +156,10 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
       }
       if (is_exp == kXExpClamp) q = lz_v4{clamp_exp(q.x, kXExpClamp), clamp_exp(q.y, kXExpClamp), clamp_exp(q.z, kXExpClamp), clamp_exp(q.w, kXExpClamp)};
       *(__attribute__((address_space(3))) lz_v4*)(addr) = q;
+      if constexpr (XCOPY != 0) {
+        const uint32_t e = (uint32_t)ch * 256u + (uint32_t)lane * 4u;
+        *(__attribute__((address_space(3))) lz_v4*)(xbase + XCOPY + 4u * (uint32_t)PLAN_SECOND_POS(e)) = q;
+      }
     }
   }
   return nan;
@@ -140,6 +168,7 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
 
 template <int R, typename MAP>
 struct LazyArcs {
+  static_assert(MAP::kXCopy == 0, "two-copy maps: split arcs only");
   uint32_t pk[R];
   float p[R];
   __device__ __forceinline__ void load(int nslot_rows, const uint2* __restrict__ wave_slots) {
@@ -180,8 +209,19 @@ struct LazyArcsSplit {
       if (s + 1 < nslot_rows) b = wave_slots[(s + 1) * 64];
       ua[s] = MAP::kUField + ((a.x & 0xffffu) << 3);
       ua[s + 1] = MAP::kUField + ((b.x & 0xffffu) << 3);
-      xp[s / 2] = (MAP::kXField + ((a.x >> 16) << 2)) | ((MAP::kXField + ((b.x >> 16) << 2)) << 16);
+      xp[s / 2] = (MAP::kXField + xfield(a.x >> 16)) | ((MAP::kXField + xfield(b.x >> 16)) << 16);
       pp[s / 2] = lz_v2f{__uint_as_float(a.y), __uint_as_float(b.y)};
+      // (opaque: a field base beyond the 16-bit offset field of ds_read would otherwise be split off and re-added per gather)
+      asm volatile("" : "+v"(ua[s]), "+v"(ua[s + 1]));
+    }
+  }
+  // byte offset of an arc's nnet-output operand from the row buffer: two-copy maps read bit 15 of the index as "the rotated copy"
+  static __device__ __forceinline__ uint32_t xfield(uint32_t idx) {
+    if constexpr (MAP::kXCopy != 0) {
+      const uint32_t n = idx & 0x7fffu;
+      return (idx & 0x8000u) ? MAP::kXCopy + 4u * (uint32_t)PLAN_SECOND_POS(n) : 4u * n;
+    } else {
+      return idx << 2;
     }
   }
   __device__ __forceinline__ void opaque4(int s) { asm volatile("" : "+v"(xp[s / 2]), "+v"(xp[s / 2 + 1])); }
@@ -220,11 +260,12 @@ __device__ __forceinline__ void lazy_group_end(const LazyWave& w, lz_v2f acc, ui
 // One frame of a recursion tile, lazy form: gathers from the state buffer at ds_read offset UOFF and the nnet-output
 // buffer at VOFF, writes the new values into the state buffer at absolute address UNEXT.  Same software pipeline as
 // tile_rows; up to 96 slot-rows per wave (three words of group-end bits).
-template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook>
-__device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers) {
+template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook, typename Late>
+__device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers, Late&& late) {
   constexpr int kChunk = 4;
   static_assert(R % kChunk == 0 && R <= 96 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
+  constexpr int kLateChunk = NC >= 4 ? NC - 2 : NC - 1;
   uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), m_2 = gr.endmask2, cm = gr.chunkmask;
   if constexpr (R > 64) asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(m_2), "+s"(cm));
   else asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
@@ -246,6 +287,7 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
     // the previous frame's totals (w.inv, w.c: first needed at the first group end) are reduced HERE, behind the
     // gathers of the first two chunks, instead of between the barrier and the first gather
     if (c == 0) after_first_gathers();
+    if (c == kLateChunk) late();                       // (the next frame's nnet-output row: lazy_recursion)
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -280,11 +322,12 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
 }
 
 // ... and over arcs in the split form (LazyArcsSplit): rows in pairs
-template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook>
-__device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers) {
+template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook, typename Late>
+__device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers, Late&& late) {
   constexpr int kChunk = 4;
   static_assert(PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
+  constexpr int kLateChunk = NC >= 4 ? NC - 2 : NC - 1;
   uint32_t m_lo = (uint32_t)gr.endmask, cm = gr.chunkmask;
   asm volatile("" : "+s"(m_lo), "+s"(cm));
   lz_v2f acc = {0.f, 0.f};
@@ -304,6 +347,7 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
         ar.template gather2<UOFF, VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k], ub[cb ^ 1][k + 1], vb[cb ^ 1][k / 2]);
     }
     if (c == 0) after_first_gathers();
+    if (c == kLateChunk) late();                       // (the next frame's nnet-output row: lazy_recursion)
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -349,7 +393,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const int Hp = a.Hp, D = a.D;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
-  const TilePlan tp = NW == 16 ? (fwd ? hd->alpha : hd->beta) : (NW == 12 ? (fwd ? hd->alpha12 : hd->beta12) : (fwd ? hd->alpha8 : hd->beta8));
+  const TilePlan tp = MAP::kXCopy != 0 ? (fwd ? hd->alpha_c : hd->beta_c)
+                      : NW == 16 ? (fwd ? hd->alpha : hd->beta) : (NW == 12 ? (fwd ? hd->alpha12 : hd->beta12) : (fwd ? hd->alpha8 : hd->beta8));
   const bool have_tile = tp.nwaves == NW;                         // (the 12-wave dealing is in the plan on request only)
   const WaveEntry we = have_tile ? reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave] : WaveEntry{};
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
@@ -399,7 +444,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const int t0 = fwd ? 0 : L - 1;
     if constexpr (MAP::kDma) {
       lz_dma_row<NW, kDmaCh>(xbuf, t0, D, wave, lane, MAP::kX0);
-      if (lz_dma_finish<NW, kDmaCh>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
+      if (lz_dma_finish<NW, kDmaCh, MAP::kXCopy>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
     } else {
       xq.load(xseq + (size_t)t0 * D, D, tid);
       if (fwd && xq.has_nan()) bad |= 2;
@@ -487,6 +532,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow.y, prow.x)), sbuf, lane4, \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
         }                                                                                                   \
+    }, [&]() {                                                                                              \
+      /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
+      /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
+      if constexpr (MAP::kDma && PYCHAIN_LATE_FINISH) {                                                     \
+        if (have_next && lz_dma_finish<NW, kDmaCh, MAP::kXCopy>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
+      }                                                                                                     \
     });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
     /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
@@ -504,7 +555,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     }                                                                                                       \
     /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
     if constexpr (MAP::kDma) {                                                                              \
-      if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
+      if constexpr (!PYCHAIN_LATE_FINISH)                                                                   \
+        if (have_next && lz_dma_finish<NW, kDmaCh, MAP::kXCopy>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
     } else if (have_next) {                                                                                 \
       if ((FWDC) && xq.has_nan()) bad |= 2;                  /* a NaN network output: not ok, NaN log-probability */ \
       xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \

@@ -214,7 +214,7 @@ struct SlotOrder {
   // bank of element n in the second copy: its 32-element block is rotated by 4 ((n >> 5) & 7) elements (whole float4s
   // stay together: the kernels write a row 16 bytes at a time), so that the two candidate banks of an arc are not tied to
   // each other the way a fixed skew would tie them
-  static int second_bank(int n) { return (n + 4 * ((n >> 5) & 7)) & 31; }
+  static int second_bank(int n) { return PLAN_SECOND_POS(n) & 31; }
   int extra_tenths(int op, int L) const {
     if (L <= 1) return 0;
     if (L == 2) return wide_op[op] ? 2 : 6;
@@ -225,6 +225,7 @@ struct SlotOrder {
   SlotOrder(const Tile& tile, const Layouts& l, bool op0_wide, bool op1_wide, bool choice = false, bool choice0 = false) : t(tile), lay(l) {
     wide_op[0] = op0_wide; wide_op[1] = op1_wide; v_choice = choice ? 1 : 0; u_choice = choice0 ? 1 : 0;
     cost_model = (int)env_long("PYCHAIN_PLAN_COST", 0);
+    targeted = env_long("PYCHAIN_PLAN_TARGETED", 1) != 0;
     w_op[0] = (int)env_long("PYCHAIN_PLAN_W0", 12); w_op[1] = (int)env_long("PYCHAIN_PLAN_W1", 12);
     int off = 0;
     for (int g : t.gsl) { cell_off.push_back(off); off += 64 * g; }
@@ -234,6 +235,7 @@ struct SlotOrder {
   struct Col { int cnt[2][2][32]; int nm[2][2][34]; int mx[2][2]; };
   static constexpr int kScale = 4;                   // energy = kScale * extra tenths + sum of squared bank loads
   int w_op[2] = {12, 12};
+  bool targeted = true;                              // PYCHAIN_PLAN_TARGETED=0: every move starts from a random cell
   // cost model 0 (default): w * (fullest bank of half 0 + of half 1), both operands alike - the model of rounds 1-2, and the
   // one the frame follows in situ (C3, 32-row loops: 1313 -> 878 of these units = 3.27 -> 3.09 ms); 1: the isolated gather costs
   // of tools/ubench/ldsbanks.hip (halves side by side, a two-way conflict nearly free) - plans that look better and run slower
@@ -292,7 +294,23 @@ struct SlotOrder {
       const double cool = iters > 1 ? pow(t1 / t0, 1.0 / (double)iters) : 1.0;
       double T = t0;
       for (long it = 0; it < iters; it++, T *= cool) {
-        const int r = rng.next() % nr, j1 = rng.next() % A;
+        int r = rng.next() % nr;
+        const int j1 = rng.next() % A;
+        if (targeted && (rng.next() & 1)) {
+          // half of the moves start from a lane that sits in the fullest bank of a conflicting half-column (a blind pick
+          // mostly proposes to move arcs that collide with nobody)
+          const int hh = rng.next() & 1, op = rng.next() & 1;
+          const Col& c = cs[j1];
+          if (c.mx[hh][op] >= 2) {
+            int bmax = 0;
+            for (int b = 1; b < 32; b++) if (c.cnt[hh][op][b] > c.cnt[hh][op][bmax]) bmax = b;
+            const std::vector<int>& bank = op ? b1 : b0;
+            int pick = -1, seen = 0;
+            for (int rr = 32 * hh; rr < std::min(nr, 32 * hh + 32); rr++)
+              if (bank[rr * A + j1] == bmax && (rng.next() % ++seen) == 0) pick = rr;
+            if (pick >= 0) r = pick;
+          }
+        }
         if ((v_choice || u_choice) && (rng.next() & 3) == 0) {   // a quarter of the moves: one arc reads the other copy of an operand
           const int i = r * A + j1, hh = r >> 5;
           if (b0[i] < 0) continue;
@@ -332,12 +350,12 @@ struct SlotOrder {
     cycles_op[0] += cyc0; cycles_op[1] += cyc1;
     cost_tenths += extra; slot_rows += A;
   }
-  // groups are independent: annealed on up to 8 host threads
+  // groups are independent: annealed on up to 32 host threads
   void run(long moves_per_cell) {
     const int n = (int)t.gsl.size();
     std::atomic<int> next{0};
     auto work = [&]() { for (int i; (i = next++) < n;) group(i, moves_per_cell); };
-    const int nthreads = (int)std::min<long>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (long)n);
+    const int nthreads = (int)std::min<long>(std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency())), (long)n);
     std::vector<std::thread> pool;
     for (int i = 1; i < nthreads; i++) pool.emplace_back(work);
     work();
@@ -659,7 +677,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
   for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
                            "PYCHAIN_PLAN_FREE", "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR",
-                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1"}) {
+                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED"}) {
     const char* v = getenv(knob);
     key = fnv64(key, knob, strlen(knob));
     if (v) key = fnv64(key, v, strlen(v));
@@ -754,15 +772,27 @@ int64_t plan_build_impl(
   }
   // (the state vectors of the recursion tiles are float2 in the lazy kernels: ds_read_b64; the occupancy tiles are
   // gathered with one width for both operands)
-  // PYCHAIN_PLAN_CHOICE: the recursion tiles may pick one of two LDS copies of an operand per arc (bit 15 of its index in
-  // the slot word; needs num_pdfs / num_states <= 32768)
-  // MODEL ONLY (default 0: no kernel keeps second copies): with both operands doubled the C3 graph still compiles to
-  // ~130-180 modelled conflict cycles per frame at 32 slot-rows per wave - not built further
-  const long choice_knob = env_long("PYCHAIN_PLAN_CHOICE", 0);          // bit 0: nnet-output row, bit 1: state vector
-  const bool choice = (choice_knob & 1) && D <= 32768, choice0 = (choice_knob & 2) && H <= 32768;
+  // Two-copy tiles (plan_format.h: alpha_c / beta_c): the kernel that keeps a second, block-rotated copy of the nnet-output
+  // row in LDS (den_lazy.inc.h: LzNarrowDma2; rows of up to 4096 pdfs) lets every arc read the copy the compiler picks for it
+  // (bit 15 of its nnet-output index) - a binary choice per arc: C3 at 32 rows per wave, fullest bank per half slot-row of
+  // that operand 1.55 -> 1.15 (the state operand stays at 1.24-1.29).  MEASURED 1.2 % SLOWER than the one-copy kernel on C3
+  // (recursion 3.14 against 3.10 ms, profiles/r03_i_two_copies.txt: writing the second copy in the serial tail of every frame
+  // costs more than the conflicts it removes), hence compiled only on request: PYCHAIN_PLAN_CHOICE=1 (3: model only, no kernel -
+  // a second copy of the state vector too).
+  const long choice_knob = env_long("PYCHAIN_PLAN_CHOICE", 0);
+  const bool choice_tiles = D <= 4096 && Hp <= 3072 && (choice_knob & 1) != 0;
+  const bool choice = false, choice0 = false;
   SlotOrder so_a(tiles[0], lay, true, false, choice, choice0), so_b(tiles[1], lay, true, false, choice, choice0), so_g(tiles[2], lay, true, true);
   auto moves = [&](const Tile& t) { return anneal_knob >= 0 ? anneal_knob : (t.fitted ? 3000L : 200L); };
   so_a.run(moves(tiles[0])); so_b.run(moves(tiles[1])); so_g.run(moves(tiles[2]));
+  SlotOrder so_ac(tiles[0], lay, true, false, true, choice_knob > 0 && (choice_knob & 2)), so_bc(tiles[1], lay, true, false, true, choice_knob > 0 && (choice_knob & 2));
+  if (choice_tiles) {
+    so_ac.run(moves(tiles[0])); so_bc.run(moves(tiles[1]));
+    if (stats)
+      fprintf(stderr, "[plan] two-copy tiles, per operand (1.0 = conflict-free): alpha state %.3f nnet-output %.3f; beta state %.3f nnet-output %.3f\n",
+              (double)so_ac.cycles_op[0] / std::max(1L, so_ac.columns.load()), (double)so_ac.cycles_op[1] / std::max(1L, so_ac.columns.load()),
+              (double)so_bc.cycles_op[0] / std::max(1L, so_bc.columns.load()), (double)so_bc.cycles_op[1] / std::max(1L, so_bc.columns.load()));
+  }
   if (stats)
     fprintf(stderr, "[plan] modelled LDS cycles per half slot-row (2.0 = conflict-free): alpha %.3f beta %.3f gamma %.3f; "
                     "half slot-rows %ld %ld %ld\n", (double)so_a.cycles / std::max(1L, so_a.columns.load()),
@@ -789,6 +819,9 @@ int64_t plan_build_impl(
   // den_wide = 2 - measured 15 % slower than the 16-wave one on C3: DESIGN.md S4 "Round 3")
   const bool twelve = env_long("PYCHAIN_PLAN_TWELVE", 0) != 0;
   BuiltTile ta12, tb12;
+  BuiltTile tac, tbc;
+  if (choice_tiles && !(choice_knob > 0 && (choice_knob & 2))) { tac = emit_tile(tiles[0], so_ac, lay, deal_a); tbc = emit_tile(tiles[1], so_bc, lay, deal_b); }
+  const bool have_c = !tac.waves.empty();
   if (twelve) {
     ta12 = emit_tile(tiles[0], so_a, lay, deal_groups(tiles[0].gsl, 12));
     tb12 = emit_tile(tiles[1], so_b, lay, deal_groups(tiles[1].gsl, 12));
@@ -818,6 +851,7 @@ int64_t plan_build_impl(
   place_tile(hd.alpha, ta); place_tile(hd.beta, tb); place_tile(hd.gamma, tg); place_tile(hd.gamma2, tg2);
   place_tile(hd.alpha8, ta8); place_tile(hd.beta8, tb8);
   if (twelve) { place_tile(hd.alpha12, ta12); place_tile(hd.beta12, tb12); }
+  if (have_c) { place_tile(hd.alpha_c, tac); place_tile(hd.beta_c, tbc); }
   auto place_vec = [&](int32_t& o, size_t n) { o = (int32_t)off; off = align16(off + n * 4); };
   place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
@@ -839,6 +873,7 @@ int64_t plan_build_impl(
   write_tile(hd.alpha, ta); write_tile(hd.beta, tb); write_tile(hd.gamma, tg); write_tile(hd.gamma2, tg2);
   write_tile(hd.alpha8, ta8); write_tile(hd.beta8, tb8);
   if (twelve) { write_tile(hd.alpha12, ta12); write_tile(hd.beta12, tb12); }
+  if (have_c) { write_tile(hd.alpha_c, tac); write_tile(hd.beta_c, tbc); }
   float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);

@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 9
+#define PLAN_VERSION 10
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -85,7 +85,14 @@ struct PlanHeader {
   int32_t payload_hash;        // FNV-1a over bytes [sizeof(PlanHeader), total_bytes): checked by pychain_hip_den_plan_info
   int32_t rec12_max_wave_groups, rec12_max_wave_slot_rows;
   TilePlan alpha12, beta12;    // ... dealt to 12 waves (experiment: option den_wide = 2; DESIGN.md S4 "Round 3")
+  // The recursion tiles once more for kernels that keep TWO copies of the nnet-output row in LDS (LzNarrowDma2): same rows,
+  // groups and dealing as `alpha` / `beta`, but bit 15 of an arc's nnet-output index says "read the second copy"
+  // (PLAN_SECOND_POS) and the slot order is annealed with that choice.  nwaves == 0: not compiled (plan.cpp).
+  TilePlan alpha_c, beta_c;
 };
+// position of element n of the nnet-output row in its second LDS copy: the 32-element block of n is rotated by 4, 8 .. 28
+// elements (float4s stay whole; never by 0, and neighbouring blocks by different amounts)
+#define PLAN_SECOND_POS(n) (((n) & ~31) | (((n) + 4 * ((((n) >> 5) % 7) + 1)) & 31))
 
 // ---- the GENERAL format: graphs the compiled tile plans do not take (more than 65 535 states or pdfs, or vectors that
 // do not fit the LDS of one CU).  The reference layout as it is (fstext.cc:49-116), plus the arcs grouped by pdf-id for

@@ -62,6 +62,35 @@ def test_wide_recursion_on_the_c3_graph_vs_its_sixteen_wave_form_and_the_oracle(
     assert bool((g8[2, 130:] == 0).all()) and bool((g8[3, 1:] == 0).all())
 
 
+def test_two_copy_recursion_on_the_c3_graph_vs_the_one_copy_form_and_the_oracle(monkeypatch):
+    """An experiment kept reproducible (measured 1.2 % slower, profiles/r03_i_two_copies.txt): under PYCHAIN_PLAN_CHOICE=1 C3's
+    plan holds two-copy tiles, and the recursion then keeps the nnet-output row twice in LDS, every arc reading the copy the plan
+    picked.  Same results to rounding as the one-copy kernel (option den_two_copy = 0), bit-identical over the occupancy
+    schedules, within 1e-4 of the oracle; ragged lengths, a one-frame sequence, a NaN."""
+    monkeypatch.setenv("PYCHAIN_PLAN_CHOICE", "1")
+    monkeypatch.setenv("PYCHAIN_PLAN_CACHE_DIR", "off")
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([301, 288, 130, 1])
+    x = syn.make_input(4, 301, cfg["D"], seed=21, device=DEV)
+    assert _names(den, cfg["D"], 4)[0] == "den_recursion_lazy_kernel<two copies>"
+    assert _names(den, cfg["D"], 4, den_two_copy=0)[0] == "den_recursion_lazy_kernel<dma>"
+    o2, g2 = _den(x, L, den)
+    o1, g1 = _den(x, L, den, den_two_copy=0)
+    assert abs(o2 - o1) <= 1e-6 * abs(o1) and rel_err(g2.cpu().numpy(), g1.cpu().numpy()) <= 1e-5
+    for nseg in (1, 3):
+        o, g = _den(x, L, den, den_stream=0, den_segments=nseg)
+        assert o == o2 and torch.equal(g, g2)
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 4), 1e-5)
+    assert abs(o2 - ro) <= 1e-4 * abs(ro) and rel_err(g2.cpu().numpy(), rg) <= 1e-4
+    assert bool((g2[2, 130:] == 0).all()) and bool((g2[3, 1:] == 0).all())
+    x[1, 17, cfg["D"] - 1] = float("nan")
+    xx = x.clone().requires_grad_(True)
+    o = ChainFunction.apply(xx, L, ChainGraphBatch(den, 4), 1e-5)
+    torch.cuda.synchronize()
+    assert int(ChainFunction.last_bad_count.sum()) > 0 and np.isnan(float(o.detach()))
+
+
 def test_twelve_wave_experiment_on_the_c3_graph(monkeypatch):
     """den_wide = 2: the 12-wave dealing (in the plan only under PYCHAIN_PLAN_TWELVE=1), 56-row loops, 163 VGPRs.  Measured
     15 % slower than the 16-wave kernel (profiles/r03_g_twelve_waves.txt) - kept as a reproducible experiment: same

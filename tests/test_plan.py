@@ -77,6 +77,46 @@ def test_plan_twelve_wave_dealing_on_request(monkeypatch):
         assert np.array_equal(emu.tile_rows(t16, U, V, hd["Hp"], np.float64), emu.tile_rows(t12, U, V, hd["Hp"], np.float64))
 
 
+def test_plan_two_copy_tiles(monkeypatch):
+    """Under PYCHAIN_PLAN_CHOICE=1 a plan carries the recursion tiles a second time for the kernel that keeps two copies of
+    the nnet-output row (alpha_c / beta_c; an experiment that measured slower): same groups, rows and dealing, the same sums;
+    bit 15 of an arc's nnet-output index picks the copy, and the launch hint says so (bit 29).  Not compiled by default, nor
+    for rows beyond 4096 pdfs."""
+    cfg = syn.CONFIGS["C3"]
+    g = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    assert emu.parse(_blob(g, cfg["D"]))["alpha_c"]["nwaves"] == 0
+    monkeypatch.setenv("PYCHAIN_PLAN_CHOICE", "1")
+    blob = _blob(g, cfg["D"])
+    hd = emu.parse(blob)
+    assert (_plan.plan_info(blob)["slot_rows"] >> 29) & 1
+    rng = np.random.default_rng(2)
+    for name in ("alpha", "beta"):
+        t, tc = hd[name], hd[name + "_c"]
+        assert tc["nwaves"] == 16 and t["max_wave_slot_rows"] <= 32
+        assert np.array_equal(t["waves"], tc["waves"]) and np.array_equal(t["groups"], tc["groups"])
+        second = (tc["idx"] >> 31) & 1
+        assert 0.2 < second[tc["p"] != 0].mean() < 0.8                       # the choice is used
+        plain = dict(tc, idx=tc["idx"] & 0x7fffffff)
+        U, V = rng.random(hd["Hp"]), rng.random(cfg["D"])
+        a, b = emu.tile_rows(t, U, V, hd["Hp"], np.float64), emu.tile_rows(plain, U, V, hd["Hp"], np.float64)
+        assert np.allclose(a, b, rtol=1e-12, atol=0)
+
+        def fullest(tile, second_copy):
+            tot = 0
+            for row in range(tile["idx"].shape[0]):
+                n = ((tile["idx"][row] >> 16) & 0x7fff).astype(np.int64)
+                rot = (n & ~31) | ((n + 4 * (((n >> 5) % 7) + 1)) & 31)
+                pos = np.where(second_copy[row] == 1, rot + 32768, n)
+                for half in (slice(0, 32), slice(32, 64)):
+                    u = np.unique(pos[half])
+                    tot += int(np.bincount(u & 31, minlength=32).max())
+            return tot
+        # what the second copy buys: fewer lanes in the fullest bank of a half slot-row (nnet-output operand)
+        assert fullest(tc, second) < 0.85 * fullest(t, np.zeros_like(second))
+    g2 = syn.make_den_graph(300, 3000, 5000, seed=1)
+    assert emu.parse(_blob(g2, 5000))["alpha_c"]["nwaves"] == 0
+
+
 def _lds_cycles(t):
     """Modelled LDS cycles per half slot-row of a tile: a wave64 ds_read_b32 is served as two 32-lane
     halves over 32 banks, a half costs as many cycles as its fullest bank (equal addresses broadcast)."""
