@@ -192,7 +192,17 @@ __device__ __forceinline__ void wave_priority_by_progress(int c) {
   // highest for the first half of the chunks, then stepping down to 0 on the last one (measured best of
   // four schedules: equal quarters 3.76 ms, front-loaded 3.78, this 3.69, two levels 3.84)
   constexpr int N = NC > 0 ? NC : 1;
+#if defined(PYCHAIN_PRIO_TABLE)                        /* experiments: eight hex digits, the level of each eighth of the chunks */
+  auto level = [](int cc) { return (int)((PYCHAIN_PRIO_TABLE >> (4 * (7 - cc * 8 / N))) & 0xfu); };
+#elif !defined(PYCHAIN_PRIO_SCHED) || PYCHAIN_PRIO_SCHED == 0
   auto level = [](int cc) { return cc * 2 / N == 0 ? 3 : max(0, 2 - (cc - N / 2) * 6 / N); };
+#elif PYCHAIN_PRIO_SCHED == 2                          /* experiments */
+  auto level = [](int cc) { return cc * 2 / N == 0 ? 0 : min(3, 1 + (cc - N / 2) * 6 / N); };
+#elif PYCHAIN_PRIO_SCHED == 3
+  auto level = [](int cc) { return cc * 4 / N >= 3 ? 0 : 3; };
+#else
+  auto level = [](int cc) { return 3 - cc * 4 / N; };
+#endif
   const int lvl = level(c), prev = c > 0 ? level(c - 1) : -1;
   if (NC >= 4 && lvl != prev) {
     switch (lvl) {                               // (s_setprio takes an immediate)

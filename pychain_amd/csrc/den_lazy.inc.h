@@ -112,6 +112,12 @@ __device__ __forceinline__ void lz_st1(uint32_t byte_addr, float v) { *(lz_lds_f
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wint-to-pointer-cast"
 typedef __attribute__((address_space(3))) void lz_lds_void;
+#ifndef PYCHAIN_LATE_BACK
+#define PYCHAIN_LATE_BACK 2                            /* the late hook of lazy_tile runs this many chunks before the end of the arc phase */
+#endif
+#ifndef PYCHAIN_GATHER_ORDER
+#define PYCHAIN_GATHER_ORDER 1                         /* split arcs, a pair of rows: 1 = both states, then both rows (C3 recursion -0.7 %); 0 = state, row, state, row */
+#endif
 #ifndef PYCHAIN_LATE_FINISH
 #define PYCHAIN_LATE_FINISH 1                          /* 0: the in-place clamp / exp of an LDS-direct row after the arc phase (ablation) */
 #endif
@@ -228,10 +234,17 @@ struct LazyArcsSplit {
   // rows s, s + 1 (s even)
   template <uint32_t UOFF, uint32_t VOFF>
   __device__ __forceinline__ void gather2(int s, lz_v2f& u0, lz_v2f& u1, lz_v2f& v) {
+#if PYCHAIN_GATHER_ORDER == 0
     u0 = lz_ld2(ua[s] + UOFF);
     v.x = lds_abs((xp[s / 2] & 0xffffu) + VOFF);
     u1 = lz_ld2(ua[s + 1] + UOFF);
     v.y = lds_abs((xp[s / 2] >> 16) + VOFF);
+#else
+    u0 = lz_ld2(ua[s] + UOFF);
+    u1 = lz_ld2(ua[s + 1] + UOFF);
+    v.x = lds_abs((xp[s / 2] & 0xffffu) + VOFF);
+    v.y = lds_abs((xp[s / 2] >> 16) + VOFF);
+#endif
   }
 };
 template <int R, typename MAP> struct LazyArcsOf { typedef LazyArcs<R, MAP> type; };
@@ -265,7 +278,7 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
   constexpr int kChunk = 4;
   static_assert(R % kChunk == 0 && R <= 96 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
-  constexpr int kLateChunk = NC >= 4 ? NC - 2 : NC - 1;
+  constexpr int kLateChunk = NC >= 4 ? NC - PYCHAIN_LATE_BACK : NC - 1;
   uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), m_2 = gr.endmask2, cm = gr.chunkmask;
   if constexpr (R > 64) asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(m_2), "+s"(cm));
   else asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
@@ -327,7 +340,7 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
   constexpr int kChunk = 4;
   static_assert(PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
-  constexpr int kLateChunk = NC >= 4 ? NC - 2 : NC - 1;
+  constexpr int kLateChunk = NC >= 4 ? NC - PYCHAIN_LATE_BACK : NC - 1;
   uint32_t m_lo = (uint32_t)gr.endmask, cm = gr.chunkmask;
   asm volatile("" : "+s"(m_lo), "+s"(cm));
   lz_v2f acc = {0.f, 0.f};
