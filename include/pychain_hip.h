@@ -95,8 +95,10 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "den_pair" ("1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of
  *   the CU count in sequences on, i.e. B >= 96 on 256 CUs - results are bit-identical to den_recursion_kernel's),
  *   "den_wide" ("1": the 8-wave lazy recursion wherever the shape allows, "2": the 12-wave one - on plans compiled
- *   under PYCHAIN_PLAN_TWELVE=1, else ok = false; default "0": both measured slower than the 16-wave kernel), "gamma_tiled", "force_general" (the streamed general kernels even where a
- *   fast one fits),
+ *   under PYCHAIN_PLAN_TWELVE=1, else ok = false; default "0": both measured slower than the 16-wave kernel),
+ *   "den_two_copy" ("0": never the recursion that keeps two copies of the nnet-output row in LDS; default: wherever the
+ *   plan holds its tiles - compiled under PYCHAIN_PLAN_CHOICE=1 only: measured no faster),
+ *   "gamma_tiled", "force_general" (the streamed general kernels even where a fast one fits),
  *   "debug_corrupt_row" ("den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the
  *   recursions and the occupancy pass, so that the 5 % invariant of chain-computation.cc:363-390 /
  *   chain-log-domain-computation.cc:289-303 can be seen to fire: `ok` false at t = 0, at any t at verbose >= 1).
@@ -146,9 +148,10 @@ int64_t pychain_hip_den_plan_build(
  * device at call time and is never read back):
  *   info[0] num_states  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes
  *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers), three
- *           10-bit fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
- *           and for 8 waves (20-29); combine several plans by taking the max of each field
- *           bit 30: every recursion wave owns few enough row groups for the lazy-normalisation recursions
+ *           fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
+ *           and for 8 waves (20-28); combine several plans by taking the max of each field
+ *           bit 29: the plan holds the two-copy recursion tiles (PYCHAIN_PLAN_CHOICE=1; AND over several plans)
+ *           bit 30: every recursion wave owns few enough row groups for the lazy-normalisation recursions (AND)
  *   info[5..7] reserved (0)
  * A blob whose payload does not match the checksum in its header (a damaged or foreign cache file) is EINVAL.
  */
