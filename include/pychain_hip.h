@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 10
+#define PYCHAIN_HIP_ABI_VERSION 11
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -293,6 +293,11 @@ int pychain_hip_chain_loss_forward(
     void* stream);
 /* data[0..n) *= *scale_dev, skipped on the device when the scalar is exactly 1. */
 int pychain_hip_rescale(float* data, size_t n, const float* scale_dev, void* stream);
+/* out[0] = (sum_b den_objf_per_seq[b] - sum_b num_objf_per_seq[b]) * scale, divided by *norm_dev if norm_dev != NULL:
+ * the scalar ChainLoss.forward returns, -(num - den) [/ sum of lengths] (pychain/loss.py:100-104), in one launch
+ * (fp64 accumulation, rounded once).  num_objf_per_seq may be NULL (denominator only).  All pointers on the device. */
+int pychain_hip_loss_total(const float* den_objf_per_seq, const float* num_objf_per_seq, int B, float scale,
+                           const float* norm_dev, float* out, void* stream);
 int pychain_hip_chain_loss_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
     const int32_t* forward_transitions, const int32_t* forward_transition_indices,

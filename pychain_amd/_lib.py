@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -45,6 +45,7 @@ _SIGNATURES = {
                                        + [_vp, _vp, _i, _i, _i] + [_vp, _vp, _vp, _f, _vp]
                                        + [_vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_rescale": (_i, [_vp, _sz, _vp, _vp]),
+    "pychain_hip_loss_total": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i,
                                              _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_batch_layout": (_i64, [_i, _i, _i, _i, _vp, _vp]),

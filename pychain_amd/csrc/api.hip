@@ -708,6 +708,35 @@ extern "C" int pychain_hip_rescale(float* data, size_t n, const float* scale_dev
   return PYCHAIN_HIP_OK;
 }
 
+// out[0] = (sum den_objf - sum num_objf) * scale [/ *norm_dev]: the scalar of ChainLoss.forward (loss.py:100-104) in ONE
+// launch instead of two reductions, a subtraction and a scaling of the host framework (each ~6 us, launch-bound, in the
+// serial tail of every step).  fp64 accumulation, one rounding.
+namespace {
+__global__ void loss_total_kernel(const float* den, const float* num, int B, float scale, const float* norm_dev, float* out) {
+  __shared__ double part[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) acc += (double)den[i] - (num ? (double)num[i] : 0.0);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = ((part[0] + part[1]) + (part[2] + part[3])) * (double)scale;
+    if (norm_dev) t /= (double)*norm_dev;
+    out[0] = (float)t;
+  }
+}
+}  // namespace
+
+extern "C" int pychain_hip_loss_total(const float* den_objf_per_seq, const float* num_objf_per_seq, int B, float scale,
+                                      const float* norm_dev, float* out, void* stream) {
+  if (!den_objf_per_seq || !out || B <= 0) return fail(PYCHAIN_HIP_EINVAL, "loss_total: null pointer or empty batch");
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, den_objf_per_seq, num_objf_per_seq, B, scale,
+                     norm_dev, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PYCHAIN_HIP_ELAUNCH, "loss_total: %s", hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
 namespace {
 int chain_loss_backward_impl(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H,

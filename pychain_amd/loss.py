@@ -161,11 +161,8 @@ class ChainLossFunction(torch.autograd.Function):
         den_objf, num_objf, bad, state = native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
             with_grad=ctx.speculative, grad_scale=ctx.host_scale)
-        objf = den_objf.sum() - num_objf.sum()           # = -(num - den), loss.py:100-102
-        if ctx.host_scale != 1.0:
-            objf = objf * ctx.host_scale
-        if ctx.dev_norm is not None:
-            objf = objf / ctx.dev_norm
+        # -(num - den) [/ frames], loss.py:100-104: one launch instead of two reductions, a subtraction and a scaling
+        objf = native.loss_total(den_objf, num_objf, ctx.host_scale, ctx.dev_norm)
         ctx.state = state
         # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
         spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)

@@ -231,6 +231,20 @@ def chain_loss_backward(st, grad_scale=1.0, grad_scale_dev=None):
     return grad, bad
 
 
+def loss_total(den_objf, num_objf, scale=1.0, norm_dev=None):
+    """(den_objf.sum() - num_objf.sum()) * scale [/ norm_dev] as a 0-dim device tensor, one launch
+    (the scalar of ChainLoss.forward, loss.py:100-104)."""
+    dev = den_objf.device
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    if norm_dev is not None:
+        norm_dev = norm_dev.detach().to(device=dev, dtype=torch.float32).contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().pychain_hip_loss_total(
+            den_objf.data_ptr(), 0 if num_objf is None else num_objf.data_ptr(), den_objf.numel(), float(scale),
+            0 if norm_dev is None else norm_dev.data_ptr(), out.data_ptr(), _stream(dev)), "pychain_hip_loss_total")
+    return out
+
+
 def rescale_(t, scale_dev):
     """t *= scale_dev (0-dim device tensor), skipped on the device when the scalar is exactly 1."""
     scale_dev = scale_dev.detach().to(device=t.device, dtype=torch.float32).contiguous()
