@@ -118,6 +118,9 @@ typedef __attribute__((address_space(3))) void lz_lds_void;
 #ifndef PYCHAIN_GATHER_ORDER
 #define PYCHAIN_GATHER_ORDER 1                         /* split arcs, a pair of rows: 1 = both states, then both rows (C3 recursion -0.7 %); 0 = state, row, state, row */
 #endif
+#ifndef PYCHAIN_BATCH_PROW
+#define PYCHAIN_BATCH_PROW 1                           /* 0: the previous row's values are read back and stored group by group (ablation) */
+#endif
 #ifndef PYCHAIN_LATE_FINISH
 #define PYCHAIN_LATE_FINISH 1                          /* 0: the in-place clamp / exp of an LDS-direct row after the arc phase (ablation) */
 #endif
@@ -539,12 +542,22 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       const int trow = (FWDC) ? j : L - j;                                                                  \
       const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
       const int lane4 = lq * 4, lane8 = lq * 8;              /* one VGPR of addresses, the group in the SGPR offset */ \
+      if constexpr (PYCHAIN_BATCH_PROW && MAP::kDma && MAP::kMaxPdfs <= 4096 && MAP::kXCopy == 0 && R == 32) {  /* all reads, ONE wait, then the */ \
+        /* stores (gbase = 0 beyond ngroups) instead of a round trip per group: C3 -0.6 %; the maps with less room would spill */ \
+        lz_v2f prow[MG];                                                                                    \
+        _Pragma("unroll") for (int g = 0; g < MG; g++) prow[g] = lz_ld2(UCUR + gbase[g] * 8 + lane8);       \
+        _Pragma("unroll") for (int g = 0; g < MG; g++)                                                      \
+          if (g < groups.ngroups)                                                                           \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow[g].y, prow[g].x)), sbuf, lane4, \
+                                                  row_off + gbase[g] * 4, kStoreDeviceScope);               \
+      } else {                                                                                              \
       _Pragma("unroll") for (int g = 0; g < MG; g++)                                                        \
         if (g < groups.ngroups) {                                                                           \
           const lz_v2f prow = lz_ld2(UCUR + gbase[g] * 8 + lane8);                                          \
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow.y, prow.x)), sbuf, lane4, \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
         }                                                                                                   \
+      }                                                                                                     \
     }, [&]() {                                                                                              \
       /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
       /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
