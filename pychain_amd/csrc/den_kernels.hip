@@ -1455,15 +1455,21 @@ hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
 }
 // the plan holds two-copy tiles (hint bit 29) and the shape fits the two-copy map: 32-row loops, rows of up to 4096 pdfs
 inline bool two_copy_shape_ok(const DenArgs& a, int hint) {
+#ifdef PYCHAIN_NO_SPLIT_ARCS
+  (void)a; (void)hint;
+  return false;
+#endif
   return ((hint >> 29) & 1) && a.knobs.den_two_copy != 0 && lazy_shape_ok(a, hint, true) && (hint & 1023) <= 32 &&
          a.D <= (int)LzNarrowDma2::kMaxPdfs && a.Hp <= (int)LzNarrowDma2::kMaxStates;
 }
 hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
+#ifndef PYCHAIN_NO_SPLIT_ARCS                          /* (the two-copy map takes arcs in the split form only) */
   if (two_copy_shape_ok(a, hint)) {
     const dim3 grid(2 * a.B);
     if ((hint & 1023) <= 16) return launch_one(den_recursion_lazy_kernel<16, LzNarrowDma2>, a, grid, LzNarrowDma2::kBytes, st);
     return launch_one(den_recursion_lazy_kernel<32, LzNarrowDma2>, a, grid, LzNarrowDma2::kBytes, st);
   }
+#endif
   // the map of C1-C3 where the shape fits it, else the one for rows of up to 9216 pdfs
   if (lazy_shape_ok(a, hint, true)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
   return launch_dma_m<LzDma>(a, hint & 1023, st);
