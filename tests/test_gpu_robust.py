@@ -129,6 +129,25 @@ def test_check_contiguous_like_the_reference():
             native.forward_backward(*bad_args)
 
 
+def test_loss_total_is_the_loss_arithmetic_of_the_reference():
+    """pychain_hip_loss_total = (sum den - sum num) * scale [/ norm]: -(num - den) and the division by the frame count of
+    pychain/loss.py:100-104 in one launch; against torch in fp64, with and without a numerator, a device-side norm, B = 1
+    and a batch larger than the kernel's block."""
+    g = torch.Generator().manual_seed(3)
+    for B in (1, 7, 64, 1000):
+        den = (torch.randn(B, generator=g) * 300 - 4000).to(DEV)
+        num = (torch.randn(B, generator=g) * 300 - 4100).to(DEV)
+        want = float(den.double().sum() - num.double().sum())
+        got = float(native.loss_total(den, num))
+        assert abs(got - want) <= 2e-7 * abs(want) + 1e-6
+        norm = torch.tensor(1234.0, device=DEV)
+        got = float(native.loss_total(den, num, 0.5, norm))
+        assert abs(got - want * 0.5 / 1234.0) <= 2e-7 * abs(want * 0.5 / 1234.0) + 1e-9
+        got = float(native.loss_total(den, None, 2.0))
+        want = 2.0 * float(den.double().sum())
+        assert abs(got - want) <= 2e-7 * abs(want)
+
+
 def test_unknown_option_is_an_error():
     with pytest.raises(_lib.PychainHipError, match="unknown option"):
         with _lib.option("no_such_option"):
