@@ -95,7 +95,7 @@ def plan_info(blob):
 # atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.  A file is only
 # believed if its header matches the request AND its payload matches the checksum in the header.
 _KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_FREE",
-          "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED")
+          "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED", "PYCHAIN_PLAN_SAMELANE")
 
 
 def _cache_dir():

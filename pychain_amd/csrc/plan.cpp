@@ -76,6 +76,7 @@ struct Balancer {
   struct Occ { int tile, row, op; };
   std::vector<std::vector<Occ>> occ[2];              // [layout A / B][state]: arcs that gather this state
   std::vector<std::vector<int>> gmax;                // [tile][group]: arc count of the group's longest row (fixed: it sets the slot-rows)
+  int same_lane_moves = 0;                           // PYCHAIN_PLAN_SAMELANE=n: n eighths of the moves keep the row's lane
   bool free_moves = true;                            // PYCHAIN_PLAN_FREE=0: only rows of equal arc count trade places, across half-groups
   Lcg rng{0x2545F491u};
 
@@ -153,7 +154,13 @@ struct Balancer {
       // rows are sorted by arc count: equal counts are neighbours.  Half of the moves stay inside p1's group of 64
       // (every permutation of a group's rows is free: its slot-row count is that of its longest row, whichever lane owns it)
       int p2;
-      if (free_moves && (rng.next() & 1)) {
+      const uint32_t kind = rng.next() & 7;
+      if ((int)kind < same_lane_moves) {
+        // the row keeps its lane - the bank its state is gathered from - and changes its half-group: only the bank
+        // histograms of its own arcs move (the two coordinates of a position are separate freedoms)
+        const int k = 1 + (int)(rng.next() % 16);
+        p2 = p1 + ((rng.next() & 1) ? 32 * k : -32 * k);
+      } else if (free_moves && (kind & 1)) {
         p2 = (p1 & ~63) + (int)(rng.next() & 63);
       } else {
         const int span = 1 + rng.next() % 512;
@@ -677,7 +684,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
   for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
                            "PYCHAIN_PLAN_FREE", "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR",
-                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED"}) {
+                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED", "PYCHAIN_PLAN_SAMELANE"}) {
     const char* v = getenv(knob);
     key = fnv64(key, knob, strlen(knob));
     if (v) key = fnv64(key, v, strlen(v));
@@ -766,6 +773,7 @@ int64_t plan_build_impl(
   {
     Balancer bal(tiles, lay);
     bal.free_moves = env_long("PYCHAIN_PLAN_FREE", 1) != 0;
+    bal.same_lane_moves = (int)env_long("PYCHAIN_PLAN_SAMELANE", 2);
     const long before = stats ? bal.overload() : 0;
     bal.run(balance_moves * K, 40.0, 0.5);
     if (stats) fprintf(stderr, "[plan] row placement: bank overload %ld -> %ld (of %ld arc operands)\n", before, bal.overload(), 6L * K);
