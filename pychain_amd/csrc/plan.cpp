@@ -233,6 +233,7 @@ struct SlotOrder {
     wide_op[0] = op0_wide; wide_op[1] = op1_wide; v_choice = choice ? 1 : 0; u_choice = choice0 ? 1 : 0;
     cost_model = (int)env_long("PYCHAIN_PLAN_COST", 0);
     targeted = env_long("PYCHAIN_PLAN_TARGETED", 1) != 0;
+    best_of = (int)env_long("PYCHAIN_PLAN_BESTOF", 0);
     w_op[0] = (int)env_long("PYCHAIN_PLAN_W0", 12); w_op[1] = (int)env_long("PYCHAIN_PLAN_W1", 12);
     int off = 0;
     for (int g : t.gsl) { cell_off.push_back(off); off += 64 * g; }
@@ -243,6 +244,7 @@ struct SlotOrder {
   static constexpr int kScale = 4;                   // energy = kScale * extra tenths + sum of squared bank loads
   int w_op[2] = {12, 12};
   bool targeted = true;                              // PYCHAIN_PLAN_TARGETED=0: every move starts from a random cell
+  int best_of = 0;                                   // PYCHAIN_PLAN_BESTOF=n: a targeted move tries n candidate columns and takes the best
   // cost model 0 (default): w * (fullest bank of half 0 + of half 1), both operands alike - the model of rounds 1-2, and the
   // one the frame follows in situ (C3, 32-row loops: 1313 -> 878 of these units = 3.27 -> 3.09 ms); 1: the isolated gather costs
   // of tools/ubench/ldsbanks.hip (halves side by side, a two-way conflict nearly free) - plans that look better and run slower
@@ -303,6 +305,7 @@ struct SlotOrder {
       for (long it = 0; it < iters; it++, T *= cool) {
         int r = rng.next() % nr;
         const int j1 = rng.next() % A;
+        bool was_targeted = false;
         if (targeted && (rng.next() & 1)) {
           // half of the moves start from a lane that sits in the fullest bank of a conflicting half-column (a blind pick
           // mostly proposes to move arcs that collide with nobody)
@@ -315,7 +318,7 @@ struct SlotOrder {
             int pick = -1, seen = 0;
             for (int rr = 32 * hh; rr < std::min(nr, 32 * hh + 32); rr++)
               if (bank[rr * A + j1] == bmax && (rng.next() % ++seen) == 0) pick = rr;
-            if (pick >= 0) r = pick;
+            if (pick >= 0) { r = pick; was_targeted = true; }
           }
         }
         if ((v_choice || u_choice) && (rng.next() & 3) == 0) {   // a quarter of the moves: one arc reads the other copy of an operand
@@ -331,20 +334,44 @@ struct SlotOrder {
           continue;
         }
         int j2 = rng.next() % (A - 1); if (j2 >= j1) j2++;
-        const int i1 = r * A + j1, i2 = r * A + j2, hh = r >> 5;
+        const int hh = r >> 5;
+        // the energy change of lane r's cells j1 and jj trading places, applied (apply it again with the cells' banks
+        // exchanged - i.e. call revert - to undo)
+        auto apply = [&](int jj) {
+          const int a1 = r * A + j1, a2 = r * A + jj;
+          int d = 0;
+          if (b0[a1] >= 0) d += col_add(cs[j1], hh, 0, b0[a1], -1) + col_add(cs[j1], hh, 1, b1[a1], -1);
+          if (b0[a2] >= 0) d += col_add(cs[jj], hh, 0, b0[a2], -1) + col_add(cs[jj], hh, 1, b1[a2], -1);
+          if (b0[a1] >= 0) d += col_add(cs[jj], hh, 0, b0[a1], +1) + col_add(cs[jj], hh, 1, b1[a1], +1);
+          if (b0[a2] >= 0) d += col_add(cs[j1], hh, 0, b0[a2], +1) + col_add(cs[j1], hh, 1, b1[a2], +1);
+          return d;
+        };
+        auto revert = [&](int jj) {
+          const int a1 = r * A + j1, a2 = r * A + jj;
+          if (b0[a2] >= 0) { col_add(cs[j1], hh, 0, b0[a2], -1); col_add(cs[j1], hh, 1, b1[a2], -1); }
+          if (b0[a1] >= 0) { col_add(cs[jj], hh, 0, b0[a1], -1); col_add(cs[jj], hh, 1, b1[a1], -1); }
+          if (b0[a2] >= 0) { col_add(cs[jj], hh, 0, b0[a2], +1); col_add(cs[jj], hh, 1, b1[a2], +1); }
+          if (b0[a1] >= 0) { col_add(cs[j1], hh, 0, b0[a1], +1); col_add(cs[j1], hh, 1, b1[a1], +1); }
+        };
+        if (was_targeted && best_of > 0) {
+          // a targeted move goes to the best of a few candidate columns instead of a random one
+          int bestj = j2, bestd = 0x7fffffff;
+          for (int t = 0; t < best_of; t++) {
+            int jj = rng.next() % (A - 1); if (jj >= j1) jj++;
+            if (b0[r * A + j1] < 0 && b0[r * A + jj] < 0) continue;
+            const int d = apply(jj);
+            revert(jj);
+            if (d < bestd) { bestd = d; bestj = jj; }
+          }
+          j2 = bestj;
+        }
+        const int i1 = r * A + j1, i2 = r * A + j2;
         if (b0[i1] < 0 && b0[i2] < 0) continue;
-        int dE = 0;
-        if (b0[i1] >= 0) dE += col_add(cs[j1], hh, 0, b0[i1], -1) + col_add(cs[j1], hh, 1, b1[i1], -1);
-        if (b0[i2] >= 0) dE += col_add(cs[j2], hh, 0, b0[i2], -1) + col_add(cs[j2], hh, 1, b1[i2], -1);
-        if (b0[i1] >= 0) dE += col_add(cs[j2], hh, 0, b0[i1], +1) + col_add(cs[j2], hh, 1, b1[i1], +1);
-        if (b0[i2] >= 0) dE += col_add(cs[j1], hh, 0, b0[i2], +1) + col_add(cs[j1], hh, 1, b1[i2], +1);
+        const int dE = apply(j2);
         if (dE <= 0 || rng.unit() < exp(-(double)dE / T)) {
           std::swap(cl[i1], cl[i2]); std::swap(b0[i1], b0[i2]); std::swap(b1[i1], b1[i2]); std::swap(alt[i1], alt[i2]); std::swap(alt0[i1], alt0[i2]);
         } else {
-          if (b0[i2] >= 0) { col_add(cs[j1], hh, 0, b0[i2], -1); col_add(cs[j1], hh, 1, b1[i2], -1); }
-          if (b0[i1] >= 0) { col_add(cs[j2], hh, 0, b0[i1], -1); col_add(cs[j2], hh, 1, b1[i1], -1); }
-          if (b0[i2] >= 0) { col_add(cs[j2], hh, 0, b0[i2], +1); col_add(cs[j2], hh, 1, b1[i2], +1); }
-          if (b0[i1] >= 0) { col_add(cs[j1], hh, 0, b0[i1], +1); col_add(cs[j1], hh, 1, b1[i1], +1); }
+          revert(j2);
         }
       }
     }
