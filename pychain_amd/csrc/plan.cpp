@@ -819,7 +819,12 @@ int64_t plan_build_impl(
   const bool choice = false, choice0 = false;
   SlotOrder so_a(tiles[0], lay, true, false, choice, choice0), so_b(tiles[1], lay, true, false, choice, choice0), so_g(tiles[2], lay, true, true);
   auto moves = [&](const Tile& t) { return anneal_knob >= 0 ? anneal_knob : (t.fitted ? 3000L : 200L); };
-  so_a.run(moves(tiles[0])); so_b.run(moves(tiles[1])); so_g.run(moves(tiles[2]));
+  {
+    // the three tiles are independent (and every group has its own random stream: the result does not depend on the threads)
+    std::thread tb([&]() { so_b.run(moves(tiles[1])); }), tg([&]() { so_g.run(moves(tiles[2])); });
+    so_a.run(moves(tiles[0]));
+    tb.join(); tg.join();
+  }
   SlotOrder so_ac(tiles[0], lay, true, false, true, choice_knob > 0 && (choice_knob & 2)), so_bc(tiles[1], lay, true, false, true, choice_knob > 0 && (choice_knob & 2));
   if (choice_tiles) {
     so_ac.run(moves(tiles[0])); so_bc.run(moves(tiles[1]));
