@@ -312,10 +312,82 @@ def gen_chaingraph_init():
     save("a4_chaingraph_init", **out)
 
 
+# ---------------------------------------------------------------- G6: benchmark-length sequences
+def _ref_batch_from(gb):
+    """Reference ChainGraphBatch carrying the tensors of a collated pychain_amd batch."""
+    rb = RefChainGraphBatch.__new__(RefChainGraphBatch)
+    for f in GRAPH_FIELDS + ["start_state", "num_states", "batch_size", "log_domain"]:
+        v = getattr(gb, f)
+        setattr(rb, f, v.clone() if torch.is_tensor(v) else v)
+    rb.num_transitions = getattr(gb, "num_transitions", None)
+    return rb
+
+
+def gen_long():
+    """G6: the long cases of tests/helpers.py:long_case through the REAL reference binary - at
+    T >= 700 its fp32 log-domain numerator (LogAdd with the -15.94 cut-off, base.h:14-32, chained through
+    chain-log-domain-computation.cc:137-158,256-266) is itself > 1e-4 from the same equations in fp64.  Stored per case:
+    objf, per-frame gradient row sums, sampled full gradient rows (the rows where the reference is furthest from the fp64
+    evaluation + evenly spread ones), the fp64 evaluation (oracle/chain_oracle.c, REAL=double) of the same rows and row
+    sums, and the reference's distance from fp64 over the WHOLE gradient."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import helpers
+    out = {}
+    for name in helpers.LONG_CASES:
+        c = helpers.long_case(name)
+        x, L, B = c["x"], c["lengths"], c["x"].shape[0]
+        if c["kind"] == "den":
+            objf, grad = run_function(x, L, RefChainGraphBatch(to_ref_graph(c["den"]), B), c["leaky"])
+        elif c["kind"] == "num":
+            if c["num_list"] is not None and len(c["num_list"]) == 1:
+                rb = RefChainGraphBatch(to_ref_graph(c["num_list"][0]), B)
+            else:
+                rb = _ref_batch_from(c["num"])
+            objf, grad = run_function(x, L, rb)
+        else:
+            gs = c["num_list"]
+            rb = RefChainGraphBatch([to_ref_graph(g) for g in gs], max_num_transitions=max(g.num_transitions for g in gs),
+                                    max_num_states=max(g.num_states for g in gs))
+            xx = x.clone().requires_grad_(True)
+            loss = RefChainLoss(to_ref_graph(c["den"]), c["leaky"], avg=True)(xx, L, rb)
+            loss.backward()
+            objf, grad = loss.detach().numpy().astype(np.float32), xx.grad.numpy()
+        o64, g64 = helpers.long_case_oracle(c, "f64")
+        o32, g32 = helpers.long_case_oracle(c, "f32")
+        ref = grad.astype(np.float64)
+        absmax = float(np.abs(ref).max())
+        dist = np.abs(ref - g64).max(-1)                              # [B, T]
+        ref_vs_f64 = float(dist.max() / np.abs(g64).max())
+        nrows = 12 if c["kind"] != "num" and x.shape[2] > 1024 else 160     # (dense rows of 8 - 14 KB)
+        worst = np.dstack(np.unravel_index(np.argsort(dist, axis=None)[::-1][:nrows // 2], dist.shape))[0]
+        live = [(b, t) for b in range(B) for t in range(int(L[b]))]
+        spread = np.array(live)[np.linspace(0, len(live) - 1, nrows - len(worst)).astype(int)]
+        rows = np.unique(np.concatenate([worst, spread]), axis=0)
+        p = name + "__"
+        out[p + "objf"] = np.float64(objf); out[p + "objf_f64"] = np.float64(o64)
+        out[p + "rows"] = rows.astype(np.int32)
+        out[p + "ref_rows"] = grad[rows[:, 0], rows[:, 1]]
+        out[p + "f64_rows"] = g64[rows[:, 0], rows[:, 1]].astype(np.float32)     # (rounding: 6e-8 of a value)
+        out[p + "ref_rowsum"] = ref.sum(-1); out[p + "f64_rowsum"] = g64.sum(-1)
+        out[p + "ref_absmax"] = np.float64(absmax)
+        out[p + "ref_vs_f64"] = np.float64(ref_vs_f64)
+        out[p + "ref_vs_f64_rowsum"] = np.float64(np.abs(ref.sum(-1) - g64.sum(-1)).max())
+        out[p + "restatement_f32_vs_ref"] = np.float64(np.abs(g32 - ref).max() / absmax)     # (what it was when generated)
+        out[p + "x_checksum"] = np.float64(helpers.long_case_checksum(c))
+        print("%-16s objf %.6f (f64 %.6f, restatement-f32 %.6f)  grad: reference vs f64 %.3e, restatement-f32 vs reference %.3e,"
+              " restatement-f32 vs f64 %.3e; %d rows" % (name, float(objf), o64, o32, ref_vs_f64, out[p + "restatement_f32_vs_ref"],
+                                                         np.abs(g32 - g64).max() / np.abs(g64).max(), len(rows)))
+    save("g6_long", **out)
+
+
 if __name__ == "__main__":
+    if "--only-g6" in sys.argv:
+        gen_long()
+        sys.exit(0)
     gen_chaingraph_init()
     if "--only-a4" in sys.argv:
         sys.exit(0)
+    gen_long()
     gen_c1()
     gen_variants()
     gen_medium()

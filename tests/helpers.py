@@ -165,3 +165,128 @@ def oracle_fanout(x_cpu, lengths, den_graph, num_graphs, grad_hip, flavours=("f3
     for p_ in procs:
         p_.join()
     return sorted(rows, key=lambda r: r["b"])
+
+
+# ---- G6: the long-sequence cases pinned by the REAL reference binary (tests/golden/g6_long.npz) -----------------------
+# The inputs are rebuilt from seeds by these builders on both sides (tests/golden/make_golden.py:gen_long runs the
+# reference on them here; the tests run the oracle restatement / the HIP path on them), so the fixture holds only the
+# reference's outputs.  Lengths where the reference's fp32 log-domain recursion (chain-log-domain-computation.cc:137-158,
+# 256-266 over base.h:14-32) is itself > 1e-4 from the same equations in fp64.
+LONG_CASES = ("c3_slice_den", "c3_slice_num", "num_shared_T720", "fold_T751")
+
+
+def _rand_num_fst(rs, H, extra, D, finals):
+    """Left-to-right numerator graph with `extra` skip arcs (the branching graphs of the parity tests)."""
+    from pychain_amd.simplefst import StdVectorFst
+    arcs = [(s, s, int(rs.randint(D)), -0.5) for s in range(H)]
+    arcs += [(s, s + 1, int(rs.randint(D)), -0.9) for s in range(H - 1)]
+    arcs += [(int(a), int(min(H - 1, a + 1 + rs.randint(3))), int(rs.randint(D)), -1.3)
+             for a in rs.randint(0, H - 1, size=extra)]
+    arcs.sort(key=lambda a: a[0])
+    return StdVectorFst.from_arcs(H, 0, arcs, finals(H))
+
+
+def long_case(name):
+    """dict(x [B,T,D] cpu f32, lengths, kind = "den" | "num" | "loss", den = ChainGraph | None,
+    num = ChainGraphBatch | None, num_list = [ChainGraph] | None (the graphs `num` was collated from), leaky)."""
+    from pychain_amd import synthetic as syn
+    if name in ("c3_slice_den", "c3_slice_num"):
+        # the C3 graph and pdf count, 4 ragged utterances up to the benchmark length (BASELINE.json configs[2])
+        cfg = syn.CONFIGS["C3"]
+        L = torch.tensor([1500, 1201, 977, 902])
+        x = syn.make_input(4, 1500, cfg["D"], seed=1)
+        if name == "c3_slice_den":
+            return dict(x=x, lengths=L, kind="den", den=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0),
+                        num=None, num_list=None, leaky=1e-5)
+        return dict(x=x, lengths=L, kind="num", den=None, num=syn.make_num_graphs(L.tolist(), cfg["D"], seed=100),
+                    num_list=None, leaky=1e-5)
+    if name == "num_shared_T720":
+        # one 700-state branching numerator graph shared by both utterances (graph stride 0), D = 48
+        rs = np.random.RandomState(5)
+        D = 48
+        fin = lambda H: {H - 1: 0.0, H - 2: -0.4}
+        _rand_num_fst(rs, 12, 20, D, fin); _rand_num_fst(rs, 9, 15, D, fin)     # (the stream position of the parity test)
+        big = ChainGraph(_rand_num_fst(rs, 700, 300, D, fin), log_domain=True)
+        return dict(x=syn.make_input(2, 720, D, seed=14), lengths=torch.tensor([720, 705]), kind="num", den=None,
+                    num=ChainGraphBatch(big, 2), num_list=[big], leaky=1e-5)
+    if name == "fold_T751":
+        # fused ChainLoss: > 1024 distinct numerator pdfs per sequence, > 512 numerator states, branching, odd T
+        rs = np.random.RandomState(11)
+        D = 2048
+        fin = lambda H: {H - 1: 0.0}
+        gs = [ChainGraph(_rand_num_fst(rs, 700, 500, D, fin), log_domain=True),
+              ChainGraph(_rand_num_fst(rs, 610, 40, D, fin), log_domain=True),
+              ChainGraph(_rand_num_fst(rs, 30, 10, D, fin), log_domain=True)]
+        gb = ChainGraphBatch(gs, max_num_transitions=max(g.num_transitions for g in gs),
+                             max_num_states=max(g.num_states for g in gs))
+        return dict(x=syn.make_input(3, 751, D, seed=29), lengths=torch.tensor([751, 640, 45]), kind="loss",
+                    den=syn.make_den_graph(120, 900, D, seed=7), num=gb, num_list=gs, leaky=1e-5)
+    raise KeyError(name)
+
+
+def long_case_checksum(case):
+    """One float64 over every input of a long case: the network output, the lengths and every graph tensor."""
+    def cs(a):
+        a = np.asarray(a, dtype=np.float64).ravel()
+        a = np.where(np.isfinite(a), a, -77.0)
+        return float((a * np.cos(np.arange(a.size, dtype=np.float64))).sum())
+    tot = cs(case["x"].numpy()) + cs(case["lengths"].numpy())
+    for g in (case["den"], case["num"]):
+        if g is None:
+            continue
+        for f in GRAPH_FIELDS:
+            v = getattr(g, f, None)
+            if v is not None:
+                tot += cs(v.numpy())
+    return tot
+
+
+def long_case_oracle(case, flavour):
+    """(objf or loss, grad [B,T,D] float64) of a long case by the oracle restatement (oracle/chain_oracle.c)."""
+    import oracle as orc
+    B = case["x"].shape[0]
+    if case["kind"] == "den":
+        o, g = orc.chain_function(case["x"], case["lengths"], ChainGraphBatch(case["den"], B), case["leaky"], flavour=flavour)
+    elif case["kind"] == "num":
+        o, g = orc.chain_function(case["x"], case["lengths"], case["num"], flavour=flavour)
+    else:
+        o, g = orc.chain_loss(case["x"], case["lengths"], case["den"], case["num"], case["leaky"], avg=True, flavour=flavour)
+    return float(o), np.asarray(g, dtype=np.float64)
+
+
+class G6Case(object):
+    """One case of tests/golden/g6_long.npz: the REAL reference's objective, per-frame gradient row sums and sampled
+    gradient rows (the rows where it is furthest from the fp64 evaluation among them), the fp64 evaluation of the same
+    rows, and the reference's own measured distance from fp64 - the yardstick of every comparison with it."""
+
+    def __init__(self, z, name):
+        p = name + "__"
+        self.name = name
+        self.objf = float(z[p + "objf"])
+        self.objf_f64 = float(z[p + "objf_f64"])
+        self.rows = np.array(z[p + "rows"])                    # [n, 2] (b, t)
+        self.ref_rows = np.array(z[p + "ref_rows"], dtype=np.float64)
+        self.f64_rows = np.array(z[p + "f64_rows"], dtype=np.float64)
+        self.ref_rowsum = np.array(z[p + "ref_rowsum"])        # [B, T] float64
+        self.f64_rowsum = np.array(z[p + "f64_rowsum"])
+        self.ref_absmax = float(z[p + "ref_absmax"])           # max |grad| of the reference over the whole batch
+        self.ref_vs_f64 = float(z[p + "ref_vs_f64"])           # max |ref - f64| / max |f64| over the WHOLE gradient
+        self.ref_vs_f64_rowsum = float(z[p + "ref_vs_f64_rowsum"])
+        self.x_checksum = float(z[p + "x_checksum"])
+
+    def check_input(self, case):
+        """the builder gave the bytes the fixture was generated from"""
+        got = long_case_checksum(case)
+        assert abs(got - self.x_checksum) <= 1e-9 * max(1.0, abs(self.x_checksum)), (got, self.x_checksum)
+
+    def dist_ref(self, grad):
+        """max |grad - reference| over the sampled rows / max |reference grad| (the survey's gradient metric)"""
+        g = np.asarray(grad)[self.rows[:, 0], self.rows[:, 1]].astype(np.float64)
+        return float(np.abs(g - self.ref_rows).max() / self.ref_absmax)
+
+    def dist_f64(self, grad):
+        g = np.asarray(grad)[self.rows[:, 0], self.rows[:, 1]].astype(np.float64)
+        return float(np.abs(g - self.f64_rows).max() / self.ref_absmax)
+
+    def dist_rowsum_ref(self, grad):
+        return float(np.abs(np.asarray(grad, dtype=np.float64).sum(-1) - self.ref_rowsum).max())

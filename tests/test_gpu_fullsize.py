@@ -24,9 +24,12 @@ def _summary(rows, fl, what="max_diff"):
 def test_full_size_c3_vs_oracle():
     """All 64 utterances of the bench batch (76 684 frames), fused loss: loss within 1e-4 of the fp32 and of the fp64
     evaluation; FUSED gradient within 1e-5 of the fp64 evaluation of the reference's equations.  Against the fp32
-    restatement of the reference the bound is the triangle inequality, nothing looser: the reference's own distance from
-    fp64 on this batch (its fp32 log-domain numerator: measured 8.6e-4 over the 64 utterances, 2.1e-4 on the four of
-    profiles/r02_parity_c3.txt) plus the 1e-5 of the line above, and a literal 1.5e-3 on top."""
+    restatement of the reference the bound is the triangle inequality, nothing looser: the restatement's own distance from
+    fp64 on this batch (the fp32 log-domain numerator: measured 8.6e-4 over the 64 utterances) plus the 1e-5 of the line
+    above.  The restatement stands for the reference here because the batch is drawn on the device; what it stands for is
+    pinned at this length by G6 (tests/golden/g6_long.npz: the REAL reference binary on the C3 graph at T = 1500, held
+    within 1e-4 of the restatement by tests/test_oracle.py::test_g6_long_sequences and compared with the HIP path
+    directly by test_gpu_parity.py::test_c3_shape_slice_vs_oracle)."""
     w = syn.make_workload("C3", device=DEV)
     x = w["x"].clone().requires_grad_(True)
     loss = ChainLoss(w["den_graph"], 1e-5, avg=False)(x, w["lengths"], w["num_graphs"])
@@ -46,7 +49,7 @@ def test_full_size_c3_vs_oracle():
                   grad_vs_f32_worst_utterance=e32u, f32_reference_vs_f64=own, f32_reference_vs_f64_worst_utterance=ownu,
                   loss=got)
     assert e64 <= 1e-5 and e64u <= 2e-5, (e64, e64u)
-    assert e32 <= own + 1e-5 and e32 <= 1.5e-3, (e32, own)
+    assert e32 <= own + 1e-5, (e32, own)
 
 
 def test_full_size_c4_vs_oracle():

@@ -106,3 +106,39 @@ def test_f64_second_opinion(golden):
     den = graph_from_npz(z, "den_")
     o, g = orc.chain_function(z["x"], z["lengths"], ChainGraphBatch(den, 2), flavour="f64")
     _check(o, g, z["objf"], z["grad"], otol=2e-6, gtol=2e-5)
+
+
+# ---- G6: benchmark-length sequences, pinned by the real reference binary ----------------------------------------------
+# measured when the fixture was generated (tests/golden/make_golden.py:gen_long prints them): distance of the fp32
+# restatement from the reference binary, max |d grad| / max |grad| over the whole gradient
+G6_RESTATEMENT_BOUND = {"c3_slice_den": 1e-5,        # measured 1.1e-6
+                        "c3_slice_num": 1e-4,        # measured 9.2e-5 (1.33e-4 before log_add used the float log1pf / expf of base.h:26)
+                        "num_shared_T720": 1e-4,     # measured 6.1e-5
+                        "fold_T751": 1e-4}           # measured 3.0e-5
+
+
+@pytest.mark.parametrize("name", list(G6_RESTATEMENT_BOUND))
+def test_g6_long_sequences(golden, name):
+    """The restatement against the REAL reference at T = 720 ... 1500, where the reference's fp32 log-domain numerator
+    (LogAdd with its -15.94 cut-off, base.h:14-32, chained through chain-log-domain-computation.cc:137-158,256-266) is itself
+    1.3e-4 ... 1.9e-4 from the same equations in fp64 - the number every GPU test against G6 uses as its yardstick.
+      fp32 flavour: objf within 1e-6, gradient rows within the measured bound above (<= 1e-4);
+      fp64 flavour: reproduces the fixture's fp64 rows (they were produced by it: guards the checker itself);
+      the fixture's own claim `ref_vs_f64` is re-measured on the stored rows (the worst rows are among them)."""
+    from helpers import G6Case, long_case, long_case_oracle
+    g6 = G6Case(golden("g6_long"), name)
+    case = long_case(name)
+    g6.check_input(case)
+    o32, g32 = long_case_oracle(case, "f32")
+    assert abs(o32 - g6.objf) <= 1e-6 * abs(g6.objf), (o32, g6.objf)
+    assert g6.dist_ref(g32) <= G6_RESTATEMENT_BOUND[name], g6.dist_ref(g32)
+    assert g6.dist_rowsum_ref(g32) <= 2e-4
+    o64, g64 = long_case_oracle(case, "f64")
+    assert abs(o64 - g6.objf_f64) <= 1e-12 * abs(g6.objf_f64)
+    assert g6.dist_f64(g64) <= 1e-7                       # (the fixture keeps the fp64 rows rounded to float)
+    own_rows = float(np.abs(g6.ref_rows - g6.f64_rows).max() / np.abs(g64).max())
+    assert abs(own_rows - g6.ref_vs_f64) <= 1e-7 + 1e-3 * g6.ref_vs_f64, (own_rows, g6.ref_vs_f64)
+    if name != "c3_slice_den":                            # the point of G6: the reference itself is not within 1e-4 of exact math
+        assert 1e-4 < g6.ref_vs_f64 < 2.5e-4, g6.ref_vs_f64
+    else:
+        assert g6.ref_vs_f64 < 2e-6
