@@ -65,6 +65,20 @@ class ChainGraph(object):
                 self.final_probs.fill_(1.0)
         self._plan_cache = {}
 
+    def __getstate__(self):
+        # The caches hold a compiled device plan and RAW HOST ADDRESSES of this object's tensors (_pack_record): neither
+        # may travel with a copy.deepcopy / pickle of the graph (DataLoader workers, torch.save) - the copy's tensors live
+        # somewhere else, and in another process the addresses mean nothing.
+        d = dict(self.__dict__)
+        d.pop("_pack_cache", None)
+        d["_plan_cache"] = {}
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.__dict__.pop("_pack_cache", None)
+        self._plan_cache = {}
+
     @classmethod
     def from_tensors(cls, forward_transitions, forward_transition_probs, forward_transition_indices,
                      backward_transitions, backward_transition_probs, backward_transition_indices,
@@ -131,6 +145,28 @@ def _layout(L, B, K, H, log_domain):
 _REC_NAMES = tuple(name for name, _s, _d in _PACKED[:9])
 
 
+def _may_pin():
+    """Pinned host memory only where this process already talks to the GPU: `ChainGraphBatch(list)` is what a DataLoader
+    `collate_fn` builds in FORKED workers, where `torch.cuda.is_available()` is still true (the parent's answer is
+    cached) but touching the HIP runtime is an error or a hang; the reference collation is pure CPU
+    (pychain/graph.py:122-175)."""
+    try:
+        import torch.utils.data as tud
+        return torch.cuda.is_initialized() and tud.get_worker_info() is None
+    except Exception:
+        return False
+
+
+def _staging_buffer(nbytes, like=None):
+    pin = like.is_pinned() if like is not None else True
+    if pin and _may_pin():
+        try:
+            return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        except RuntimeError:
+            pass                                               # (out of pinnable memory: pageable works, one sync copy)
+    return torch.empty(nbytes, dtype=torch.uint8)
+
+
 def _pack_record(g):
     """(num_transitions, num_states, start_state, addresses of the nine tensors in _PACKED order), or None if a
     tensor is not a contiguous CPU int32 / float32 tensor of the expected size.  Remembered on the graph for as long
@@ -138,12 +174,15 @@ def _pack_record(g):
     d = g.__dict__
     c = d.get("_pack_cache")
     if c is not None and c[1] == (g.num_transitions, g.num_states, g.start_state):
-        ts = c[0]
+        ts, rec = c[0], c[2]
         for i in range(9):
-            if d[_REC_NAMES[i]] is not ts[i]:
+            t = d[_REC_NAMES[i]]
+            # the same tensor OBJECT is not enough: a cache that reached this graph through a copy of its __dict__ (or a
+            # tensor whose storage was swapped by set_ / resize_) points at memory that is not this tensor's
+            if t is not ts[i] or (rec is not None and (t.data_ptr() if t is not None else 0) != rec[3 + i]):
                 break
         else:
-            return c[2]
+            return rec
     rec = _pack_record_uncached(g)
     d["_pack_cache"] = (tuple(d[n] for n in _REC_NAMES), (g.num_transitions, g.num_states, g.start_state), rec)
     return rec
@@ -195,6 +234,32 @@ class ChainGraphBatch(object):
                 "ChainGraphBatch should be either initialized by a "
                 "single ChainGraph object or a list of ChainGraph objects "
                 "but given {}".format(type(graphs)))
+
+    def __getstate__(self):
+        # device copies never travel; a batch built from a list travels as its ONE buffer (the ten tensors are views of it
+        # and are re-made on arrival - pickled one by one they would stop sharing storage and the one-copy upload with them)
+        d = dict(self.__dict__)
+        d["_device_cache"] = {}
+        if self.shared_graph is None and self._packed_consistent():
+            for name, _shape, _dt in _PACKED:
+                d.pop(name, None)
+            d["_staging"] = self._staging.clone()            # (pageable: the receiver decides about pinning)
+            d["_repack"] = True
+        return d
+
+    def __setstate__(self, d):
+        repack = d.pop("_repack", False)
+        self.__dict__.update(d)
+        self._device_cache = {}
+        if repack:
+            st = self._staging
+            if _may_pin():
+                try:
+                    st = st.pin_memory()
+                except RuntimeError:
+                    pass
+            B, K, H = self._shape
+            self._install(st, self._offs, self._rows, B, K, H)
 
     def initialized_by_one(self, graph):
         # Same shapes/values as the reference's .repeat(B, ...) but zero-stride
@@ -251,7 +316,7 @@ class ChainGraphBatch(object):
             self.log_domain = graphs[0].log_domain
             self.num_states, self.num_transitions = H, K
             total, offs, rows = _layout(L, B, K, H, self.log_domain)
-            staging = torch.empty(total, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            staging = _staging_buffer(total)
             rec = np.array(recs, dtype=np.uint64)
             from . import _lib
             _lib.check(L.pychain_hip_batch_pack(B, K, H, int(self.log_domain), rec.ctypes.data_as(ctypes.c_void_p),
@@ -305,7 +370,7 @@ class ChainGraphBatch(object):
             B_out = int(order.numel())
             total, offs, rows = _layout(L, B_out, K, H, self.log_domain)
             old, old_cache = self._staging, self._device_cache
-            staging = torch.empty(total, dtype=torch.uint8, pin_memory=old.is_pinned())
+            staging = _staging_buffer(total, like=old)
             _lib.check(L.pychain_hip_batch_reorder(B_in, B_out, K, H, int(self.log_domain), old.data_ptr(), staging.data_ptr(),
                                                    order.data_ptr()), "pychain_hip_batch_reorder")
             old_key = self._device_key_packed()

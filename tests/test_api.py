@@ -219,3 +219,98 @@ def test_native_batch_pack_matches_the_python_collation(monkeypatch):
         assert torch.equal(c.final_probs[0], native.final_probs[1]) and c._staging is None
     with pytest.raises(_lib.PychainHipError):
         ChainGraphBatch(num, max_num_transitions=2, max_num_states=50)     # a graph larger than the batch allows
+
+
+def _small_num_graphs():
+    return [ChainGraph(syn.make_num_fst(h, 9, 300 + i), log_domain=True) for i, h in enumerate([5, 3, 4])]
+
+
+def _collate(graphs):
+    return ChainGraphBatch(list(graphs), max_num_transitions=max(g.num_transitions for g in graphs),
+                           max_num_states=max(g.num_states for g in graphs))
+
+
+def test_pack_cache_does_not_follow_a_copied_graph():
+    """the native collation remembers the host ADDRESSES of a graph's tensors on the graph.  A
+    copy.deepcopy / pickle of a collated graph must not carry them along (its tensors live elsewhere; in another
+    process the addresses are garbage): an edit of the copy has to show in a batch collated from the copy, also after
+    the original is gone."""
+    import copy
+    import gc
+    import pickle
+    graphs = _small_num_graphs()
+    _collate(graphs)                                           # (fills the caches)
+    for clone in (copy.deepcopy, lambda g: pickle.loads(pickle.dumps(g)), copy.copy):
+        g2 = clone(graphs[0])
+        assert "_pack_cache" not in g2.__dict__ and g2._plan_cache == {}
+        if clone is not copy.copy:                             # (a shallow copy shares its tensors: nothing to edit apart)
+            g2.forward_transition_probs.fill_(-5.0)
+        others = _small_num_graphs()[1:]
+        gb = _collate([g2] + others)
+        k = g2.num_transitions
+        assert torch.equal(gb.forward_transition_probs[0, :k], g2.forward_transition_probs)
+        assert torch.equal(gb.forward_transitions[0, :k], g2.forward_transitions)
+    # the original dies, its memory is reused, the copy is collated again
+    g2 = copy.deepcopy(graphs[0])
+    g2.forward_transition_probs.fill_(-7.0)
+    del graphs
+    gc.collect()
+    junk = [torch.full((64,), float(i)) for i in range(256)]     # noqa: F841  (recycles the freed blocks)
+    gb = _collate([g2])
+    assert torch.equal(gb.forward_transition_probs[0], g2.forward_transition_probs)
+    # a tensor whose storage is swapped under the same object (set_) is noticed too
+    g3 = _small_num_graphs()[0]
+    _collate([g3])
+    g3.forward_transition_probs.set_(torch.full_like(g3.forward_transition_probs, -9.0))
+    assert torch.equal(_collate([g3]).forward_transition_probs[0], g3.forward_transition_probs)
+
+
+def test_batch_survives_pickling_as_one_buffer():
+    """A batch built from a list travels (DataLoader worker -> trainer) as its ONE buffer and arrives with the ten
+    tensors as views of it again: the one-copy upload and the native reorder still apply on the other side."""
+    import pickle
+    gb = _collate(_small_num_graphs())
+    assert gb._packed_consistent()
+    gb2 = pickle.loads(pickle.dumps(gb))
+    assert gb2._packed_consistent() and gb2._device_cache == {}
+    for name in GRAPH_FIELDS + ["start_state"]:
+        a, b = getattr(gb, name), getattr(gb2, name)
+        assert (a is None and b is None) or torch.equal(a, b), name
+    gb2.reorder(torch.tensor([2, 0, 1]))
+    gb.reorder(torch.tensor([2, 0, 1]))
+    assert gb2._packed_consistent() and torch.equal(gb.forward_transitions, gb2.forward_transitions)
+
+
+class _UttSet(torch.utils.data.Dataset):
+    def __init__(self, graphs):
+        self.graphs = graphs
+
+    def __len__(self):
+        return 6
+
+    def __getitem__(self, i):
+        return self.graphs[i % len(self.graphs)]
+
+
+def _collate_fn(graphs):
+    gb = _collate(graphs)
+    assert not gb._staging.is_pinned()                         # a worker never touches the GPU runtime
+    return gb
+
+
+@pytest.mark.parametrize("ctx", ["fork", "spawn"])
+def test_collation_in_dataloader_workers(ctx):
+    """`ChainGraphBatch(list)` inside a DataLoader collate_fn with num_workers > 0 (the upstream usage
+    pattern) - pure CPU in the worker (no pinned allocation there), bit-equal to a collation in this process."""
+    graphs = _small_num_graphs()
+    want = _collate(graphs)
+    dl = torch.utils.data.DataLoader(_UttSet(graphs), batch_size=3, collate_fn=_collate_fn, num_workers=2,
+                                     multiprocessing_context=ctx)
+    n = 0
+    for gb in dl:
+        assert gb._packed_consistent()
+        for name in GRAPH_FIELDS:
+            a, b = getattr(want, name), getattr(gb, name)
+            assert (a is None and b is None) or torch.equal(a, b), name
+        n += 1
+    assert n == 2

@@ -160,6 +160,7 @@ def test_batch_is_staged_with_one_copy_and_reordered_on_the_device():
     in-place edit of a host tensor re-stages.  Reference: pychain/graph.py:122-194."""
     from pychain_amd.graph import _PACKED
     L = [50, 37, 44, 21]
+    torch.cuda.init()        # (pinned staging only in a process that already talks to the GPU - never in a DataLoader worker)
     gb = syn.make_num_graphs(L, 40, seed=100, max_states=12)
     assert gb._staging is not None and gb._staging.is_pinned()
     dev = torch.device(DEV)
