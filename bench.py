@@ -7,12 +7,18 @@ A step = one ChainLoss forward + backward (denominator + per-utterance numerator
 x.grad produced) over one synthetic minibatch already resident in HBM.  For N > 1 there is
 one rank per GPU: either the caller launched them (torch.distributed.run: WORLD_SIZE is
 set and must equal --gpus), or - WORLD_SIZE unset - this script re-executes itself under
-`python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1.  Every rank owns B
-utterances (weak scaling: global batch = N*B), and the only exchange per step is one RCCL
-all-reduce of [objf, n_frames, n_bad].
+`python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1.  The run is the PRODUCT'S
+sharded path (pychain_amd/parallel.py): every rank builds the same global minibatch of N*B
+utterances (weak scaling; --workload C3 at N = 8 is BASELINE.json's C5: global B = 512),
+takes its shard with `parallel.shard_batch` (length-sorted serpentine deal), draws the network
+output of exactly the utterances it owns, and steps `parallel.ShardedChainLoss`: the only
+exchange per step is ONE RCCL all-reduce of [objf, n_frames, n_bad].  N = 1
+goes through the same code with a world of one.
 
-`--dry-run` checks the launch / collective / JSON plumbing on a box without a GPU (gloo, the
-step is a no-op with a made-up frame count, "value" is meaningless and the line says so).
+`--dry-run` runs that very path on a box without a GPU (gloo, tiny shapes, a stand-in loss that
+is a plain torch function of the shard - no kernels, "value" is meaningless and the line says so)
+and checks what sharding can get wrong: every utterance owned once, frames add up, the global
+loss equals the single-process loss (tests/test_bench_launch.py).
 
 Rank 0 prints ONE JSON line: the driver contract plus
   "roofline"     for the dominant kernel (the denominator's alpha/beta recursion launch), measured here with
@@ -263,20 +269,20 @@ def fresh_num_graphs(w, dev, reps=5):
             "note": "per step on the launching thread; NOT in `value` (the reference pays the same work in Python: graph.py:122-194)"}
 
 
-def grad_slab_allreduce(x, world, rank, dev, iters=2):
+def grad_slab_allreduce(x, idx, global_batch, dev, iters=2):
     """OPTION measured beside the hot path: one fused all-reduce of the scalars
-    and the [B_global,T,D] gradient slab, so that every rank holds the whole gradient."""
+    and the [B_global,T,D] gradient slab, so that every rank holds the whole gradient.  `idx`: this rank's utterances."""
     from pychain_amd.parallel import allreduce_grad_slab
     B, T, D = x.shape
-    idx = torch.arange(B, device=dev) * world + rank
+    idx = idx.to(dev)
     stats = torch.zeros(3, device=dev)
-    buf = torch.empty(3 + B * world * T * D, dtype=torch.float32, device=dev)
+    buf = torch.empty(3 + global_batch * T * D, dtype=torch.float32, device=dev)
     g = x.grad if x.grad is not None else torch.zeros_like(x)
-    allreduce_grad_slab(g, idx, B * world, stats, out=buf)
+    allreduce_grad_slab(g, idx, global_batch, stats, out=buf)
     torch.cuda.synchronize(); dist.barrier(device_ids=[dev.index]); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        allreduce_grad_slab(g, idx, B * world, stats, out=buf)
+        allreduce_grad_slab(g, idx, global_batch, stats, out=buf)
     torch.cuda.synchronize(); dist.barrier(device_ids=[dev.index]); torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
     return {"ms_per_step": round(ms, 3), "bytes": int(buf.numel()) * 4,
@@ -410,46 +416,69 @@ def _cpu_all_cores(w, order, sec_per_utt):
                       "%d repetitions each, slowest worker %.1f s" % (int(order.numel()), nw, reps, tmax)}
 
 
-def dry_run(args, rank, world):
-    """The N-rank plumbing of main() with the GPU work taken out: gloo group, the per-step stats
-    all-reduce, max-over-ranks timing, ONE JSON line from rank 0."""
-    from pychain_amd.parallel import allreduce_stats
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
-    local_frames = 1000 + rank
-    for _ in range(args.warmup):
-        allreduce_stats(torch.zeros(()), float(local_frames), None)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        stats = allreduce_stats(torch.tensor(-1.0), float(local_frames), None)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    mine = torch.tensor([dt, float(local_frames)], dtype=torch.float64)
-    per_rank = [torch.zeros_like(mine) for _ in range(world)]
-    if world > 1:
-        dist.all_gather(per_rank, mine)
+class _DenOnlyLoss(torch.nn.Module):
+    """`loss_cls` of ShardedChainLoss for the workloads without numerators (C2, C4): the denominator ChainFunction."""
+    reports_bad_count = True
+
+    def __init__(self, den_graph, leaky, avg=False):
+        super().__init__()
+        self.den_graph, self.leaky = den_graph, leaky
+
+    def forward(self, x, lengths, num_graphs):
+        from pychain_amd import ChainFunction, ChainGraphBatch
+        return ChainFunction.apply(x, lengths, ChainGraphBatch(self.den_graph, x.size(0)), self.leaky)
+
+
+class _DryLoss(torch.nn.Module):
+    """--dry-run stand-in for the per-rank loss (no kernels, no GPU): a plain torch function of the shard that depends on
+    every input the sharding moves - the network output of each utterance up to ITS length and ITS numerator graph - so a
+    wrong deal, a wrong reorder or a lost utterance changes the global sum."""
+
+    def __init__(self, den_graph, leaky, avg=False):
+        super().__init__()
+
+    def forward(self, x, lengths, num_graphs):
+        T = x.size(1)
+        live = (torch.arange(T)[None, :] < torch.as_tensor(lengths)[:, None]).to(x.dtype)
+        per_utt = (x.double().sum(-1) * live).sum(-1)
+        tag = num_graphs.forward_transitions.double().sum((1, 2)) + num_graphs.final_probs.clamp(min=-1e3).double().sum(1)
+        return (per_utt * (1.0 + 1e-3 * tag)).sum().float()
+
+
+def rank_shard(args, world, rank, dev, dry=False):
+    """The global minibatch of the run, identical on every rank, and THIS rank's shard of it through the product's
+    partitioner (parallel.shard_batch).  Returns (shard dict like synthetic.make_workload's, global dict, idx)."""
+    from pychain_amd import synthetic as syn
+    from pychain_amd.parallel import shard_batch
+    if dry:
+        B, T, D = 3, 24, 16                                # per rank; tiny: the stand-in loss is a torch expression
+        cfg = dict(B=B, T=T, H=12, K=40, D=D, lengths="ragged", num=True, B_global=B * world, name="dry")
+        lengths = syn.make_lengths(B * world, T, "ragged", seed=2)
+        g = dict(cfg=cfg, lengths=lengths, den_graph=syn.make_den_graph(12, 40, D, seed=0),
+                 num_graphs=syn.make_num_graphs(lengths.tolist(), D, seed=100, max_states=6))
+    elif world == 1:
+        # the configuration BASELINE.json's metric is quoted on, the same bytes as in every earlier round
+        w = syn.make_workload(args.workload, device=dev)
+        g = dict(cfg=dict(w["cfg"], B_global=w["cfg"]["B"]), lengths=w["lengths"], den_graph=w["den_graph"],
+                 num_graphs=w["num_graphs"], x=w["x"])
     else:
-        per_rank = [mine]
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        print(json.dumps({
-            "metric": "LF-MMI frames/sec (fwd+bwd)", "value": None, "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax) / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
-            "dry_run": True, "frames_per_step_all_ranks": float(stats[1]),
-            "per_rank": {"ms_per_step": [round(float(p[0]) / args.steps * 1e3, 4) for p in per_rank],
-                         "frames": [int(p[1]) for p in per_rank]},
-            "config": {"workload": "dry run (no kernels)", "parallelism": "utterance-sharded dp%d" % world,
-                       "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"}}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        g = syn.make_global_workload(args.workload, world)
+    cfg = g["cfg"]
+    xs, ls, gs, idx = shard_batch(g.pop("x", None), g["lengths"], g["num_graphs"], world, rank)
+    if xs is None:
+        xs = syn.make_input_utterances(idx, cfg["T"], cfg["D"], seed=1, device=dev)
+    shard = dict(cfg=dict(cfg, B=int(idx.numel()), name=args.workload), x=xs, lengths=ls, lengths_dev=ls.to(dev),
+                 den_graph=g["den_graph"], num_graphs=gs)
+    return shard, g, idx
+
+
+def workload_label(args, cfg, world, local_frames, global_frames):
+    name = "C5" if (args.workload == "C3" and world == 8) else (args.workload if world == 1 else "%sx%d" % (args.workload, world))
+    what = "%d pdfs, den %d states/%d arcs%s" % (cfg["D"], cfg["H"], cfg["K"], " + per-utt log-domain numerators" if cfg["num"] else "")
+    if world == 1:
+        return "%s: B=%d ragged T<=%d (%d frames), %s" % (name, cfg["B"], cfg["T"], local_frames, what)
+    return ("%s: global B=%d ragged T<=%d (%d frames), batch-sharded over %d GPUs by parallel.shard_batch (%d utterances, "
+            "%d frames on rank 0), %s" % (name, cfg["B_global"], cfg["T"], global_frames, world, cfg["B"], local_frames, what))
 
 
 def main():
@@ -461,118 +490,146 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
-    if args.dry_run:
-        return dry_run(args, rank, world)
-    if not torch.cuda.is_available():
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the LF-MMI path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
-    from pychain_amd import ChainFunction, ChainLoss, synthetic as syn
-    from pychain_amd.parallel import allreduce_stats
+    from pychain_amd.parallel import ShardedChainLoss
 
-    # every rank draws its own utterances (seed offset by rank): weak scaling, global B = world * B
-    w = syn.make_workload(args.workload, device=dev, seed=0, data_seed=1000 * rank)
-    w["cfg"]["name"] = args.workload
+    w, glob, idx = rank_shard(args, world, rank, dev, dry)
     cfg = w["cfg"]
-    w["lengths_dev"] = w["lengths"].to(dev)
     x = w["x"].requires_grad_(True)
-    loss_fn = ChainLoss(w["den_graph"], 1e-5, avg=False)
+    loss_cls = _DryLoss if dry else (None if cfg["num"] else _DenOnlyLoss)
+    loss_fn = ShardedChainLoss(w["den_graph"], 1e-5, avg=False, loss_cls=loss_cls)
     local_frames = int(w["lengths"].sum())
-    frames_t = torch.tensor([float(local_frames)], device=dev)
+    lengths_step = w["lengths"] if dry else w["lengths_dev"]
 
     def step():
         x.grad = None
-        if w["num_graphs"] is not None:
-            loss = loss_fn(x, w["lengths_dev"], w["num_graphs"])
-        else:
-            from pychain_amd import ChainGraphBatch
-            loss = ChainFunction.apply(x, w["lengths_dev"], ChainGraphBatch(w["den_graph"], cfg["B"]))
+        loss = loss_fn(x, lengths_step, w["num_graphs"])     # local evaluation + the ONE all-reduce of [objf, frames, bad]
         loss.backward()
-        stats = allreduce_stats(loss.detach(), frames_t, ChainFunction.last_bad_count)
-        return stats
+        return loss
 
     def fence():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+            dist.barrier(device_ids=None if dry else [local_rank])
+        if not dry:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stats = step()
+        loss = step()
     fence()
     dt = time.perf_counter() - t0
-    # per-rank view (imbalance between the shards is the only thing that can cost the scaling): each rank's own
-    # time for the K steps and its frame count, gathered once after the timed region
-    mine = torch.tensor([dt, float(local_frames)], device=dev, dtype=torch.float64)
+    stats = loss_fn.last_stats
+    # per-rank view (imbalance between the shards is the only thing that can cost the scaling): each rank's own time
+    # for the K steps, its frame count, its longest sequence and its utterance count, gathered once after the timed region
+    mine = torch.tensor([dt, float(local_frames), float(w["lengths"].max()), float(idx.numel())], device=dev, dtype=torch.float64)
     per_rank = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
         dist.all_gather(per_rank, mine)
     else:
         per_rank = [mine]
+    owned = [torch.full((cfg["B"],), -1, dtype=torch.int64, device=dev) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(owned, idx.to(dev))
+    else:
+        owned = [idx.to(dev)]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     total_frames = float(stats[1])            # all-reduced frame count of one step
     n_bad = int(stats[2])
+    global_frames = int(glob["lengths"].sum())
     slab = None
-    if world > 1 and not args.no_grad_slab:
+    if world > 1 and not args.no_grad_slab and not dry:
         try:
-            slab = grad_slab_allreduce(x, world, rank, dev)
+            slab = grad_slab_allreduce(x, idx, cfg["B_global"], dev)
         except Exception as e:      # an option beside the metric: never lose the bench line to it
             slab = {"error": str(e)[:200]}
 
     if rank == 0:
-        # (N > 1: the other ranks idle in a barrier behind this: 3 launches per kernel there, ~50 ms)
-        roof = None if args.no_rooflines else kernel_rooflines(w, dev, 3 if world > 1 else max(3, min(args.steps, 10)), d2d=world == 1)
-        out = {
-            "metric": "LF-MMI frames/sec (fwd+bwd)", "value": round(total_frames * args.steps / dt, 1),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: B=%d/GPU ragged T<=%d (%d frames/GPU), %d pdfs, den %d states/%d arcs%s"
-                                   % (args.workload, cfg["B"], cfg["T"], local_frames, cfg["D"], cfg["H"],
-                                      cfg["K"], " + per-utt log-domain numerators" if cfg["num"] else ""),
-                       "global_batch": cfg["B"] * world, "parallelism": "utterance-sharded dp%d" % world,
-                       "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"},
-            "n_bad": n_bad, "roofline": roof,
-            "per_rank": {"ms_per_step": [round(float(p[0]) / args.steps * 1e3, 4) for p in per_rank],
-                         "frames": [int(p[1]) for p in per_rank],
-                         "ms_per_step_min": round(min(float(p[0]) for p in per_rank) / args.steps * 1e3, 4),
-                         "ms_per_step_max": round(max(float(p[0]) for p in per_rank) / args.steps * 1e3, 4)},
+        frames_pr = [int(p[1]) for p in per_rank]
+        ms_pr = [float(p[0]) / args.steps * 1e3 for p in per_rank]
+        all_owned = torch.cat([o.cpu() for o in owned]).sort().values
+        sharding = {
+            "partitioner": "pychain_amd.parallel.shard_batch (length-sorted serpentine deal) + ShardedChainLoss",
+            "every_utterance_owned_once": bool(torch.equal(all_owned, torch.arange(cfg["B_global"]))),
+            "frames_add_up": bool(sum(frames_pr) == global_frames and abs(total_frames - global_frames) < 0.5),
+            "frames_imbalance_max_over_mean": round(max(frames_pr) * world / max(1, sum(frames_pr)), 4),
+            "ms_imbalance_max_over_min": round(max(ms_pr) / max(1e-9, min(ms_pr)), 4),
         }
-        if roof is None:
-            out["roofline_note"] = "per-kernel rooflines skipped (--no-rooflines)"
-        if slab is not None:
-            out["grad_slab_allreduce"] = slab
-        if world == 1 and cfg["num"] and not args.no_fresh_num_graphs:
-            try:
-                out["host_graph_batch"] = fresh_num_graphs(w, dev)
-            except Exception as e:
-                out["host_graph_batch"] = {"error": str(e)[:200]}
-        if world == 1 and not args.no_other_workloads and args.workload == "C3":
-            keep = {k: w[k] for k in ("cfg", "lengths", "den_graph", "num_graphs")}
-            x_cpu = w["x"].detach().float().cpu() if not args.no_cpu_baseline else None
-            del x
-            w.pop("x")
-            torch.cuda.empty_cache()
-            out["other_workloads"] = other_workloads(dev)
-            if x_cpu is not None:
-                keep["x"] = x_cpu
-            w = keep
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
-        print(json.dumps(out))
+        per_rank_out = {"ms_per_step": [round(m, 4) for m in ms_pr], "frames": frames_pr,
+                        "longest_sequence": [int(p[2]) for p in per_rank], "utterances": [int(p[3]) for p in per_rank],
+                        "ms_per_step_min": round(min(ms_pr), 4), "ms_per_step_max": round(max(ms_pr), 4)}
+        config = {"workload": "dry run (no kernels): " + workload_label(args, cfg, world, local_frames, global_frames) if dry
+                  else workload_label(args, cfg, world, local_frames, global_frames),
+                  "global_batch": cfg["B_global"], "parallelism": "utterance-sharded dp%d" % world,
+                  "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"}
+        if dry:
+            # what only a CPU run can afford: the whole global batch in ONE process against the sharded sum
+            from pychain_amd import synthetic as syn
+            xg = syn.make_input_utterances(range(cfg["B_global"]), cfg["T"], cfg["D"], seed=1)
+            single = float(_DryLoss(None, 0)(xg, glob["lengths"], glob["num_graphs"]))
+            sharding["loss_equals_single_process"] = bool(abs(float(loss.detach()) - single) <= 1e-5 * max(1.0, abs(single)))
+            print(json.dumps({
+                "metric": "LF-MMI frames/sec (fwd+bwd)", "value": None, "unit": "frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                "dry_run": True, "frames_per_step_all_ranks": total_frames, "global_frames": global_frames,
+                "loss": float(loss.detach()), "loss_single_process": single,
+                "per_rank": per_rank_out, "sharding": sharding, "config": config}))
+        else:
+            # (N > 1: the other ranks idle in a barrier behind this: 3 launches per kernel there, ~50 ms)
+            roof = None if args.no_rooflines else kernel_rooflines(w, dev, 3 if world > 1 else max(3, min(args.steps, 10)), d2d=world == 1)
+            out = {
+                "metric": "LF-MMI frames/sec (fwd+bwd)", "value": round(total_frames * args.steps / dt, 1),
+                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config,
+                "n_bad": n_bad, "roofline": roof, "per_rank": per_rank_out, "sharding": sharding,
+            }
+            if roof is None:
+                out["roofline_note"] = "per-kernel rooflines skipped (--no-rooflines)"
+            if slab is not None:
+                out["grad_slab_allreduce"] = slab
+            if world == 1 and cfg["num"] and not args.no_fresh_num_graphs:
+                try:
+                    out["host_graph_batch"] = fresh_num_graphs(w, dev)
+                except Exception as e:
+                    out["host_graph_batch"] = {"error": str(e)[:200]}
+            if world == 1 and not args.no_other_workloads and args.workload == "C3":
+                keep = {k: w[k] for k in ("cfg", "lengths", "den_graph", "num_graphs")}
+                x_cpu = w["x"].detach().float().cpu() if not args.no_cpu_baseline else None
+                del x
+                w.pop("x")
+                torch.cuda.empty_cache()
+                out["other_workloads"] = other_workloads(dev)
+                if x_cpu is not None:
+                    keep["x"] = x_cpu
+                w = keep
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
+            print(json.dumps(out))
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=None if dry else [local_rank])
         dist.destroy_process_group()
 
 

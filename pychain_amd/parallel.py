@@ -33,11 +33,13 @@ def shard_indices(lengths, world_size, rank):
 
 
 def shard_batch(x, lengths, num_graphs, world_size, rank):
-    """Slice (x, lengths, num_graphs) down to this rank's shard."""
+    """Slice (x, lengths, num_graphs) down to this rank's shard: (x_shard, lengths_shard, num_graphs_shard, idx) with
+    idx = this rank's utterance indices in the global batch.  `x` may be None when the caller materialises only its own
+    rows (a data loader that reads utterances `idx`; bench.py at N > 1, where the global [B,T,D] does not exist)."""
     from .graph import ChainGraphBatch
     idx = shard_indices(lengths, world_size, rank)
     lengths = torch.as_tensor(lengths)
-    xs = x.index_select(0, idx.to(x.device))
+    xs = x.index_select(0, idx.to(x.device)) if x is not None else None
     ls = lengths.index_select(0, idx.to(lengths.device))
     gs = None
     if num_graphs is not None:
@@ -95,16 +97,22 @@ class ShardedChainLoss(torch.nn.Module):
 
     def __init__(self, den_graph, leaky_coefficient=1e-5, avg=True, group=None, loss_cls=None):
         super().__init__()
+        self._native = loss_cls is None or bool(getattr(loss_cls, "reports_bad_count", False))
         if loss_cls is None:
             from .loss import ChainLoss as loss_cls
         self.local = loss_cls(den_graph, leaky_coefficient, avg=False)
         self.avg = avg
         self.group = group
+        self.last_stats = None      # [global objf, global frames, global bad count] of the last step (device, never synced here)
 
     def forward(self, x, x_lengths, num_graphs):
         local = self.local(x, x_lengths, num_graphs)                  # sum over local utterances
         frames = torch.as_tensor(x_lengths).sum()
-        stats = allreduce_stats(local, frames, None, self.group)
+        bad = None
+        if self._native:                                              # the reference's `ok` of every rank rides along
+            from .loss import ChainFunction
+            bad = ChainFunction.last_bad_count
+        stats = self.last_stats = allreduce_stats(local, frames, bad, self.group)
         # value: global; gradient: d(local)/dx scaled by the global normaliser
         denom = stats[1] if self.avg else torch.ones((), device=stats.device)
         return (local - local.detach() + stats[0]) / denom

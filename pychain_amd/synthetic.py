@@ -17,7 +17,8 @@ from .graph import ChainGraph, ChainGraphBatch
 from .simplefst import StdVectorFst
 
 __all__ = ["CONFIGS", "uniform", "normal", "make_den_fst", "make_den_graph", "make_num_fst",
-           "make_num_graphs", "make_lengths", "make_input", "make_workload"]
+           "make_num_graphs", "make_lengths", "make_input", "make_input_utterances", "make_global_workload",
+           "make_workload"]
 
 CONFIGS = {
     "C1": dict(B=2, T=50, H=20, K=60, D=40, lengths=[50, 37], num=True),
@@ -128,6 +129,34 @@ def make_input(B, T, D, seed=1, scale=2.0, device="cpu"):
         return torch.randn(B, T, D, generator=g, device=device, dtype=torch.float32) * scale
     x = normal(seed, B * T * D).astype(np.float32) * np.float32(scale)
     return torch.from_numpy(x.reshape(B, T, D))
+
+
+def make_input_utterances(indices, T, D, seed=1, scale=2.0, device="cpu"):
+    """Rows `indices` of a GLOBAL [B,T,D] network output that is never materialised: utterance i is its own random stream
+    (seed, i), so every rank of a sharded run draws exactly the utterances it owns and all ranks agree on what utterance
+    i is (bench.py --gpus N; a data loader reading utterances by index does the same)."""
+    idx = [int(i) for i in indices]
+    out = torch.empty(len(idx), T, D, dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    for j, i in enumerate(idx):
+        g.manual_seed(int(seed) * 1000003 + i)
+        out[j] = torch.randn(T, D, generator=g, device=device, dtype=torch.float32)
+    return out.mul_(scale)
+
+
+def make_global_workload(name, world_size, seed=0):
+    """The global minibatch of a `world_size`-GPU run of BASELINE config `name`: world_size x B utterances (BASELINE.json's
+    C5 = C3 at world_size 8: global B = 512) - lengths, the shared denominator graph and all numerator graphs, on the host,
+    identical on every rank.  The network output is drawn per utterance (make_input_utterances)."""
+    cfg = dict(CONFIGS[name])
+    cfg["B_global"] = cfg["B"] * int(world_size)
+    mode = cfg["lengths"]
+    if isinstance(mode, (list, tuple)):
+        mode = sorted(list(mode) * int(world_size), reverse=True)
+    lengths = make_lengths(cfg["B_global"], cfg["T"], mode, seed=seed + 2)
+    den = make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=seed)
+    num = make_num_graphs(lengths.tolist(), cfg["D"], seed=seed + 100) if cfg["num"] else None
+    return dict(lengths=lengths, den_graph=den, num_graphs=num, cfg=cfg)
 
 
 def make_workload(name, device="cpu", seed=0, data_seed=None):

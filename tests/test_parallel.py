@@ -95,3 +95,24 @@ def test_training_example_two_ranks_ddp_on_gloo():
     assert sorted(seen) == [0, 1], r.stdout
     assert seen[0] == seen[1]                         # the value every rank holds is the global one
     assert seen[0][1] < seen[0][0]                    # and it fell
+
+
+def test_global_workload_is_the_same_on_every_rank_and_sharded_without_materialising_it():
+    """bench.py --gpus N: every rank builds the same global minibatch (lengths, graphs), owns the utterances shard_batch deals
+    to it and draws the network output of exactly those (synthetic.make_input_utterances) - the global [B,T,D] never exists."""
+    world = 4
+    g = syn.make_global_workload("C1", world)
+    g2 = syn.make_global_workload("C1", world)
+    assert torch.equal(g["lengths"], g2["lengths"]) and g["cfg"]["B_global"] == 2 * world
+    assert torch.equal(g["num_graphs"].forward_transitions, g2["num_graphs"].forward_transitions)
+    T, D = g["cfg"]["T"], g["cfg"]["D"]
+    whole = syn.make_input_utterances(range(2 * world), T, D, seed=1)
+    seen = []
+    for r in range(world):
+        xs, ls, gs, idx = parallel.shard_batch(None, g["lengths"], g["num_graphs"], world, r)
+        assert xs is None and gs.batch_size == idx.numel() == 2
+        assert torch.equal(ls, g["lengths"][idx])
+        assert torch.equal(gs.forward_transitions, g["num_graphs"].forward_transitions[idx])
+        assert torch.equal(syn.make_input_utterances(idx, T, D, seed=1), whole[idx])
+        seen += idx.tolist()
+    assert sorted(seen) == list(range(2 * world))
