@@ -240,10 +240,14 @@ class ChainGraphBatch(object):
         # and are re-made on arrival - pickled one by one they would stop sharing storage and the one-copy upload with them)
         d = dict(self.__dict__)
         d["_device_cache"] = {}
+        d.pop("_pickle_keepalive", None)
         if self.shared_graph is None and self._packed_consistent():
             for name, _shape, _dt in _PACKED:
                 d.pop(name, None)
-            d["_staging"] = self._staging.clone()            # (pageable: the receiver decides about pinning)
+            # a pageable copy travels (torch's pickler moves a tensor's storage into shared memory IN PLACE, which would
+            # un-pin this batch's buffer and re-stage it); the receiver decides about pinning.  The copy has to outlive the
+            # pickling - the receiver maps its shared-memory file later - so it stays with the batch.
+            d["_staging"] = self.__dict__["_pickle_keepalive"] = self._staging.clone()
             d["_repack"] = True
         return d
 

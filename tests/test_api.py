@@ -314,3 +314,23 @@ def test_collation_in_dataloader_workers(ctx):
             assert (a is None and b is None) or torch.equal(a, b), name
         n += 1
     assert n == 2
+
+
+def _child_sum(gb, q):
+    q.put(float(gb.forward_transition_probs.sum()) if gb._packed_consistent() else None)
+
+
+def test_batch_as_an_argument_of_a_spawned_process():
+    """What tests/helpers.py:oracle_fanout and bench.py's all-cores CPU leg do: a collated batch (and a copy.copy of one)
+    handed to `torch.multiprocessing` spawn workers.  The buffer that travels must outlive the pickling."""
+    import copy
+    import torch.multiprocessing as mp
+    gb = _collate(_small_num_graphs())
+    ctx = mp.get_context("spawn")
+    for obj in (gb, copy.copy(gb)):
+        q = ctx.Queue()
+        p = ctx.Process(target=_child_sum, args=(obj, q))
+        p.start()
+        got = q.get(timeout=120)
+        p.join()
+        assert p.exitcode == 0 and got == float(gb.forward_transition_probs.sum())
