@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 11
+#define PYCHAIN_HIP_ABI_VERSION 12
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -180,14 +180,19 @@ int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t 
  * bad_count: dev int32[1]; zeroed by the call, incremented by every frame or
  *   sequence whose normaliser is not finite-positive (the reference's `ok`
  *   flag, chain-computation.cc:367-390, without a host sync).
+ * totals: dev float[4] or NULL.  The call's last kernel adds up what a caller otherwise computes in several
+ *   launch-bound scalar kernels behind it (the reference: `tot_log_prob.sum()`, chain-computation.cc:229):
+ *   totals[0] = totals[3] = sum_b objf_per_seq[b] (fp64 accumulation, rounded once), totals[1] = sum_b len_b,
+ *   totals[2] = bad_count as a float.
  */
+#define PYCHAIN_HIP_TOTALS 4
 size_t pychain_hip_den_workspace_bytes(int B, int T, int num_states, int num_pdfs);
 int pychain_hip_den_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows,
     int num_states, int num_pdfs,
     const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
     int B, int T, float leaky_hmm_coefficient, float grad_scale,
-    float* objf_per_seq, float* grad, int32_t* bad_count,
+    float* objf_per_seq, float* grad, int32_t* bad_count, float* totals,
     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -257,6 +262,7 @@ int pychain_hip_chain_loss_forward_backward(
     /* shared */
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs, float grad_scale,
     float* den_objf_per_seq, float* num_objf_per_seq, float* grad, int32_t* bad_count,
+    float loss_scale, const float* loss_norm_dev, float* totals,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
 
@@ -277,6 +283,11 @@ int pychain_hip_chain_loss_forward_backward(
  *              read on the device: no host sync and no extra pass over [B,T,D] to apply it
  *              (the reference multiplies the stored gradient again, loss.py:85).
  * bad_count: dev int32[2] for _forward, dev int32[2] for _backward (may be the same words).
+ * totals (dev float[4] or NULL; _forward and _forward_backward): the scalars of ChainLoss.forward from the call's last
+ *   kernel instead of from half a dozen scalar kernels of the host framework behind it (pychain/loss.py:100-104):
+ *   totals[0] = (sum_b den_objf[b] - sum_b num_objf[b]) * loss_scale [/ *loss_norm_dev]  = -(num - den) [/ frames],
+ *   totals[1] = sum_b len_b, totals[2] = bad_count[0] + bad_count[1] as a float (what a sharded trainer all-reduces
+ *   with the loss), totals[3] = sum den - sum num unscaled.  loss_norm_dev: device float or NULL.
  */
 int pychain_hip_chain_loss_forward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
@@ -289,6 +300,7 @@ int pychain_hip_chain_loss_forward(
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs,
     float* den_objf_per_seq, float* num_objf_per_seq,
     float* grad /* may be NULL */, float grad_scale, int32_t* bad_count,
+    float loss_scale, const float* loss_norm_dev, float* totals /* may be NULL */,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
 /* data[0..n) *= *scale_dev, skipped on the device when the scalar is exactly 1. */

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -34,15 +34,15 @@ _SIGNATURES = {
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pychain_hip_den_plan_info": (_i, [_vp, _sz, _vp]),
     "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _f,
-                                              _vp, _vp, _vp, _vp, _sz, _vp]),
+                                              _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pychain_hip_num_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "pychain_hip_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
                                               _vp, _vp, _vp, _vp, _sz, _vp]),
     "pychain_hip_chain_loss_forward_backward": (_i, [_vp, _i64, _i, _i, _f] + [_vp] * 8 + [_i, _i, _i]
-                                                + [_vp, _vp, _i, _i, _i, _f] + [_vp] * 4
+                                                + [_vp, _vp, _i, _i, _i, _f] + [_vp] * 4 + [_f, _vp, _vp]
                                                 + [_vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_chain_loss_forward": (_i, [_vp, _i64, _i, _i, _f] + [_vp] * 8 + [_i, _i, _i]
-                                       + [_vp, _vp, _i, _i, _i] + [_vp, _vp, _vp, _f, _vp]
+                                       + [_vp, _vp, _i, _i, _i] + [_vp, _vp, _vp, _f, _vp] + [_f, _vp, _vp]
                                        + [_vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_rescale": (_i, [_vp, _sz, _vp, _vp]),
     "pychain_hip_loss_total": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),

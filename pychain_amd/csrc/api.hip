@@ -242,6 +242,8 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.seq_progress = (int32_t*)(ws + align256(4 * (size_t)B * T * a.Hp) + align256(4 * (size_t)B * (T + 1) * a.Hp));   // [2][B]
   a.progress = (int32_t*)((char*)a.seq_progress + align256(8 * (size_t)B));
   a.stream_next = a.progress + 32;
+  a.finish_count = a.progress + 40;
+  a.loss_out = nullptr; a.loss_num_objf = nullptr; a.loss_scale = 1.f; a.loss_norm_dev = nullptr; a.bad_words = 1;
   a.stream = 0;
   a.tot_a = (float*)((char*)a.progress + 256);
   a.tot_b = (float*)((char*)a.tot_a + align256(4 * (size_t)B * (T + 2)));
@@ -372,6 +374,12 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
                             hipEvent_t gamma_wait) {
   const int gmax = (a.D + 63) / 64;
   const int user_mask = a.phase_mask;
+  // ONE memset per call for every counter the launches of a call share: per-sequence progress, gate counters, the queue head
+  // of the streamed occupancy pass, den_finish_kernel's arrival counter
+  if (user_mask & 1) {
+    const hipError_t em = hipMemsetAsync(a.seq_progress, 0, align256(8 * (size_t)a.B) + 256, st);
+    if (em != hipSuccess) return em;
+  }
   if (resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) {
     // a plan in the general format: den_general.hip, no overlap (rows in den_recursion_kernel's normalised form)
     a.lazy = 0; a.pair = 0; a.wide = 0;
@@ -435,8 +443,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     // launch: what is left when the recursions end is the last ring of every sequence.
     a.stream = 1; a.sig_n = 1; a.stream_blocks = device_cu_count();
     a.seg_bound[0] = std::min(a.T, (a.T / 2 + 31) / 32 * 32);
-    e = hipMemsetAsync(a.seq_progress, 0, align256(8 * (size_t)a.B) + 256, st);    // per-sequence progress, gate counters, queue head
-    if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);
+    if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // (the occupancy launch must see the zeroed counters)
     if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
     a.phase_mask = 1; a.seg_begin = 0; a.seg_end = 0x7fffffff;
     if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
@@ -454,7 +461,6 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     // steps below seg_bound[s] are done, and a one-wave gate kernel in front of occupancy launch s (side
     // stream) waits for all 2B of them.  No relaunch of the persistent workgroups at the segment ends.
     a.sig_n = nseg - 1;
-    e = hipMemsetAsync(a.progress, 0, 16 * sizeof(int32_t), st);
     if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // the gates must see the zeroed counters
     if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
     a.phase_mask = 1; a.seg_begin = 0; a.seg_end = 0x7fffffff;
@@ -519,13 +525,14 @@ extern "C" int pychain_hip_den_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int H, int D,
     const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
     int B, int T, float leaky_hmm_coefficient, float grad_scale,
-    float* objf_per_seq, float* grad, int32_t* bad_count,
+    float* objf_per_seq, float* grad, int32_t* bad_count, float* totals,
     void* workspace, size_t workspace_bytes, void* stream) {
   DenArgs a;
   int rc = fill_den_args(a, plans_dev, plan_stride_bytes, resident_slot_rows, H, D, nnet_output, input_is_exp, seq_lengths, B, T,
                          leaky_hmm_coefficient, grad_scale, objf_per_seq, grad, bad_count, workspace,
                          workspace_bytes, "den_forward_backward");
   if (rc != PYCHAIN_HIP_OK) return rc;
+  a.loss_out = totals;                                 // (sum of the per-sequence objectives, frames, bad count: den_finish_kernel)
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: hipMemsetAsync failed");
@@ -636,6 +643,7 @@ extern "C" int pychain_hip_chain_loss_forward(
     const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
     float* den_objf, float* num_objf, float* grad, float grad_scale, int32_t* bad_count,
+    float loss_scale, const float* loss_norm_dev, float* totals,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
   const char* who = "chain_loss_forward";
   if (!bad_count) return fail(PYCHAIN_HIP_EINVAL, "%s: null bad_count", who);
@@ -650,6 +658,8 @@ extern "C" int pychain_hip_chain_loss_forward(
                      grad ? grad : (float*)num_ws, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   na.watch_nan = 0;              // the denominator's alpha workgroups watch every element of every row (NumArgs::watch_nan)
+  // the scalars of ChainLoss.forward from den_finish_kernel's last workgroup (DenArgs::loss_out)
+  da.loss_out = totals; da.loss_num_objf = num_objf; da.loss_scale = loss_scale; da.loss_norm_dev = loss_norm_dev; da.bad_words = 2;
   hipStream_t st = (hipStream_t)stream;
   SideStream* side = side_streams_for(st);
   if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "%s: cannot create the side stream", who);
@@ -674,8 +684,10 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (e == hipSuccess && grad) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
   da.phase_mask = 3;
-  if (e == hipSuccess) e = run_den(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr);
+  // (den_finish_kernel reads the numerator's objectives and its bad count for `totals`: the join precedes it)
+  if (e == hipSuccess) e = run_den_launches(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
+  if (e == hipSuccess) e = launch_den_finish(da, st);
   if (e == hipSuccess && grad && !fold) e = launch_num_scatter(na, st, &why);      // grad -= grad_scale * gamma_num
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
@@ -792,12 +804,13 @@ extern "C" int pychain_hip_chain_loss_forward_backward(
     const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
     const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D, float grad_scale,
     float* den_objf, float* num_objf, float* grad, int32_t* bad_count,
+    float loss_scale, const float* loss_norm_dev, float* totals,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
   if (!grad) return fail(PYCHAIN_HIP_EINVAL, "chain_loss_forward_backward: null grad");
   return pychain_hip_chain_loss_forward(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky, ft, fi, fp, bt,
                                         bi, bp, initial, final_, graph_batch_stride, num_H, num_K, nnet_output,
-                                        seq_lengths, B, T, D, den_objf, num_objf, grad, grad_scale, bad_count, den_ws,
-                                        den_ws_bytes, num_ws, num_ws_bytes, stream);
+                                        seq_lengths, B, T, D, den_objf, num_objf, grad, grad_scale, bad_count, loss_scale,
+                                        loss_norm_dev, totals, den_ws, den_ws_bytes, num_ws, num_ws_bytes, stream);
 }
 
 // ---- on-device reorder of a staged batch (include/pychain_hip.h: batch containers) ------------------------------------

@@ -77,6 +77,15 @@ struct DenArgs {
   const int32_t* fold_ucount;    // [B]
   int fold_K;
   float fold_scale;
+  // Step totals (include/pychain_hip.h: loss_out): the den_finish_kernel workgroup that finishes LAST adds up what the host
+  // framework would otherwise compute in half a dozen launch-bound scalar kernels behind it (sums of the per-sequence
+  // objectives, the loss arithmetic of pychain/loss.py:100-104, frame and bad counts).  Null = not wanted.
+  float* loss_out;               // [4]: loss, frames, bad total, sum den - sum num (unscaled)
+  const float* loss_num_objf;    // [B] numerator objectives (written by an earlier launch), or null: denominator only
+  float loss_scale;              // loss = (sum den - sum num) * loss_scale [/ *loss_norm_dev]
+  const float* loss_norm_dev;    // optional device scalar (the frame count of avg = True when the lengths live on the device)
+  int32_t* finish_count;         // [1], zeroed with the progress counters
+  int bad_words;                 // bad[0 .. bad_words) are added up into loss_out[2]
   CallKnobs knobs;               // this call's snapshot of the library settings (host side only)
 };
 

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
   const float objf = (float)logp;
   int bad = 0;
   if (tid == 0) {
-    a.objf[b] = objf;
+    __hip_atomic_store(a.objf + b, objf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the last workgroup: loss_out)
     if (!(objf - objf == 0.f)) bad = 1;                    // -inf (the graph cannot end), NaN
   }
   if (a.check) {
@@ -432,6 +432,36 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
     }
   }
   if (bad) atomicAdd(a.bad, 1);
+  if (a.loss_out == nullptr) return;
+  // ---- step totals by the workgroup that finishes last (DenArgs::loss_out).  Every workgroup publishes its sequence's
+  // objective and its `bad` increment with the release half of the counter increment; the last one acquires them all.
+  __shared__ int s_last;
+  __syncthreads();                                           // (tid 0 wrote objf[b] and counted into bad above)
+  if (tid == 0)
+    s_last = __hip_atomic_fetch_add(a.finish_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  double acc = 0.0, frames = 0.0;
+  for (int i = tid; i < a.B; i += kFinNT) {
+    acc += (double)__hip_atomic_load(a.objf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.loss_num_objf) acc -= (double)a.loss_num_objf[i];
+    frames += (double)seq_len(a.lengths, i, a.T);
+  }
+  sh[tid] = acc;
+  __syncthreads();
+  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
+  const double total = sh[0];
+  __syncthreads();
+  sh[tid] = frames;
+  __syncthreads();
+  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    double t = total * (double)a.loss_scale;                 // -(num - den) [* 1/frames], pychain/loss.py:100-104, rounded once
+    if (a.loss_norm_dev) t /= (double)*a.loss_norm_dev;
+    int nbad = 0;
+    for (int i = 0; i < a.bad_words; i++) nbad += __hip_atomic_load(a.bad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.loss_out[0] = (float)t; a.loss_out[1] = (float)sh[0]; a.loss_out[2] = (float)nbad; a.loss_out[3] = (float)total;
+  }
 }
 
 // block total of per-wave partials: red[16] in LDS (entries >= kNW stay zero)

@@ -34,12 +34,14 @@ class ChainFunction(torch.autograd.Function):
                 "input batch size ({}) does not equal to graph batch size ({})"
                 .format(B, graphs.batch_size))
         x = input.detach()
-        objf, input_grad, bad = ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient)
+        objf, input_grad, bad = ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient, totals=True)
         return ChainFunction._forward_tail(ctx, input, x, input_lengths, graphs, leaky_coefficient, objf, input_grad, bad)
 
     @staticmethod
-    def _occupancies(x, input_lengths, graphs, leaky_coefficient):
-        """(objf per sequence, occupancies = gradient for an upstream gradient of 1, bad_count)."""
+    def _occupancies(x, input_lengths, graphs, leaky_coefficient, totals=False):
+        """(objf per sequence, occupancies = gradient for an upstream gradient of 1, bad_count).  `totals`: the
+        denominator's last kernel also leaves [sum objf, frames, bad, sum objf] in ChainFunction.last_totals, and the sum
+        is returned in place of the per-sequence values (no reduction launch behind the call)."""
         D = x.size(2)
         if not graphs.log_domain:   # usually the denominator
             if graphs.shared_graph is not None:
@@ -58,9 +60,16 @@ class ChainFunction(torch.autograd.Function):
                     hit = _plan.batch_plans({n: getattr(graphs, n) for n in names}, D, x.device)
                     graphs._device_cache[key] = hit
                 plan = hit
-            objf, input_grad, bad = native.den_forward_backward(
-                plan, x, input_lengths, leaky_coefficient, input_is_exp=False)
+            if totals:
+                objf, input_grad, bad, tot = native.den_forward_backward(
+                    plan, x, input_lengths, leaky_coefficient, input_is_exp=False, totals=True)
+                ChainFunction.last_totals = tot
+                objf = tot[0]                  # (a view: no launch)
+            else:
+                objf, input_grad, bad = native.den_forward_backward(
+                    plan, x, input_lengths, leaky_coefficient, input_is_exp=False)
         else:                       # usually the numerator
+            ChainFunction.last_totals = None
             gt = graphs.device_tensors(x.device)
             gstride = 0 if graphs.shared_graph is not None else 1
             objf, input_grad, bad = native.num_forward_backward(
@@ -85,9 +94,10 @@ class ChainFunction(torch.autograd.Function):
         ctx.in_dtype = input.dtype   # fp16 / bf16 inputs are evaluated in fp32; the gradient goes back in their dtype
         ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
         ChainFunction.last_bad_count = bad
-        return objf.sum()
+        return objf.sum() if objf.dim() else objf              # (0-dim: the sum came with the call, a view of `last_totals`)
 
     retain_grad_buffer = False
+    last_totals = None           # device float[4] of the last native call that produced them (include/pychain_hip.h: totals)
 
     @staticmethod
     def backward(ctx, objf_grad):
@@ -158,17 +168,19 @@ class ChainLossFunction(torch.autograd.Function):
         # with the recursions, for an upstream gradient of 1 (what `loss.backward()` sends);
         # backward then only rescales if the upstream gradient turns out to differ.
         ctx.speculative = bool(ctx.needs_input_grad[0]) and ChainLossFunction.overlap
-        den_objf, num_objf, bad, state = native.chain_loss_forward(
+        den_objf, num_objf, bad, state, totals = native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
-            with_grad=ctx.speculative, grad_scale=ctx.host_scale)
-        # -(num - den) [/ frames], loss.py:100-104: one launch instead of two reductions, a subtraction and a scaling
-        objf = native.loss_total(den_objf, num_objf, ctx.host_scale, ctx.dev_norm)
+            with_grad=ctx.speculative, grad_scale=ctx.host_scale, loss_scale=ctx.host_scale, norm_dev=ctx.dev_norm)
+        # -(num - den) [/ frames], loss.py:100-104, comes with the call (the last workgroup of its last kernel adds the
+        # per-sequence objectives up): no reduction / subtraction / scaling launches behind it
+        objf = totals[0]                       # (a view: no launch)
+        ChainFunction.last_totals = totals
         ctx.state = state
         # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
         spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)
         ctx.again = _recompute(x, lambda: native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
-            with_grad=spec, grad_scale=hscale), lambda r: (r[3], r[2]))
+            with_grad=spec, grad_scale=hscale), lambda r: (r[3], r[2]))      # (state, bad)
         ctx.in_dtype = input.dtype
         ChainFunction.last_bad_count = bad       # int32[2]: denominator, numerator; never synced here
         return objf

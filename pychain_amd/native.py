@@ -61,9 +61,10 @@ def _check_lengths(lengths, B, T):
             raise ValueError("sequence lengths must be in [1, %d]" % T)
 
 
-def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=False, grad_scale=1.0):
+def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=False, grad_scale=1.0, totals=False):
     """Denominator on the GPU.  `plan`: _plan.DevicePlan.
-    Returns (objf_per_seq[B], grad[B,T,D], bad_count[1])."""
+    Returns (objf_per_seq[B], grad[B,T,D], bad_count[1]) and, `totals`, the device float[4] of
+    include/pychain_hip.h (sum of the objectives, frames, bad count - from the call's last kernel, no extra launch)."""
     num_states = plan.num_states
     _require_device(x, "nnet_output")
     x = x.contiguous()
@@ -78,15 +79,17 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
         objf = torch.empty(B, dtype=torch.float32, device=dev)
         grad = torch.empty_like(x)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
+        tot = torch.empty(4, dtype=torch.float32, device=dev) if totals else None
         nws = L.pychain_hip_den_workspace_bytes(B, T, int(num_states), D)
         ws = _workspace(nws, dev, "den")
         _lib.check(L.pychain_hip_den_forward_backward(
             plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(),
             int(bool(input_is_exp)),
             ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
-            objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+            objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), tot.data_ptr() if totals else 0,
+            ws.data_ptr(), ws.numel(), _stream(dev)),
             "pychain_hip_den_forward_backward")
-    return objf, grad, bad
+    return (objf, grad, bad, tot) if totals else (objf, grad, bad)
 
 
 def num_forward_backward(gt, graph_stride, num_states, x, lengths, grad_mode=_lib.GRAD_LINEAR,
@@ -154,7 +157,7 @@ def chain_loss_forward_backward(plan, gt, graph_stride, num_states_num, x, lengt
             gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
             int(num_states_num), K,
             x.data_ptr(), ld.data_ptr(), B, T, D, float(grad_scale),
-            den_objf.data_ptr(), num_objf.data_ptr(), grad.data_ptr(), bad.data_ptr(),
+            den_objf.data_ptr(), num_objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), 1.0, 0, 0,
             dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_forward_backward")
     return den_objf, num_objf, grad, bad
@@ -168,9 +171,11 @@ class ChainLossState(object):
 
 
 def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky_coefficient=1e-5,
-                       with_grad=False, grad_scale=1.0):
+                       with_grad=False, grad_scale=1.0, loss_scale=1.0, norm_dev=None):
     """Recursions (and, `with_grad`, the occupancy passes overlapped with them: state.grad =
-    grad_scale * (gamma_den - gamma_num)).  Returns (den_objf[B], num_objf[B], bad_count[2], state)."""
+    grad_scale * (gamma_den - gamma_num)).  Returns (den_objf[B], num_objf[B], bad_count[2], state, totals) with
+    totals = device float[4] [(sum den - sum num) * loss_scale [/ norm_dev], frames, bad count, sum den - sum num]
+    written by the call's last kernel (include/pychain_hip.h)."""
     _require_device(x, "nnet_output")
     x = x.contiguous()
     if x.dtype != torch.float32:
@@ -186,6 +191,9 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
         den_objf = torch.empty(B, dtype=torch.float32, device=dev)
         num_objf = torch.empty(B, dtype=torch.float32, device=dev)
         bad = torch.empty(2, dtype=torch.int32, device=dev)
+        totals = torch.empty(4, dtype=torch.float32, device=dev)
+        if norm_dev is not None:
+            norm_dev = norm_dev.detach().to(device=dev, dtype=torch.float32).contiguous()
         # per-call workspaces (they must survive until backward); the caching allocator makes this cheap
         dws = torch.empty(L.pychain_hip_den_workspace_bytes(B, T, plan.num_states, D), dtype=torch.uint8, device=dev)
         nws = torch.empty(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dtype=torch.uint8,
@@ -199,12 +207,13 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
             gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
             int(num_states_num), K, x.data_ptr(), ld.data_ptr(), B, T, D,
             den_objf.data_ptr(), num_objf.data_ptr(), grad.data_ptr() if with_grad else 0, float(grad_scale),
-            bad.data_ptr(), dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
+            bad.data_ptr(), float(loss_scale), 0 if norm_dev is None else norm_dev.data_ptr(), totals.data_ptr(),
+            dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_forward")
     st.grad = grad
     st.plan, st.gt, st.graph_stride, st.num_states_num = plan, gt, int(graph_stride), int(num_states_num)
     st.x, st.lengths_dev, st.den_ws, st.num_ws, st.shape = x, ld, dws, nws, (B, T, D, K)
-    return den_objf, num_objf, bad, st
+    return den_objf, num_objf, bad, st, totals
 
 
 def chain_loss_backward(st, grad_scale=1.0, grad_scale_dev=None):

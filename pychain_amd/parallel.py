@@ -90,10 +90,28 @@ def allreduce_grad_slab(local_grad, global_idx, global_batch, stats=None, group=
     return (buf[:n] if n else None), slab
 
 
+class _GlobalLoss(torch.autograd.Function):
+    """value: the all-reduced loss [/ the all-reduced frame count]; gradient: that of the LOCAL loss, scaled alike."""
+
+    @staticmethod
+    def forward(ctx, local, stats, avg):
+        ctx.denom = stats[1] if avg else None
+        return stats[0] / stats[1] if avg else stats[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if ctx.denom is None else g / ctx.denom), None, None
+
+
 class ShardedChainLoss(torch.nn.Module):
     """ChainLoss over a utterance-sharded global minibatch: each rank evaluates its shard,
     the loss value is the global one (sum over ranks / global frame count when `avg`), and
-    autograd yields the correctly scaled gradient for the local shard."""
+    autograd yields the correctly scaled gradient for the local shard.
+
+    `last_stats` (device fp32, never synced here) holds [global objf, global frames, global bad count] of the last step.
+    With the native ChainLoss the three scalars come out of the loss call's last kernel (ChainFunction.last_totals) and
+    are all-reduced as they are - no scalar kernels of the host framework around the collective; a world of one does
+    nothing at all here."""
 
     def __init__(self, den_graph, leaky_coefficient=1e-5, avg=True, group=None, loss_cls=None):
         super().__init__()
@@ -103,10 +121,25 @@ class ShardedChainLoss(torch.nn.Module):
         self.local = loss_cls(den_graph, leaky_coefficient, avg=False)
         self.avg = avg
         self.group = group
-        self.last_stats = None      # [global objf, global frames, global bad count] of the last step (device, never synced here)
+        self.last_stats = None
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def forward(self, x, x_lengths, num_graphs):
         local = self.local(x, x_lengths, num_graphs)                  # sum over local utterances
+        totals = None
+        if self._native:
+            from .loss import ChainFunction
+            totals = ChainFunction.last_totals                        # [loss, frames, bad, ...] of the call above, on the device
+        if totals is not None:
+            if self._world() == 1:
+                self.last_stats = totals[:3]
+                return local / totals[1] if self.avg else local
+            stats = totals[:3].clone()
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+            self.last_stats = stats
+            return _GlobalLoss.apply(local, stats, self.avg)
         frames = torch.as_tensor(x_lengths).sum()
         bad = None
         if self._native:                                              # the reference's `ok` of every rank rides along

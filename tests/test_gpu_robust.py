@@ -148,6 +148,46 @@ def test_loss_total_is_the_loss_arithmetic_of_the_reference():
         assert abs(got - want) <= 2e-7 * abs(want)
 
 
+def test_step_totals_come_with_the_call():
+    """The scalars of a step - the loss of pychain/loss.py:100-104, the frame count, the bad count - are written by the
+    LAST workgroup of the call's last kernel (include/pychain_hip.h: totals) instead of by a chain of launch-bound scalar
+    kernels of the host framework: fused ChainLoss (host and device lengths, avg on / off), the denominator ChainFunction,
+    a batch larger than den_finish_kernel's block, a failing `ok`."""
+    w = syn.make_workload("C1")
+    x = w["x"].to(DEV)
+    for avg in (True, False):
+        for lengths in (w["lengths"], w["lengths"].to(DEV)):
+            xx = x.clone().requires_grad_(True)
+            loss = ChainLoss(w["den_graph"], 1e-5, avg=avg)(xx, lengths, w["num_graphs"])
+            t = ChainFunction.last_totals
+            assert t is not None and t.shape == (4,) and float(t[0]) == float(loss)
+            assert float(t[1]) == float(w["lengths"].sum()) and float(t[2]) == 0.0
+            ref = ChainLoss(w["den_graph"], 1e-5, avg=avg)
+            ref.fused = False
+            want = float(ref(x, w["lengths"], w["num_graphs"]))
+            assert abs(float(loss) - want) <= 1e-5 * abs(want)
+            raw = float(t[3])
+            assert abs(raw - want * (float(w["lengths"].sum()) if avg else 1.0)) <= 1e-5 * abs(raw)
+            loss.backward()
+            assert torch.isfinite(xx.grad).all()
+    # denominator only, B = 300 > 256 threads of the finishing workgroup; unequal lengths
+    den = syn.make_den_graph(20, 60, 40, seed=0)
+    B = 300
+    L = torch.randint(1, 21, (B,), generator=torch.Generator().manual_seed(1))
+    xb = syn.make_input(B, 20, 40, seed=3, device=DEV)
+    per_seq, _, _ = native.den_forward_backward(_plan.graph_plan(den, 40, torch.device(DEV)), xb, L, 1e-5)
+    o = ChainFunction.apply(xb, L, ChainGraphBatch(den, B), 1e-5)
+    t = ChainFunction.last_totals
+    assert abs(float(o) - float(per_seq.double().sum())) <= 1e-6 * abs(float(o)) and float(t[0]) == float(o)
+    assert float(t[1]) == float(L.sum()) and float(t[2]) == 0.0
+    # a NaN network output: the bad count rides in the totals
+    xn = x.clone()
+    xn[1, 3, 5] = float("nan")
+    ChainLoss(w["den_graph"], 1e-5)(xn, w["lengths"], w["num_graphs"])
+    t = ChainFunction.last_totals
+    assert float(t[2]) >= 1.0 and float(t[2]) == float(ChainFunction.last_bad_count.sum())
+
+
 def test_unknown_option_is_an_error():
     with pytest.raises(_lib.PychainHipError, match="unknown option"):
         with _lib.option("no_such_option"):
