@@ -74,10 +74,12 @@ void        pychain_hip_set_den_phase_mask(int mask);
 void        pychain_hip_set_den_lazy(int on);
 /* Which kernels a denominator call with this plan hint (pychain_hip_den_plan_info: info[4]), these sizes and the
  * calling thread's current options would launch: "recursion,occupancy" into buf, e.g.
- * "den_recursion_lazy_kernel,den_gamma2_kernel".  Recursion: den_recursion_lazy_kernel (16 waves, D <= 4096),
- * den_recursion_lazy_kernel<wide> (8 waves, D <= 9216), den_recursion_pair_kernel (two sequences per workgroup,
- * shared plan, B >= 3/8 of the CU count), den_recursion_kernel (everything else).  Measurement tools and the
- * kernel-selection test label by it.  plans_shared = 1: one plan for all sequences (plan stride 0). */
+ * "den_recursion_lazy_kernel<dma>,den_gamma2_kernel".  Recursion: den_recursion_lazy_kernel<small> (4 waves: plans that
+ * hold the four-wave dealing), den_recursion_lazy_kernel<dma> (16 waves, nnet-output rows of up to 9216 pdfs by LDS-direct
+ * loads), den_recursion_lazy_kernel (16 waves, rows through registers: option den_dma = 0), den_recursion_pair_kernel (two
+ * sequences per workgroup, shared plan, B >= 3/8 of the CU count), den_recursion_kernel (everything else),
+ * den_general_recursion_kernel (plans in the general format).  Measurement tools and the kernel-selection test label by it.
+ * plans_shared = 1: one plan for all sequences (plan stride 0). */
 int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states, int num_pdfs, int B, int plans_shared,
                                          char* buf, size_t buf_bytes);
 /* Settings.  A call reads them ONCE when it starts (process-wide defaults overlaid with the calling thread's
@@ -86,23 +88,23 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  * pychain_hip_set_thread_option overrides it for the calling host thread only (value NULL removes the override,
  * "" = unset for this thread); pychain_hip_get_option copies the value in effect for the calling thread into buf and
  * returns its length (0 = unset).  pychain_hip_set_verbose_level / _set_den_phase_mask / _set_den_lazy are the
- * process-wide "verbose" / "den_phase_mask" / "den_lazy".  Names:
- *   "verbose" (base.h:34-42), "den_phase_mask", "den_lazy",
- *   "den_segments" (n time segments of the denominator, 1 = no overlap), "den_bounds" ("0.7,0.85": their ends as
- *   fractions of T), "den_relaunch" (one recursion launch per segment instead of progress counters + gate kernels),
- *   "no_fold" (numerator accumulated into the stored gradient instead of folded into the occupancy launch),
- *   "gamma16" (one-frame occupancy kernel), "num_no_staging_waves",
- *   "den_pair" ("1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of
- *   the CU count in sequences on, i.e. B >= 96 on 256 CUs - results are bit-identical to den_recursion_kernel's),
- *   "den_wide" ("1": the 8-wave lazy recursion wherever the shape allows, "2": the 12-wave one - on plans compiled
- *   under PYCHAIN_PLAN_TWELVE=1, else ok = false; default "0": both measured slower than the 16-wave kernel),
- *   "den_two_copy" ("0": never the recursion that keeps two copies of the nnet-output row in LDS; default: wherever the
- *   plan holds its tiles - compiled under PYCHAIN_PLAN_CHOICE=1 only: measured no faster),
- *   "gamma_tiled", "force_general" (the streamed general kernels even where a fast one fits),
- *   "debug_corrupt_row" ("den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the
- *   recursions and the occupancy pass, so that the 5 % invariant of chain-computation.cc:363-390 /
- *   chain-log-domain-computation.cc:289-303 can be seen to fire: `ok` false at t = 0, at any t at verbose >= 1).
- * Every combination but the last gives the same results to rounding (the tests compare them); unknown name: EINVAL. */
+ * process-wide "verbose" / "den_phase_mask" / "den_lazy".  The eight names - every one selects between SHIPPED kernel
+ * families so that the tests can compare them (all give the same results to rounding; most bit for bit), or is a test hook:
+ *   "verbose"        base.h:34-42: >= 1 checks the reference's invariant on every frame instead of frame 0
+ *   "den_phase_mask" bit 0 recursion launch, bit 1 occupancy launch (measurement aid)
+ *   "den_lazy"       "0": the two-barrier recursion (den_recursion_kernel) instead of the lazy-normalisation one
+ *   "den_dma"        "0": nnet-output rows of the lazy recursion through registers instead of LDS-direct loads
+ *   "den_segments"   n >= 1: the occupancy pass in n gated time segments (1 = after the recursions, no overlap) instead of
+ *                    the streamed persistent launch
+ *   "den_pair"       "1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of
+ *                    the CU count in sequences on, i.e. B >= 96 on 256 CUs - bit-identical to den_recursion_kernel
+ *   "gamma16"        the one-frame occupancy kernel (and with it the numerator accumulated into the stored gradient
+ *                    instead of folded into the occupancy launch) also where the two-frame kernel fits
+ *   "debug_corrupt_row" "den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the
+ *                    recursions and the occupancy pass, so that the 5 % invariant of chain-computation.cc:363-390 /
+ *                    chain-log-domain-computation.cc:289-303 can be seen to fire: `ok` false at t = 0, at any t at verbose >= 1
+ * Unknown name: EINVAL.  (Kernel variants that measured slower - 8 / 12 waves, two copies of the nnet-output row, a
+ * recursion relaunched per segment - are not in the library; their measurements are under profiles/r03_*.) */
 int         pychain_hip_set_option(const char* name, const char* value);
 int         pychain_hip_set_thread_option(const char* name, const char* value);
 int         pychain_hip_get_option(const char* name, char* buf, size_t buf_bytes);
@@ -146,14 +148,16 @@ int64_t pychain_hip_den_plan_build(
 
 /* Facts about a filled HOST blob that the launcher needs (the blob itself lives on the
  * device at call time and is never read back):
- *   info[0] num_states  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes
+ *   info[0] num_states  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes, low 31 bits (info[5]: the rest)
  *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers), three
  *           fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
  *           and for 8 waves (20-28); combine several plans by taking the max of each field
- *           bit 29: the plan holds the two-copy recursion tiles (PYCHAIN_PLAN_CHOICE=1; AND over several plans)
+ *           bit 29: the plan also holds its recursion tiles dealt to FOUR waves (small graphs: 256-thread recursion
+ *                   workgroups); the recursion field is then that dealing's row count (AND over several plans)
  *           bit 30: every recursion wave owns few enough row groups for the lazy-normalisation recursions (AND)
- *   info[5..7] reserved (0)
- * A blob whose payload does not match the checksum in its header (a damaged or foreign cache file) is EINVAL.
+ *   info[5] plan bytes >> 31 (general-format plans may exceed 2 GiB)   info[6..7] reserved (0)
+ * A blob whose header or payload does not match the checksums in its header, or whose header points outside the blob
+ * (a damaged or foreign cache file), is EINVAL.
  */
 int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t info[8]);
 

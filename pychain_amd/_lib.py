@@ -90,8 +90,7 @@ def lib():
     return _lib
 
 
-OPTIONS = ("den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves", "den_pair",
-           "den_wide", "den_dma", "den_two_copy", "den_stream", "gamma_tiled", "force_general", "verbose", "den_phase_mask", "den_lazy", "debug_corrupt_row")
+OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row")
 
 _thread_values = threading.local()       # what this thread's overrides currently are (for restoring)
 

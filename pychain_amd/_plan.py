@@ -58,7 +58,7 @@ def build_plan_blob(forward_transitions, forward_transition_indices, forward_tra
                 rc = L.pychain_hip_den_plan_info(blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes,
                                                  info.ctypes.data_as(ctypes.c_void_p))
                 # (plan_info also verifies the checksum of the payload behind the header)
-                if rc == 0 and (int(info[0]), int(info[1]), int(info[2]), int(info[3])) == (H, K, int(num_pdfs), blob.nbytes):
+                if rc == 0 and (int(info[0]), int(info[1]), int(info[2]), int(info[3]) + (int(info[5]) << 31)) == (H, K, int(num_pdfs), blob.nbytes):
                     return blob
         except (OSError, ValueError):
             pass
@@ -84,7 +84,7 @@ def plan_info(blob):
     _lib.check(_lib.lib().pychain_hip_den_plan_info(blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes,
                                                     info.ctypes.data_as(ctypes.c_void_p)), "den_plan_info")
     return dict(num_states=int(info[0]), num_transitions=int(info[1]), num_pdfs=int(info[2]),
-                bytes=int(info[3]), slot_rows=int(info[4]))
+                bytes=int(info[3]) + (int(info[5]) << 31), slot_rows=int(info[4]))
 
 
 # ---- on-disk cache of compiled plans -------------------------------------------------------------
@@ -94,8 +94,7 @@ def plan_info(blob):
 # ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans, created 0700; "0" / "off" disables).  Writes are
 # atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.  A file is only
 # believed if its header matches the request AND its payload matches the checksum in the header.
-_KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_FREE",
-          "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED", "PYCHAIN_PLAN_SAMELANE")
+_KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_LINEAR")
 
 
 def _cache_dir():
@@ -177,7 +176,13 @@ def batch_plans(tensors, num_pdfs, device):
     H = ts[1].shape[1]
     same = all(bool((t[1:] == t[:1]).all()) for t in ts) if B > 1 else True
     rows = [0] if same else range(B)
-    blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
+    # (the compiler is native code behind ctypes, which releases the GIL: the plans of a list of graphs compile side by side)
+    if len(rows) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(rows), os.cpu_count() or 1, 16)) as ex:
+            blobs = list(ex.map(lambda b: build_plan_blob(*[t[b] for t in ts], num_pdfs), rows))
+    else:
+        blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
     hints = [plan_info(b)["slot_rows"] for b in blobs]
     if any(h == HINT_GENERAL for h in hints):
         # the format follows from the sizes (and PYCHAIN_PLAN_GENERAL): all plans of one batch are alike
@@ -185,7 +190,7 @@ def batch_plans(tensors, num_pdfs, device):
         slot_rows = HINT_GENERAL
     else:
         slot_rows = sum(max((h >> sh) & mask for h in hints) << sh for sh, mask in ((0, 1023), (10, 1023), (20, 511)))
-        for bit in (29, 30):                       # every plan holds two-copy tiles / fits the lazy recursion (<= 4 groups per wave)
+        for bit in (29, 30):                       # every plan holds four-wave tiles / fits the lazy recursion (<= 4 groups per wave)
             if all((h >> bit) & 1 for h in hints):
                 slot_rows |= 1 << bit
     if same:

@@ -5,6 +5,7 @@
 Every translation unit is compiled to an object of its own (in parallel, only the stale ones: an object
 depends on its source and on every header), then linked.  Objects live under build/obj (git-ignored).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,8 +16,9 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(_HERE, "libpychain_hip.so")
 OBJ = os.path.join(os.path.dirname(_HERE), "build", "obj")
-SOURCES = ["plan.cpp", "fst.cpp", "pack.cpp", "den_kernels.hip", "den_general.hip", "num_kernels.hip", "api.hip"]
-HEADERS = ["common.h", "plan_format.h", "den_kernels.h", "num_kernels.h", "device_utils.h", "den_lazy.inc.h",
+SOURCES = ["den_rec.hip", "den_lazy.hip", "den_kernels.hip", "plan.cpp", "fst.cpp", "pack.cpp", "den_general.hip", "num_kernels.hip",
+           "api.hip"]          # (the slowest translation units first: they are compiled side by side)
+HEADERS = ["common.h", "plan_format.h", "den_kernels.h", "num_kernels.h", "device_utils.h", "den_common.inc.h", "den_lazy.inc.h",
            "den_pair.inc.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-fno-slp-vectorize"]   # v_pk_*_f32 pairs cost v_movs and lengthen the dependent chains here
@@ -56,7 +58,9 @@ def build(force=False, verbose=False, extra_flags=(), lib=None):
     variant = bool(extra_flags) or lib is not None
     if not force and not variant and not needs_build():
         return out
-    objdir = OBJ if not variant else OBJ + "_" + str(abs(hash((tuple(extra_flags), out))) % 100000)
+    # (a variant's objects live under a name derived from its flags and output - stable from process to process, so a
+    # rebuilt ablation reuses its directory instead of leaving a new one behind every time)
+    objdir = OBJ if not variant else OBJ + "_" + hashlib.sha1(repr((tuple(extra_flags), os.path.abspath(out))).encode()).hexdigest()[:10]
     os.makedirs(objdir, exist_ok=True)
     htime = _header_time()
     jobs = []

@@ -27,9 +27,8 @@ std::mutex g_option_lock;
 typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
-const char* const kKnownOptions[] = {"den_segments", "den_relaunch", "den_bounds", "no_fold", "gamma16", "num_no_staging_waves",
-                                     "den_pair", "den_wide", "den_dma", "den_two_copy", "den_stream", "gamma_tiled", "force_general", "verbose", "den_phase_mask",
-                                     "den_lazy", "debug_corrupt_row"};
+const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
+                                     "debug_corrupt_row"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -63,26 +62,10 @@ CallKnobs call_knobs() {
   k.den_phase_mask = option_int("den_phase_mask", 3) & 3;
   k.den_lazy = option_int("den_lazy", 1) ? 1 : 0;
   k.den_segments = option_int("den_segments", 0);
-  k.den_relaunch = option_set("den_relaunch");
-  k.no_fold = option_set("no_fold");
   k.gamma16 = option_set("gamma16");
-  k.num_no_staging_waves = option_set("num_no_staging_waves");
   k.den_pair = option_int("den_pair", -1);
-  k.den_wide = option_int("den_wide", -1);
   k.den_dma = option_int("den_dma", -1);
-  k.den_two_copy = option_int("den_two_copy", -1);
-  k.den_stream = option_int("den_stream", -1);
-  k.gamma_tiled = option_int("gamma_tiled", -1);
-  k.force_general = option_int("force_general", 0) ? 1 : 0;
   std::string v;
-  if (option_value("den_bounds", &v)) {       // "0.7,0.85" = ends of all segments but the last, as fractions of T
-    for (const char* p = v.c_str(); *p && k.nbounds < 16;) {
-      char* q; const double f = strtod(p, &q);
-      if (q == p) break;
-      k.bounds[k.nbounds++] = f;
-      p = *q == ',' ? q + 1 : q;
-    }
-  }
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
     if (sscanf(v.c_str(), "%3[a-z],%d,%d,%f", what, &b, &t, &sc) == 4 && b >= 0 && t >= 0) {
@@ -128,7 +111,6 @@ extern "C" void pychain_hip_set_den_lazy(int on) { set_process_int("den_lazy", o
 
 namespace {
 bool den_call_is_pair(const DenArgs& a, int resident_slot_rows);
-bool den_call_is_wide(const DenArgs& a, int resident_slot_rows);
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows);
 int den_call_shape(const DenArgs& a, int resident_slot_rows);
 }  // namespace
@@ -146,7 +128,7 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
   }
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
-  a.wide = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
+  a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   snprintf(buf, buf_bytes, "%s,%s", den_recursion_kernel_name(a, resident_slot_rows),
            den_occupancy_kernel_name(a, (D + 63) / 64, resident_slot_rows));
   return PYCHAIN_HIP_OK;
@@ -160,11 +142,22 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
     if (blob_bytes < sizeof(GeneralPlanHeader) || gh->version != PLAN_VERSION || (size_t)gh->total_bytes > blob_bytes ||
         (size_t)gh->total_bytes < sizeof(GeneralPlanHeader))
       return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: not a plan of this library version");
-    if ((int32_t)general_payload_hash(host_blob, (size_t)gh->total_bytes) != gh->payload_hash)
-      return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: plan payload does not match its checksum (corrupted or foreign file)");
+    if ((int32_t)general_payload_hash(host_blob, (size_t)gh->total_bytes) != gh->payload_hash ||
+        (int32_t)general_header_hash(*gh) != gh->reserved[0])
+      return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: plan does not match its checksums (corrupted or foreign file)");
+    {
+      const int64_t n = gh->total_bytes, H8 = (int64_t)gh->H * 8, K8 = (int64_t)gh->K * 8, K4 = (int64_t)gh->K * 4, Hp4 = (int64_t)gh->Hp * 4;
+      const int64_t offs[12] = {gh->off_a_idx, gh->off_a_arc, gh->off_a_p, gh->off_b_idx, gh->off_b_arc, gh->off_b_p,
+                                gh->off_g_idx, gh->off_g_arc, gh->off_g_p, gh->off_leaky, gh->off_init, gh->off_final};
+      const int64_t lens[12] = {H8, K8, K4, H8, K8, K4, ((int64_t)gh->D + 1) * 4, K8, K4, Hp4, Hp4, Hp4};
+      for (int i = 0; i < 12; i++)
+        if (offs[i] < (int64_t)sizeof(GeneralPlanHeader) || offs[i] + lens[i] > n)
+          return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: a table of the plan lies outside the blob");
+    }
     memset(info, 0, 8 * sizeof(int32_t));
     info[0] = gh->H; info[1] = gh->K; info[2] = gh->D;
-    info[3] = gh->total_bytes > 0x7fffffff ? 0x7fffffff : (int32_t)gh->total_bytes;
+    info[3] = (int32_t)(gh->total_bytes & 0x7fffffff);   // plan bytes = info[3] + (info[5] << 31): plans beyond 2 GiB keep their exact size
+    info[5] = (int32_t)(gh->total_bytes >> 31);
     info[4] = PYCHAIN_HIP_HINT_GENERAL;          // launch hint: the general kernels (den_general.hip)
     return PYCHAIN_HIP_OK;
   }
@@ -174,8 +167,11 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
     return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: not a plan of this library version");
   // the kernels follow the blob's offsets, wave tables and packed LDS addresses unchecked: a blob that comes back from a
   // file (the on-disk plan cache) must be the bytes pychain_hip_den_plan_build wrote
-  if ((int32_t)plan_payload_hash(host_blob, (size_t)hd->total_bytes) != hd->payload_hash)
-    return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: plan payload does not match its checksum (corrupted or foreign file)");
+  if ((int32_t)plan_payload_hash(host_blob, (size_t)hd->total_bytes) != hd->payload_hash ||
+      (int32_t)plan_header_hash(*hd) != hd->header_hash)
+    return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: plan does not match its checksums (corrupted or foreign file)");
+  if (!plan_header_in_bounds(*hd))
+    return fail(PYCHAIN_HIP_EINVAL, "den_plan_info: a table of the plan lies outside the blob");
   memset(info, 0, 8 * sizeof(int32_t));
   info[0] = hd->H; info[1] = hd->K; info[2] = hd->D; info[3] = hd->total_bytes;
   int m = hd->alpha.max_wave_slot_rows;
@@ -186,9 +182,13 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (gm2 > 1023) gm2 = 1023;
   // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (10 bits) << 10 | occupancy rows, 8 waves (9 bits) << 20
   if (gm2 > 511) gm2 = 511;
+  // bit 29: the plan holds the recursion tiles dealt to FOUR waves (small graphs: den_recursion_lazy_kernel<small>); the
+  // recursion field is then the row count of THAT dealing (>= the 16-wave one: a kernel sized by it fits either)
+  const bool small = hd->alpha4.nwaves == PLAN_REC4_WAVES && hd->beta4.nwaves == PLAN_REC4_WAVES &&
+                     hd->rec4_max_wave_groups >= 1 && hd->rec4_max_wave_groups <= 4;
+  if (small) m = std::max(m, std::max(hd->alpha4.max_wave_slot_rows, hd->beta4.max_wave_slot_rows));
   info[4] = m | (gmm << 10) | (gm2 << 20);
-  // bit 29: the plan holds the two-copy recursion tiles (alpha_c / beta_c)
-  if (hd->alpha_c.nwaves == PLAN_REC_WAVES && hd->beta_c.nwaves == PLAN_REC_WAVES) info[4] |= 1 << 29;
+  if (small) info[4] |= 1 << 29;
   // bit 30: every recursion wave owns at most 4 groups (what den_recursion_lazy_kernel keeps in registers)
   if (hd->rec_max_wave_groups >= 1 && hd->rec_max_wave_groups <= 4) info[4] |= 1 << 30;
   return PYCHAIN_HIP_OK;
@@ -252,7 +252,7 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.lazy = 0;
   a.check = 0; a.check_all = a.knobs.verbose >= 1 ? 1 : 0;
   a.sig_n = 0;
-  a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_seg = 0; a.gam_nseg = 0;
+  a.gam_seg = 0; a.gam_nseg = 0;
   return PYCHAIN_HIP_OK;
 }
 }  // namespace
@@ -310,6 +310,9 @@ int den_segments(const DenArgs& a) {
   // T=640: 2.01 / 1.93 / 1.72 / 1.72, T=384: 1.21 / 1.22 / 1.07 / 1.11
   if (T >= 768) return 4;
   if (T >= 256) return 3;
+  // small graphs in four-wave workgroups leave most of the chip idle and their frames are short: the occupancy pass
+  // overlaps from 64 frames on (C2, T = 150)
+  if (a.lazy && a.shape == kShapeSmall && T >= 64) return 2;
   return 1;
 }
 
@@ -330,33 +333,32 @@ int device_cu_count() {
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
   return cus[dev] = n;
 }
+bool den_call_is_small(const DenArgs& a, int resident_slot_rows) {
+  return a.knobs.den_dma != 0 && den_small_eligible(a, resident_slot_rows);
+}
 bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
-  if (a.knobs.den_relaunch || !den_pair_eligible(a, resident_slot_rows)) return false;
+  if (!den_pair_eligible(a, resident_slot_rows)) return false;
   if (a.knobs.den_pair >= 0) return a.knobs.den_pair != 0;
+  // small graphs run in four-wave workgroups, several to a CU: nothing to gain from pairing sequences
+  if (a.knobs.den_lazy && den_call_is_small(a, resident_slot_rows)) return false;
   // measured on the C3 graph (tools/time_step.py B 1500): B = 96 +3.5 %, B = 128 +27 %, B = 256 +13 %; below 3/4 of the
   // CUs the one-sequence workgroups leave enough of the chip to the occupancy launches and their chain is shorter
   return 8 * a.B >= 3 * device_cu_count();
 }
-// the 8-wave shape of the lazy recursion: only on request (option den_wide = "1", wherever the shape allows).  MEASURED
-// SLOWER than both alternatives - C3 5.02 ms against 3.43 ms for the 16-wave shape, C4 7.64 ms against 5.96 ms for
-// den_recursion_kernel (profiles/r03_a_time_matrix.txt): two waves per SIMD keep too few gathers in flight for the LDS.
-bool den_call_is_wide(const DenArgs& a, int resident_slot_rows) {
-  return a.knobs.den_wide > 0 && den_wide_eligible(a, resident_slot_rows);
-}
 // the nnet-output rows of the lazy recursions come in by LDS-direct loads (default wherever a lazy shape fits: on the
-// 16-wave map of C1-C3 it is 2 % faster than rows through registers and bit-identical, and it is what makes rows of
+// 16-wave map of C3 it is 2 % faster than rows through registers and bit-identical, and it is what makes rows of
 // 4096 < D <= 9216 pdfs - C4 - fit a 128-VGPR wave at all); option den_dma = "0": rows through registers, i.e. the
 // 16-wave map for D <= 4096 and den_recursion_kernel beyond
 bool den_call_is_dma(const DenArgs& a, int resident_slot_rows) {
   return a.knobs.den_dma != 0 && den_dma_eligible(a, resident_slot_rows);
 }
-int den_call_shape(const DenArgs& a, int resident_slot_rows) {     // DenArgs::wide
-  if (den_call_is_wide(a, resident_slot_rows)) return 1;
-  return den_call_is_dma(a, resident_slot_rows) ? 2 : 0;
+int den_call_shape(const DenArgs& a, int resident_slot_rows) {     // DenArgs::shape
+  if (den_call_is_small(a, resident_slot_rows)) return kShapeSmall;
+  return den_call_is_dma(a, resident_slot_rows) ? kShapeDma : kShapeRegs;
 }
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
-  return a.knobs.den_lazy && !a.knobs.den_relaunch && !den_call_is_pair(a, resident_slot_rows) &&
-         (den_lazy_eligible(a, resident_slot_rows) || den_call_is_wide(a, resident_slot_rows) || den_call_is_dma(a, resident_slot_rows));
+  return a.knobs.den_lazy && !den_call_is_pair(a, resident_slot_rows) &&
+         (den_lazy_eligible(a, resident_slot_rows) || den_call_is_small(a, resident_slot_rows) || den_call_is_dma(a, resident_slot_rows));
 }
 
 // option debug_corrupt_row: row[0..n) *= scale, between the recursion and the occupancy launches
@@ -382,7 +384,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   }
   if (resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) {
     // a plan in the general format: den_general.hip, no overlap (rows in den_recursion_kernel's normalised form)
-    a.lazy = 0; a.pair = 0; a.wide = 0;
+    a.lazy = 0; a.pair = 0; a.shape = 0;
     a.check = (occupancy && user_mask == 3) ? 1 : 0;
     const bool corrupt_g = a.knobs.corrupt_what == 1 && a.knobs.corrupt_b < a.B && a.knobs.corrupt_t < a.T;
     a.phase_mask = user_mask & 1;
@@ -397,13 +399,12 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   }
   // (a corrupted row - option debug_corrupt_row - is written between the recursion and the occupancy launches: no overlap)
   const bool corrupt = a.knobs.corrupt_what == 1 && a.knobs.corrupt_b < a.B && a.knobs.corrupt_t < a.T;
-  const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt) ? den_segments(a) : 1;
-  // the lazy-normalisation recursion runs a whole sequence in one launch: not with the relaunch schedule
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
-  a.wide = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
+  a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   // two sequences per workgroup once the 2B one-sequence workgroups would fill the chip (option den_pair: 1 always
   // where the shape allows, 0 never); rows in den_recursion_kernel's form
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
+  const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt) ? den_segments(a) : 1;
   // the invariant check (DenArgs::tot_a) needs the recursions and the occupancy launches of ONE call
   a.check = (occupancy && user_mask == 3) ? 1 : 0;
   hipError_t e = hipSuccess;
@@ -433,9 +434,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     const double frac = s == nseg - 1 ? 1.0 : 1.0 - 1.0 / (double)(2 << s);
     a.seg_bound[s] = s == nseg - 1 ? a.T : ((int)(frac * a.T) + 31) / 32 * 32;
   }
-  for (int s = 0; s < a.knobs.nbounds && s < nseg - 1; s++)   // option den_bounds: ends of all segments but the last, as fractions of T
-    a.seg_bound[s] = std::min(a.T, ((int)(std::max(a.knobs.bounds[s], 0.5) * a.T) + 31) / 32 * 32);   // nothing is computable before T/2
-  if (!a.knobs.den_relaunch && a.knobs.den_stream != 0 && den_stream_eligible(a, gmax, resident_slot_rows)) {
+  if (a.knobs.den_segments == 0 && den_stream_eligible(a, gmax, resident_slot_rows)) {
     // Streamed schedule (DenArgs::stream, den_kernels.hip: stream_take): ONE recursion launch whose workgroups report
     // per-sequence progress, ONE persistent occupancy launch on the side stream - released when every recursion
     // workgroup has passed T/2 (nothing is computable before; the numerator has the idle CUs until then) - that draws
@@ -445,7 +444,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     a.seg_bound[0] = std::min(a.T, (a.T / 2 + 31) / 32 * 32);
     if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // (the occupancy launch must see the zeroed counters)
     if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
-    a.phase_mask = 1; a.seg_begin = 0; a.seg_end = 0x7fffffff;
+    a.phase_mask = 1;
     if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
     if (e == hipSuccess) e = launch_den_gate(a.progress, den_recursion_blocks(a), a.bad, side->stream2);
     if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
@@ -456,52 +455,30 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     a.phase_mask = user_mask; a.sig_n = 0; a.stream = 0;
     return e;
   }
-  if (!a.knobs.den_relaunch) {
-    // Gated schedule: ONE recursion launch; its workgroups count themselves into progress[s] when their
-    // steps below seg_bound[s] are done, and a one-wave gate kernel in front of occupancy launch s (side
-    // stream) waits for all 2B of them.  No relaunch of the persistent workgroups at the segment ends.
-    a.sig_n = nseg - 1;
-    if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // the gates must see the zeroed counters
-    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
-    a.phase_mask = 1; a.seg_begin = 0; a.seg_end = 0x7fffffff;
-    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
-    a.phase_mask = 2; a.gam_nseg = nseg;
-    for (int s = 0; s < nseg - 1 && e == hipSuccess; s++) {
-      a.gam_seg = s;
-      e = launch_den_gate(a.progress + s, den_recursion_blocks(a), a.bad, side->stream2);
-      if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
-      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
-    }
-    // the last occupancy launch follows the recursion in stream order on the caller's stream
-    a.gam_seg = nseg - 1;
-    if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(st, gamma_wait, 0);
-    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
-    if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
-    a.phase_mask = user_mask; a.gam_nseg = 0; a.sig_n = 0;
-    return e;
+  // Gated schedule (rounds 1-2; the fallback for the two-barrier recursion and per-sequence plans, and what option
+  // den_segments = n asks for): ONE recursion launch; its workgroups count themselves into progress[s] when their steps
+  // below seg_bound[s] are done, and a one-wave gate kernel in front of occupancy launch s (side stream) waits for all
+  // of them.  (One recursion launch per segment with stream events in between - the first form of this schedule - measured
+  // 2 % slower and is gone: profiles/r01_*.)
+  a.sig_n = nseg - 1;
+  if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // the gates must see the zeroed counters
+  if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
+  a.phase_mask = 1;
+  if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
+  a.phase_mask = 2; a.gam_nseg = nseg;
+  for (int s = 0; s < nseg - 1 && e == hipSuccess; s++) {
+    a.gam_seg = s;
+    e = launch_den_gate(a.progress + s, den_recursion_blocks(a), a.bad, side->stream2);
+    if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
+    if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
   }
-  // Relaunch schedule (option den_relaunch): one recursion launch per segment, stream events in between.
-  for (int s = 0; s < nseg && e == hipSuccess; s++) {
-    a.phase_mask = 1; a.seg_begin = s ? a.seg_bound[s - 1] : 0; a.seg_end = s == nseg - 1 ? 0x7fffffff : a.seg_bound[s];
-    e = launch_den(a, gmax, resident_slot_rows, st, why);
-    a.phase_mask = 2; a.gam_seg = s; a.gam_nseg = nseg;
-    if (s < nseg - 1) {
-      if (e == hipSuccess) e = hipEventRecord(side->seg[s], st);
-      if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[s], 0);
-      if (e == hipSuccess && s == 0 && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
-      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
-    } else {
-      // the last occupancy launch has nothing to overlap with: it follows the last recursion segment in
-      // stream order on the caller's stream (no cross-stream event on the exposed part of the call);
-      // the numerator rows it folds in were finished long ago, but the caller's stream has to say so
-      if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(st, gamma_wait, 0);
-      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
-    }
-  }
+  // the last occupancy launch follows the recursion in stream order on the caller's stream
+  a.gam_seg = nseg - 1;
+  if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(st, gamma_wait, 0);
+  if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
   if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
-  a.phase_mask = user_mask; a.seg_begin = 0; a.seg_end = 0x7fffffff; a.gam_nseg = 0;
+  a.phase_mask = user_mask; a.gam_nseg = 0; a.sig_n = 0;
   return e;
 }
 // ... and, behind all of them on the caller's stream, den_finish_kernel: objf from the per-frame totals and
@@ -590,7 +567,6 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 32;
   const CallKnobs knobs = call_knobs();
   a.check_all = knobs.verbose >= 1 ? 1 : 0;
-  a.no_staging_waves = knobs.num_no_staging_waves;
   if (knobs.corrupt_what == 2 && knobs.corrupt_b < B && knobs.corrupt_t < T) {
     a.corrupt_b = knobs.corrupt_b; a.corrupt_t = knobs.corrupt_t; a.corrupt_log = logf(knobs.corrupt_scale);
   } else a.corrupt_b = -1;
@@ -668,8 +644,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
-  const bool no_fold = da.knobs.no_fold != 0;                             // test / tuning option
-  const bool fold = grad && !no_fold && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL &&
+  const bool fold = grad && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL &&
                     den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
   if (fold) {
     da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
@@ -765,7 +740,7 @@ int chain_loss_backward_impl(
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
   da.lazy = den_call_is_lazy(da, resident_slot_rows) ? 1 : 0;
-  da.wide = da.lazy ? den_call_shape(da, resident_slot_rows) : 0;
+  da.shape = da.lazy ? den_call_shape(da, resident_slot_rows) : 0;
   NumArgs na;
   // the occupancy launch reads only the forward transitions / indices / log-probs of the graphs
   rc = fill_num_args(na, ft, fi, fp, ft, fi, fp, fp, fp,

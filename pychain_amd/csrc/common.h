@@ -18,18 +18,12 @@ char* last_error_buffer();          // thread-local, 512 bytes (api.hip)
 struct CallKnobs {
   int verbose;                // reference's verbose level (base.h:34-42): >= 1 checks every frame
   int den_phase_mask;         // bit 0 recursion launch, bit 1 occupancy launches (measurement aid)
-  int den_lazy;               // 0: never the lazy-normalisation recursions
-  int den_segments;           // 0 = automatic
-  int den_relaunch, no_fold, gamma16, num_no_staging_waves;
+  int den_lazy;               // 0: never the lazy-normalisation recursions (the two-barrier kernel: second opinion of the tests)
+  int den_segments;           // 0 = automatic (the streamed occupancy pass where the shape allows, else gated segments);
+                              // n >= 1: the gated schedule with n time segments (1 = no overlap)
+  int gamma16;                // 1: the one-frame occupancy kernel also where the two-frame one fits
   int den_pair;               // -1 automatic, 0 never, 1 wherever the shape allows
-  int den_wide;               // -1 automatic, 0 never, 1 wherever the shape allows (8-wave lazy recursion)
   int den_dma;                // 0: nnet-output rows of the lazy recursions through registers, else (default) by LDS-direct loads
-  int den_two_copy;           // 0: never the two-copy recursion (LzNarrowDma2), else (default) wherever the plan holds its tiles and the shape fits
-  int den_stream;             // 0: the occupancy pass in gated segments (rounds 1-2), else (default) as one persistent launch
-  int gamma_tiled;            // -1 automatic, 0 never, 1 wherever the shape allows (two-frame occupancy kernel tiled over pdfs)
-  int force_general;          // 1: the streamed general kernels even where a fast one fits (tests)
-  int nbounds;
-  double bounds[16];          // den_bounds: segment ends as fractions of T
   // debug_corrupt_row = "den|num,b,t,scale": one stored alpha row is scaled before the occupancy pass reads it,
   // so that the reference's 5 % invariant (chain-computation.cc:363-390, chain-log-domain-computation.cc:289-303)
   // can be seen to fire

@@ -9,6 +9,8 @@
 
 namespace pychain_hip {
 
+enum { kShapeRegs = 0, kShapeDma = 2, kShapeSmall = 3 };
+
 struct DenArgs {
   const char* plans;         // device plan(s)
   int64_t plan_stride;       // bytes between per-sequence plans, 0 = shared
@@ -26,9 +28,10 @@ struct DenArgs {
   // 1: the recursions run as den_recursion_pair_kernel (den_pair.inc.h): two sequences per workgroup, ceil(B/2)
   // workgroups per direction; rows as den_recursion_kernel stores them (lazy = 0).  Shared plan only.
   int pair;
-  // which shape the lazy recursions run in (den_lazy.inc.h): 0 = LzNarrow (16 waves, D <= 4096), 1 = LzWide (8 waves),
-  // 2 = LzDma (16 waves, nnet-output rows of up to 9216 pdfs brought in by LDS-direct loads)
-  int wide;
+  // which shape the lazy recursions run in (den_lazy.inc.h): kShapeRegs = LzNarrow (16 waves, D <= 4096, rows through
+  // registers), kShapeDma = LzNarrowDma / LzDma (16 waves, rows by LDS-direct loads, up to 9216 pdfs), kShapeSmall = LzSmall
+  // (4 waves over the plan's four-wave dealing: small graphs)
+  int shape;
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
   //     objf = sum_t log tot_a(t) + log fin_dot        (ComputeTotLogLike, chain-computation.cc:209-230)
@@ -47,11 +50,9 @@ struct DenArgs {
   int input_is_exp;
   int frames_per_block;      // gamma kernel: frames one workgroup handles
   int phase_mask;            // bit0 recursion launch, bit1 gamma launch (bench aid)
-  // Time segmentation (overlap of the occupancy pass with the recursions):
-  // the recursion launch executes steps [seg_begin, seg_end) of every sequence; the occupancy
-  // launch number gam_seg (of gam_nseg) handles exactly the frames whose
-  // alpha' and beta rows became available with recursion segment gam_seg.  gam_nseg = 0: all.
-  int seg_begin, seg_end;
+  // Time segmentation (the gated schedule: overlap of the occupancy pass with the recursions): the
+  // occupancy launch number gam_seg (of gam_nseg) handles exactly the frames whose alpha' and beta rows exist once every
+  // recursion has done its steps below seg_bound[gam_seg].  gam_nseg = 0: all.
   int gam_seg, gam_nseg;
   int seg_bound[16];         // recursion segment s covers steps [seg_bound[s-1], seg_bound[s]) (seg_bound[-1] = 0)
   // Streamed occupancy pass (`stream` = 1): the recursion workgroup of (direction, sequence) publishes in
@@ -92,9 +93,9 @@ struct DenArgs {
 // true if the recursion of this call runs as den_recursion_lazy_kernel (decided once per call; the occupancy
 // launches - also those of a later chain_loss_backward on the same workspace - must be told: DenArgs::lazy)
 bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows);
-// ... in its 8-wave shape (DenArgs::wide); checked before den_lazy_eligible, which is the 16-wave shape
-bool den_wide_eligible(const DenArgs& a, int resident_slot_rows);
+// ... with LDS-direct rows (16 waves), and in four-wave workgroups (DenArgs::shape)
 bool den_dma_eligible(const DenArgs& a, int resident_slot_rows);
+bool den_small_eligible(const DenArgs& a, int resident_slot_rows);
 // true if the occupancy pass of this call can run as ONE persistent launch beside the recursion (DenArgs::stream): the
 // recursion kernel of the call reports per-sequence progress (lazy and pair forms), one plan for all sequences
 bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
@@ -108,6 +109,11 @@ int den_recursion_blocks(const DenArgs& a);
 
 // true if launch_den would run the two-frame occupancy kernel (the only one that can fold the numerator in)
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
+
+// the recursion launch of a call by its kernel family (den_lazy.hip: lazy / pair by a.pair, a.shape; den_rec.hip: the two-
+// barrier kernel): called by launch_den
+hipError_t launch_den_lazy_family(const DenArgs& a, int hint, hipStream_t st);
+hipError_t launch_den_rec2b(const DenArgs& a, int hint, size_t lds_rec, hipStream_t st);
 
 // Enqueues the two launches on `st`.  On failure returns the HIP error and, when the
 // shape is unsupported, a reason in *why.

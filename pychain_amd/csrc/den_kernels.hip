@@ -47,324 +47,7 @@ namespace pychain_hip {
 
 namespace {
 
-#ifdef PYCHAIN_PROFILE_PHASES
-#define PH_T() __builtin_readcyclecounter()
-#else
-#define PH_T() 0ull
-#endif
-
-constexpr int kNW = PLAN_REC_WAVES;        // waves per workgroup (both kernels)
-constexpr int kNT = kNW * 64;              // threads per workgroup
-static_assert(PLAN_REC_WAVES == PLAN_GAM_WAVES, "one workgroup shape for both kernels");
-static_assert(kNW <= 16, "block totals are reduced inside one 16-lane DPP row");
-constexpr int kMaxResident = PLAN_REC_WAVES > 12 ? PLAN_RESIDENT_2 : 44;   // slot-rows per wave kept in VGPRs
-static_assert(PLAN_REC_WAVES <= 12 || (PLAN_RESIDENT_0 == 16 && PLAN_RESIDENT_1 == 32), "the plan compiler sizes its slack for these loop lengths");
-
-// ---- one frame of a tile plan: out[row] = sum_k p_k * U[i0_k] * V[i1_k] ------------------
-// The first R slot-rows of a wave are held in registers as ABSOLUTE LDS byte addresses of
-// the two operands plus the arc probability (R = 0: everything is streamed from the
-// L2-resident plan).  The plan of a wave is loop-invariant over frames, so this is loaded
-// ONCE per workgroup and the per-frame inner loop touches only LDS.
-#ifndef PYCHAIN_ARC_PACKED
-#define PYCHAIN_ARC_PACKED (PLAN_REC_WAVES > 12)   // 16 waves: 128 VGPRs/lane -> 2 registers per slot-row
-#endif
-template <int R>
-struct ArcRegs {
-#if PYCHAIN_ARC_PACKED
-  // 2 VGPRs per slot-row: both absolute LDS byte addresses packed 16:16, and the probability.
-  uint32_t pk[R > 0 ? R : 1];
-#else
-  // 3 VGPRs per slot-row: the two absolute LDS byte addresses and the probability.
-  uint32_t o0[R > 0 ? R : 1];
-  uint32_t o1[R > 0 ? R : 1];
-#endif
-  float p[R > 0 ? R : 1];
-  __device__ __forceinline__ void load(const int nslot_rows, const uint2* __restrict__ wave_slots,
-                                       uint32_t lds_u, uint32_t lds_v) {
-#pragma unroll
-    for (int s = 0; s < R; s++) {
-      uint2 a = make_uint2(0u, 0u);                    // rows past the plan: p = 0, harmless addresses
-      if (s < nslot_rows) a = wave_slots[s * 64];
-      uint32_t a0 = lds_u + ((a.x & 0xffffu) << 2), a1 = lds_v + ((a.x >> 16) << 2);
-#ifdef PYCHAIN_EXP_NOCONFLICT      // timing experiment: lane-linear gathers (wrong results)
-      a0 = lds_u + (((threadIdx.x & 63) + 64 * (s & 7)) << 2); a1 = lds_v + (((threadIdx.x & 63) + 64 * (s & 7)) << 2);
-#endif
-#if PYCHAIN_ARC_PACKED
-      pk[s] = a0 | (a1 << 16);
-#else
-      o0[s] = a0; o1[s] = a1;
-      asm volatile("" : "+v"(o0[s]), "+v"(o1[s]));    // opaque: no re-derivation from the packed word per frame
-#endif
-      p[s] = __uint_as_float(a.y);
-    }
-  }
-  // the two gathered operands of slot-row s
-  // Opaque per frame and chunk: otherwise the optimiser hoists both unpacked addresses of every
-  // slot-row out of the frame loop (3 VGPRs per arc instead of 2).  One statement per chunk:
-  // every inline asm costs a hazard s_nop.
-  template <int N>
-  __device__ __forceinline__ void opaque(int s) {
-#if PYCHAIN_ARC_PACKED
-    if constexpr (N == 4) asm volatile("" : "+v"(pk[s]), "+v"(pk[s + 1]), "+v"(pk[s + 2]), "+v"(pk[s + 3]));
-    else for (int k = 0; k < N; k++) asm volatile("" : "+v"(pk[s + k]));
-#endif
-  }
-  template <int VOFF = 0>         // VOFF: compile-time byte offset of operand V (folds into the ds_read offset field)
-  __device__ __forceinline__ void gather(int s, float& u, float& v) {
-#if PYCHAIN_ARC_PACKED
-    const uint32_t a0 = pk[s] & 0xffffu, a1 = pk[s] >> 16;
-#else
-    const uint32_t a0 = o0[s], a1 = o1[s];
-#endif
-#ifndef PYCHAIN_EXP_NOLDS
-    u = lds_abs(a0); v = lds_abs(a1 + VOFF);
-#else
-    u = __uint_as_float(a0); v = __uint_as_float(a1);
-#endif
-  }
-};
-
-#ifndef PYCHAIN_CHUNK
-#define PYCHAIN_CHUNK 4      // slot-rows gathered ahead per step of the software pipeline
-#endif
-
-// The wave's group table lives in registers: lane i of `base` / `n` = output base and
-// slot-row count of the wave's i-th group (read back with v_readlane), `endmask` bit s =
-// resident slot-row s closes a group.  The frame loop issues NO memory instruction for
-// bookkeeping.  (A table in global memory costs a vmcnt wait per group, and vmcnt is
-// in-order: it would also wait for the nnet-output prefetch from HBM.)
-struct GroupRegs {
-  int base, n;
-  unsigned long long endmask;
-  uint32_t endmask2;        // ... slot-rows 64 .. 95 (the 8-wave recursion keeps up to 80)
-  uint32_t chunkmask;       // bit c = chunk c of the resident slot-rows contains a group end
-  int ngroups, nslots;      // of this wave
-  int tail_g, tail_rem;     // group / slot-rows left in it when the streamed tail (slot-row R) starts
-  template <int R>
-  __device__ __forceinline__ void load(const WaveEntry we, const GroupEntry* __restrict__ gtab, int lane) {
-    ngroups = __builtin_amdgcn_readfirstlane(we.ngroups);
-    nslots = __builtin_amdgcn_readfirstlane(we.nslot_rows);
-    const int first = __builtin_amdgcn_readfirstlane(we.first_group);
-    base = 0; n = 0;
-    if (lane < ngroups) { const GroupEntry e = gtab[first + lane]; base = e.out_base; n = e.nslots; }
-    endmask = 0ull; endmask2 = 0u; tail_g = 0; tail_rem = 0;
-    int cum = 0;
-    bool tail_set = false;
-    for (int gi = 0; gi < ngroups; gi++) {
-      const int cnt = __builtin_amdgcn_readlane(n, gi);
-      if (cnt > 0) {
-        if (!tail_set && cum + cnt > R) { tail_g = gi; tail_rem = cum + cnt - (cum > R ? cum : R); tail_set = true; }
-        cum += cnt;
-        if (cum - 1 < R && cum - 1 < 64) endmask |= 1ull << (cum - 1);
-        else if (cum - 1 < R && cum - 1 < 96) endmask2 |= 1u << (cum - 1 - 64);
-      }
-    }
-    chunkmask = 0u;
-    for (int c = 0; c * PYCHAIN_CHUNK < 64; c++)
-      if ((endmask >> (c * PYCHAIN_CHUNK)) & ((1ull << PYCHAIN_CHUNK) - 1ull)) chunkmask |= 1u << c;
-    for (int c = 0; c * PYCHAIN_CHUNK < 32; c++)
-      if ((endmask2 >> (c * PYCHAIN_CHUNK)) & ((1u << PYCHAIN_CHUNK) - 1u)) chunkmask |= 1u << (c + 64 / PYCHAIN_CHUNK);
-  }
-};
-
-// MODE 0: out[out_base+lane] = acc (recursions).  MODE 1: out[row_map[out_base+lane]] = acc
-// (occupancy pass: plan order -> natural pdf order, row_map in LDS, -1 = padding row).
-template <int MODE>
-__device__ __forceinline__ void tile_store(float acc, int pos, float* __restrict__ out, const int* __restrict__ row_map) {
-  if constexpr (MODE == 0) {
-    out[pos] = acc;
-  } else {
-    const int nat = row_map[pos];
-    if (nat >= 0) out[nat] = acc;
-  }
-}
-
-// s_waitcnt on lgkmcnt only (gfx9 encoding: vmcnt[3:0] expcnt[6:4] lgkmcnt[11:8] vmcnt_hi[15:14])
-#define PYCHAIN_WAIT_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
-
-// Issue priority of a wave falls as it progresses through the chunks of a frame: the waves of a SIMD
-// that are behind catch up, so all of them finish the arc phase together.  With equal priorities the
-// arbiter serves the oldest wave first and the youngest runs its last chunks alone, latency-bound
-// (measured per wave: 3000 / 4000 / 4700 / 5300 cycles; with this: recursion 4.02 -> 3.69 ms).
-template <int NC>
-__device__ __forceinline__ void wave_priority_by_progress(int c) {
-#ifndef PYCHAIN_EXP_NOPRIO
-  // highest for the first half of the chunks, then stepping down to 0 on the last one (measured best of
-  // four schedules: equal quarters 3.76 ms, front-loaded 3.78, this 3.69, two levels 3.84)
-  constexpr int N = NC > 0 ? NC : 1;
-#if defined(PYCHAIN_PRIO_TABLE)                        /* experiments: eight hex digits, the level of each eighth of the chunks */
-  auto level = [](int cc) { return (int)((PYCHAIN_PRIO_TABLE >> (4 * (7 - cc * 8 / N))) & 0xfu); };
-#elif !defined(PYCHAIN_PRIO_SCHED) || PYCHAIN_PRIO_SCHED == 0
-  auto level = [](int cc) { return cc * 2 / N == 0 ? 3 : max(0, 2 - (cc - N / 2) * 6 / N); };
-#elif PYCHAIN_PRIO_SCHED == 2                          /* experiments */
-  auto level = [](int cc) { return cc * 2 / N == 0 ? 0 : min(3, 1 + (cc - N / 2) * 6 / N); };
-#elif PYCHAIN_PRIO_SCHED == 3
-  auto level = [](int cc) { return cc * 4 / N >= 3 ? 0 : 3; };
-#else
-  auto level = [](int cc) { return 3 - cc * 4 / N; };
-#endif
-  const int lvl = level(c), prev = c > 0 ? level(c - 1) : -1;
-  if (NC >= 4 && lvl != prev) {
-    switch (lvl) {                               // (s_setprio takes an immediate)
-      case 3: __builtin_amdgcn_s_setprio(3); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      default: __builtin_amdgcn_s_setprio(0); break;
-    }
-  }
-#endif
-}
-
-// One frame of a tile plan.  The resident loop is written for instruction count (the arc phase
-// is bound by LDS gather cycles, then by instructions issued - DESIGN.md §4):
-// per chunk of kChunk slot-rows 2 unpack + 2 ds_read + mul + fma per slot-row, ONE s_waitcnt and
-// ONE s_bitcmp/s_cbranch pair.  Nothing but `acc` is carried through the chunks: a group end
-// (a few per frame, out of line) finds its group by a popcount of the end mask and adds to the
-// row sums in place.
-template <int R, int MODE, int VOFF = 0>
-__device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
-                                          const uint2* __restrict__ tail_slots, int lane,
-                                          const float* __restrict__ U, const float* __restrict__ V,
-                                          float* __restrict__ out, const int* __restrict__ row_map,
-                                          const float* __restrict__ wvec, float& s0, float& s1) {
-  float acc = 0.f;
-#ifndef PYCHAIN_CHUNK
-#define PYCHAIN_CHUNK 4
-#endif
-  constexpr int kChunk = PYCHAIN_CHUNK;
-  static_assert(R % kChunk == 0 && 32 % kChunk == 0 && R <= 64, "whole chunks; a chunk never straddles the mask words");
-  constexpr int NC = R / kChunk;
-  // Opaque per call: otherwise the optimiser precomputes per-slot-row lane masks outside the
-  // frame loop and spills them.
-  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), cm = gr.chunkmask;
-  asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
-  // Software pipeline: the gathers of chunk c+1 are issued BEFORE chunk c is consumed; LDS
-  // returns in order, so one wait for "all but the newest 2*kChunk" covers the whole chunk.
-  // Rows past the wave's plan carry p = 0 and valid addresses: no bound check.
-  float ub[2][kChunk], vb[2][kChunk];
-  if (R > 0) {
-    ar.template opaque<kChunk>(0);
-#pragma unroll
-    for (int k = 0; k < kChunk; k++) ar.template gather<VOFF>(k, ub[0][k], vb[0][k]);
-  }
-#pragma unroll
-  for (int c = 0; c < NC; c++) {
-    const int cb = c & 1;
-    wave_priority_by_progress<NC>(c);
-    if (c + 1 < NC) {
-      ar.template opaque<kChunk>((c + 1) * kChunk);
-#pragma unroll
-      for (int k = 0; k < kChunk; k++) ar.template gather<VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k], vb[cb ^ 1][k]);
-    }
-#if !defined(PYCHAIN_EXP_NOLDS) && !defined(PYCHAIN_EXP_NOWAIT)
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    // the common case unconditionally; a chunk with a group end (a few per frame) redoes it
-    float nacc = acc;
-#pragma unroll
-    for (int k = 0; k < kChunk; k++) nacc = fmaf(ar.p[c * kChunk + k] * ub[cb][k], vb[cb][k], nacc);   // (p*u) rounded, then fused with v
-    if (__builtin_expect(((cm >> c) & 1u) != 0u, 0)) {
-      nacc = acc;
-#pragma unroll
-      for (int k = 0; k < kChunk; k++) {
-        const int sidx = c * kChunk + k;
-        nacc = fmaf(ar.p[sidx] * ub[cb][k], vb[cb][k], nacc);
-        if (((sidx < 32 ? m_lo : m_hi) >> (sidx & 31)) & 1u) {
-          // group index = number of group ends before this slot-row
-          const uint32_t lo_before = sidx < 32 ? (m_lo & ((1u << (sidx & 31)) - 1u)) : m_lo;
-          const uint32_t hi_before = sidx < 32 ? 0u : (m_hi & ((1u << (sidx & 31)) - 1u));
-          const int g = __builtin_popcount(lo_before) + __builtin_popcount(hi_before);
-          const int pos = __builtin_amdgcn_readlane(gr.base, g) + lane;
-          tile_store<MODE>(nacc, pos, out, row_map);
-          if constexpr (MODE == 0) {
-            // row sums, updated IN PLACE (tied asm operands): a plain `s0 += nacc` makes s0/s1 loop-carried
-            // values of the chunk chain and costs register copies on the common path of every chunk
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(s0) : "v"(nacc));
-            if (wvec) { const float wv = wvec[pos]; asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s1) : "v"(nacc), "v"(wv)); }
-          }
-          nacc = 0.f;
-        }
-      }
-    }
-    acc = nacc;
-  }
-  int g = __builtin_popcount(m_lo) + __builtin_popcount(m_hi);     // groups closed by the resident rows
-  if (gr.nslots > R) {                           // plan larger than the register budget: stream the tail
-    const uint2* sp = tail_slots;
-    g = gr.tail_g;
-    int cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
-    int remaining = gr.tail_rem;
-    for (int s = R; s < gr.nslots; s++) {
-      const uint2 a = *sp;
-      sp += 64;
-      acc = fmaf(__uint_as_float(a.y) * U[a.x & 0xffffu], V[a.x >> 16], acc);
-      if (--remaining == 0) {
-        tile_store<MODE>(acc, cur_base + lane, out, row_map);
-        if constexpr (MODE == 0) { s0 += acc; if (wvec) s1 += acc * wvec[cur_base + lane]; }
-        acc = 0.f;
-        g++;
-        cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
-        remaining = __builtin_amdgcn_readlane(gr.n, g & 63);
-      }
-    }
-  }
-  for (; g < gr.ngroups; g++)                    // trailing groups whose rows have no arcs: zeros
-    tile_store<MODE>(0.f, __builtin_amdgcn_readlane(gr.base, g & 63) + lane, out, row_map);
-}
-
-// Normalise the frame's raw sums into the gather operand and stream the row to HBM, 16 bytes
-// per lane:  alpha: v = raw/tot + coef*leaky   (AlphaSum/AlphaDash, chain-computation.cc:97-110,178-194)
-//            beta:  v = (raw + coef*sum_i leaky_i raw_i)/sum_i raw_i  (Beta, :313-330; unit-sum scale)
-// The row also goes to the trajectory store behind `sbuf` (byte offset row_off, < 0 = not stored), with a
-// device-scope write-through store (sc1): the occupancy kernel may read it on another XCD while this
-// kernel is still running (gated schedule), and the row is not read again here, so it need not stay in
-// this XCD's L2.
-constexpr int kStoreDeviceScope = 16;    // cache-policy operand of the buffer store: sc1
-// `cl0` = coef * leaky probs of this thread's first four states (constant over the frames: kept in
-// registers by the frame loop, `have_cl0`, instead of read from LDS and multiplied in every frame).
-__device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const float* lk, float* cur, XBuf sbuf, int row_off,
-                                              float inv, float coef, float add, int H, int Hp, int tid,
-                                              bool have_cl0 = false, float4 cl0 = make_float4(0.f, 0.f, 0.f, 0.f)) {
-  for (int i = tid * 4; i < Hp; i += kNT * 4) {
-    const float4 r = *reinterpret_cast<const float4*>(raw + i);
-    float4 v;
-    if (fwd) {
-      float4 cl;
-      if (have_cl0 && i == tid * 4) cl = cl0;
-      else {
-        const float4 l = *reinterpret_cast<const float4*>(lk + i);
-        cl = make_float4(coef * l.x, coef * l.y, coef * l.z, coef * l.w);
-      }
-      v = make_float4(r.x * inv + cl.x, r.y * inv + cl.y, r.z * inv + cl.z, r.w * inv + cl.w);
-    } else {
-      // (positions >= H are padding: nothing gathers them and the occupancy pass skips them, so they are
-      // allowed to carry add * inv instead of zero - masking costs 8 VALU per thread on the critical path)
-      const float ai = add * inv;                     // (r + add) * inv as one fma per element
-      v = make_float4(__builtin_fmaf(r.x, inv, ai), __builtin_fmaf(r.y, inv, ai), __builtin_fmaf(r.z, inv, ai), __builtin_fmaf(r.w, inv, ai));
-    }
-    *reinterpret_cast<float4*>(cur + i) = v;
-    if (row_off >= 0) {
-      u32x4 q;
-      q.x = __float_as_uint(v.x); q.y = __float_as_uint(v.y); q.z = __float_as_uint(v.z); q.w = __float_as_uint(v.w);
-      __builtin_amdgcn_raw_buffer_store_b128(q, sbuf, i * 4, row_off, kStoreDeviceScope);
-    }
-  }
-}
-
-// natural log on the v_log_f32 unit (1 ulp of log2): all lanes, no divergent libm call
-__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.693147182464599609375f; }
-
-// The reference's `ok` (BetaGeneralFrameDebug, chain-computation.cc:345-391): alpha'.beta' and the frame's
-// derivative sum within 5 % of 1.  With free per-frame scales the same statement reads
-// log G(t) + la[t] + lb[t+2] = log P (DenArgs::la); true = violated (also for NaN).
-// The occupancy kernels only record G(t) (the recursions may still be running when an overlapped occupancy
-// launch evaluates frame 0 of a short sequence); den_finish_kernel compares after the last launch of the call.
-__device__ __forceinline__ void den_record_frame_total(const DenArgs& a, int b, int t, float frame_total) {
-  a.gtot[(size_t)b * a.T + t] = frame_total;
-}
-
+#include "den_common.inc.h"
 // objf and the invariant check from the stored per-frame totals (DenArgs::tot_a).  One workgroup per sequence.
 //   rows of den_recursion_lazy_kernel: alpha row t carries prod_{tau<t} tot(tau); the beta row frame t's occupancy
 //       reads, b(t+1,.) + c(t+1), carries prod_{tau>=t+2} n(tau); objf = sum_{t<L} log tot(t) + log fin_dot
@@ -464,242 +147,6 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
   }
 }
 
-// block total of per-wave partials: red[16] in LDS (entries >= kNW stay zero)
-__device__ __forceinline__ float block_total(const float* red, int lane) { return dpp_row_sum(red[lane & 15]); }
-
-// ------------------------------------------------------------------------------------
-// launch 1: alpha and beta recursions
-// ------------------------------------------------------------------------------------
-// DB: the nnet-output row is double-buffered in LDS (two 16 KiB regions, D <= 4096), so the row of
-// the next frame is exp'd and stored by each wave right after ITS arc work - while slower waves
-// still gather - instead of by all waves at once between the two barriers.
-constexpr int kXOff = 16384;
-template <int VEC, int XCH, int R, bool DB>
-__global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool fwd = blockIdx.x < (unsigned)a.B;
-  const int b = fwd ? blockIdx.x : blockIdx.x - a.B;
-  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
-  const int nsteps = fwd ? L : L - 1;
-  const int j_begin = a.seg_begin, j_end = min(a.seg_end, nsteps);
-  if (j_begin > 0 && j_begin >= nsteps) return;      // this sequence finished in an earlier segment
-#ifdef PYCHAIN_EXP_ONLY_DIR                          // timing experiment: 0 = alpha workgroups only, 1 = beta only
-  if ((int)fwd == PYCHAIN_EXP_ONLY_DIR) return;
-#endif
-  const int Hp = a.Hp, H = a.H, D = a.D, Dp = (D + 3) & ~3;
-  const char* plan = a.plans + (size_t)b * a.plan_stride;
-  const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
-  const TilePlan tp = fwd ? hd->alpha : hd->beta;
-  const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
-  const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
-  const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
-
-  // LDS: cur = normalised state vector of the previous frame (gather operand U), xr = exp'd
-  // nnet-output row (operand V), raw = this frame's un-normalised sums, lk = leaky probs.
-  float* xr = reinterpret_cast<float*>(smem_raw);                      // DB: xr = buffer 0, xr + kXOff/4 = buffer 1
-  float* cur = xr + (DB ? 2 * (kXOff / 4) : Dp);
-  float* raw = cur + Hp;
-  float* lk = raw + Hp;
-  float* red = lk + Hp;              // [2][16]
-
-  GroupRegs groups;
-  groups.load<R>(we, gtab, lane);
-  const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
-  ArcRegs<R> arcs;
-  arcs.load(groups.nslots, wave_slots, lds_addr(cur), lds_addr(xr));
-  const uint2* tail_slots = wave_slots + (size_t)R * 64;
-
-  const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
-  const float* start_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_init_a : hd->off_final_b));
-  const float* xseq = a.x + (size_t)b * a.T * D;
-  float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
-  const float coef = a.coef;
-  const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
-  const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));   // < 2 GiB: checked at launch
-
-  float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2);   // per-frame totals for den_finish_kernel (DenArgs::tot_a)
-  int bad = (fwd && a.seg_begin == 0 && seq_len_bad(a.lengths, b, a.T)) ? 1 : 0;   // bit 0 not ok, bit 1 a NaN network output (den_lazy.inc.h)
-  float tot, wtot;
-  XRow<kNT, VEC, XCH> xq;
-  if (tid < 32) red[tid] = 0.f;
-  if (j_begin == 0) {
-    // ---- frame 0 (alpha) / frame L (beta): chain-computation.cc:92-95,97-110,178-194 / :232-245,313-330
-    float p0 = 0.f, p1 = 0.f;
-    for (int i = tid; i < Hp; i += kNT) {
-      const float l = leaky_g[i], s = start_g[i];
-      lk[i] = l; raw[i] = s;
-      p0 += s; p1 += s * l;
-    }
-    p0 = wave_sum(p0); p1 = wave_sum(p1);
-    {
-      const int t0 = fwd ? 0 : L - 1;                 // first nnet-output row this side consumes
-      xq.load(xseq + (size_t)t0 * D, D, tid);
-      if (fwd && xq.has_nan()) bad |= 2;               // a NaN network output: not ok, NaN log-probability
-      if (xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp) && fwd) bad |= 2;
-    }
-    __syncthreads();                                   // red zeroed
-    if (lane == 0) { red[wave] = p0; red[16 + wave] = p1; }
-    __syncthreads();
-    tot = block_total(red, lane); wtot = block_total(red + 16, lane);
-    const float inv = __builtin_amdgcn_rcpf(tot);
-    if (!(tot > 0.f) || !(inv > 0.f)) bad |= 1;
-    if (tid == 0) totv[fwd ? 0 : L] = tot;
-    normalise_row(fwd, raw, lk, cur, sbuf, (fwd ? 0 : L) * Hp * 4, inv, coef, coef * wtot, H, Hp, tid);
-  } else {
-    // ---- resume a later time segment: the state vector is the row the previous segment stored last
-    const float* row = store + (size_t)(fwd ? j_begin : L - j_begin) * Hp;
-    for (int i = tid * 4; i < Hp; i += kNT * 4) {
-      *reinterpret_cast<float4*>(cur + i) = *reinterpret_cast<const float4*>(row + i);
-      *reinterpret_cast<float4*>(lk + i) = *reinterpret_cast<const float4*>(leaky_g + i);
-    }
-    const int t0 = fwd ? j_begin : L - 1 - j_begin;
-    xq.load(xseq + (size_t)t0 * D, D, tid);
-    xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp);   // j_begin is even: buffer 0
-  }
-  __syncthreads();
-
-  float4 cl0 = make_float4(0.f, 0.f, 0.f, 0.f);       // coef * leaky probs of the states this thread normalises (alpha)
-  if (fwd && tid * 4 < Hp) {
-    const float4 l = *reinterpret_cast<const float4*>(lk + tid * 4);
-    cl0 = make_float4(coef * l.x, coef * l.y, coef * l.z, coef * l.w);
-  }
-  // ---- general frames.  alpha: step j produces alpha'(j+1) from alpha'(j) and x(j), j = 0..L-1
-  //                        beta:  step j produces beta(t) from beta(t+1) and x(t), t = L-1-j, j = 0..L-2
-#ifdef PYCHAIN_PROFILE_PHASES
-  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
-#define PH_ADD(i, t0) ph[i] += PH_T() - (t0)
-#else
-#define PH_ADD(i, t0) (void)(t0)
-#endif
-  // One frame step.  VOFF = byte offset of the nnet-output buffer this step gathers from (double-
-  // buffered form: even steps read buffer 0 and fill buffer 1, odd steps the reverse; the frame
-  // loop is unrolled by two IN SOURCE ORDER - a branch between two inlined copies of the arc loop
-  // makes the optimiser hoist their common address arithmetic above the branch and spill it).
-#define PYCHAIN_REC_STEP(J, VOFF)                                                                          \
-  do {                                                                                                      \
-    const int j = (J);                                                                                      \
-    unsigned long long pt = PH_T();                                                                         \
-    const int tn = fwd ? j + 1 : L - 2 - j;          /* nnet-output row of the NEXT step */                \
-    const bool have_next = fwd ? (tn < L) : (tn >= 1);                                                      \
-    const float* xrow_next = xseq + (size_t)(have_next ? tn : 0) * D;                                       \
-    if (kWithX && have_next) {                       /* in flight during the arc work */                    \
-      if constexpr (VEC == 4 && XCH > 0) xq.load_row(xbuf, have_next ? tn : 0, D, tid);                      \
-      else xq.load(xrow_next, D, tid);                                                                      \
-    }                                                                                                       \
-    float s0 = 0.f, s1 = 0.f;                                                                               \
-    if (kWithArcs)                                                                                          \
-      tile_rows<R, 0, VOFF>(arcs, groups, tail_slots, lane, cur, xr + (VOFF) / 4, raw, nullptr, fwd ? nullptr : lk, s0, s1); \
-    else { s0 = 1.f; s1 = 1.f; }                                                                            \
-    /* double-buffered: the other buffer was last read in the previous step, which every wave has left */   \
-    if (DB && kWithX && have_next) {                                                                        \
-      if (fwd && xq.has_nan()) bad |= 2;                                                                    \
-      xq.store(xr + (kXOff - (VOFF)) / 4, xrow_next, D, tid, a.input_is_exp);                               \
-    }                                                                                                       \
-    if (kArcsOnly) { if (s0 == 12345.f) raw[tid] = s0; if (kArcsOnly == 2) __syncthreads(); break; }        \
-    PH_ADD(0, pt); pt = PH_T();                                                                             \
-    s0 = wave_sum(s0);                                                                                      \
-    if (!fwd) s1 = wave_sum(s1);                                                                            \
-    if (lane == 0) { red[wave] = s0; red[16 + wave] = s1; }                                                 \
-    PH_ADD(1, pt); pt = PH_T();                                                                             \
-    __syncthreads();                                 /* every gather of this frame is done */               \
-    PH_ADD(2, pt); pt = PH_T();                                                                             \
-    tot = block_total(red, lane);                                                                           \
-    wtot = fwd ? 0.f : block_total(red + 16, lane);                                                         \
-    const float inv = __builtin_amdgcn_rcpf(tot);                                                           \
-    if (!(tot > 0.f) || !(inv > 0.f)) bad |= 1;                                                             \
-    const int tstore = fwd ? j + 1 : L - 1 - j;                                                             \
-    if (tid == 0) totv[tstore] = tot;                /* the scale divided out of this frame (den_finish_kernel) */ \
-    const bool do_store = fwd ? (tstore < L) : true;                                                        \
-    if (kWithNorm)                                                                                          \
-      normalise_row(fwd, raw, lk, cur, sbuf, do_store ? tstore * Hp * 4 : -1, inv, coef, coef * wtot, H, Hp, tid, true, cl0); \
-    PH_ADD(3, pt); pt = PH_T();                                                                             \
-    if (!DB && kWithX && have_next) {                                                                       \
-      if (fwd && xq.has_nan()) bad |= 2;                                                                    \
-      if (xq.store(xr, xrow_next, D, tid, a.input_is_exp) && fwd) bad |= 2;   /* (rows staged without registers) */ \
-    }                                                                                                       \
-    PH_ADD(4, pt); pt = PH_T();                                                                             \
-    __syncthreads();                                                                                        \
-    PH_ADD(5, pt);                                                                                          \
-  } while (0)
-  // (PYCHAIN_EXP_*: ablation builds for timing only - results are wrong)
-#ifdef PYCHAIN_EXP_NO_X
-  constexpr bool kWithX = false;
-#else
-  constexpr bool kWithX = true;
-#endif
-#ifdef PYCHAIN_EXP_NO_ARCS
-  constexpr bool kWithArcs = false;
-#else
-  constexpr bool kWithArcs = true;
-#endif
-#ifdef PYCHAIN_EXP_NO_NORM
-  constexpr bool kWithNorm = false;
-#else
-  constexpr bool kWithNorm = true;
-#endif
-#ifdef PYCHAIN_EXP_ARCS_ONLY
-  constexpr int kArcsOnly = PYCHAIN_EXP_ARCS_ONLY;
-#else
-  constexpr int kArcsOnly = 0;
-#endif
-  // Progress signal of the gated schedule: once the steps below seg_bound[s] are done, every wave waits for
-  // its own row stores (device-scope write-through, normalise_row: the L2s of the XCDs are not coherent with
-  // one another and the occupancy kernel runs on all of them), then one thread counts the workgroup in.
-  int next_sig = 0;
-  int next_bound = a.sig_n > 0 ? a.seg_bound[0] : 0x7fffffff;
-#define PYCHAIN_REC_SIGNAL(DONE)                                                                            \
-  while ((DONE) >= next_bound) {                                                                            \
-    __builtin_amdgcn_s_waitcnt(0);                     /* this wave's row stores are acknowledged */          \
-    __syncthreads();                                                                                        \
-    if (tid == 0) __hip_atomic_fetch_add(a.progress + next_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    next_sig++;                                                                                             \
-    next_bound = next_sig < a.sig_n ? a.seg_bound[next_sig] : 0x7fffffff;                                   \
-  }
-  if constexpr (DB) {
-    // segments start at even steps (seg bounds are multiples of 32), so step parity = buffer parity
-    for (int jj = j_begin; jj < j_end; jj += 2) {      // (the macro declares `j`)
-      PYCHAIN_REC_STEP(jj, 0);
-      if (jj + 1 < j_end) PYCHAIN_REC_STEP(jj + 1, kXOff);
-      PYCHAIN_REC_SIGNAL(jj + 2);                      // bounds are even
-    }
-  } else {
-    for (int jj = j_begin; jj < j_end; jj++) { PYCHAIN_REC_STEP(jj, 0); PYCHAIN_REC_SIGNAL(jj + 1); }
-  }
-  PYCHAIN_REC_SIGNAL(next_sig < a.sig_n ? 0x7ffffffe : 0);   // a sequence shorter than a bound is done with it now
-#undef PYCHAIN_REC_SIGNAL
-#undef PYCHAIN_REC_STEP
-#ifdef PYCHAIN_PROFILE_PHASES
-  if (lane == 0 && (b == 0))
-    printf("dir %d wave %d steps %d cycles/step: arcs %llu wsum %llu bar1 %llu update %llu xstore %llu bar2 %llu\n", (int)fwd, wave,
-           nsteps, ph[0] / max(1, j_end - j_begin), ph[1] / max(1, j_end - j_begin), ph[2] / max(1, j_end - j_begin),
-           ph[3] / max(1, j_end - j_begin), ph[4] / max(1, j_end - j_begin), ph[5] / max(1, j_end - j_begin));
-#endif
-
-  if (j_end >= nsteps && fwd) {
-    // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i alpha'(L,i) final(i) + sum_t log tot(t)
-    const float* fin = reinterpret_cast<const float*>(plan + hd->off_final_a);
-    float f = 0.f;
-    for (int i = tid; i < Hp; i += kNT) f += cur[i] * fin[i];
-    f = wave_sum(f);
-    if (lane == 0) red[wave] = f;
-    if (tid == 0) red[16] = 0.f;
-    __syncthreads();
-    if (bad & 2) red[16] = 1.f;                        // somebody staged a NaN network output
-    __syncthreads();
-    const float fs = block_total(red, lane);
-    if (tid == 0) {
-      a.fin_dot[b] = red[16] != 0.f ? __builtin_nanf("") : fs;       // den_finish_kernel: objf = sum_t log tot(t) + log of this
-      if (!(fs > 0.f)) bad |= 1;
-    }
-  }
-  if (bad && lane == 0) atomicAdd(a.bad, 1);
-}
-
-#include "den_lazy.inc.h"
-#include "den_pair.inc.h"
 
 // Which recursion segment makes frame t of a length-L sequence computable: its alpha'(t) row
 // exists once the forward recursion has run t steps, its beta(t+1) row once the backward
@@ -1391,14 +838,6 @@ __global__ void den_gate_kernel(const int32_t* progress, int target, int32_t* ba
   }
 }
 
-template <typename K>
-hipError_t launch_one(K kern, const DenArgs& a, dim3 grid, size_t lds, hipStream_t st, int nthreads = kNT) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(nthreads), lds, st, a);
-  return hipGetLastError();
-}
-
 // the two-frame occupancy kernel: what it supports, and its launch
 inline size_t gamma2_lds_bytes(const DenArgs& a, int gamma_max_groups) {
   return sizeof(float) * (4 * (size_t)a.Hp + (a.fold_rows ? 6 : 2) * (size_t)((a.D + 3) & ~3) + (size_t)gamma_max_groups * 64 + 32);
@@ -1408,16 +847,6 @@ inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
   return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
          a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) + kStaticLds <= 160 * 1024;
 }
-// rows = slot-rows per wave the plan needs (0 = unknown: stream everything); plans larger
-// than kMaxResident keep the first kMaxResident rows in registers and stream their tail.
-inline int pick_r(const DenArgs& a, int rows, int lds_words) {
-  if (rows <= 0 || (PYCHAIN_ARC_PACKED && lds_words * 4 > 65535)) return 0;   // packed 16-bit LDS addresses
-  if (rows <= 16) return 16;
-  if (rows <= 32) return 32;
-  if (rows <= PLAN_RESIDENT_FIT && kMaxResident > PLAN_RESIDENT_FIT) return PLAN_RESIDENT_FIT;
-  return kMaxResident;
-}
-
 template <int XCH, bool STREAM>
 hipError_t launch_gamma2(const DenArgs& a, int rows2, size_t lds, dim3 grid, hipStream_t st) {
   if (rows2 <= 16) return launch_one(den_gamma2_kernel<XCH, 16, STREAM>, a, grid, lds, st, kNT2);
@@ -1438,114 +867,11 @@ inline bool gamma_stream_shape_ok(const DenArgs& a, int hint, int gamma_max_grou
   return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && r > 0;
 }
 
-// The lazy-normalisation recursion (den_lazy.inc.h) in its 16-wave shape serves the shape the benchmarks run: nnet-output
-// row and state vector within its fixed LDS map, every arc of a wave in registers, at most LzNarrow::kMaxGroups groups
-// per wave (bit 30 of the plan hint), the whole sequence in one launch.
-// (`dma`: rows by LDS-direct loads, which take any row length; rows through registers are float4 loads: D % 4 == 0)
-inline bool lazy_shape_ok(const DenArgs& a, int hint, bool dma = false) {
-  const int rows = hint & 1023;
-  return ((hint >> 30) & 1) && (dma || a.D % 4 == 0) && a.D <= (int)LzNarrow::kMaxPdfs && a.Hp <= (int)LzNarrow::kMaxStates && rows > 0 &&
-         rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
-}
-hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
-  const dim3 grid(2 * a.B);
-  const int rows = hint & 1023;
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, LzNarrow>, a, grid, kLzBytes, st);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, LzNarrow>, a, grid, kLzBytes, st);
-  if (rows <= PLAN_RESIDENT_FIT) return launch_one(den_recursion_lazy_kernel<PLAN_RESIDENT_FIT, LzNarrow>, a, grid, kLzBytes, st);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident, LzNarrow>, a, grid, kLzBytes, st);
-}
-// ... and in its 8-wave shape (LzWide): the plan's 8-wave dealing joins the 16 waves in pairs, so a wave owns at most
-// twice the slot-rows and twice the groups of the 16-wave hint.  Chosen where the 16-wave shape does not fit (D > 4096).
-inline bool wide_shape_ok(const DenArgs& a, int hint) {
-  const int rows = hint & 1023;
-  return ((hint >> 30) & 1) && a.D % 4 == 0 && a.D <= (int)LzWide<5>::kMaxPdfs && a.Hp <= (int)LzWide<5>::kMaxStates && rows > 0 &&
-         rows <= 40 && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
-}
-template <int XCH>
-hipError_t launch_wide_x(const DenArgs& a, int rows, hipStream_t st) {
-  const dim3 grid(2 * a.B);
-  typedef LzWide<XCH> M;
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<32, M>, a, grid, M::kBytes, st, M::kWaves * 64);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<64, M>, a, grid, M::kBytes, st, M::kWaves * 64);
-  return launch_one(den_recursion_lazy_kernel<80, M>, a, grid, M::kBytes, st, M::kWaves * 64);
-}
-// the 16-wave shape with LDS-direct nnet-output rows (LzDma): D <= 9216, Hp <= 3072
-inline bool dma_shape_ok(const DenArgs& a, int hint) {
-  const int rows = hint & 1023;
-  return ((hint >> 30) & 1) && a.D <= (int)LzDma::kMaxPdfs && a.Hp <= (int)LzDma::kMaxStates && rows > 0 &&
-         rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
-}
-template <typename M>
-hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
-  const dim3 grid(2 * a.B);
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M>, a, grid, M::kBytes, st);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M>, a, grid, M::kBytes, st);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident, M>, a, grid, M::kBytes, st);
-}
-// the plan holds two-copy tiles (hint bit 29) and the shape fits the two-copy map: 32-row loops, rows of up to 4096 pdfs
-inline bool two_copy_shape_ok(const DenArgs& a, int hint) {
-#ifdef PYCHAIN_NO_SPLIT_ARCS
-  (void)a; (void)hint;
-  return false;
-#endif
-  return ((hint >> 29) & 1) && a.knobs.den_two_copy != 0 && lazy_shape_ok(a, hint, true) && (hint & 1023) <= 32 &&
-         a.D <= (int)LzNarrowDma2::kMaxPdfs && a.Hp <= (int)LzNarrowDma2::kMaxStates;
-}
-hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
-#ifndef PYCHAIN_NO_SPLIT_ARCS                          /* (the two-copy map takes arcs in the split form only) */
-  if (two_copy_shape_ok(a, hint)) {
-    const dim3 grid(2 * a.B);
-    if ((hint & 1023) <= 16) return launch_one(den_recursion_lazy_kernel<16, LzNarrowDma2>, a, grid, LzNarrowDma2::kBytes, st);
-    return launch_one(den_recursion_lazy_kernel<32, LzNarrowDma2>, a, grid, LzNarrowDma2::kBytes, st);
-  }
-#endif
-  // the map of C1-C3 where the shape fits it, else the one for rows of up to 9216 pdfs
-  if (lazy_shape_ok(a, hint, true)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
-  return launch_dma_m<LzDma>(a, hint & 1023, st);
-}
-hipError_t launch_wide(const DenArgs& a, int hint, hipStream_t st) {
-  const int rows = hint & 1023;
-  if (a.knobs.den_wide == 2 && lazy_shape_ok(a, hint, true))       // experiment: twelve waves (rows of a wave <= 56, checked by the kernel)
-    return launch_one(den_recursion_lazy_kernel<56, LzNarrowDma12>, a, dim3(2 * a.B), LzNarrowDma12::kBytes, st, 12 * 64);
-  return a.D <= (int)LzWide<2>::kMaxPdfs ? launch_wide_x<2>(a, rows, st) : launch_wide_x<5>(a, rows, st);
-}
-
-// Two sequences per workgroup (den_pair.inc.h): one plan for all sequences, nnet-output rows and state vectors
-// within its fixed LDS map, every arc of a plan wave in registers, the whole sequence in one launch.
-inline bool pair_shape_ok(const DenArgs& a, int hint) {
-  const int rows = hint & 1023;
-  return a.plan_stride == 0 && a.D % 4 == 0 && a.D <= 4096 && a.Hp <= 4096 && rows > 0 && rows <= kMaxResident &&
-         PLAN_REC_WAVES == 16 && a.B >= 2;
-}
-hipError_t launch_pair(const DenArgs& a, int hint, hipStream_t st) {
-  const dim3 grid(2 * ((a.B + 1) / 2));
-  const int rows = hint & 1023;
-  if (rows <= 16) return launch_one(den_recursion_pair_kernel<16>, a, grid, kPrBytes, st, kPrNT);
-  if (rows <= 32) return launch_one(den_recursion_pair_kernel<32>, a, grid, kPrBytes, st, kPrNT);
-  return launch_one(den_recursion_pair_kernel<kMaxResident>, a, grid, kPrBytes, st, kPrNT);
-}
-
 template <int VEC, int XCH>
 hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, int gx, hipStream_t st, int gamma_max_groups) {
   hipError_t e = hipSuccess;
-  if ((a.phase_mask & 1) && a.pair) {
-    e = launch_pair(a, hint, st);
-    if (e != hipSuccess) return e;
-  } else if ((a.phase_mask & 1) && a.lazy) {
-    e = a.wide == 1 ? launch_wide(a, hint, st) : (a.wide == 2 ? launch_dma(a, hint, st) : launch_lazy(a, hint, st));
-    if (e != hipSuccess) return e;
-  } else if (a.phase_mask & 1) {
-    const dim3 grid(2 * a.B);
-    // <4, 1> (D <= 4096, D % 4 == 0) double-buffers the nnet-output row: gathered operands end at 32 KiB + 4 Hp
-    constexpr bool DB = VEC == 4 && XCH == 1;
-    switch (pick_r(a, hint & 1023, DB ? 2 * (kXOff / 4) + a.Hp : a.Hp + ((a.D + 3) & ~3))) {
-      case 0: e = launch_one(den_recursion_kernel<VEC, XCH, 0, DB>, a, grid, lds_rec, st); break;
-      case 16: e = launch_one(den_recursion_kernel<VEC, XCH, 16, DB>, a, grid, lds_rec, st); break;
-      case 32: e = launch_one(den_recursion_kernel<VEC, XCH, 32, DB>, a, grid, lds_rec, st); break;
-      case PLAN_RESIDENT_FIT: e = launch_one(den_recursion_kernel<VEC, XCH, PLAN_RESIDENT_FIT, DB>, a, grid, lds_rec, st); break;
-      default: e = launch_one(den_recursion_kernel<VEC, XCH, kMaxResident, DB>, a, grid, lds_rec, st); break;
-    }
+  if (a.phase_mask & 1) {                                // (den_lazy.hip / den_rec.hip)
+    e = (a.pair || a.lazy) ? launch_den_lazy_family(a, hint, st) : launch_den_rec2b(a, hint, lds_rec, st);
     if (e != hipSuccess) return e;
   }
   if (a.phase_mask & 2) {
@@ -1598,23 +924,18 @@ hipError_t launch_den_gate(const int32_t* progress, int target, int32_t* bad, hi
   return hipGetLastError();
 }
 
-bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows); }
 bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
   return (a.lazy || a.pair) && gamma_stream_shape_ok(a, resident_slot_rows, gamma_max_groups);
 }
-bool den_wide_eligible(const DenArgs& a, int resident_slot_rows) { return wide_shape_ok(a, resident_slot_rows); }
-bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) || dma_shape_ok(a, resident_slot_rows); }
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
+  (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";
-  if (a.lazy && a.wide == 1 && a.knobs.den_wide == 2) return "den_recursion_lazy_kernel<12 waves>";
-  if (a.lazy && a.wide == 2 && two_copy_shape_ok(a, resident_slot_rows)) return "den_recursion_lazy_kernel<two copies>";
-  if (a.lazy) return a.wide == 1 ? "den_recursion_lazy_kernel<wide>" : (a.wide == 2 ? "den_recursion_lazy_kernel<dma>" : "den_recursion_lazy_kernel");
+  if (a.lazy) return a.shape == kShapeSmall ? "den_recursion_lazy_kernel<small>" : (a.shape == kShapeDma ? "den_recursion_lazy_kernel<dma>" : "den_recursion_lazy_kernel");
   return "den_recursion_kernel";
 }
 const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
   return gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
 }
-bool den_pair_eligible(const DenArgs& a, int resident_slot_rows) { return pair_shape_ok(a, resident_slot_rows); }
 int den_recursion_blocks(const DenArgs& a) { return a.pair ? 2 * ((a.B + 1) / 2) : 2 * a.B; }
 
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {

@@ -1,0 +1,93 @@
+// den_lazy.hip - the recursions that run the benchmarks: the lazy-normalisation alpha / beta recursion in its three shapes
+// (den_lazy.inc.h) and the two-sequences-per-workgroup recursion (den_pair.inc.h), with their shape predicates and launches.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <type_traits>
+#include <stdint.h>
+
+#include "common.h"
+#include "den_kernels.h"
+#include "device_utils.h"
+#include "plan_format.h"
+
+namespace pychain_hip {
+
+namespace {
+
+#include "den_common.inc.h"
+#include "den_lazy.inc.h"
+#include "den_pair.inc.h"
+
+// The lazy-normalisation recursion (den_lazy.inc.h) in its 16-wave shape serves the shape the benchmarks run: nnet-output
+// row and state vector within its fixed LDS map, every arc of a wave in registers, at most LzNarrow::kMaxGroups groups
+// per wave (bit 30 of the plan hint), the whole sequence in one launch.
+// (`dma`: rows by LDS-direct loads, which take any row length; rows through registers are float4 loads: D % 4 == 0)
+inline bool lazy_shape_ok(const DenArgs& a, int hint, bool dma = false) {
+  const int rows = hint & 1023;
+  return ((hint >> 30) & 1) && (dma || a.D % 4 == 0) && a.D <= (int)LzNarrow::kMaxPdfs && a.Hp <= (int)LzNarrow::kMaxStates && rows > 0 &&
+         rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
+}
+hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
+  const dim3 grid(2 * a.B);
+  const int rows = hint & 1023;
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, LzNarrow>, a, grid, kLzBytes, st);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, LzNarrow>, a, grid, kLzBytes, st);
+  if (rows <= PLAN_RESIDENT_FIT) return launch_one(den_recursion_lazy_kernel<PLAN_RESIDENT_FIT, LzNarrow>, a, grid, kLzBytes, st);
+  return launch_one(den_recursion_lazy_kernel<kMaxResident, LzNarrow>, a, grid, kLzBytes, st);
+}
+// the 16-wave shape with LDS-direct nnet-output rows (LzDma): D <= 9216, Hp <= 3072
+inline bool dma_shape_ok(const DenArgs& a, int hint) {
+  const int rows = hint & 1023;
+  return ((hint >> 30) & 1) && a.D <= (int)LzDma::kMaxPdfs && a.Hp <= (int)LzDma::kMaxStates && rows > 0 &&
+         rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
+}
+template <typename M>
+hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
+  const dim3 grid(2 * a.B);
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+  return launch_one(den_recursion_lazy_kernel<kMaxResident, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+}
+hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
+  // the map of C3 where the shape fits it, else the one for rows of up to 9216 pdfs
+  if (lazy_shape_ok(a, hint, true)) return launch_dma_m<LzNarrowDma>(a, hint & 1023, st);
+  return launch_dma_m<LzDma>(a, hint & 1023, st);
+}
+// Four-wave workgroups over the plan's four-wave dealing (hint bit 29: every plan of the call holds alpha4 / beta4, and the
+// hint's row count is that dealing's): small graphs, LDS-direct rows.
+inline bool small_shape_ok(const DenArgs& a, int hint) {
+  const int rows = hint & 1023;
+  return ((hint >> 29) & 1) && a.D <= (int)LzSmall::kMaxPdfs && a.Hp <= (int)LzSmall::kMaxStates && rows > 0 && rows <= kMaxResident &&
+         a.plan_stride >= 0;
+}
+hipError_t launch_small(const DenArgs& a, int hint, hipStream_t st) { return launch_dma_m<LzSmall>(a, hint & 1023, st); }
+
+// Two sequences per workgroup (den_pair.inc.h): one plan for all sequences, nnet-output rows and state vectors
+// within its fixed LDS map, every arc of a plan wave in registers, the whole sequence in one launch.
+inline bool pair_shape_ok(const DenArgs& a, int hint) {
+  const int rows = hint & 1023;
+  return a.plan_stride == 0 && a.D % 4 == 0 && a.D <= 4096 && a.Hp <= 4096 && rows > 0 && rows <= kMaxResident &&
+         PLAN_REC_WAVES == 16 && a.B >= 2;
+}
+hipError_t launch_pair(const DenArgs& a, int hint, hipStream_t st) {
+  const dim3 grid(2 * ((a.B + 1) / 2));
+  const int rows = hint & 1023;
+  if (rows <= 16) return launch_one(den_recursion_pair_kernel<16>, a, grid, kPrBytes, st, kPrNT);
+  if (rows <= 32) return launch_one(den_recursion_pair_kernel<32>, a, grid, kPrBytes, st, kPrNT);
+  return launch_one(den_recursion_pair_kernel<kMaxResident>, a, grid, kPrBytes, st, kPrNT);
+}
+
+}  // namespace
+
+bool den_lazy_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows); }
+bool den_small_eligible(const DenArgs& a, int resident_slot_rows) { return small_shape_ok(a, resident_slot_rows); }
+bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) || dma_shape_ok(a, resident_slot_rows); }
+bool den_pair_eligible(const DenArgs& a, int resident_slot_rows) { return pair_shape_ok(a, resident_slot_rows); }
+
+// the recursion launch of a call whose DenArgs say pair or lazy (launch_den)
+hipError_t launch_den_lazy_family(const DenArgs& a, int hint, hipStream_t st) {
+  if (a.pair) return launch_pair(a, hint, st);
+  return a.shape == kShapeSmall ? launch_small(a, hint, st) : (a.shape == kShapeDma ? launch_dma(a, hint, st) : launch_lazy(a, hint, st));
+}
+
+}  // namespace pychain_hip

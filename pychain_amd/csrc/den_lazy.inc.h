@@ -1,4 +1,4 @@
-// den_lazy.inc.h - the alpha / beta recursions with LAZY normalisation (included by den_kernels.hip
+// den_lazy.inc.h - the alpha / beta recursions with LAZY normalisation (included by den_lazy.hip
 // inside its anonymous namespace).  Replaces chain-computation.cc:97-110,150-194 (AlphaSum, AlphaDash,
 // AlphaGeneralFrame) and :289-330 (BetaDashGeneralFrame, Beta) like den_recursion_kernel does, with a
 // different frame structure: ONE barrier per frame and no normalise pass.
@@ -26,11 +26,14 @@
 // for den_finish_kernel (log-probability, invariant check).  The state vector and the nnet-output row are both
 // double-buffered, so a frame writes only buffers nobody reads until the barrier.
 //
-// Two workgroup shapes share this code (template parameter MAP):
-//   LzNarrow  16 waves x 128 VGPRs, <= 40 slot-rows per wave, D <= 4096: the shape of C1 - C3 (measured fastest there);
-//   LzWide     8 waves x 256 VGPRs, <= 80 slot-rows per wave (the plan's 8-wave dealing: pairs of the 16 waves), nnet-output
-//              rows of up to 9216 pdfs: five float4 of a row per thread stay in registers across the arc loop, which the
-//              128-VGPR shape cannot afford (C4: D = 8408).
+// Workgroup shapes that share this code (template parameter MAP; all 128 VGPRs per wave, <= 40 slot-rows per wave):
+//   LzNarrow / LzNarrowDma  16 waves, D <= 4096, Hp <= 4096: C3 (rows through registers / by LDS-direct loads);
+//   LzDma                   16 waves, rows of up to 9216 pdfs by LDS-direct loads, Hp <= 3072: C4;
+//   LzSmall                  4 waves, Hp <= 1024, D <= 4096, over the plan's four-wave dealing (alpha4 / beta4): small graphs
+//                            (C1, C2) - a frame of theirs is a few hundred gathers, and sixteen waves walking their loops and
+//                            meeting at a barrier for four groups of work cost what a C3-size frame costs.
+// (8 and 12 waves with 256 / 168 VGPRs were built and measured in round 3: +46 % / +15 %, profiles/r03_a_time_matrix.txt,
+// r03_g_twelve_waves.txt; so was a map with two copies of the nnet-output row: +0.3 %, r03_i_two_copies.txt.)
 // LDS maps (absolute byte addresses; the dynamic segment starts at 0, checked).  An arc is two VGPRs as in
 // den_recursion_kernel: {kUField + 8*i0 | (kXField + 4*i1) << 16, p}; the buffer of a frame is selected by the ds_read
 // OFFSET field (16 bits: buffer base - field base, <= 65535), which costs no instruction.
@@ -40,52 +43,18 @@ struct LzNarrow {
   //   [96K, ...)  partial sums, beta's leaky probs
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 1;
   static constexpr bool kDma = false;
-  static constexpr uint32_t kXCopy = 0;               // byte offset of a second copy of the nnet-output row (0: one copy)
   static constexpr uint32_t kU0 = 0, kU1 = 32768, kX0 = 65536, kX1 = 81920, kUField = 0, kXField = 49152;
   static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
   static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
 };
 // the same map with the nnet-output rows brought in by LDS-direct loads (lazy_recursion: kDma): the default of C1-C3
 struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static constexpr int kXch = 0; };
-// ... with TWELVE waves (168 VGPRs each, <= 56 slot-rows per wave over the plan's 12-wave dealing): option den_wide = 2, an
-// experiment
-struct LzNarrowDma12 : LzNarrowDma { static constexpr int kWaves = 12; };
-// ... and with TWO copies of the nnet-output row, the second one with its 32-element blocks rotated (PLAN_SECOND_POS): the
-// plan's two-copy tiles (alpha_c / beta_c) say per arc which copy to read - a free binary choice per arc for the plan
-// compiler, which removes most bank conflicts of that operand at 32 slot-rows per wave.  The row is loaded once; the wave
-// that clamps / exp's a chunk in place writes the rotated copy too.  Arcs in the split form only (loops of <= 32 rows).
-//   [0, 16K) row 0   [16K, 32K) row 0, rotated   [32K, 48K) row 1   [48K, 64K) row 1, rotated
-//   [64K, 96K) state buffer 0   [96K, 128K) state buffer 1   [128K, ...) partial sums, beta's leaky probs
-struct LzNarrowDma2 {
-  static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
-  static constexpr bool kDma = true;
-  static constexpr uint32_t kXCopy = 16384;
-  static constexpr uint32_t kX0 = 0, kX1 = 32768, kU0 = 65536, kU1 = 98304, kUField = 65536, kXField = 0;
-  static constexpr uint32_t kRed = 131072, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
-  static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
-};
-static_assert(LzNarrowDma2::kX1 + LzNarrowDma2::kXCopy + 4 * LzNarrowDma2::kMaxPdfs <= LzNarrowDma2::kU0 && LzNarrowDma2::kBytes <= 160u * 1024u &&
-              LzNarrowDma2::kXField + LzNarrowDma2::kXCopy + 4 * (LzNarrowDma2::kMaxPdfs - 1) <= 65535u && LzNarrowDma2::kX1 - LzNarrowDma2::kXField <= 65535u &&
-              LzNarrowDma2::kU1 - LzNarrowDma2::kUField <= 65535u, "two-copy map");
-template <int XCH>
-struct LzWide {
-  //   [0, 36K)    nnet-output buffer 0: float[<= 9216]  [36K, 72K)  nnet-output buffer 1
-  //   [72K, 96K)  state buffer 0: float2[<= 3072]       [96K, 120K) state buffer 1
-  //   [120K, ...) beta's leaky probs, partial sums
-  static constexpr int kWaves = 8, kMaxGroups = 8, kXch = XCH;
-  static constexpr uint32_t kXCopy = 0;
-  static constexpr bool kDma = false;
-  static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
-  static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = XCH * 4 * 8 * 64 < 9216 ? XCH * 4 * 8 * 64 : 9216;
-  static constexpr uint32_t kLk = 122880, kRed = kLk + kMaxStates * 4, kBytes = kRed + 2 * 2 * 64 * 4;
-};
 // 16 waves x 128 VGPRs AND nnet-output rows of up to 9216 pdfs (C4): the rows never pass through registers.  Every wave
 // requests its 1 KiB chunks of the NEXT step's raw row with `buffer_load_dwordx4 ... lds` (lane l's 16 bytes land at
 // chunk base + 16 l: tools/ubench/ldsdma.hip) at the start of a frame, straight into the buffer the next frame gathers
 // from, and clamps / exp's its own chunks IN PLACE at the end of the frame.
 struct LzDma {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
-  static constexpr uint32_t kXCopy = 0;
   static constexpr bool kDma = true;
   static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 9216;
@@ -96,7 +65,17 @@ template <typename MAP> constexpr bool lz_map_ok() {
          MAP::kUField + 8u * (MAP::kMaxStates - 1) <= 65535u && MAP::kXField + 4u * (MAP::kMaxPdfs - 1) <= 65535u &&
          MAP::kBytes <= 160u * 1024u;
 }
-static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzWide<5>>() && lz_map_ok<LzWide<2>>() && lz_map_ok<LzDma>(), "ds_read offset fields are 16 bits");
+// Four waves, small graphs: everything below 64 KiB, three workgroups per CU by LDS.
+//   [0, 8K) state buffer 0: float2[<= 1024]   [8K, 16K) state buffer 1   [16K, 32K) nnet-output buffer 0   [32K, 48K) buffer 1
+//   [48K, ...) partial sums, beta's leaky probs
+struct LzSmall {
+  static constexpr int kWaves = 4, kMaxGroups = 4, kXch = 0;
+  static constexpr bool kDma = true;
+  static constexpr uint32_t kU0 = 0, kU1 = 8192, kX0 = 16384, kX1 = 32768, kUField = 0, kXField = 16384;
+  static constexpr uint32_t kMaxStates = 1024, kMaxPdfs = 4096;
+  static constexpr uint32_t kRed = 49152, kLk = kRed + 2 * 2 * 64 * 4, kBytes = kLk + kMaxStates * 4;
+};
+static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzDma>() && lz_map_ok<LzSmall>(), "ds_read offset fields are 16 bits");
 constexpr uint32_t kLzBytes = LzNarrow::kBytes;
 
 typedef float lz_v2f __attribute__((ext_vector_type(2)));
@@ -146,8 +125,7 @@ __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int
   }
 }
 // this wave's chunks of the row at xbase: raw -> clamp / exp, in place; returns true if a NaN was seen
-// (XCOPY != 0: ... and once more, block-rotated, at xbase + XCOPY)
-template <int NW, int NCH, uint32_t XCOPY = 0>
+template <int NW, int NCH>
 __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_t xbase, int is_exp) {
   bool nan = false;
   PYCHAIN_WAIT_VM0();                                   // this wave's loads have landed
@@ -165,10 +143,6 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
       }
       if (is_exp == kXExpClamp) q = lz_v4{clamp_exp(q.x, kXExpClamp), clamp_exp(q.y, kXExpClamp), clamp_exp(q.z, kXExpClamp), clamp_exp(q.w, kXExpClamp)};
       *(__attribute__((address_space(3))) lz_v4*)(addr) = q;
-      if constexpr (XCOPY != 0) {
-        const uint32_t e = (uint32_t)ch * 256u + (uint32_t)lane * 4u;
-        *(__attribute__((address_space(3))) lz_v4*)(xbase + XCOPY + 4u * (uint32_t)PLAN_SECOND_POS(e)) = q;
-      }
     }
   }
   return nan;
@@ -177,7 +151,6 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
 
 template <int R, typename MAP>
 struct LazyArcs {
-  static_assert(MAP::kXCopy == 0, "two-copy maps: split arcs only");
   uint32_t pk[R];
   float p[R];
   __device__ __forceinline__ void load(int nslot_rows, const uint2* __restrict__ wave_slots) {
@@ -218,19 +191,10 @@ struct LazyArcsSplit {
       if (s + 1 < nslot_rows) b = wave_slots[(s + 1) * 64];
       ua[s] = MAP::kUField + ((a.x & 0xffffu) << 3);
       ua[s + 1] = MAP::kUField + ((b.x & 0xffffu) << 3);
-      xp[s / 2] = (MAP::kXField + xfield(a.x >> 16)) | ((MAP::kXField + xfield(b.x >> 16)) << 16);
+      xp[s / 2] = (MAP::kXField + ((a.x >> 16) << 2)) | ((MAP::kXField + ((b.x >> 16) << 2)) << 16);
       pp[s / 2] = lz_v2f{__uint_as_float(a.y), __uint_as_float(b.y)};
       // (opaque: a field base beyond the 16-bit offset field of ds_read would otherwise be split off and re-added per gather)
       asm volatile("" : "+v"(ua[s]), "+v"(ua[s + 1]));
-    }
-  }
-  // byte offset of an arc's nnet-output operand from the row buffer: two-copy maps read bit 15 of the index as "the rotated copy"
-  static __device__ __forceinline__ uint32_t xfield(uint32_t idx) {
-    if constexpr (MAP::kXCopy != 0) {
-      const uint32_t n = idx & 0x7fffu;
-      return (idx & 0x8000u) ? MAP::kXCopy + 4u * (uint32_t)PLAN_SECOND_POS(n) : 4u * n;
-    } else {
-      return idx << 2;
     }
   }
   __device__ __forceinline__ void opaque4(int s) { asm volatile("" : "+v"(xp[s / 2]), "+v"(xp[s / 2 + 1])); }
@@ -409,9 +373,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const int Hp = a.Hp, D = a.D;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
-  const TilePlan tp = MAP::kXCopy != 0 ? (fwd ? hd->alpha_c : hd->beta_c)
-                      : NW == 16 ? (fwd ? hd->alpha : hd->beta) : (NW == 12 ? (fwd ? hd->alpha12 : hd->beta12) : (fwd ? hd->alpha8 : hd->beta8));
-  const bool have_tile = tp.nwaves == NW;                         // (the 12-wave dealing is in the plan on request only)
+  static_assert(NW == PLAN_REC_WAVES || NW == PLAN_REC4_WAVES, "the plan deals the recursion tiles to 16 and to 4 waves");
+  const TilePlan tp = NW == PLAN_REC_WAVES ? (fwd ? hd->alpha : hd->beta) : (fwd ? hd->alpha4 : hd->beta4);
+  const bool have_tile = tp.nwaves == NW;                         // (the four-wave dealing is in the plans of small graphs only)
   const WaveEntry we = have_tile ? reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave] : WaveEntry{};
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
@@ -460,7 +424,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const int t0 = fwd ? 0 : L - 1;
     if constexpr (MAP::kDma) {
       lz_dma_row<NW, kDmaCh>(xbuf, t0, D, wave, lane, MAP::kX0);
-      if (lz_dma_finish<NW, kDmaCh, MAP::kXCopy>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
+      if (lz_dma_finish<NW, kDmaCh>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
     } else {
       xq.load(xseq + (size_t)t0 * D, D, tid);
       if (fwd && xq.has_nan()) bad |= 2;
@@ -542,7 +506,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       const int trow = (FWDC) ? j : L - j;                                                                  \
       const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
       const int lane4 = lq * 4, lane8 = lq * 8;              /* one VGPR of addresses, the group in the SGPR offset */ \
-      if constexpr (PYCHAIN_BATCH_PROW && MAP::kDma && MAP::kMaxPdfs <= 4096 && MAP::kXCopy == 0 && R == 32) {  /* all reads, ONE wait, then the */ \
+      if constexpr (PYCHAIN_BATCH_PROW && MAP::kDma && MAP::kMaxPdfs <= 4096 && R == 32) {  /* all reads, ONE wait, then the */ \
         /* stores (gbase = 0 beyond ngroups) instead of a round trip per group: C3 -0.6 %; the maps with less room would spill */ \
         lz_v2f prow[MG];                                                                                    \
         _Pragma("unroll") for (int g = 0; g < MG; g++) prow[g] = lz_ld2(UCUR + gbase[g] * 8 + lane8);       \
@@ -562,7 +526,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
       /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
       if constexpr (MAP::kDma && PYCHAIN_LATE_FINISH) {                                                     \
-        if (have_next && lz_dma_finish<NW, kDmaCh, MAP::kXCopy>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
+        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
       }                                                                                                     \
     });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
@@ -582,7 +546,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
     if constexpr (MAP::kDma) {                                                                              \
       if constexpr (!PYCHAIN_LATE_FINISH)                                                                   \
-        if (have_next && lz_dma_finish<NW, kDmaCh, MAP::kXCopy>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
+        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
     } else if (have_next) {                                                                                 \
       if ((FWDC) && xq.has_nan()) bad |= 2;                  /* a NaN network output: not ok, NaN log-probability */ \
       xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \

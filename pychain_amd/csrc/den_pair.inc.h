@@ -1,4 +1,4 @@
-// den_pair.inc.h - alpha / beta recursions of TWO sequences per workgroup (included by den_kernels.hip inside
+// den_pair.inc.h - alpha / beta recursions of TWO sequences per workgroup (included by den_lazy.hip inside
 // its anonymous namespace, after den_lazy.inc.h).
 //
 // From B = 128 on the 2B workgroups of den_recursion_kernel fill the chip and nothing overlaps them any more

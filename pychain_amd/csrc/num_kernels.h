@@ -38,7 +38,6 @@ struct NumArgs {
   // workgroups watch every element of every row and turn the loss into NaN, and the row-staging waves, whose
   // instruction count sets the pace of a numerator step, skip the check (num_fb 8 % faster).
   int watch_nan;
-  int no_staging_waves;      // option num_no_staging_waves (this call's snapshot, common.h:CallKnobs)
   // option debug_corrupt_row "num,b,t,scale": log(scale) is added to the stored alpha(t,.) of utterance b between the
   // recursions and the occupancy pass, so that the 5 % invariant can be seen to fire; corrupt_b < 0: off
   int corrupt_b, corrupt_t;

@@ -76,8 +76,8 @@ struct Balancer {
   struct Occ { int tile, row, op; };
   std::vector<std::vector<Occ>> occ[2];              // [layout A / B][state]: arcs that gather this state
   std::vector<std::vector<int>> gmax;                // [tile][group]: arc count of the group's longest row (fixed: it sets the slot-rows)
-  int same_lane_moves = 0;                           // PYCHAIN_PLAN_SAMELANE=n: n eighths of the moves keep the row's lane
-  bool free_moves = true;                            // PYCHAIN_PLAN_FREE=0: only rows of equal arc count trade places, across half-groups
+  static constexpr int same_lane_moves = 2;          // eighths of the moves that keep the row's lane (C3: -0.8 % against none)
+  static constexpr bool free_moves = true;           // rows of a group permute freely; rows of different arc counts trade where no group grows
   Lcg rng{0x2545F491u};
 
   Balancer(std::vector<Tile>& t, Layouts& l) : tiles(t), lay(l) {
@@ -213,15 +213,6 @@ struct SlotOrder {
   // profiles/r03_ubench_ldsbanks.txt): ds_read_b32  L=2 +0.6, L=4 +2.8, L=8 +7.0;  ds_read_b64  L=2 +0.2, L=4 +2.8, L=8 +7.1.
   // (A conflict-free wave64 gather occupies the LDS for 2.0 / 2.3 cycles - an all-padding slot-row costs that too.)
   int wide_op[2] = {0, 0};                           // operand gathered with ds_read_b64 (state vectors of the lazy recursions)
-  // Two copies of operand 1 in LDS (the nnet-output row, the second one skewed by 16 banks): every arc reads the copy the
-  // compiler picks for it (bit 15 of its operand-1 index), which all but removes the conflicts of that operand - the
-  // expensive ones - and leaves the slot order free to serve operand 0.  0 = one copy.
-  int v_choice = 0, u_choice = 0;                    // operand 1 / operand 0 have a second copy
-  static constexpr int kChoiceBit = 0x8000, kChoiceBit0 = 0x4000;   // in a cell: operand 1 / operand 0 read their second copy
-  // bank of element n in the second copy: its 32-element block is rotated by 4 ((n >> 5) & 7) elements (whole float4s
-  // stay together: the kernels write a row 16 bytes at a time), so that the two candidate banks of an arc are not tied to
-  // each other the way a fixed skew would tie them
-  static int second_bank(int n) { return PLAN_SECOND_POS(n) & 31; }
   int extra_tenths(int op, int L) const {
     if (L <= 1) return 0;
     if (L == 2) return wide_op[op] ? 2 : 6;
@@ -229,30 +220,20 @@ struct SlotOrder {
     return 10 * L - 12;
   }
 
-  SlotOrder(const Tile& tile, const Layouts& l, bool op0_wide, bool op1_wide, bool choice = false, bool choice0 = false) : t(tile), lay(l) {
-    wide_op[0] = op0_wide; wide_op[1] = op1_wide; v_choice = choice ? 1 : 0; u_choice = choice0 ? 1 : 0;
-    cost_model = (int)env_long("PYCHAIN_PLAN_COST", 0);
-    targeted = env_long("PYCHAIN_PLAN_TARGETED", 1) != 0;
-    best_of = (int)env_long("PYCHAIN_PLAN_BESTOF", 0);
-    w_op[0] = (int)env_long("PYCHAIN_PLAN_W0", 12); w_op[1] = (int)env_long("PYCHAIN_PLAN_W1", 12);
+  SlotOrder(const Tile& tile, const Layouts& l, bool op0_wide, bool op1_wide) : t(tile), lay(l) {
+    wide_op[0] = op0_wide; wide_op[1] = op1_wide;
     int off = 0;
     for (int g : t.gsl) { cell_off.push_back(off); off += 64 * g; }
     cell.assign(off, -1);
   }
   // one slot-row (column) of a group: bank loads of both halves and both operands
   struct Col { int cnt[2][2][32]; int nm[2][2][34]; int mx[2][2]; };
-  static constexpr int kScale = 4;                   // energy = kScale * extra tenths + sum of squared bank loads
-  int w_op[2] = {12, 12};
-  bool targeted = true;                              // PYCHAIN_PLAN_TARGETED=0: every move starts from a random cell
-  int best_of = 0;                                   // PYCHAIN_PLAN_BESTOF=n: a targeted move tries n candidate columns and takes the best
-  // cost model 0 (default): w * (fullest bank of half 0 + of half 1), both operands alike - the model of rounds 1-2, and the
-  // one the frame follows in situ (C3, 32-row loops: 1313 -> 878 of these units = 3.27 -> 3.09 ms); 1: the isolated gather costs
-  // of tools/ubench/ldsbanks.hip (halves side by side, a two-way conflict nearly free) - plans that look better and run slower
-  int cost_model = 0;
-  int col_energy_op(const Col& c, int op) const {
-    if (cost_model == 0) return w_op[op] * (c.mx[0][op] + c.mx[1][op]);
-    return kScale * extra_tenths(op, std::max(c.mx[0][op], c.mx[1][op]));
-  }
+  // Energy of a column and operand: w * (fullest bank of half 0 + of half 1), both operands alike, + the sum of squared bank
+  // loads.  This is the model the frame follows in situ (C3, 32-row loops: 1313 -> 878 of these units = 3.27 -> 3.09 ms,
+  // profiles/r03_h_split_arcs.txt); a model built on the ISOLATED gather costs of tools/ubench/ldsbanks.hip (halves side by
+  // side, a two-way conflict nearly free) gives plans that look better and run slower.
+  static constexpr int kW = 12;
+  int col_energy_op(const Col& c, int op) const { return kW * (c.mx[0][op] + c.mx[1][op]); }
   int col_add(Col& c, int hh, int op, int b, int d) const {   // returns the energy change
     int& x = c.cnt[hh][op][b];
     const int before = col_energy_op(c, op) + x * x;
@@ -270,7 +251,7 @@ struct SlotOrder {
     int* cl = &cell[cell_off[g]];                    // [row][slot]
     std::vector<Col> cs(A);
     for (auto& c : cs) { memset(&c, 0, sizeof(c)); for (int hh = 0; hh < 2; hh++) c.nm[hh][0][0] = c.nm[hh][1][0] = 32; }
-    std::vector<int> b0(nr * A, -1), b1(nr * A, -1), alt(nr * A, -1), alt0(nr * A, -1);   // banks of a cell's arc; alt / alt0 = operand 1 / 0 in its other copy
+    std::vector<int> b0(nr * A, -1), b1(nr * A, -1);   // banks of a cell's arc
     // greedy: rows with most arcs first; each arc goes to the free slot of its row with fewest collisions in its half
     std::vector<int> rorder(nr);
     std::iota(rorder.begin(), rorder.end(), 0);
@@ -280,33 +261,26 @@ struct SlotOrder {
       const auto& arcs = arcs_of(r);
       const int hh = r >> 5;
       for (int a = 0; a < (int)arcs.size(); a++) {
-        const int uc[2] = {lay.bank(t.lay[0], arcs[a].e0), second_bank(lay.pos[t.lay[0]][arcs[a].e0])};
-        const int xc[2] = {lay.bank(t.lay[1], arcs[a].e1), second_bank(lay.pos[t.lay[1]][arcs[a].e1])};
-        int best = -1, bc = 0, bch = 0, bch0 = 0;
+        const int x0 = lay.bank(t.lay[0], arcs[a].e0), x1 = lay.bank(t.lay[1], arcs[a].e1);
+        int best = -1, bc = 0;
         for (int j = 0; j < A; j++) {
           if (cl[r * A + j] >= 0) continue;
-          for (int ch0 = 0; ch0 <= u_choice; ch0++)
-            for (int ch = 0; ch <= v_choice; ch++) {
-              const int cst = cs[j].cnt[hh][0][uc[ch0]] + cs[j].cnt[hh][1][xc[ch]];
-              if (best < 0 || cst < bc) { best = j; bc = cst; bch = ch; bch0 = ch0; }
-            }
+          const int cst = cs[j].cnt[hh][0][x0] + cs[j].cnt[hh][1][x1];
+          if (best < 0 || cst < bc) { best = j; bc = cst; }
         }
-        const int x0 = uc[bch0], x1 = xc[bch];
-        alt[r * A + best] = xc[bch ^ 1]; alt0[r * A + best] = uc[bch0 ^ 1];
-        cl[r * A + best] = a | (bch ? kChoiceBit : 0) | (bch0 ? kChoiceBit0 : 0); b0[r * A + best] = x0; b1[r * A + best] = x1;
+        cl[r * A + best] = a; b0[r * A + best] = x0; b1[r * A + best] = x1;
         col_add(cs[best], hh, 0, x0, +1); col_add(cs[best], hh, 1, x1, +1);
       }
     }
     if (A >= 2) {
       const long iters = moves_per_cell * nr * A;
-      const double t0 = 0.01 * (double)env_long("PYCHAIN_PLAN_T0", 300), t1 = 0.01 * (double)env_long("PYCHAIN_PLAN_T1", 3);
+      const double t0 = 3.0, t1 = 0.03;
       const double cool = iters > 1 ? pow(t1 / t0, 1.0 / (double)iters) : 1.0;
       double T = t0;
       for (long it = 0; it < iters; it++, T *= cool) {
         int r = rng.next() % nr;
         const int j1 = rng.next() % A;
-        bool was_targeted = false;
-        if (targeted && (rng.next() & 1)) {
+        if (rng.next() & 1) {
           // half of the moves start from a lane that sits in the fullest bank of a conflicting half-column (a blind pick
           // mostly proposes to move arcs that collide with nobody)
           const int hh = rng.next() & 1, op = rng.next() & 1;
@@ -318,25 +292,12 @@ struct SlotOrder {
             int pick = -1, seen = 0;
             for (int rr = 32 * hh; rr < std::min(nr, 32 * hh + 32); rr++)
               if (bank[rr * A + j1] == bmax && (rng.next() % ++seen) == 0) pick = rr;
-            if (pick >= 0) { r = pick; was_targeted = true; }
+            if (pick >= 0) r = pick;
           }
-        }
-        if ((v_choice || u_choice) && (rng.next() & 3) == 0) {   // a quarter of the moves: one arc reads the other copy of an operand
-          const int i = r * A + j1, hh = r >> 5;
-          if (b0[i] < 0) continue;
-          const int op = (u_choice && (!v_choice || (rng.next() & 1))) ? 0 : 1;
-          std::vector<int>& cur = op ? b1 : b0;
-          std::vector<int>& other = op ? alt : alt0;
-          const int nb = other[i];
-          const int dE = col_add(cs[j1], hh, op, cur[i], -1) + col_add(cs[j1], hh, op, nb, +1);
-          if (dE <= 0 || rng.unit() < exp(-(double)dE / T)) { cl[i] ^= op ? kChoiceBit : kChoiceBit0; other[i] = cur[i]; cur[i] = nb; }
-          else { col_add(cs[j1], hh, op, nb, -1); col_add(cs[j1], hh, op, cur[i], +1); }
-          continue;
         }
         int j2 = rng.next() % (A - 1); if (j2 >= j1) j2++;
         const int hh = r >> 5;
-        // the energy change of lane r's cells j1 and jj trading places, applied (apply it again with the cells' banks
-        // exchanged - i.e. call revert - to undo)
+        // the energy change of lane r's cells j1 and j2 trading places, applied; `revert` undoes it
         auto apply = [&](int jj) {
           const int a1 = r * A + j1, a2 = r * A + jj;
           int d = 0;
@@ -353,23 +314,11 @@ struct SlotOrder {
           if (b0[a2] >= 0) { col_add(cs[jj], hh, 0, b0[a2], +1); col_add(cs[jj], hh, 1, b1[a2], +1); }
           if (b0[a1] >= 0) { col_add(cs[j1], hh, 0, b0[a1], +1); col_add(cs[j1], hh, 1, b1[a1], +1); }
         };
-        if (was_targeted && best_of > 0) {
-          // a targeted move goes to the best of a few candidate columns instead of a random one
-          int bestj = j2, bestd = 0x7fffffff;
-          for (int t = 0; t < best_of; t++) {
-            int jj = rng.next() % (A - 1); if (jj >= j1) jj++;
-            if (b0[r * A + j1] < 0 && b0[r * A + jj] < 0) continue;
-            const int d = apply(jj);
-            revert(jj);
-            if (d < bestd) { bestd = d; bestj = jj; }
-          }
-          j2 = bestj;
-        }
         const int i1 = r * A + j1, i2 = r * A + j2;
         if (b0[i1] < 0 && b0[i2] < 0) continue;
         const int dE = apply(j2);
         if (dE <= 0 || rng.unit() < exp(-(double)dE / T)) {
-          std::swap(cl[i1], cl[i2]); std::swap(b0[i1], b0[i2]); std::swap(b1[i1], b1[i2]); std::swap(alt[i1], alt[i2]); std::swap(alt0[i1], alt0[i2]);
+          std::swap(cl[i1], cl[i2]); std::swap(b0[i1], b0[i2]); std::swap(b1[i1], b1[i2]);
         } else {
           revert(j2);
         }
@@ -461,23 +410,6 @@ int max_wave_rows(const std::vector<int>& gsl, int nwaves) {
   return mx;
 }
 
-// The waves of a dealing joined in pairs (heaviest with lightest): half as many waves, none with more than twice
-// the slot-rows or groups of the heaviest wave before.  Groups in descending slot count inside a wave.
-std::vector<std::vector<int>> pair_waves(const std::vector<std::vector<int>>& deal, const std::vector<int>& gsl) {
-  const int n = (int)deal.size();
-  std::vector<int> load(n, 0), by_load(n);
-  for (int w = 0; w < n; w++) for (int g : deal[w]) load[w] += gsl[g];
-  std::iota(by_load.begin(), by_load.end(), 0);
-  std::stable_sort(by_load.begin(), by_load.end(), [&](int a, int b) { return load[a] > load[b]; });
-  std::vector<std::vector<int>> out((n + 1) / 2);
-  for (int i = 0; i < (n + 1) / 2; i++) {
-    out[i] = deal[by_load[i]];
-    if (n - 1 - i != i) out[i].insert(out[i].end(), deal[by_load[n - 1 - i]].begin(), deal[by_load[n - 1 - i]].end());
-    std::stable_sort(out[i].begin(), out[i].end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
-  }
-  return out;
-}
-
 // Lay the slot stream of a tile out in wave order for a given dealing of its groups to waves.
 BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, const std::vector<std::vector<int>>& per_wave) {
   BuiltTile o;
@@ -505,11 +437,8 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, cons
           if (pos >= (int)t.order.size()) continue;
           const int ac = so.cell[so.cell_off[g] + l * A + j];
           if (ac < 0) continue;
-          const int a = ac & ~(SlotOrder::kChoiceBit | SlotOrder::kChoiceBit0);
-          const Arc& arc = (*t.rows)[t.order[pos]][a];
-          // (bit 15 of an index = "read the second copy of this operand": PlanHeader::choices)
-          words[l] = ((uint32_t)lay.pos[t.lay[0]][arc.e0] | ((ac & SlotOrder::kChoiceBit0) ? 0x8000u : 0u)) |
-                     (((uint32_t)lay.pos[t.lay[1]][arc.e1] | ((ac & SlotOrder::kChoiceBit) ? 0x8000u : 0u)) << 16);
+          const Arc& arc = (*t.rows)[t.order[pos]][ac];
+          words[l] = (uint32_t)lay.pos[t.lay[0]][arc.e0] | ((uint32_t)lay.pos[t.lay[1]][arc.e1] << 16);
           probs[l] = arc.p; real[l] = true;
           if (!fill[l >> 5]) fill[l >> 5] = words[l];
         }
@@ -573,20 +502,36 @@ std::vector<int> sort_by_degree(const std::vector<int>& deg, const std::vector<i
   return o;
 }
 
+// slot-rows of every group of 64 row positions without slack: the arc count of the group's longest row
+std::vector<int> group_rows(const std::vector<std::vector<Arc>>& rows, const std::vector<int>& order, int npos, bool recursion) {
+  const int ng = npos / 64;
+  std::vector<int> gsl(ng, 0);
+  for (int g = 0; g < ng; g++)
+    for (int l = 0; l < 64; l++) {
+      const int pos = g * 64 + l;
+      if (pos < (int)order.size()) gsl[g] = std::max(gsl[g], (int)rows[order[pos]].size());
+    }
+  // a recursion group without arcs still gets one (all-padding) slot-row: every group then has a group end
+  // in every frame, which is where the lazy-normalisation kernel writes a row's value (zeros here)
+  if (recursion)
+    for (int g = 0; g < ng; g++) gsl[g] = std::max(gsl[g], 1);
+  return gsl;
+}
+// a dealing to `nwaves` waves in which no wave owns more than `max_rows` slot-rows or `max_groups` groups?
+bool dealing_fits(const std::vector<int>& gsl, int nwaves, int max_rows, int max_groups) {
+  for (const auto& w : deal_groups(gsl, nwaves)) {
+    int n = 0;
+    for (int g : w) n += gsl[g];
+    if (n > max_rows || (int)w.size() > max_groups) return false;
+  }
+  return true;
+}
+
 void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::vector<int>& order, int npos,
                int lay0, int lay1, int own_layout, int weight, int slack, int nwaves) {
   t.rows = &rows; t.order = order; t.npos = npos; t.lay[0] = lay0; t.lay[1] = lay1; t.own_layout = own_layout; t.weight = weight;
   const int ng = npos / 64;
-  t.gsl.assign(ng, 0);
-  for (int g = 0; g < ng; g++)
-    for (int l = 0; l < 64; l++) {
-      const int pos = g * 64 + l;
-      if (pos < (int)order.size()) t.gsl[g] = std::max(t.gsl[g], (int)rows[order[pos]].size());
-    }
-  // a recursion group without arcs still gets one (all-padding) slot-row: every group then has a group end
-  // in every frame, which is where the lazy-normalisation kernel writes a row's value (zeros here)
-  if (own_layout >= 0)
-    for (int g = 0; g < ng; g++) t.gsl[g] = std::max(t.gsl[g], 1);
+  t.gsl = group_rows(rows, order, npos, own_layout >= 0);
   // freedom 2: spare slot-rows per group.  The kernels keep 16, 32 or 40 slot-rows of a wave in
   // registers and walk all of them every frame, so slack is free up to the next of those sizes:
   // take the smallest size that leaves room for >= 2 spare rows per group, then as many (<= slack)
@@ -673,6 +618,7 @@ int64_t build_general(const int32_t* ft, const int32_t* fi, const float* fp, con
   memcpy(base + hd.off_leaky, leaky, (size_t)H * 4); memcpy(base + hd.off_init, initial, (size_t)H * 4);
   memcpy(base + hd.off_final, final_, (size_t)H * 4);
   hd.payload_hash = (int32_t)pychain_hip::general_payload_hash(base, off);
+  hd.reserved[0] = (int32_t)pychain_hip::general_header_hash(hd);
   memcpy(base, &hd, sizeof(hd));
   return (int64_t)off;
 }
@@ -710,8 +656,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   key = fnv64(key, bt, (size_t)K * 12); key = fnv64(key, bi, (size_t)H * 8); key = fnv64(key, bp, (size_t)K * 4);
   key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
   for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
-                           "PYCHAIN_PLAN_FREE", "PYCHAIN_PLAN_COST", "PYCHAIN_PLAN_T0", "PYCHAIN_PLAN_T1", "PYCHAIN_PLAN_LINEAR",
-                           "PYCHAIN_PLAN_CHOICE", "PYCHAIN_PLAN_TWELVE", "PYCHAIN_PLAN_W0", "PYCHAIN_PLAN_W1", "PYCHAIN_PLAN_TARGETED", "PYCHAIN_PLAN_SAMELANE"}) {
+                           "PYCHAIN_PLAN_LINEAR"}) {
     const char* v = getenv(knob);
     key = fnv64(key, knob, strlen(knob));
     if (v) key = fnv64(key, v, strlen(v));
@@ -790,8 +735,17 @@ int64_t plan_build_impl(
   // The occupancy tiles take no slack: their kernels are not bound by gather cycles and the two-frame
   // kernel keeps exactly 64 slot-rows per wave in registers.
   std::vector<Tile> tiles(3);
-  init_tile(tiles[0], rows_a, sort_by_degree(indeg, ids), Hp, kLayA, kLayX, kLayA, 2, slack, PLAN_REC_WAVES);   // the recursions are the critical path
-  init_tile(tiles[1], rows_b, sort_by_degree(outdeg, ids), Hp, kLayB, kLayX, kLayB, 2, slack, PLAN_REC_WAVES);
+  // A graph whose recursion tiles fit FOUR waves (<= PLAN_RESIDENT_2 slot-rows and <= 4 groups per wave: a few hundred states,
+  // a few thousand arcs) gets its slack fitted to that dealing and carries it as alpha4 / beta4: its recursions then run in
+  // 256-thread workgroups (den_lazy.inc.h: LzSmall) instead of sixteen waves meeting at a barrier for four groups of work.
+  const std::vector<int> order_a = sort_by_degree(indeg, ids), order_b = sort_by_degree(outdeg, ids);
+  bool small = Hp <= 64 * 4 * PLAN_REC4_WAVES && D <= 4096 &&
+               dealing_fits(group_rows(rows_a, order_a, Hp, true), PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4) &&
+               dealing_fits(group_rows(rows_b, order_b, Hp, true), PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4);
+  const int rec_waves = small ? PLAN_REC4_WAVES : PLAN_REC_WAVES;
+  init_tile(tiles[0], rows_a, order_a, Hp, kLayA, kLayX, kLayA, 2, slack, rec_waves);   // the recursions are the critical path
+  init_tile(tiles[1], rows_b, order_b, Hp, kLayB, kLayX, kLayB, 2, slack, rec_waves);
+  small = small && dealing_fits(tiles[0].gsl, PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4) && dealing_fits(tiles[1].gsl, PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4);
   init_tile(tiles[2], rows_g, sort_by_degree(gdeg, gids), gpos, kLayA, kLayB, -1, 1, 0, PLAN_GAM_WAVES);
   Layouts lay;
   lay.pos[kLayA].assign(H, 0); lay.pos[kLayB].assign(H, 0); lay.pos[kLayX].resize(D);
@@ -799,39 +753,19 @@ int64_t plan_build_impl(
   std::iota(lay.pos[kLayX].begin(), lay.pos[kLayX].end(), 0);
   {
     Balancer bal(tiles, lay);
-    bal.free_moves = env_long("PYCHAIN_PLAN_FREE", 1) != 0;
-    bal.same_lane_moves = (int)env_long("PYCHAIN_PLAN_SAMELANE", 2);
     const long before = stats ? bal.overload() : 0;
     bal.run(balance_moves * K, 40.0, 0.5);
     if (stats) fprintf(stderr, "[plan] row placement: bank overload %ld -> %ld (of %ld arc operands)\n", before, bal.overload(), 6L * K);
   }
   // (the state vectors of the recursion tiles are float2 in the lazy kernels: ds_read_b64; the occupancy tiles are
   // gathered with one width for both operands)
-  // Two-copy tiles (plan_format.h: alpha_c / beta_c): the kernel that keeps a second, block-rotated copy of the nnet-output
-  // row in LDS (den_lazy.inc.h: LzNarrowDma2; rows of up to 4096 pdfs) lets every arc read the copy the compiler picks for it
-  // (bit 15 of its nnet-output index) - a binary choice per arc: C3 at 32 rows per wave, fullest bank per half slot-row of
-  // that operand 1.55 -> 1.15 (the state operand stays at 1.24-1.29).  MEASURED 1.2 % SLOWER than the one-copy kernel on C3
-  // (recursion 3.14 against 3.10 ms, profiles/r03_i_two_copies.txt: writing the second copy in the serial tail of every frame
-  // costs more than the conflicts it removes), hence compiled only on request: PYCHAIN_PLAN_CHOICE=1 (3: model only, no kernel -
-  // a second copy of the state vector too).
-  const long choice_knob = env_long("PYCHAIN_PLAN_CHOICE", 0);
-  const bool choice_tiles = D <= 4096 && Hp <= 3072 && (choice_knob & 1) != 0;
-  const bool choice = false, choice0 = false;
-  SlotOrder so_a(tiles[0], lay, true, false, choice, choice0), so_b(tiles[1], lay, true, false, choice, choice0), so_g(tiles[2], lay, true, true);
+  SlotOrder so_a(tiles[0], lay, true, false), so_b(tiles[1], lay, true, false), so_g(tiles[2], lay, true, true);
   auto moves = [&](const Tile& t) { return anneal_knob >= 0 ? anneal_knob : (t.fitted ? 3000L : 200L); };
   {
     // the three tiles are independent (and every group has its own random stream: the result does not depend on the threads)
     std::thread tb([&]() { so_b.run(moves(tiles[1])); }), tg([&]() { so_g.run(moves(tiles[2])); });
     so_a.run(moves(tiles[0]));
     tb.join(); tg.join();
-  }
-  SlotOrder so_ac(tiles[0], lay, true, false, true, choice_knob > 0 && (choice_knob & 2)), so_bc(tiles[1], lay, true, false, true, choice_knob > 0 && (choice_knob & 2));
-  if (choice_tiles) {
-    so_ac.run(moves(tiles[0])); so_bc.run(moves(tiles[1]));
-    if (stats)
-      fprintf(stderr, "[plan] two-copy tiles, per operand (1.0 = conflict-free): alpha state %.3f nnet-output %.3f; beta state %.3f nnet-output %.3f\n",
-              (double)so_ac.cycles_op[0] / std::max(1L, so_ac.columns.load()), (double)so_ac.cycles_op[1] / std::max(1L, so_ac.columns.load()),
-              (double)so_bc.cycles_op[0] / std::max(1L, so_bc.columns.load()), (double)so_bc.cycles_op[1] / std::max(1L, so_bc.columns.load()));
   }
   if (stats)
     fprintf(stderr, "[plan] modelled LDS cycles per half slot-row (2.0 = conflict-free): alpha %.3f beta %.3f gamma %.3f; "
@@ -848,23 +782,16 @@ int64_t plan_build_impl(
             (double)so_b.cycles_op[0] / std::max(1L, so_b.columns.load()), (double)so_b.cycles_op[1] / std::max(1L, so_b.columns.load()));
 
   const auto deal_a = deal_groups(tiles[0].gsl, PLAN_REC_WAVES), deal_b = deal_groups(tiles[1].gsl, PLAN_REC_WAVES);
-  static_assert(PLAN_REC8_WAVES * 2 == PLAN_REC_WAVES || PLAN_REC_WAVES != 16, "the 8-wave dealing joins the 16 waves in pairs");
   BuiltTile ta = emit_tile(tiles[0], so_a, lay, deal_a);
   BuiltTile tb = emit_tile(tiles[1], so_b, lay, deal_b);
   BuiltTile tg = emit_tile(tiles[2], so_g, lay, deal_groups(tiles[2].gsl, PLAN_GAM_WAVES));
   BuiltTile tg2 = emit_tile(tiles[2], so_g, lay, deal_groups(tiles[2].gsl, PLAN_GAM2_WAVES));
-  BuiltTile ta8 = emit_tile(tiles[0], so_a, lay, PLAN_REC_WAVES == 16 ? pair_waves(deal_a, tiles[0].gsl) : deal_groups(tiles[0].gsl, PLAN_REC8_WAVES));
-  BuiltTile tb8 = emit_tile(tiles[1], so_b, lay, PLAN_REC_WAVES == 16 ? pair_waves(deal_b, tiles[1].gsl) : deal_groups(tiles[1].gsl, PLAN_REC8_WAVES));
-  // the 12-wave dealing of the recursion tiles: only on request (PYCHAIN_PLAN_TWELVE=1; the kernel that reads it - option
-  // den_wide = 2 - measured 15 % slower than the 16-wave one on C3: DESIGN.md S4 "Round 3")
-  const bool twelve = env_long("PYCHAIN_PLAN_TWELVE", 0) != 0;
-  BuiltTile ta12, tb12;
-  BuiltTile tac, tbc;
-  if (choice_tiles && !(choice_knob > 0 && (choice_knob & 2))) { tac = emit_tile(tiles[0], so_ac, lay, deal_a); tbc = emit_tile(tiles[1], so_bc, lay, deal_b); }
-  const bool have_c = !tac.waves.empty();
-  if (twelve) {
-    ta12 = emit_tile(tiles[0], so_a, lay, deal_groups(tiles[0].gsl, 12));
-    tb12 = emit_tile(tiles[1], so_b, lay, deal_groups(tiles[1].gsl, 12));
+  // the recursion tiles once more for four-wave workgroups, where the whole graph fits them (a wave keeps at most
+  // PLAN_RESIDENT_2 slot-rows in registers and four groups: den_lazy.inc.h, LzSmall)
+  BuiltTile ta4, tb4;
+  if (small) {
+    ta4 = emit_tile(tiles[0], so_a, lay, deal_groups(tiles[0].gsl, PLAN_REC4_WAVES));
+    tb4 = emit_tile(tiles[1], so_b, lay, deal_groups(tiles[1].gsl, PLAN_REC4_WAVES));
   }
 
   // ---- lay the blob out
@@ -875,12 +802,9 @@ int64_t plan_build_impl(
   hd.H = H; hd.K = K; hd.D = D; hd.Hp = Hp;
   for (const BuiltTile* t : {&ta, &tb})
     for (const WaveEntry& we : t->waves) hd.rec_max_wave_groups = std::max(hd.rec_max_wave_groups, we.ngroups);
-  for (const BuiltTile* t : {&ta8, &tb8})
-    for (const WaveEntry& we : t->waves) hd.rec8_max_wave_groups = std::max(hd.rec8_max_wave_groups, we.ngroups);
-  if (twelve) for (const BuiltTile* t : {&ta12, &tb12}) {
-    for (const WaveEntry& we : t->waves) hd.rec12_max_wave_groups = std::max(hd.rec12_max_wave_groups, we.ngroups);
-    hd.rec12_max_wave_slot_rows = std::max(hd.rec12_max_wave_slot_rows, t->max_wave);
-  }
+  if (small)
+    for (const BuiltTile* t : {&ta4, &tb4})
+      for (const WaveEntry& we : t->waves) hd.rec4_max_wave_groups = std::max(hd.rec4_max_wave_groups, we.ngroups);
   auto place_tile = [&](TilePlan& tp, const BuiltTile& t) {
     tp.ngroups = (int)t.groups.size(); tp.nwaves = (int)t.waves.size();
     tp.total_slot_rows = t.total_slot_rows; tp.max_wave_slot_rows = t.max_wave; tp.nrows = t.nrows;
@@ -889,9 +813,7 @@ int64_t plan_build_impl(
     tp.off_slots = (int32_t)off; off = align16(off + std::max<size_t>(1, t.slots.size()) * 4);
   };
   place_tile(hd.alpha, ta); place_tile(hd.beta, tb); place_tile(hd.gamma, tg); place_tile(hd.gamma2, tg2);
-  place_tile(hd.alpha8, ta8); place_tile(hd.beta8, tb8);
-  if (twelve) { place_tile(hd.alpha12, ta12); place_tile(hd.beta12, tb12); }
-  if (have_c) { place_tile(hd.alpha_c, tac); place_tile(hd.beta_c, tbc); }
+  if (small) { place_tile(hd.alpha4, ta4); place_tile(hd.beta4, tb4); }
   auto place_vec = [&](int32_t& o, size_t n) { o = (int32_t)off; off = align16(off + n * 4); };
   place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
@@ -911,9 +833,7 @@ int64_t plan_build_impl(
     memcpy(base + tp.off_slots, t.slots.data(), t.slots.size() * 4);
   };
   write_tile(hd.alpha, ta); write_tile(hd.beta, tb); write_tile(hd.gamma, tg); write_tile(hd.gamma2, tg2);
-  write_tile(hd.alpha8, ta8); write_tile(hd.beta8, tb8);
-  if (twelve) { write_tile(hd.alpha12, ta12); write_tile(hd.beta12, tb12); }
-  if (have_c) { write_tile(hd.alpha_c, tac); write_tile(hd.beta_c, tbc); }
+  if (small) { write_tile(hd.alpha4, ta4); write_tile(hd.beta4, tb4); }
   float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);
@@ -925,7 +845,9 @@ int64_t plan_build_impl(
   for (int i = 0; i < gpos; i++) row_pdf[i] = i < (int)tiles[2].order.size() ? tiles[2].order[i] : -1;
   // integrity of everything behind the header: the kernels follow the blob's offsets and packed LDS addresses
   // unchecked, so a plan that comes back from a cache file is verified first (pychain_hip_den_plan_info)
-  reinterpret_cast<PlanHeader*>(base)->payload_hash = (int32_t)pychain_hip::plan_payload_hash(base, off);
+  PlanHeader* out_hd = reinterpret_cast<PlanHeader*>(base);
+  out_hd->payload_hash = (int32_t)pychain_hip::plan_payload_hash(base, off);
+  out_hd->header_hash = (int32_t)pychain_hip::plan_header_hash(*out_hd);
   return (int64_t)off;
 }
 }  // namespace

@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 10
+#define PLAN_VERSION 11
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -40,8 +40,9 @@
 #define PLAN_RESIDENT_2 40
 #define PLAN_RESIDENT_FIT 36   // between the last two: reached with per-group slack fitted to the wave budget (plan.cpp: fit_slack)
 #define PLAN_GAM2_WAVES 8      // the gamma plan again, scheduled for the two-frame occupancy kernel (8 waves x 256 VGPRs)
-#define PLAN_REC8_WAVES 8      // the alpha / beta plans again, for the 8-wave ("wide") lazy recursion: the waves of the 16-wave
-                               // dealing joined in pairs, so a wave owns at most twice the slot-rows and groups
+#define PLAN_REC4_WAVES 4      // the alpha / beta plans again, dealt to FOUR waves: small graphs (a few hundred states, a few thousand
+                               // arcs: BASELINE.json's C2) run their recursions in 256-thread workgroups - sixteen waves meeting at
+                               // a barrier for four groups of work are the wrong shape (den_lazy.inc.h: LzSmall)
 
 struct TilePlan {              // all offsets are bytes from the start of the blob
   int32_t ngroups;
@@ -78,21 +79,15 @@ struct PlanHeader {
   int32_t off_leaky_b;         // float[Hp]  leaky_probs,   beta numbering
   int32_t off_final_b;         // float[Hp]  final_probs,   beta numbering
   int32_t off_row_pdf;         // int32[gamma.ngroups*64] natural pdf-id of each gamma row, -1 = padding
-  int32_t reserved1[2];
+  int32_t rec4_max_wave_groups;  // most groups any wave of alpha4 / beta4 owns (0: those tiles are not in the plan)
+  int32_t header_hash;         // FNV-1a over this header with both hash fields zero: checked by pychain_hip_den_plan_info
   TilePlan gamma2;             // same rows as `gamma` (row_pdf applies), dealt to PLAN_GAM2_WAVES waves
-  TilePlan alpha8, beta8;      // same rows and slot order as `alpha` / `beta`, dealt to PLAN_REC8_WAVES waves
-  int32_t rec8_max_wave_groups;
+  // same rows and slot order as `alpha` / `beta`, dealt to PLAN_REC4_WAVES waves; nwaves == 0: the graph is too large for a
+  // four-wave workgroup (a wave would own more than PLAN_RESIDENT_2 slot-rows or more than four groups) and they are left out
+  TilePlan alpha4, beta4;
   int32_t payload_hash;        // FNV-1a over bytes [sizeof(PlanHeader), total_bytes): checked by pychain_hip_den_plan_info
-  int32_t rec12_max_wave_groups, rec12_max_wave_slot_rows;
-  TilePlan alpha12, beta12;    // ... dealt to 12 waves (experiment: option den_wide = 2; DESIGN.md S4 "Round 3")
-  // The recursion tiles once more for kernels that keep TWO copies of the nnet-output row in LDS (LzNarrowDma2): same rows,
-  // groups and dealing as `alpha` / `beta`, but bit 15 of an arc's nnet-output index says "read the second copy"
-  // (PLAN_SECOND_POS) and the slot order is annealed with that choice.  nwaves == 0: not compiled (plan.cpp).
-  TilePlan alpha_c, beta_c;
+  int32_t reserved[3];
 };
-// position of element n of the nnet-output row in its second LDS copy: the 32-element block of n is rotated by 4, 8 .. 28
-// elements (float4s stay whole; never by 0, and neighbouring blocks by different amounts)
-#define PLAN_SECOND_POS(n) (((n) & ~31) | (((n) + 4 * ((((n) >> 5) % 7) + 1)) & 31))
 
 // ---- the GENERAL format: graphs the compiled tile plans do not take (more than 65 535 states or pdfs, or vectors that
 // do not fit the LDS of one CU).  The reference layout as it is (fstext.cc:49-116), plus the arcs grouped by pdf-id for
@@ -106,7 +101,7 @@ struct GeneralPlanHeader {
   int64_t off_b_idx, off_b_arc, off_b_p;   // arcs by source:      int32[H][2],           int32[K][2] {dst, pdf}, float[K]
   int64_t off_g_idx, off_g_arc, off_g_p;   // arcs by pdf-id:      int32[D + 1],          int32[K][2] {src, dst}, float[K]
   int64_t off_leaky, off_init, off_final;  // float[Hp], natural state order
-  int32_t payload_hash, reserved[3];
+  int32_t payload_hash, reserved[3];     // reserved[0] = FNV-1a over this header with both hash words zero (general_header_hash)
 };
 
 #ifdef __cplusplus
@@ -133,6 +128,41 @@ inline uint32_t plan_payload_hash(const void* blob, size_t total_bytes) {
   uint32_t h = 2166136261u;
   for (size_t i = sizeof(PlanHeader); i < total_bytes; i++) { h ^= p[i]; h *= 16777619u; }
   return h;
+}
+// ... and over the header itself, its two hash fields taken as zero: the kernels follow the header's tile offsets and wave
+// tables unchecked, so a cache file with a damaged or foreign header over an intact payload must not pass either
+inline uint32_t plan_header_hash(const PlanHeader& hd) {
+  PlanHeader c = hd;
+  c.header_hash = 0; c.payload_hash = 0;
+  const unsigned char* p = (const unsigned char*)&c;
+  uint32_t h = 2166136261u;
+  for (size_t i = 0; i < sizeof(PlanHeader); i++) { h ^= p[i]; h *= 16777619u; }
+  return h;
+}
+inline uint32_t general_header_hash(const GeneralPlanHeader& hd) {
+  GeneralPlanHeader c = hd;
+  c.payload_hash = 0; c.reserved[0] = 0;
+  const unsigned char* p = (const unsigned char*)&c;
+  uint32_t h = 2166136261u;
+  for (size_t i = 0; i < sizeof(GeneralPlanHeader); i++) { h ^= p[i]; h *= 16777619u; }
+  return h;
+}
+// every tile of a header lies inside the blob (offsets + sizes against total_bytes)
+inline bool tile_in_bounds(const TilePlan& tp, size_t total_bytes) {
+  if (tp.nwaves == 0 && tp.ngroups == 0) return true;       // (a tile that is not in the plan)
+  if (tp.nwaves < 0 || tp.ngroups < 0 || tp.total_slot_rows < 0 || tp.off_wave_tab < 0 || tp.off_group_tab < 0 || tp.off_slots < 0) return false;
+  return (size_t)tp.off_wave_tab + (size_t)tp.nwaves * sizeof(WaveEntry) <= total_bytes &&
+         (size_t)tp.off_group_tab + (size_t)tp.ngroups * sizeof(GroupEntry) <= total_bytes &&
+         (size_t)tp.off_slots + (size_t)tp.total_slot_rows * 64 * 8 <= total_bytes;
+}
+inline bool plan_header_in_bounds(const PlanHeader& hd) {
+  const size_t n = (size_t)hd.total_bytes;
+  if (hd.H <= 0 || hd.Hp < hd.H || hd.D <= 0) return false;
+  for (const TilePlan* tp : {&hd.alpha, &hd.beta, &hd.gamma, &hd.gamma2, &hd.alpha4, &hd.beta4})
+    if (!tile_in_bounds(*tp, n)) return false;
+  for (int32_t off : {hd.off_init_a, hd.off_leaky_a, hd.off_final_a, hd.off_leaky_b, hd.off_final_b})
+    if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
+  return hd.off_row_pdf >= 0 && (size_t)hd.off_row_pdf + (size_t)hd.gamma.ngroups * 64 * 4 <= n;
 }
 }  // namespace pychain_hip
 #endif

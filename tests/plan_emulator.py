@@ -7,7 +7,7 @@ against the oracle without a GPU.  Mirrors the kernels step by step.
 """
 import numpy as np
 
-HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4 * 8  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 10), in int32 words
+HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 11), in int32 words
 
 
 def parse(blob):
@@ -27,9 +27,8 @@ def parse(blob):
         t["p"] = s[:, :, 1].copy().view(np.float32)
         return t
     hd["alpha"], hd["beta"], hd["gamma"] = tile(8), tile(16), tile(24)
-    hd["gamma2"], hd["alpha8"], hd["beta8"] = tile(40), tile(48), tile(56)
-    hd["rec_max_wave_groups"], hd["rec8_max_wave_groups"], hd["payload_hash"] = int(h[7]), int(h[64]), int(h[65])
-    hd["alpha12"], hd["beta12"], hd["alpha_c"], hd["beta_c"] = tile(68), tile(76), tile(84), tile(92)
+    hd["gamma2"], hd["alpha4"], hd["beta4"] = tile(40), tile(48), tile(56)
+    hd["rec_max_wave_groups"], hd["rec4_max_wave_groups"], hd["header_hash"], hd["payload_hash"] = int(h[7]), int(h[38]), int(h[39]), int(h[64])
     offs = [int(v) for v in h[32:38]]
     Hp = hd["Hp"]
     vec = lambda o: b[o:o + 4 * Hp].view(np.float32).copy()

@@ -175,13 +175,13 @@ def _den_with(x, L, den, corrupt=None, verbose=0, **opts):
             c.__exit__()
 
 
-@pytest.mark.parametrize("form", ["lazy", "two_barrier", "pair", "wide"])
+@pytest.mark.parametrize("form", ["lazy", "lazy_registers", "two_barrier", "pair", "small"])
 def test_five_percent_invariant_fires_denominator(form):
-    cfg = syn.CONFIGS["C3"]
+    cfg = syn.CONFIGS["C2" if form == "small" else "C3"]      # (C2's graph runs in four-wave workgroups)
     den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
     L = torch.tensor([90, 77, 64, 90])
     x = syn.make_input(4, 90, cfg["D"], seed=43, device=DEV)
-    opts = {"lazy": {}, "two_barrier": {"den_lazy": 0}, "pair": {"den_pair": 1}, "wide": {"den_wide": 1}}[form]
+    opts = {"lazy": {}, "lazy_registers": {"den_dma": 0}, "two_barrier": {"den_lazy": 0}, "pair": {"den_pair": 1}, "small": {}}[form]
     o0, g0, bad = _den_with(x, L, den, **opts)
     assert bad == 0
     # frame 0 is checked always (as in the reference)

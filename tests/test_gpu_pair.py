@@ -50,7 +50,7 @@ def test_pair_kernel_is_bit_identical_to_the_one_sequence_kernel(one_sequence_fo
     x = syn.make_input(5, T, D, seed=81, device=DEV)
     ref = _den(x, L, den, pair=False)
     for nseg in (1, 2, 3, 4):
-        with _lib.option("den_segments", str(nseg)), _lib.option("den_stream", 0):
+        with _lib.option("den_segments", str(nseg)):
             o, g, bad = _den(x, L, den, pair=True)
         assert bad == 0 and torch.equal(o, ref[0]) and torch.equal(g, ref[1]), nseg
     # the streamed occupancy pass (default): the pair workgroups report the progress of BOTH their sequences

@@ -279,7 +279,7 @@ def test_streamed_and_gated_schedules_with_a_second_process_on_the_gpu():
         t0 = time.time()
         n = 0
         while time.time() - t0 < 6 and hog.poll() is None:
-            for opts in ({}, {"den_stream": 0}):
+            for opts in ({}, {"den_segments": 3}):
                 ctx = [_lib.option(k, v) for k, v in opts.items()]
                 for c in ctx:
                     c.__enter__()

@@ -37,8 +37,8 @@ def test_streamed_equals_segmented_and_the_oracle(H, K, D):
     L = torch.tensor(lengths)
     x = syn.make_input(len(lengths), 411, D, seed=61, device=DEV)
     x[3, 333:] = float("nan")                                   # padding frames may hold anything
-    o0, g0, bad0 = _den(x, L, den, den_stream=0, den_segments=1)
-    o1, g1, bad1 = _den(x, L, den, den_stream=0)
+    o0, g0, bad0 = _den(x, L, den, den_segments=1)
+    o1, g1, bad1 = _den(x, L, den, den_segments=3)
     for rep in range(3):                                        # (the queue is drawn in a different interleaving every time)
         o2, g2, bad2 = _den(x, L, den)
         assert bad0 == 0 and bad1 == 0 and bad2 == 0
@@ -69,11 +69,11 @@ def test_streamed_fused_loss_with_the_numerator_folded_in():
         finally:
             for c in reversed(ctx):
                 c.__exit__()
-    l0, g0, b0 = run(den_stream=0)
+    l0, g0, b0 = run(den_segments=3)
     for rep in range(3):
         l1, g1, b1 = run()
         assert b0 == [0, 0] and b1 == [0, 0] and torch.equal(l0, l1) and torch.equal(g0, g1), rep
-    l2, g2, b2 = run(no_fold=1)
+    l2, g2, b2 = run(gamma16=1)            # one-frame occupancy kernel, numerator accumulated into the stored gradient
     assert torch.equal(l0, l2) and torch.equal(g0, g2)
     rl, rg = orc.chain_loss(x.cpu(), L, den, numg, 1e-5, avg=False, flavour="f64")
     assert abs(float(l1) - float(rl)) <= 1e-4 * abs(float(rl)) and rel_err(g1.cpu().numpy(), rg) <= 1e-5

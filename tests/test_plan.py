@@ -35,86 +35,52 @@ def test_plan_structure():
     assert set(hd["row_pdf"][hd["row_pdf"] >= 0].tolist()) == set(g.forward_transitions[:, 2].tolist())
 
 
-def test_plan_eight_wave_dealing_and_checksum():
-    """The 8-wave dealing of the recursion tiles (den_recursion_lazy_kernel<wide>) joins the 16 waves in pairs: same
-    slot-rows, at most twice the rows and groups per wave, the same sums; and a plan whose payload was damaged on its
-    way through the disk cache is refused by pychain_hip_den_plan_info."""
-    g = syn.make_den_graph(1200, 12000, 2000, seed=4)
-    blob = _blob(g, 2000)
-    hd = emu.parse(blob)
-    rng = np.random.default_rng(0)
-    for name in ("alpha", "beta"):
-        t16, t8 = hd[name], hd[name + "8"]
-        assert t8["nwaves"] == 8 and t16["nwaves"] == 16
-        assert t8["total_slot_rows"] == t16["total_slot_rows"] and t8["ngroups"] == t16["ngroups"]
-        assert t8["max_wave_slot_rows"] <= 2 * t16["max_wave_slot_rows"] <= 80
-        assert t8["waves"][:, 1].max() <= 2 * t16["waves"][:, 1].max()
-        U, V = rng.random(hd["Hp"]), rng.random(2000)
-        assert np.array_equal(emu.tile_rows(t16, U, V, hd["Hp"], np.float64), emu.tile_rows(t8, U, V, hd["Hp"], np.float64))
-    assert hd["rec8_max_wave_groups"] <= 2 * hd["rec_max_wave_groups"]
-    assert _plan.plan_info(blob)["num_states"] == 1200
-    bad = blob.copy()
-    bad[len(bad) // 2] ^= 0x40
-    info = np.zeros(8, dtype=np.int32)
-    rc = _lib.lib().pychain_hip_den_plan_info(bad.ctypes.data_as(ctypes.c_void_p), bad.nbytes, info.ctypes.data_as(ctypes.c_void_p))
-    assert rc < 0 and b"checksum" in _lib.lib().pychain_hip_last_error()
-
-
-def test_plan_twelve_wave_dealing_on_request(monkeypatch):
-    """PYCHAIN_PLAN_TWELVE=1 adds the recursion tiles dealt to 12 waves (the den_wide = 2 experiment): the same groups
-    and sums, C3's rows within the kernel's 56-row / 4-group loops; absent otherwise."""
-    cfg = syn.CONFIGS["C3"]
+def test_plan_four_wave_dealing_of_small_graphs_and_checksums():
+    """A graph whose recursion tiles fit FOUR waves (C2: 200 states, 2000 arcs) also carries them dealt to four waves
+    (den_recursion_lazy_kernel<small>: 256-thread workgroups): same slot-rows and sums as the 16-wave dealing, at most
+    40 rows and 4 groups per wave, the launch hint says so (bit 29) and carries THAT dealing's row count; a large graph
+    (C3) does not.  A plan damaged on its way through the disk cache - payload OR header - is refused."""
+    cfg = syn.CONFIGS["C2"]
     g = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
-    assert emu.parse(_blob(g, cfg["D"]))["alpha12"]["nwaves"] == 0
-    monkeypatch.setenv("PYCHAIN_PLAN_TWELVE", "1")
-    hd = emu.parse(_blob(g, cfg["D"]))
-    rng = np.random.default_rng(1)
-    for name in ("alpha", "beta"):
-        t16, t12 = hd[name], hd[name + "12"]
-        assert t12["nwaves"] == 12 and t12["total_slot_rows"] == t16["total_slot_rows"] and t12["ngroups"] == t16["ngroups"]
-        assert t12["max_wave_slot_rows"] <= 56 and t12["waves"][:, 1].max() <= 4
-        U, V = rng.random(hd["Hp"]), rng.random(cfg["D"])
-        assert np.array_equal(emu.tile_rows(t16, U, V, hd["Hp"], np.float64), emu.tile_rows(t12, U, V, hd["Hp"], np.float64))
-
-
-def test_plan_two_copy_tiles(monkeypatch):
-    """Under PYCHAIN_PLAN_CHOICE=1 a plan carries the recursion tiles a second time for the kernel that keeps two copies of
-    the nnet-output row (alpha_c / beta_c; an experiment that measured slower): same groups, rows and dealing, the same sums;
-    bit 15 of an arc's nnet-output index picks the copy, and the launch hint says so (bit 29).  Not compiled by default, nor
-    for rows beyond 4096 pdfs."""
-    cfg = syn.CONFIGS["C3"]
-    g = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
-    assert emu.parse(_blob(g, cfg["D"]))["alpha_c"]["nwaves"] == 0
-    monkeypatch.setenv("PYCHAIN_PLAN_CHOICE", "1")
     blob = _blob(g, cfg["D"])
     hd = emu.parse(blob)
-    assert (_plan.plan_info(blob)["slot_rows"] >> 29) & 1
-    rng = np.random.default_rng(2)
+    rng = np.random.default_rng(0)
+    hint = _plan.plan_info(blob)["slot_rows"]
+    assert (hint >> 29) & 1 and (hint >> 30) & 1
     for name in ("alpha", "beta"):
-        t, tc = hd[name], hd[name + "_c"]
-        assert tc["nwaves"] == 16 and t["max_wave_slot_rows"] <= 32
-        assert np.array_equal(t["waves"], tc["waves"]) and np.array_equal(t["groups"], tc["groups"])
-        second = (tc["idx"] >> 31) & 1
-        assert 0.2 < second[tc["p"] != 0].mean() < 0.8                       # the choice is used
-        plain = dict(tc, idx=tc["idx"] & 0x7fffffff)
+        t16, t4 = hd[name], hd[name + "4"]
+        assert t4["nwaves"] == 4 and t16["nwaves"] == 16
+        assert t4["total_slot_rows"] == t16["total_slot_rows"] and t4["ngroups"] == t16["ngroups"]
+        assert t4["max_wave_slot_rows"] <= 40 and t4["waves"][:, 1].max() <= 4 and t4["max_wave_slot_rows"] <= (hint & 1023)
         U, V = rng.random(hd["Hp"]), rng.random(cfg["D"])
-        a, b = emu.tile_rows(t, U, V, hd["Hp"], np.float64), emu.tile_rows(plain, U, V, hd["Hp"], np.float64)
-        assert np.allclose(a, b, rtol=1e-12, atol=0)
-
-        def fullest(tile, second_copy):
-            tot = 0
-            for row in range(tile["idx"].shape[0]):
-                n = ((tile["idx"][row] >> 16) & 0x7fff).astype(np.int64)
-                rot = (n & ~31) | ((n + 4 * (((n >> 5) % 7) + 1)) & 31)
-                pos = np.where(second_copy[row] == 1, rot + 32768, n)
-                for half in (slice(0, 32), slice(32, 64)):
-                    u = np.unique(pos[half])
-                    tot += int(np.bincount(u & 31, minlength=32).max())
-            return tot
-        # what the second copy buys: fewer lanes in the fullest bank of a half slot-row (nnet-output operand)
-        assert fullest(tc, second) < 0.85 * fullest(t, np.zeros_like(second))
-    g2 = syn.make_den_graph(300, 3000, 5000, seed=1)
-    assert emu.parse(_blob(g2, 5000))["alpha_c"]["nwaves"] == 0
+        assert np.array_equal(emu.tile_rows(t16, U, V, hd["Hp"], np.float64), emu.tile_rows(t4, U, V, hd["Hp"], np.float64))
+    assert 1 <= hd["rec4_max_wave_groups"] <= 4
+    big = syn.make_den_graph(1200, 12000, 2000, seed=4)
+    bblob = _blob(big, 2000)
+    bh = emu.parse(bblob)
+    assert bh["alpha4"]["nwaves"] == 0 and bh["beta4"]["nwaves"] == 0 and not (_plan.plan_info(bblob)["slot_rows"] >> 29) & 1
+    assert _plan.plan_info(bblob)["num_states"] == 1200
+    info = np.zeros(8, dtype=np.int32)
+    for where, what in ((len(bblob) // 2, b"checksum"), (8 * 4 + 2 * 4, b"checksum"), (6 * 4, b"")):     # payload, a tile offset, total_bytes
+        bad = bblob.copy()
+        bad[where] ^= 0x40
+        rc = _lib.lib().pychain_hip_den_plan_info(bad.ctypes.data_as(ctypes.c_void_p), bad.nbytes, info.ctypes.data_as(ctypes.c_void_p))
+        assert rc < 0 and what in _lib.lib().pychain_hip_last_error()
+    # a header that points outside the blob is refused even with hashes that match it (a foreign writer)
+    def fnv(b):
+        h = 2166136261
+        for x in b:
+            h = ((h ^ int(x)) * 16777619) & 0xffffffff
+        return h
+    bad = bblob.copy()
+    w = bad[:emu.HDR_INTS * 4].view(np.int32)
+    w[8 + 4] = int(w[6]) - 64                                  # alpha.off_slots close to the end of the blob
+    w[39] = 0; w[64] = 0
+    hh = fnv(bad[:emu.HDR_INTS * 4])                           # (header hash: over the header with both hash words zero)
+    w[64] = np.uint32(fnv(bad[emu.HDR_INTS * 4:int(w[6])])).view(np.int32)
+    w[39] = np.uint32(hh).view(np.int32)
+    rc = _lib.lib().pychain_hip_den_plan_info(bad.ctypes.data_as(ctypes.c_void_p), bad.nbytes, info.ctypes.data_as(ctypes.c_void_p))
+    assert rc < 0 and b"outside the blob" in _lib.lib().pychain_hip_last_error()
 
 
 def _lds_cycles(t):

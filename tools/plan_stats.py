@@ -20,4 +20,4 @@ def tile(off, tname):
             print("  wave %2d groups %2d rows %3d" % (w, n, nsr), gs)
 for i, tname in enumerate(("alpha", "beta", "gamma")):
     tile(32 + 32 * i, tname)
-tile(32 + 32 * 3 + 32, "gamma2")
+tile(160, "gamma2"); tile(192, "alpha4"); tile(224, "beta4")

@@ -1,5 +1,5 @@
 """Time the fused step (or the denominator-only step for workloads without numerators) for a list of
-(workload, options) cells in ONE process: tools/time_matrix.py "C3" "C3:den_wide=1" "C4" "C4:den_wide=0" "C3@128" ...
+(workload, options) cells in ONE process: tools/time_matrix.py "C3" "C3:den_dma=0" "C4" "C2:den_lazy=0" "C3@128" "C3:PLAN_LINEAR=1" ...
 A cell is  WORKLOAD[@B][:opt=value[;opt=value...]] ; prints one line per cell (median of 5 groups of 6 steps) and, with
 --parts, the recursion / occupancy launches in isolation."""
 import os, sys
