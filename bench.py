@@ -152,6 +152,14 @@ def kernel_rooflines(w, dev, iters, d2d=True):
             "achieved": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9, 2),
             "frac": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
     }
+    # the numerator's launches (side stream, hidden beside the first half of the recursion at B = 64, CU time from B = 128
+    # on): the fused call with the denominator's launches masked out - recursions only (num_fb_kernel), then with the
+    # compact occupancy rows (num_prep + num_fb + num_occ_wave)
+    if w.get("num_graphs") is not None:
+        try:
+            roof["other_kernels"].update(numerator_rooflines(w, plan, dev, iters, stream))
+        except Exception as e:          # a context figure: never lose the bench line to it
+            roof["other_kernels"]["numerator"] = {"error": str(e)[:200]}
     # context: what a plain device-to-device copy reaches on this box
     if not d2d:
         return roof
@@ -165,6 +173,38 @@ def kernel_rooflines(w, dev, iters, d2d=True):
     except Exception:
         roof["d2d_copy_GBps"] = None
     return roof
+
+
+def numerator_rooflines(w, plan, dev, iters, stream):
+    """ms per launch of the numerator kernels and their algorithmic bytes (8 U_n + 8 (H_n + 1) per live
+    frame in a fused loss - the utterance's distinct pdfs read by both recursions, its state row written and read - split as
+    recursions 8 U_n + 4 (H_n + 1), occupancy 4 (H_n + 1))."""
+    from pychain_amd import _lib, native
+    ng = w["num_graphs"]
+    gt = ng.device_tensors(dev)
+    gstride = 0 if ng.shared_graph is not None else 1
+    x, ld = w["x"].detach(), w["lengths_dev"]
+    call = lambda g: native.chain_loss_forward(plan, gt, gstride, ng.num_states, x, ld, 1e-5, with_grad=g)
+    with _lib.option("den_phase_mask", 0):
+        call(True); torch.cuda.synchronize()
+        ms_fb = event_time_ms(lambda: call(False), iters, stream)
+        ms_all = event_time_ms(lambda: call(True), iters, stream)
+    native.release_workspaces()
+    L = w["lengths"].tolist()
+    ft, fi = ng.forward_transitions, ng.forward_transition_indices
+    bytes_fb = bytes_occ = 0
+    for b, Lb in enumerate(L):
+        kused = int(fi[b, :, 1].max())
+        U = int(torch.unique(ft[b, :kused, 2]).numel())
+        Hn = int((fi[b, :, 1] > fi[b, :, 0]).sum())                 # states with arcs (the padding has none)
+        bytes_fb += Lb * (8 * U + 4 * (Hn + 1))
+        bytes_occ += Lb * 4 * (Hn + 1)
+    ms_occ = max(ms_all - ms_fb, 1e-6)
+    mk = lambda ms, nbytes: {"ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes),
+                             "achieved": round(nbytes / (ms * 1e-3) / 1e9, 2), "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    return {"num_fb_kernel": dict(mk(ms_fb, bytes_fb), bound="latency: T dependent frames of one barrier each, one state per thread; not HBM"),
+            "num_prep_kernel+num_occ_wave_kernel": dict(mk(ms_occ, bytes_occ), note="time-parallel; by difference: fused call with - without the compact occupancy rows"),
+            "numerator_forward_backward": mk(ms_all, bytes_fb + bytes_occ)}
 
 
 def _adhoc_workload(name, B, dev):

@@ -658,11 +658,11 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (e == hipSuccess && na.corrupt_b >= 0) e = launch_num_corrupt(na, side->stream);
   if (e == hipSuccess && grad) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
-  da.phase_mask = 3;
+  da.phase_mask = da.knobs.den_phase_mask == 0 ? 0 : 3;     // (mask 0: only the numerator's launches - a measurement aid, outputs not meaningful)
   // (den_finish_kernel reads the numerator's objectives and its bad count for `totals`: the join precedes it)
   if (e == hipSuccess) e = run_den_launches(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
-  if (e == hipSuccess) e = launch_den_finish(da, st);
+  if (e == hipSuccess && (da.phase_mask & 1)) e = launch_den_finish(da, st);     // (phase mask 0: the numerator alone - bench.py times it so)
   if (e == hipSuccess && grad && !fold) e = launch_num_scatter(na, st, &why);      // grad -= grad_scale * gamma_num
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));

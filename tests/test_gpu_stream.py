@@ -73,8 +73,10 @@ def test_streamed_fused_loss_with_the_numerator_folded_in():
     for rep in range(3):
         l1, g1, b1 = run()
         assert b0 == [0, 0] and b1 == [0, 0] and torch.equal(l0, l1) and torch.equal(g0, g1), rep
-    l2, g2, b2 = run(gamma16=1)            # one-frame occupancy kernel, numerator accumulated into the stored gradient
-    assert torch.equal(l0, l2) and torch.equal(g0, g2)
+    # the one-frame occupancy kernel, numerator accumulated into the stored gradient afterwards: the same values to rounding
+    # (16 waves instead of 8 sum a frame's total in another order)
+    l2, g2, b2 = run(gamma16=1)
+    assert torch.equal(l0, l2) and rel_err(g2.cpu().numpy(), g0.cpu().numpy()) <= 1e-6
     rl, rg = orc.chain_loss(x.cpu(), L, den, numg, 1e-5, avg=False, flavour="f64")
     assert abs(float(l1) - float(rl)) <= 1e-4 * abs(float(rl)) and rel_err(g1.cpu().numpy(), rg) <= 1e-5
 
