@@ -43,7 +43,6 @@ struct LzNarrow {
   //   [96K, ...)  partial sums, beta's leaky probs
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 1;
   static constexpr bool kDma = false;
-  static constexpr int kXDepth = 2;                   // nnet-output buffers: the row of step j sits in buffer j % kXDepth
   static constexpr uint32_t kU0 = 0, kU1 = 32768, kX0 = 65536, kX1 = 81920, kUField = 0, kXField = 49152;
   static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
   static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
@@ -57,33 +56,25 @@ struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static conste
 struct LzDma {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
   static constexpr bool kDma = true;
-  static constexpr int kXDepth = 2;
   static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 9216;
   static constexpr uint32_t kLk = 122880, kRed = kLk + kMaxStates * 4, kBytes = kRed + 2 * 2 * 64 * 4;
 };
 template <typename MAP> constexpr bool lz_map_ok() {
-  return MAP::kU1 - MAP::kUField <= 65535u && MAP::kU0 >= MAP::kUField && MAP::kX0 >= MAP::kXField &&
-         MAP::kX0 + (uint32_t)(MAP::kXDepth - 1) * (MAP::kX1 - MAP::kX0) - MAP::kXField <= 65535u && (MAP::kX1 - MAP::kX0) >= 4u * MAP::kMaxPdfs &&
+  return MAP::kU1 - MAP::kUField <= 65535u && MAP::kU0 >= MAP::kUField && MAP::kX1 - MAP::kXField <= 65535u && MAP::kX0 >= MAP::kXField &&
          MAP::kUField + 8u * (MAP::kMaxStates - 1) <= 65535u && MAP::kXField + 4u * (MAP::kMaxPdfs - 1) <= 65535u &&
          MAP::kBytes <= 160u * 1024u;
 }
-// Four waves, small graphs.  A frame of theirs is a few hundred cycles of gathers - shorter than the round trip of the
-// LDS-direct load of the next row - so the rows are requested TWO steps ahead into a ring of four buffers (the row of step
-// j + 2 at the start of step j; the late hook of step j waits for the loads of step j - 1's request only: vmcnt counts down in
-// issue order) and the frame barrier does not drain the loads in flight.
-//   [0, 8K) state buffer 0: float2[<= 1024]   [8K, 16K) state buffer 1   [16K, 80K) nnet-output buffers 0 .. 3
-//   [80K, ...) partial sums, beta's leaky probs
+// Four waves, small graphs: everything below 64 KiB, three workgroups per CU by LDS.
+//   [0, 8K) state buffer 0: float2[<= 1024]   [8K, 16K) state buffer 1   [16K, 32K) nnet-output buffer 0   [32K, 48K) buffer 1
+//   [48K, ...) partial sums, beta's leaky probs
 struct LzSmall {
   static constexpr int kWaves = 4, kMaxGroups = 4, kXch = 0;
   static constexpr bool kDma = true;
-  static constexpr int kXDepth = 4;
   static constexpr uint32_t kU0 = 0, kU1 = 8192, kX0 = 16384, kX1 = 32768, kUField = 0, kXField = 16384;
   static constexpr uint32_t kMaxStates = 1024, kMaxPdfs = 4096;
-  static constexpr uint32_t kRed = 81920, kLk = kRed + 2 * 2 * 64 * 4, kBytes = kLk + kMaxStates * 4;
+  static constexpr uint32_t kRed = 49152, kLk = kRed + 2 * 2 * 64 * 4, kBytes = kLk + kMaxStates * 4;
 };
-// byte address of nnet-output buffer i of a map
-template <typename MAP> constexpr uint32_t lz_xbuf(int i) { return MAP::kX0 + (uint32_t)i * (MAP::kX1 - MAP::kX0); }
 static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzDma>() && lz_map_ok<LzSmall>(), "ds_read offset fields are 16 bits");
 constexpr uint32_t kLzBytes = LzNarrow::kBytes;
 
@@ -114,35 +105,10 @@ typedef __attribute__((address_space(3))) void lz_lds_void;
 #endif
 typedef float lz_v4 __attribute__((ext_vector_type(4)));
 #define PYCHAIN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)     /* vmcnt(0) only (gfx9 encoding) */
-// ... all but the newest n vector-memory operations of this wave - loads and stores alike - have completed (on gfx9
-// vmcnt counts both and counts down in issue order, which is also what the compiler's own wait insertion relies on; the
-// immediate wants a constant: n is wave-uniform and at most 8 here)
-__device__ __forceinline__ void lz_wait_vm_all_but(int n) {
-  switch (n) {
-    case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-    case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
-    case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
-    case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
-    case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
-    case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
-    case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
-    case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
-    default: __builtin_amdgcn_s_waitcnt(0x0F78); break;
-  }
-}
-// the 1 KiB chunks of a D-float row that wave `wave` of NW requests (lz_dma_row)
-template <int NW, int NCH>
-__device__ __forceinline__ int lz_dma_chunks(int D, int wave) {
-  int n = 0;
-#pragma unroll
-  for (int c = 0; c < NCH; c++) n += ((wave + c * NW) * 1024 < D * 4) ? 1 : 0;
-  return n;
-}
 // row t of the sequence behind `buf` -> LDS at byte address xbase, 1 KiB chunks dealt to the NW waves; lanes past the
 // row's end re-read its last 16 bytes (a chunk may run past the end of the whole slab otherwise)
 template <int NW, int NCH>
 __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int lane, uint32_t xbase) {
-  static_assert(NCH <= 4, "lz_wait_vm_all_but leaves at most four loads (and four row stores) in flight");
   const int row_bytes = D * 4;
   const int soff = __builtin_amdgcn_readfirstlane(t * row_bytes);
 #pragma unroll
@@ -159,11 +125,10 @@ __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int
   }
 }
 // this wave's chunks of the row at xbase: raw -> clamp / exp, in place; returns true if a NaN was seen
-// (`newer`: loads this wave has issued SINCE the ones of this row - they stay in flight)
 template <int NW, int NCH>
-__device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_t xbase, int is_exp, int newer = 0) {
+__device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_t xbase, int is_exp) {
   bool nan = false;
-  lz_wait_vm_all_but(newer);                            // this wave's loads of this row have landed
+  PYCHAIN_WAIT_VM0();                                   // this wave's loads have landed
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int ch = wave + c * NW;
@@ -446,7 +411,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
   XRow<NT, 4, MAP::kXch> xq;
   constexpr int kDmaCh = ((int)MAP::kMaxPdfs / 256 + NW - 1) / NW;   // 1 KiB chunks of a row one wave may own
-  const int dma_chunks = __builtin_amdgcn_readfirstlane(lz_dma_chunks<NW, kDmaCh>(D, wave));   // ... and does, for this D
   {
     float p0 = 0.f, p1 = 0.f;
     for (int i = tid; i < (int)MAP::kMaxStates; i += NT) {
@@ -461,8 +425,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if constexpr (MAP::kDma) {
       lz_dma_row<NW, kDmaCh>(xbuf, t0, D, wave, lane, MAP::kX0);
       if (lz_dma_finish<NW, kDmaCh>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
-      // a ring of more than two buffers runs two steps ahead: the row of step 1 is requested here, finished in step 0
-      if constexpr (MAP::kXDepth > 2) { if (1 < nsteps) lz_dma_row<NW, kDmaCh>(xbuf, fwd ? 1 : L - 2, D, wave, lane, lz_xbuf<MAP>(1)); }
     } else {
       xq.load(xseq + (size_t)t0 * D, D, tid);
       if (fwd && xq.has_nan()) bad |= 2;
@@ -520,7 +482,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     last_tot = tot;                                                                                         \
   } while (0)
   // One frame step j: alpha produces a(j+1,.) from a(j,.) and x(j); beta produces b(t,.), t = L-1-j, from b(t+1,.) and x(t).
-#define PYCHAIN_LZ_STEP(J, PAR, PARX, FWDC)                                                                 \
+#define PYCHAIN_LZ_STEP(J, PAR, FWDC)                                                                       \
   do {                                                                                                      \
     const int j = (J);                                                                                      \
     /* thread and lane index made opaque per frame: everything derived from them (LDS and buffer offsets) is */ \
@@ -530,22 +492,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const int lq = tq & 63;                                                                                 \
     constexpr uint32_t UCUR = (PAR) ? MAP::kU1 : MAP::kU0, UNEXT = (PAR) ? MAP::kU0 : MAP::kU1;             \
     constexpr uint32_t UOFF = UCUR - MAP::kUField;                                                          \
-    constexpr uint32_t VOFF = lz_xbuf<MAP>(PARX) - MAP::kXField;              /* nnet-output buffer PARX = j % kXDepth */ \
-    constexpr uint32_t XNEXT = lz_xbuf<MAP>(((PARX) + 1) % MAP::kXDepth);     /* the row of step j + 1: finished in this step */ \
+    constexpr uint32_t VOFF = ((PAR) ? MAP::kX1 : MAP::kX0) - MAP::kXField;   /* nnet-output buffer PAR */   \
     const int tn = (FWDC) ? j + 1 : L - 2 - j;               /* nnet-output row of the NEXT step */          \
-    const bool have_next = j + 1 < nsteps;                   /* (beta never consumes row 0) */               \
-    /* a ring of kXDepth > 2 buffers requests the row of step j + 2 now; `ahead` = the loads that leaves in flight when */ \
-    /* this step's late hook waits for the row of step j + 1 (requested a step ago), plus this step's row stores */ \
-    int ahead = 0;                                                                                          \
+    const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
     LZ_PH0();                                                                                               \
-    if constexpr (MAP::kDma && MAP::kXDepth > 2) {                                                          \
-      if (j + 2 < nsteps) {                                                                                 \
-        lz_dma_row<NW, kDmaCh>(xbuf, (FWDC) ? j + 2 : L - 3 - j, D, wave, lq, lz_xbuf<MAP>(((PARX) + 2) % MAP::kXDepth)); \
-        ahead = dma_chunks;                                                                                 \
-      }                                                                                                     \
-      ahead += groups.ngroups + ((wave == 0 && j > 0) ? 1 : 0);   /* (+ the total thread 0 stores for den_finish_kernel) */ \
-    } else if constexpr (MAP::kDma) {                        /* straight into the other buffer, in flight during the arc work */ \
-      if (have_next) lz_dma_row<NW, kDmaCh>(xbuf, tn, D, wave, lq, XNEXT);                                  \
+    if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
+      if (have_next) lz_dma_row<NW, kDmaCh>(xbuf, tn, D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1);            \
     } else if (have_next) xq.load_row(xbuf, tn, D, tq);      /* in flight during the arc work */             \
     lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, [&]() {                                \
       if (j > 0) PYCHAIN_LZ_TOTALS((PAR) ^ 1, j - 1, (FWDC), lq, tq);   /* (step 0: the start vector's, above) */ \
@@ -574,7 +526,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
       /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
       if constexpr (MAP::kDma && PYCHAIN_LATE_FINISH) {                                                     \
-        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, XNEXT, a.input_is_exp, ahead) && (FWDC)) bad |= 2; \
+        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
       }                                                                                                     \
     });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
@@ -594,10 +546,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
     if constexpr (MAP::kDma) {                                                                              \
       if constexpr (!PYCHAIN_LATE_FINISH)                                                                   \
-        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, XNEXT, a.input_is_exp, ahead) && (FWDC)) bad |= 2; \
+        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
     } else if (have_next) {                                                                                 \
       if ((FWDC) && xq.has_nan()) bad |= 2;                  /* a NaN network output: not ok, NaN log-probability */ \
-      xq.store(reinterpret_cast<float*>(smem_raw + XNEXT), xseq, D, tq, a.input_is_exp);                    \
+      xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \
     }                                                                                                       \
     LZ_PH(1);                                                /* LDS re-reads issued, nnet-output row clamped / exp'd / stored */ \
     float s0 = 0.f, s1 = 0.f;                                                                               \
@@ -614,10 +566,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       if (!(FWDC)) { const float r1 = dpp_row_sum(s1); red[(PAR) * 128 + 64 + wave * 4 + (lq >> 4)] = r1; } \
     }                                                                                                       \
     LZ_PH(2);                                                /* previous row completed and stored, row sums */ \
-    /* every gather of this frame is done; the new vector is complete.  (Deep rings: the barrier must not drain the row */ \
-    /* loads in flight, which __syncthreads() - s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier - would: LDS only.) */ \
-    if constexpr (MAP::kXDepth > 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
-    else __syncthreads();                                                                                   \
+    __syncthreads();                                         /* every gather of this frame is done; the new vector is complete */ \
     LZ_PH(3);                                                /* wait at the barrier */                       \
     /* (this frame's totals: reduced by the next step behind its first gathers, or after the loop) */       \
   } while (0)
@@ -630,27 +579,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();                                                                                        \
     if (tid == 0) __hip_atomic_store(my_progress, (P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         \
   } while (0)
-  if constexpr (MAP::kXDepth == 4) {
-    // (the frame loop is unrolled over the buffer ring IN SOURCE ORDER: buffers are ds_read offset fields, compile-time)
-    for (int jj = 0; jj < nsteps; jj += 4) {
-      PYCHAIN_LZ_STEP(jj, 0, 0, fwd);
-      if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, 1, fwd);
-      PYCHAIN_LZ_SIGNAL(jj + 1);
-      if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
-      if (jj + 2 < nsteps) PYCHAIN_LZ_STEP(jj + 2, 0, 2, fwd);
-      if (jj + 3 < nsteps) PYCHAIN_LZ_STEP(jj + 3, 1, 3, fwd);
-      PYCHAIN_LZ_SIGNAL(jj + 3);
-      if (a.stream && stream_report_due(a.T, jj + 4) && jj + 4 < nsteps) PYCHAIN_LZ_REPORT(jj + 4);
-    }
-  } else {
-    static_assert(MAP::kXDepth == 2 || MAP::kXDepth == 4, "the frame loop is unrolled for rings of two and of four buffers");
-    for (int jj = 0; jj < nsteps; jj += 2) {
-      PYCHAIN_LZ_STEP(jj, 0, 0, fwd);
-      if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, 1, fwd);
-      PYCHAIN_LZ_SIGNAL(jj + 1);                              // (rows lag one step: after jj + 2 steps the rows of steps < jj + 1 are out)
-      // step j stores the row of the frame before it (alpha row j, beta row L - j): after steps 0 .. jj + 1, jj + 2 rows
-      if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
-    }
+  for (int jj = 0; jj < nsteps; jj += 2) {
+    PYCHAIN_LZ_STEP(jj, 0, fwd);
+    if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
+    PYCHAIN_LZ_SIGNAL(jj + 1);                                // (rows lag one step: after jj + 2 steps the rows of steps < jj + 1 are out)
+    // step j stores the row of the frame before it (alpha row j, beta row L - j): after steps 0 .. jj + 1, jj + 2 rows
+    if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
   }
   if (nsteps > 0) PYCHAIN_LZ_TOTALS((nsteps - 1) & 1, nsteps - 1, fwd, lane, tid);   // the last step's
   if constexpr (!fwd) {
