@@ -522,8 +522,8 @@ extern "C" int pychain_hip_den_forward_backward(
 }
 
 namespace {
-struct NumCarve { size_t alpha, beta, logp, rows, upd, ucount, uidx, frac, total; };
-NumCarve num_carve(int B, int T, int H, int K) {
+struct NumCarve { size_t alpha, beta, logp, rows, upd, ucount, uidx, frac, gacc, total; };
+NumCarve num_carve(int B, int T, int H, int K, int D) {
   NumCarve c;
   c.alpha = 0;
   c.beta = c.alpha + align256(8 * (size_t)B * (T + 1) * H);
@@ -533,7 +533,8 @@ NumCarve num_carve(int B, int T, int H, int K) {
   c.ucount = c.upd + align256(4 * (size_t)B * K);
   c.uidx = c.ucount + align256(4 * (size_t)B);
   c.frac = c.uidx + align256(4 * (size_t)B * K);
-  c.total = c.frac + align256(4 * (size_t)B * T * K) + 256;
+  c.gacc = c.frac + align256(4 * (size_t)B * T * K);           // general kernels only (num_general.hip): accumulator rows
+  c.total = c.gacc + (num_needs_general(H, K, D) ? align256(num_general_acc_bytes(D)) : 0) + 256;
   return c;
 }
 
@@ -549,15 +550,13 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
     return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
   if (B <= 0 || T <= 0 || H <= 0 || D <= 0 || K <= 0)
     return fail(PYCHAIN_HIP_EINVAL, "%s: bad sizes B=%d T=%d H=%d K=%d D=%d", who, B, T, H, K, D);
-  if (H > 65535 || D > 65535)
-    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: num_states and num_pdfs must be <= 65535", who);
   if (graph_batch_stride != 0 && graph_batch_stride != 1)
     return fail(PYCHAIN_HIP_EINVAL, "%s: graph_batch_stride must be 0 or 1", who);
   if (grad_mode < PYCHAIN_HIP_GRAD_LOG || grad_mode > PYCHAIN_HIP_GRAD_ACCUM)
     return fail(PYCHAIN_HIP_EINVAL, "%s: unknown grad_mode %d", who, grad_mode);
   if (((uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)fi | (uintptr_t)bi) & 15)
     return fail(PYCHAIN_HIP_EINVAL, "%s: nnet_output, grad and index tensors must be 16-byte aligned", who);
-  const NumCarve c = num_carve(B, T, H, K);
+  const NumCarve c = num_carve(B, T, H, K, D);
   if (workspace_bytes < c.total) return fail(PYCHAIN_HIP_EWORKSPACE, "%s: workspace too small", who);
   memset(&a, 0, sizeof(a));
   a.fwd_trans = ft; a.fwd_idx = fi; a.fwd_probs = fp; a.bwd_trans = bt; a.bwd_idx = bi; a.bwd_probs = bp;
@@ -575,14 +574,15 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.alpha_ws = (double*)(ws + c.alpha); a.beta_ws = (double*)(ws + c.beta); a.logp_ws = (double*)(ws + c.logp);
   a.rows_ws = (float*)(ws + c.rows); a.upd_ws = (int32_t*)(ws + c.upd); a.ucount_ws = (int32_t*)(ws + c.ucount);
   a.uidx_ws = (int32_t*)(ws + c.uidx); a.frac_ws = (float*)(ws + c.frac);
+  a.general = num_needs_general(H, K, D) ? 1 : 0;             // graphs beyond the tile kernels: num_general.hip
+  a.gen_acc = ws + c.gacc;
   return PYCHAIN_HIP_OK;
 }
 }  // namespace
 
 extern "C" size_t pychain_hip_num_workspace_bytes(int B, int T, int H, int K, int D) {
-  (void)D;
-  if (B <= 0 || T <= 0 || H <= 0 || K <= 0) return 0;
-  return num_carve(B, T, H, K).total;
+  if (B <= 0 || T <= 0 || H <= 0 || K <= 0 || D <= 0) return 0;
+  return num_carve(B, T, H, K, D).total;
 }
 
 extern "C" int pychain_hip_num_forward_backward(
@@ -644,7 +644,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
-  const bool fold = grad && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL &&
+  const bool fold = grad && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL && !na.general &&
                     den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
   if (fold) {
     da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
@@ -656,14 +656,15 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (e == hipSuccess && grad) e = launch_num_prep(na, side->stream, &why);
   if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
   if (e == hipSuccess && na.corrupt_b >= 0) e = launch_num_corrupt(na, side->stream);
-  if (e == hipSuccess && grad) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
+  if (e == hipSuccess && grad && !na.general) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
   da.phase_mask = da.knobs.den_phase_mask == 0 ? 0 : 3;     // (mask 0: only the numerator's launches - a measurement aid, outputs not meaningful)
   // (den_finish_kernel reads the numerator's objectives and its bad count for `totals`: the join precedes it)
   if (e == hipSuccess) e = run_den_launches(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
   if (e == hipSuccess && (da.phase_mask & 1)) e = launch_den_finish(da, st);     // (phase mask 0: the numerator alone - bench.py times it so)
-  if (e == hipSuccess && grad && !fold) e = launch_num_scatter(na, st, &why);      // grad -= grad_scale * gamma_num
+  if (e == hipSuccess && grad && !fold)                                             // grad -= grad_scale * gamma_num
+    e = na.general ? launch_num_occ(na, false, st, &why) : launch_num_scatter(na, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
   return PYCHAIN_HIP_OK;

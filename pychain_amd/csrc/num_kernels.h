@@ -42,7 +42,20 @@ struct NumArgs {
   // recursions and the occupancy pass, so that the 5 % invariant can be seen to fire; corrupt_b < 0: off
   int corrupt_b, corrupt_t;
   float corrupt_log;
+  // graphs beyond the tile kernels (num_needs_general): the launches below run num_general.hip instead; gen_acc = the
+  // occupancy launch's accumulator rows in the workspace (kNumGeneralBlocks x D 64-bit words)
+  int general;
+  void* gen_acc;
 };
+
+// Numerator graphs the tile kernels do not take - more than 65 535 states or pdfs, or state vectors + nnet-output rows +
+// arcs beyond the LDS - run on kernels that gather everything from global memory (num_general.hip): slow, complete, like
+// the reference's CPU path (chain-log-domain-computation.cc:123-159 has no size limit).
+constexpr int kNumGeneralBlocks = 256;
+bool num_needs_general(int H, int K, int D);
+size_t num_general_acc_bytes(int D);
+hipError_t launch_num_general_fb(const NumArgs& a, hipStream_t st);
+hipError_t launch_num_general_occ(const NumArgs& a, void* acc, hipStream_t st);
 
 size_t num_fb_lds_bytes(int H, int K, int D);
 // forward and backward recursions (launch 1, 2B workgroups): reads x + graphs, writes objf, logp_ws, alpha_ws, beta_ws

@@ -595,6 +595,7 @@ size_t num_occ_lds_bytes(int H, int K, int D) {
 }
 
 hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
+  if (a.general) return launch_num_general_fb(a, st);
   const size_t lds = num_fb_lds_bytes(a.H, a.K, a.D);
   if (lds > 160 * 1024) {
     *why = "numerator graph + nnet-output rows do not fit the 160 KiB LDS of one CU";
@@ -628,6 +629,7 @@ hipError_t launch_num_corrupt(const NumArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_num_prep(const NumArgs& a, hipStream_t st, const char** why) {
+  if (a.general) return hipSuccess;                          // (compact rows are a tile-path form)
   const size_t lds = 4 * (size_t)a.D + 16 + 4 * kOcNT + 64;
   if (lds > 160 * 1024) { *why = "pdf table does not fit the 160 KiB LDS of one CU"; return hipErrorInvalidValue; }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(num_prep_kernel),
@@ -650,6 +652,10 @@ size_t num_occ_wave_lds_bytes(int H, int K) {
 }
 
 hipError_t launch_num_occ(const NumArgs& a, bool compact, hipStream_t st, const char** why) {
+  if (a.general) {
+    if (compact) { *why = "compact occupancy rows are not produced for graphs on the general numerator kernels"; return hipErrorInvalidValue; }
+    return launch_num_general_occ(a, a.gen_acc, st);
+  }
   if (compact && a.D <= 65535 && a.K <= 32767 && num_occ_wave_lds_bytes(a.H, a.K) <= 64 * 1024) {
     const size_t lds = num_occ_wave_lds_bytes(a.H, a.K);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(num_occ_wave_kernel),
