@@ -31,7 +31,10 @@
 //   LzDma                   16 waves, rows of up to 9216 pdfs by LDS-direct loads, Hp <= 3072: C4;
 //   LzSmall                  4 waves, Hp <= 1024, D <= 4096, over the plan's four-wave dealing (alpha4 / beta4): small graphs
 //                            (C1, C2) - a frame of theirs is a few hundred gathers, and sixteen waves walking their loops and
-//                            meeting at a barrier for four groups of work cost what a C3-size frame costs.
+//                            meeting at a barrier for four groups of work cost what a C3-size frame costs.  Measured on C2
+//                            and not kept (profiles/r04_c2_small_*): the rows requested two steps ahead into a ring of four
+//                            buffers (0.209 against 0.199 ms - a frame is not waiting for its row), a wave leaving the arc loop
+//                            after its last real chunk (0.266 ms: the row's clamp / exp then sits in the serial tail).
 // (8 and 12 waves with 256 / 168 VGPRs were built and measured in round 3: +46 % / +15 %, profiles/r03_a_time_matrix.txt,
 // r03_g_twelve_waves.txt; so was a map with two copies of the nnet-output row: +0.3 %, r03_i_two_copies.txt.)
 // LDS maps (absolute byte addresses; the dynamic segment starts at 0, checked).  An arc is two VGPRs as in
@@ -43,7 +46,6 @@ struct LzNarrow {
   //   [96K, ...)  partial sums, beta's leaky probs
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 1;
   static constexpr bool kDma = false;
-  static constexpr bool kEarly = false;               // (LzSmall: a wave leaves the arc loop after its last real chunk)
   static constexpr uint32_t kU0 = 0, kU1 = 32768, kX0 = 65536, kX1 = 81920, kUField = 0, kXField = 49152;
   static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
   static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
@@ -57,7 +59,6 @@ struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static conste
 struct LzDma {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
   static constexpr bool kDma = true;
-  static constexpr bool kEarly = false;
   static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 9216;
   static constexpr uint32_t kLk = 122880, kRed = kLk + kMaxStates * 4, kBytes = kRed + 2 * 2 * 64 * 4;
@@ -73,10 +74,6 @@ template <typename MAP> constexpr bool lz_map_ok() {
 struct LzSmall {
   static constexpr int kWaves = 4, kMaxGroups = 4, kXch = 0;
   static constexpr bool kDma = true;
-  // With one wave per SIMD a chunk of the arc loop is a dependent LDS round trip (~325 cycles, whatever it gathers:
-  // profiles/r04_c2_small_phase_timers_ring4.txt): a wave walks only the chunks that hold its slot-rows, not the loop's
-  // full length (sixteen waves hide each other's round trips; there the uniform loop is the faster one).
-  static constexpr bool kEarly = true;
   static constexpr uint32_t kU0 = 0, kU1 = 8192, kX0 = 16384, kX1 = 32768, kUField = 0, kXField = 16384;
   static constexpr uint32_t kMaxStates = 1024, kMaxPdfs = 4096;
   static constexpr uint32_t kRed = 49152, kLk = kRed + 2 * 2 * 64 * 4, kBytes = kLk + kMaxStates * 4;
@@ -322,26 +319,20 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
   ar.opaque4(0);
 #pragma unroll
   for (int k = 0; k < kChunk; k += 2) ar.template gather2<UOFF, VOFF>(k, ub[0][k], ub[0][k + 1], vb[0][k / 2]);
-  // MAP::kEarly: this wave's chunks (uniform; at least one, so that both hooks run); the late hook then sits in the last
-  // one - the row it finishes was requested at the start of a frame that is now short
-  const int nch = MAP::kEarly ? max(1, (gr.nslots + kChunk - 1) / kChunk) : NC;
-  const int late_c = MAP::kEarly ? nch - 1 : kLateChunk;
 #pragma unroll
   for (int c = 0; c < NC; c++) {
     const int cb = c & 1;
-    if (MAP::kEarly && c >= nch) break;
     wave_priority_by_progress<NC>(c);
-    const bool more = c + 1 < NC && (!MAP::kEarly || c + 1 < nch);
-    if (more) {
+    if (c + 1 < NC) {
       ar.opaque4((c + 1) * kChunk);
 #pragma unroll
       for (int k = 0; k < kChunk; k += 2)
         ar.template gather2<UOFF, VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k], ub[cb ^ 1][k + 1], vb[cb ^ 1][k / 2]);
     }
     if (c == 0) after_first_gathers();
-    if (c == late_c) late();                           // (the next frame's nnet-output row: lazy_recursion)
+    if (c == kLateChunk) late();                       // (the next frame's nnet-output row: lazy_recursion)
     __builtin_amdgcn_sched_barrier(0);
-    if (more) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
+    if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
     __builtin_amdgcn_sched_barrier(0);
     lz_v2f wk[kChunk / 2];
 #pragma unroll

@@ -35,16 +35,17 @@ __device__ __forceinline__ double fresh(const double* p) { return __hip_atomic_l
 // torch.clamp(x, -30, 30) keeps a NaN (pychain/loss.py:30): so does this
 __device__ __forceinline__ float gclamp(float x) { return x != x ? x : fminf(fmaxf(x, -30.f), 30.f); }
 
-// log-sum-exp over float64 terms with fp32 transcendentals on small differences (num_kernels.hip: Lse)
+// log-sum-exp over float64 terms with fp32 transcendentals on small differences (num_kernels.hip: Lse); the sum itself is
+// kept in fp64 here - a state of these graphs may have tens of thousands of arcs, and a float sum of 70 000 terms is 2e-5 off
 struct GLse {
-  double m; float s;
-  __device__ __forceinline__ void init() { m = -INFINITY; s = 0.f; }
+  double m, s;
+  __device__ __forceinline__ void init() { m = -INFINITY; s = 0.0; }
   __device__ __forceinline__ void push(double e) {
     if (e != e) { m = e; return; }                                     // a NaN network output reaches the log-probability
-    if (e > m) { s = (m == -INFINITY) ? 1.f : s * gexp((float)(m - e)) + 1.f; m = e; }
-    else if (e != -INFINITY) { s += gexp((float)(e - m)); }
+    if (e > m) { s = (m == -INFINITY) ? 1.0 : s * (double)gexp((float)(m - e)) + 1.0; m = e; }
+    else if (e != -INFINITY) { s += (double)gexp((float)(e - m)); }
   }
-  __device__ __forceinline__ double value() const { return m == -INFINITY ? -INFINITY : m + (double)glog(s); }
+  __device__ __forceinline__ double value() const { return m == -INFINITY ? -INFINITY : m + log(s); }
 };
 
 __device__ __forceinline__ double block_max(double v, double* red, int tid) {     // red[17]; every thread gets the result

@@ -111,8 +111,10 @@ def test_numerator_graphs_beyond_the_tile_kernels_vs_oracle(H, D, T):
     g = xx.grad.cpu().numpy()
     ro64, rg64 = orc.chain_function(x.cpu(), L, gb, flavour="f64")
     assert abs(float(o.detach()) - ro64) <= 1e-5 * abs(ro64) and rel_err(g, rg64) <= 1e-5, rel_err(g, rg64)
+    # the fp32 restatement: within 1e-4 where its own sums are short; a fan-in of 70 000 float LogAdds is itself 1.4e-3 from
+    # exact arithmetic, and the bound is then that distance + 1e-5 (triangle inequality)
     ro, rg = orc.chain_function(x.cpu(), L, gb)
-    assert abs(float(o.detach()) - ro) <= 1e-4 * abs(ro) and rel_err(g, rg) <= 1e-4
+    assert abs(float(o.detach()) - ro) <= 1e-4 * abs(ro) and rel_err(g, rg) <= max(1e-4, rel_err(rg, rg64) + 1e-5)
     assert bool((xx.grad[1, int(L[1]):] == 0).all())
     assert abs(float(xx.grad[0, 0].sum()) - 1.0) <= 1e-4          # a frame's occupancies sum to one
     # the reference's log-gradient contract (-inf where zero) through the pychain_C surface
