@@ -448,29 +448,26 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
   const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
-  const int K = a.K, D = a.D, T = a.T, H = a.H, Hq = (H + 1) & ~1;
+  const int K = a.K, T = a.T, H = a.H, Hq = (H + 3) & ~3;
   const int t_wg = blockIdx.x * (4 * kOwFrames);
   if (t_wg >= L) return;
   char* p = smem_raw;
-  uint32_t* sd = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)K;                 // src | dst << 16
-  float* lp = reinterpret_cast<float*>(p); p += 4 * (size_t)K;
-  int32_t* pdf_u = reinterpret_cast<int32_t*>(p); p += 4 * (size_t)K;                // pdf | compact row << 16
+  uint32_t* su = reinterpret_cast<uint32_t*>(p); p += 4 * (size_t)K;                 // src | compact row << 16
   p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 15) & ~uintptr_t(15));
-  const size_t per_wave = 16 * (size_t)Hq + 8 * (size_t)K;
-  double* arow = reinterpret_cast<double*>(p + wave * per_wave);
-  double* brow = arow + Hq;
-  unsigned long long* acc = reinterpret_cast<unsigned long long*>(brow + Hq);        // [U]
+  // per wave: the log-occupancy of every state of the frame (ONE fp32 row: alpha + beta - logP is formed in fp64 from the
+  // prefetched rows and rounded once - a number of magnitude < 100 whose rounding moves an occupancy by < 1e-6 of itself)
+  // and the merge accumulator; 4 KiB + 8 K bytes per wave let four workgroups share a CU (two while the fp64 rows sat here)
+  const size_t per_wave = 4 * (size_t)Hq + 8 * (size_t)K;
+  float* strow = reinterpret_cast<float*>(p + wave * per_wave);
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(strow + Hq);       // [U]
   const size_t g = (size_t)b * a.graph_stride;
   const int32_t* ft = a.fwd_trans + g * K * 3;
-  const float* fp = a.fwd_probs + g * K;
   const int32_t* uidx = a.uidx_ws + (size_t)b * K;
   const int U = a.ucount_ws[b];
   int kused = 0;
   for (int k = tid; k < K; k += kOcNT) {
     const int u = uidx[k];
-    sd[k] = (uint32_t)ft[3 * k] | ((uint32_t)ft[3 * k + 1] << 16);
-    lp[k] = fp[k];
-    pdf_u[k] = ft[3 * k + 2] | (max(u, 0) << 16);
+    su[k] = (uint32_t)ft[3 * k] | ((uint32_t)max(u, 0) << 16);
     if (u >= 0) kused = k + 1;
   }
   for (int u = lane; u < U; u += 64) acc[u] = 0ull;
@@ -488,7 +485,7 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   int bad = 0;
   const int t0 = t_wg + wave * kOwFrames, t1 = min(t0 + kOwFrames, L);
   // Software pipeline: a wave has nobody to hide its own global latencies behind, so the rows and the
-  // nnet-output values of frame t+1 are loaded into registers while frame t is evaluated (kWX arcs and
+  // log-shares of frame t+1 are loaded into registers while frame t is evaluated (kWX arcs and
   // kWR row elements per lane are staged; larger graphs read the rest directly).
   constexpr int kWX = 16, kWR = 8;
   float px[kWX];
@@ -508,12 +505,12 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   // occupancy = exp(alpha(t,src) + beta(t,src) - logP + r_k(t)), see num_occ_kernel
 #define NUM_OCCW_ARC(k, rk)                                                                        \
   do {                                                                                             \
-    const int src = sd[k] & 0xffffu;                                                               \
-    const double st = arow[src] + brow[src] - logp;                                                \
-    const float v = st == -INFINITY ? 0.f : fexp((float)(st + (double)(rk)));                      \
+    const uint32_t w_ = su[k];                                                                     \
+    const float st = strow[w_ & 0xffffu];                                                          \
+    const float v = st == -INFINITY ? 0.f : fexp(st + (rk));                                       \
     fsum += v;                                                                                     \
     if (v > 0.f) {                                                                                 \
-      if (v <= 2.f) atomicAdd(&acc[pdf_u[k] >> 16], (unsigned long long)(v * kFixScale));          \
+      if (v <= 2.f) atomicAdd(&acc[w_ >> 16], (unsigned long long)(v * kFixScale));                \
       else bad = 1;                                                                                \
     } else if (v != 0.f) {                                                                         \
       bad = 1;                                  /* NaN */                                          \
@@ -523,8 +520,8 @@ __global__ __launch_bounds__(kOcNT) void num_occ_wave_kernel(const NumArgs a) {
   for (int t = t0; t < t1; t++) {
     const float* frow = fseq + (size_t)t * K;
 #pragma unroll
-    for (int i = 0; i < kWR; i++) { const int h = lane + 64 * i; if (h < H) { arow[h] = pa[i]; brow[h] = pb[i]; } }
-    for (int h = lane + 64 * kWR; h < H; h += 64) { arow[h] = aws[(size_t)t * H + h]; brow[h] = bws[(size_t)t * H + h]; }
+    for (int i = 0; i < kWR; i++) { const int h = lane + 64 * i; if (h < H) strow[h] = (float)(pa[i] + pb[i] - logp); }
+    for (int h = lane + 64 * kWR; h < H; h += 64) strow[h] = (float)(aws[(size_t)t * H + h] + bws[(size_t)t * H + h] - logp);
     float xc[kWX];
     float fsum = 0.f;                                   // this lane's share of the frame's occupancy total
 #pragma unroll
@@ -647,8 +644,8 @@ hipError_t launch_num_scatter(const NumArgs& a, hipStream_t st, const char** why
 }
 
 size_t num_occ_wave_lds_bytes(int H, int K) {
-  const size_t Hq = (H + 1) & ~1;
-  return 12 * (size_t)K + 16 + 4 * (16 * Hq + 8 * (size_t)K) + 64;
+  const size_t Hq = (H + 3) & ~3;
+  return 4 * (size_t)K + 16 + 4 * (4 * Hq + 8 * (size_t)K) + 64;
 }
 
 hipError_t launch_num_occ(const NumArgs& a, bool compact, hipStream_t st, const char** why) {
