@@ -171,9 +171,9 @@ __global__ __launch_bounds__(kNGT) void num_general_occ_kernel(const NumArgs a, 
     for (int h = tid; h < H; h += kNGT) {
       const int2 be = fi[h];
       if (be.y <= be.x) continue;
-      const double st = arow[h] + brow[h] - logp;     // log occupancy of the source state
+      const float st = (float)(arow[h] + brow[h] - logp);     // log occupancy of the source state (fp64, rounded once: as the tile kernels)
       for (int k = be.x; k < be.y; k++) {
-        const float v = st == -INFINITY ? 0.f : gexp((float)(st + (double)frow[k]));
+        const float v = st == -INFINITY ? 0.f : gexp(st + frow[k]);
         fsum += v;
         if (v > 0.f) {
           if (v <= 2.f) atomicAdd(&acc[ft[3 * k + 2]], (unsigned long long)(v * kGFixScale));

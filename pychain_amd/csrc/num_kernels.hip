@@ -381,8 +381,9 @@ __global__ __launch_bounds__(kOcNT) void num_occ_kernel(const NumArgs a) {
       do {                                                                                         \
         const int src = sd[k] & 0xffffu;                                                           \
         const int n = pdf[k];                                                                      \
-        const double st = arow[src] + brow[src] - logp;          /* log occupancy of the source state */ \
-        const float v = st == -INFINITY ? 0.f : fexp((float)(st + (double)(rk)));                  \
+        /* log occupancy of the source state: formed in fp64, rounded ONCE to fp32 (as num_occ_wave_kernel keeps it in LDS) */ \
+        const float st = (float)(arow[src] + brow[src] - logp);                                    \
+        const float v = st == -INFINITY ? 0.f : fexp(st + (rk));                                   \
         fsum += v;                                                                                 \
         if (v > 0.f) {                                                                             \
           if (v <= 2.f) atomicAdd(&acc[n], (unsigned long long)(v * kFixScale));                   \
