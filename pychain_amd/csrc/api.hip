@@ -243,6 +243,7 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.progress = (int32_t*)((char*)a.seq_progress + align256(8 * (size_t)B));
   a.stream_next = a.progress + 32;
   a.finish_count = a.progress + 40;
+  a.occ_done = a.progress + 41; a.occ_done_target = 0;
   a.loss_out = nullptr; a.loss_num_objf = nullptr; a.loss_scale = 1.f; a.loss_norm_dev = nullptr; a.bad_words = 1;
   a.stream = 0;
   a.tot_a = (float*)((char*)a.progress + 256);
@@ -278,16 +279,15 @@ SideStream* side_streams_for(hipStream_t caller) {
   SideStream& s = table[std::make_pair(dev, caller)];
   if (!s.ready) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    // the occupancy launches only fill idle CUs: lowest priority, so that the persistent recursion
-    // workgroups of the next segment (caller's stream) are dispatched first
+    // the occupancy launches only fill idle CUs: lowest priority
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
     if (hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join2, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return nullptr;
     for (int i = 0; i < kMaxSegments; i++)
-      if (hipEventCreateWithFlags(&s.seg[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&s.seg[i], hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return nullptr;
     s.ready = true;
   }
   return &s;
@@ -370,18 +370,32 @@ hipError_t launch_scale_row(float* row, int n, float scale, hipStream_t st) {
   return hipGetLastError();
 }
 
+// Every word a call's launches count in - the caller's bad count(s) and the workspace's counters (per-sequence progress, gate
+// counters, the queue head of the streamed occupancy pass, den_finish_kernel's arrival counter) - zeroed by ONE small launch
+// (two hipMemsetAsync are two fill kernels with a gap between them: 18 us at the head of every step).
+__global__ void zero_words_kernel(int32_t* p0, int n0, int32_t* p1, int n1) {
+  for (int i = threadIdx.x; i < n0; i += blockDim.x) p0[i] = 0;
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) p1[i] = 0;
+}
+hipError_t launch_zero_words(int32_t* p0, int n0, int32_t* p1, int n1, hipStream_t st) {
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, p0, n0, p1, n1);
+  return hipGetLastError();
+}
+int den_counter_words(const DenArgs& a) { return (int)((align256(8 * (size_t)a.B) + 256) / 4); }
+
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
 // `gamma_wait`: event every occupancy launch has to wait for (the numerator rows it folds in), or null
+// `zeroed`: an event the caller recorded on `st` behind the zeroing of the counters (the fused loss forks its numerator
+// stream there), or null: recorded here.  An event record costs the caller's stream ~7 us in front of the recursion launch.
+// `finish_early`: in/out - in: den_finish_kernel may be launched here (the caller has nothing else it must wait for);
+// out: it was (behind the recursion launch of the streamed schedule, DenArgs::occ_done), the caller must not launch it again
 hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
-                            hipEvent_t gamma_wait) {
+                            hipEvent_t gamma_wait, hipEvent_t zeroed = nullptr, bool* finish_early = nullptr) {
+  const bool may_finish = finish_early && *finish_early;
+  if (finish_early) *finish_early = false;
   const int gmax = (a.D + 63) / 64;
   const int user_mask = a.phase_mask;
-  // ONE memset per call for every counter the launches of a call share: per-sequence progress, gate counters, the queue head
-  // of the streamed occupancy pass, den_finish_kernel's arrival counter
-  if (user_mask & 1) {
-    const hipError_t em = hipMemsetAsync(a.seq_progress, 0, align256(8 * (size_t)a.B) + 256, st);
-    if (em != hipSuccess) return em;
-  }
+  // (the counters the launches of a call share were zeroed with the bad count by the caller: launch_zero_words)
   if (resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) {
     // a plan in the general format: den_general.hip, no overlap (rows in den_recursion_kernel's normalised form)
     a.lazy = 0; a.pair = 0; a.shape = 0;
@@ -442,17 +456,24 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     // launch: what is left when the recursions end is the last ring of every sequence.
     a.stream = 1; a.sig_n = 1; a.stream_blocks = device_cu_count();
     a.seg_bound[0] = std::min(a.T, (a.T / 2 + 31) / 32 * 32);
-    if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // (the occupancy launch must see the zeroed counters)
-    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
+    // (The other way round - the recursion launch on the side stream, gate and occupancy launch on the caller's, so that the
+    // launch that ends last is followed in queue order - was measured: the wake-up of a queue that waits for another queue's
+    // event costs 11-19 us wherever it sits, and there the recursion paid it at the head of the step:
+    // profiles/r04_i_C3_step_timeline_recursion_on_side_stream.txt.)
+    if (e == hipSuccess && !zeroed) e = hipEventRecord(side->seg[0], st);      // (the occupancy launch must see the zeroed counters)
+    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, zeroed ? zeroed : side->seg[0], 0);
     a.phase_mask = 1;
     if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
     if (e == hipSuccess) e = launch_den_gate(a.progress, den_recursion_blocks(a), a.bad, side->stream2);
     if (e == hipSuccess && gamma_wait) e = hipStreamWaitEvent(side->stream2, gamma_wait, 0);
     a.phase_mask = 2; a.gam_nseg = 0; a.gam_seg = 0; a.stream = 3;
+    a.occ_done_target = may_finish ? a.stream_blocks : 0;
     if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
     if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
     a.phase_mask = user_mask; a.sig_n = 0; a.stream = 0;
+    if (e == hipSuccess && may_finish) { e = launch_den_finish(a, st); *finish_early = true; }   // (DenArgs::occ_done)
+    a.occ_done_target = 0;
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
     return e;
   }
   // Gated schedule (rounds 1-2; the fallback for the two-barrier recursion and per-sequence plans, and what option
@@ -461,8 +482,8 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   // of them.  (One recursion launch per segment with stream events in between - the first form of this schedule - measured
   // 2 % slower and is gone: profiles/r01_*.)
   a.sig_n = nseg - 1;
-  if (e == hipSuccess) e = hipEventRecord(side->seg[0], st);                 // the gates must see the zeroed counters
-  if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, side->seg[0], 0);
+  if (e == hipSuccess && !zeroed) e = hipEventRecord(side->seg[0], st);      // the gates must see the zeroed counters
+  if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, zeroed ? zeroed : side->seg[0], 0);
   a.phase_mask = 1;
   if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
   a.phase_mask = 2; a.gam_nseg = nseg;
@@ -485,8 +506,9 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
 // the reference's invariant check (DenArgs::tot_a)
 hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream_t st, const char** why,
                    hipEvent_t gamma_wait = nullptr) {
-  hipError_t e = run_den_launches(a, resident_slot_rows, occupancy, st, why, gamma_wait);
-  if (e == hipSuccess && (a.phase_mask & 1)) e = launch_den_finish(a, st);       // objf (+ the check) from the stored totals
+  bool finished = gamma_wait == nullptr;                 // (a caller with an event of its own launches den_finish_kernel itself)
+  hipError_t e = run_den_launches(a, resident_slot_rows, occupancy, st, why, gamma_wait, nullptr, &finished);
+  if (e == hipSuccess && (a.phase_mask & 1) && !finished) e = launch_den_finish(a, st);   // objf (+ the check) from the stored totals
   return e;
 }
 }  // namespace
@@ -511,8 +533,8 @@ extern "C" int pychain_hip_den_forward_backward(
   if (rc != PYCHAIN_HIP_OK) return rc;
   a.loss_out = totals;                                 // (sum of the per-sequence objectives, frames, bad count: den_finish_kernel)
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
-    return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: hipMemsetAsync failed");
+  if (launch_zero_words(bad_count, 1, a.seq_progress, den_counter_words(a), st) != hipSuccess)
+    return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: cannot zero the counters");
   const char* why = nullptr;
   hipError_t e = run_den(a, resident_slot_rows, true, st, &why);
   if (e != hipSuccess)
@@ -640,7 +662,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   SideStream* side = side_streams_for(st);
   if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "%s: cannot create the side stream", who);
   const char* why = nullptr;
-  hipError_t e = hipMemsetAsync(bad_count, 0, 2 * sizeof(int32_t), st);
+  hipError_t e = launch_zero_words(bad_count, 2, da.seq_progress, den_counter_words(da), st);
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
@@ -660,9 +682,14 @@ extern "C" int pychain_hip_chain_loss_forward(
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
   da.phase_mask = da.knobs.den_phase_mask == 0 ? 0 : 3;     // (mask 0: only the numerator's launches - a measurement aid, outputs not meaningful)
   // (den_finish_kernel reads the numerator's objectives and its bad count for `totals`: the join precedes it)
-  if (e == hipSuccess) e = run_den_launches(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr);
-  if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);   // join
-  if (e == hipSuccess && (da.phase_mask & 1)) e = launch_den_finish(da, st);     // (phase mask 0: the numerator alone - bench.py times it so)
+  // (den_finish_kernel needs the numerator's objectives and bad count: early only where the occupancy launch waits for them)
+  bool finished = fold;
+  if (e == hipSuccess) e = run_den_launches(da, resident_slot_rows, grad != nullptr, st, &why, fold ? side->join : nullptr, side->fork, &finished);
+  // join (a call whose occupancy launch folded the numerator in has it behind it already: that launch waited for the numerator's
+  // event and the caller's stream for that launch - one barrier packet less, ~5 us, between it and den_finish_kernel)
+  const bool joined = fold && da.phase_mask == 3;     // (every schedule of run_den_launches puts the wait in front of its first occupancy launch)
+  if (e == hipSuccess && !joined) e = hipStreamWaitEvent(st, side->join, 0);
+  if (e == hipSuccess && (da.phase_mask & 1) && !finished) e = launch_den_finish(da, st);     // (phase mask 0: the numerator alone - bench.py times it so)
   if (e == hipSuccess && grad && !fold)                                             // grad -= grad_scale * gamma_num
     e = na.general ? launch_num_occ(na, false, st, &why) : launch_num_scatter(na, st, &why);
   if (e != hipSuccess)

@@ -317,7 +317,8 @@ __device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_log
 // The occupancy kernels only record G(t) (the recursions may still be running when an overlapped occupancy
 // launch evaluates frame 0 of a short sequence); den_finish_kernel compares after the last launch of the call.
 __device__ __forceinline__ void den_record_frame_total(const DenArgs& a, int b, int t, float frame_total) {
-  a.gtot[(size_t)b * a.T + t] = frame_total;
+  // (device scope: den_finish_kernel may read it while the occupancy launch is still running - DenArgs::occ_done)
+  __hip_atomic_store(a.gtot + (size_t)b * a.T + t, frame_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // block total of per-wave partials: red[16] in LDS (entries >= kNW stay zero)

@@ -87,6 +87,13 @@ struct DenArgs {
   const float* loss_norm_dev;    // optional device scalar (the frame count of avg = True when the lengths live on the device)
   int32_t* finish_count;         // [1], zeroed with the progress counters
   int bad_words;                 // bad[0 .. bad_words) are added up into loss_out[2]
+  // den_finish_kernel launched BEHIND THE RECURSION on the caller's stream while the streamed occupancy launch is still running
+  // on its own: it waits (one thread per workgroup, s_sleep) until occ_done - which every workgroup of that launch counts itself
+  // into when the queue is empty and its stores are acknowledged - reaches occ_done_target, instead of for the launch's stream
+  // event: the wake-up of a queue that waits for another queue's event costs 12-19 us, and the kernel's own 9 us follow it.
+  // (The caller's stream still waits for the event behind it: what comes next needs the gradient.)  0: no waiting.
+  int32_t* occ_done;             // [1], zeroed with the progress counters
+  int occ_done_target;
   CallKnobs knobs;               // this call's snapshot of the library settings (host side only)
 };
 

@@ -54,29 +54,55 @@ namespace {
 //   rows of den_recursion_kernel (normalised): alpha'(t)/tot(t) carries prod_{tau<=t} tot(tau); beta(t+1) carries
 //       prod_{tau>=t+1} n(tau); objf = sum_{t<=L} log tot(t) + log fin_dot
 constexpr int kFinNT = 256;
+// block sums of two doubles per thread with ONE barrier: ds_bpermute butterflies inside a wave, then every thread adds the
+// kFinNT / 64 wave partials in the same order (the kernel sits in the serial tail of every step: its latency chain counts)
+__device__ __forceinline__ void fin_block_sum2(double& x, double& y, double (*part)[kFinNT / 64], int tid) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
+  if ((tid & 63) == 0) { part[0][tid >> 6] = x; part[1][tid >> 6] = y; }
+  __syncthreads();
+  x = 0.0; y = 0.0;
+#pragma unroll
+  for (int w = 0; w < kFinNT / 64; w++) { x += part[0][w]; y += part[1][w]; }
+}
 __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
-  __shared__ double sh[kFinNT];
-  __shared__ double sh_total_a, sh_total_b;
+  __shared__ double part[2][kFinNT / 64], part2[2][kFinNT / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int L = seq_len(a.lengths, b, a.T);
   const float* ta = a.tot_a + (size_t)b * (a.T + 2);
   const float* tb = a.tot_b + (size_t)b * (a.T + 2);
   const int na = a.lazy ? L : L + 1;                       // alpha totals 0 .. na-1 make up the log-probability
-  // (the math library's log: this is off every critical path and feeds a value compared at 1e-4 relative)
-  double sa = 0.0, sb = 0.0;
-  for (int t = tid; t < na; t += kFinNT) sa += log((double)ta[t]);
-  for (int t = tid + 1; t <= L; t += kFinNT) sb += log((double)tb[t]);
-  sh[tid] = sa;
-  __syncthreads();
-  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
-  if (tid == 0) sh_total_a = sh[0];
-  __syncthreads();
-  sh[tid] = sb;
-  __syncthreads();
-  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
-  if (tid == 0) sh_total_b = sh[0];
-  __syncthreads();
-  const double logp = sh_total_a + log((double)a.fin_dot[b]);
+  // sum_t log tot(t) as the log of a product: a thread multiplies the mantissas of its totals (fp64: exact to 2^-53 per factor,
+  // no overflow - a mantissa lies in [0.5, 1)) and adds up their exponents, so it evaluates ONE fp64 log for its 2 x T / 256
+  // totals instead of one each.  A total that is zero, negative, infinite or NaN keeps its meaning: the product turns
+  // 0 / negative / inf / NaN and so does the log.
+  auto log_of_product = [](const float* v, int first, int end) -> double {
+    double m = 1.0; long ex = 0;
+    for (int t = first; t < end; t += kFinNT) {
+      const float x = v[t];
+      if (x > 0.f && x < __builtin_inff()) { int e; m *= (double)__builtin_frexpf(x, &e); ex += e; }
+      else m *= (double)x;
+      if (m < 0x1p-900) { m *= 0x1p+800; ex -= 800; }      // (> 900 factors per thread: T > 230 000)
+    }
+    return log(m) + (double)ex * 0.69314718055994530942;
+  };
+  if (a.occ_done_target) {                                 // the streamed occupancy launch is still running (DenArgs::occ_done)
+    if (tid == 0) {
+      const unsigned long long t0 = wall_clock64();        // 100 MHz
+      while (__hip_atomic_load(a.occ_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.occ_done_target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 2000000000ull) { atomicAdd(a.bad, 1); break; }   // 20 s
+      }
+    }
+    __syncthreads();
+  }
+  // (what thread 0 needs after the sums: requested before them)
+  const float fin_dot = a.fin_dot[b];
+  const float g0 = a.check && L >= 1 ? __hip_atomic_load(a.gtot + (size_t)b * a.T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1.f;
+  const float ta0 = ta[0], tb1 = L >= 1 ? tb[1] : 1.f;
+  double sh_total_a = log_of_product(ta, tid, na), sh_total_b = log_of_product(tb, tid + 1, L + 1);
+  fin_block_sum2(sh_total_a, sh_total_b, part, tid);
+  const double logp = sh_total_a + log((double)fin_dot);
   const float objf = (float)logp;
   int bad = 0;
   if (tid == 0) {
@@ -90,9 +116,9 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
     const float* g = a.gtot + (size_t)b * a.T;
     if (!a.check_all) {
       if (tid == 0) {
-        const double pa = a.lazy ? 0.0 : log((double)ta[0]);
-        const double sbt = sh_total_b - (a.lazy && L >= 1 ? log((double)tb[1]) : 0.0);   // lazy: tau >= 2; else tau >= 1
-        const double est = log((double)g[0]) + pa + sbt;
+        const double pa = a.lazy ? 0.0 : log((double)ta0);
+        const double sbt = sh_total_b - (a.lazy && L >= 1 ? log((double)tb1) : 0.0);   // lazy: tau >= 2; else tau >= 1
+        const double est = log((double)(L >= 1 ? g0 : g[0])) + pa + sbt;
         if (!(fabs(est - logp) <= 0.0487901642)) bad = 1;  // log(1.05); NaN counts
       }
     } else {
@@ -130,20 +156,14 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
     if (a.loss_num_objf) acc -= (double)a.loss_num_objf[i];
     frames += (double)seq_len(a.lengths, i, a.T);
   }
-  sh[tid] = acc;
-  __syncthreads();
-  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
-  const double total = sh[0];
-  __syncthreads();
-  sh[tid] = frames;
-  __syncthreads();
-  for (int o = kFinNT / 2; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
+  fin_block_sum2(acc, frames, part2, tid);
+  const double total = acc;
   if (tid == 0) {
     double t = total * (double)a.loss_scale;                 // -(num - den) [* 1/frames], pychain/loss.py:100-104, rounded once
     if (a.loss_norm_dev) t /= (double)*a.loss_norm_dev;
     int nbad = 0;
     for (int i = 0; i < a.bad_words; i++) nbad += __hip_atomic_load(a.bad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.loss_out[0] = (float)t; a.loss_out[1] = (float)sh[0]; a.loss_out[2] = (float)nbad; a.loss_out[3] = (float)total;
+    a.loss_out[0] = (float)t; a.loss_out[1] = (float)frames; a.loss_out[2] = (float)nbad; a.loss_out[3] = (float)total;
   }
 }
 
@@ -248,6 +268,11 @@ __device__ __forceinline__ bool stream_take(const DenArgs& a, int* slot, StreamI
   }
   __syncthreads();
   it.b = slot[0]; it.lo = slot[1]; it.hi = slot[2]; it.L = slot[3]; it.pad = slot[4];
+  if (it.b < 0 && a.occ_done_target) {                  // the queue is empty: this workgroup is done (DenArgs::occ_done)
+    __builtin_amdgcn_s_waitcnt(0);                      // ... and its stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(a.occ_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   return it.b >= 0;
 }
 constexpr size_t kStaticLds = 64;       // the occupancy kernels' own static LDS (the queue slot) beside their dynamic segment

@@ -60,7 +60,17 @@ inline bool small_shape_ok(const DenArgs& a, int hint) {
   return ((hint >> 29) & 1) && a.D <= (int)LzSmall::kMaxPdfs && a.Hp <= (int)LzSmall::kMaxStates && rows > 0 && rows <= kMaxResident &&
          a.plan_stride >= 0;
 }
-hipError_t launch_small(const DenArgs& a, int hint, hipStream_t st) { return launch_dma_m<LzSmall>(a, hint & 1023, st); }
+// A frame of a small graph is the arc loop's chunks, one dependent LDS round trip each with one wave per SIMD, whatever the
+// wave gathers (profiles/r04_c2_small_phase_timers_ring4.txt): the loop is as long as the longest wave's rows, in steps of 8 from 16 on.
+hipError_t launch_small(const DenArgs& a, int hint, hipStream_t st) {
+  const dim3 grid(2 * a.B);
+  const int rows = hint & 1023;
+  typedef LzSmall M;
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 24) return launch_one(den_recursion_lazy_kernel<24, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+  return launch_one(den_recursion_lazy_kernel<kMaxResident, M>, a, grid, M::kBytes, st, M::kWaves * 64);
+}
 
 // Two sequences per workgroup (den_pair.inc.h): one plan for all sequences, nnet-output rows and state vectors
 // within its fixed LDS map, every arc of a plan wave in registers, the whole sequence in one launch.

@@ -103,6 +103,9 @@ typedef __attribute__((address_space(3))) void lz_lds_void;
 #ifndef PYCHAIN_BATCH_PROW
 #define PYCHAIN_BATCH_PROW 1                           /* 0: the previous row's values are read back and stored group by group (ablation) */
 #endif
+#ifndef PYCHAIN_SUMS_AT_GROUP_END
+#define PYCHAIN_SUMS_AT_GROUP_END 1                    /* a wave adds up its rows' new values where it forms them (two live registers); 0: re-read from LDS after the arc phase - C3 recursion 3.03 -> 2.96 ms, C4 4.71 -> 4.54, C2 0.176 -> 0.167: profiles/r04_j_time_matrix*.txt */
+#endif
 #ifndef PYCHAIN_LATE_FINISH
 #define PYCHAIN_LATE_FINISH 1                          /* 0: the in-place clamp / exp of an LDS-direct row after the arc phase (ablation) */
 #endif
@@ -221,6 +224,7 @@ template <int R, typename MAP> struct LazyArcsOf { typedef LazyArcs<R, MAP> type
 #ifndef PYCHAIN_NO_SPLIT_ARCS
 template <typename MAP> struct LazyArcsOf<16, MAP> { typedef LazyArcsSplit<16, MAP> type; };
 template <typename MAP> struct LazyArcsOf<32, MAP> { typedef LazyArcsSplit<32, MAP> type; };
+template <typename MAP> struct LazyArcsOf<24, MAP> { typedef LazyArcsSplit<24, MAP> type; };     // (the four-wave shape: launch_small)
 #endif
 
 // what a wave carries from frame to frame besides its arcs
@@ -233,18 +237,19 @@ struct LazyWave {
 // next frame gathers from.  Totals and the HBM row are built after the arc phase from those LDS words
 // (lazy_frame_end): nothing of it is live in registers while the gather buffers are.
 template <bool FWD>
-__device__ __forceinline__ void lazy_group_end(const LazyWave& w, lz_v2f acc, uint32_t lds_dst) {
+__device__ __forceinline__ float lazy_group_end(const LazyWave& w, lz_v2f acc, uint32_t lds_dst) {
   float val;
   if constexpr (FWD) val = __builtin_fmaf(acc.x, w.inv, acc.y);
   else val = __builtin_fmaf(w.c, acc.y, acc.x) * w.inv;
   lz_st1(lds_dst, val);
+  return val;
 }
 
 // One frame of a recursion tile, lazy form: gathers from the state buffer at ds_read offset UOFF and the nnet-output
 // buffer at VOFF, writes the new values into the state buffer at absolute address UNEXT.  Same software pipeline as
 // tile_rows; up to 96 slot-rows per wave (three words of group-end bits).
 template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook, typename Late>
-__device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers, Late&& late) {
+__device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, float& s0, float& s1, Hook&& after_first_gathers, Late&& late) {
   constexpr int kChunk = 4;
   static_assert(R % kChunk == 0 && R <= 96 && PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
@@ -295,7 +300,11 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
           int g = __builtin_popcount(lo_before) + __builtin_popcount(hi_before);
           if constexpr (R > 64) if (sidx >= 64) g += __builtin_popcount(m_2 & below);
           const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
-          lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
+          const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
+          if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
+            s0 += val;
+            if constexpr (!FWD) s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+          }
           nacc = lz_v2f{0.f, 0.f};
         }
       }
@@ -306,7 +315,7 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
 
 // ... and over arcs in the split form (LazyArcsSplit): rows in pairs
 template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook, typename Late>
-__device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, Hook&& after_first_gathers, Late&& late) {
+__device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, float& s0, float& s1, Hook&& after_first_gathers, Late&& late) {
   constexpr int kChunk = 4;
   static_assert(PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
   constexpr int NC = R / kChunk;
@@ -353,7 +362,11 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
         if ((m_lo >> sidx) & 1u) {
           const int g = __builtin_popcount(m_lo & ((1u << sidx) - 1u));
           const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
-          lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
+          const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
+          if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
+            s0 += val;
+            if constexpr (!FWD) s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+          }
           nacc = lz_v2f{0.f, 0.f};
         }
       }
@@ -502,7 +515,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
       if (have_next) lz_dma_row<NW, kDmaCh>(xbuf, tn, D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1);            \
     } else if (have_next) xq.load_row(xbuf, tn, D, tq);      /* in flight during the arc work */             \
-    lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, [&]() {                                \
+    float s0 = 0.f, s1 = 0.f;                                                                               \
+    lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, s0, s1, [&]() {                        \
       if (j > 0) PYCHAIN_LZ_TOTALS((PAR) ^ 1, j - 1, (FWDC), lq, tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) - it sits in the buffer this */ \
       /* frame gathers from - is completed and leaves for HBM, also behind the first gathers */              \
@@ -536,7 +550,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
     /* lane's rows (and, beta, their leaky probs) for the totals */                                         \
     float val[MG], lkv[MG];                                                                                 \
-    {                                                                                                       \
+    if constexpr (!PYCHAIN_SUMS_AT_GROUP_END) {                                                             \
       const int lane8 = lq * 8;                                                                             \
       _Pragma("unroll") for (int g = 0; g < MG; g++) {                                                      \
         val[g] = 0.f; lkv[g] = 0.f;                                                                         \
@@ -555,8 +569,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \
     }                                                                                                       \
     LZ_PH(1);                                                /* LDS re-reads issued, nnet-output row clamped / exp'd / stored */ \
-    float s0 = 0.f, s1 = 0.f;                                                                               \
-    if constexpr (MG == 4) {                                                                                \
+    if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {                                                              \
+    } else if constexpr (MG == 4) {                                                                         \
       s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                           \
       if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
     } else {                                                                                                \

@@ -6,6 +6,7 @@ def short(n):
     m = re.search(r'(den_\w+|num_\w+|rescale_kernel|__amd\w+|\w+_kernel\w*)', n)
     return (m.group(1) if m else n)[:30]
 idx = [i for i, r in enumerate(rows) if 'num_prep' in r[0]]
+if not idx: idx = [i for i, r in enumerate(rows) if 'zero_words' in r[0]]      # a denominator-only workload
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 i0 = idx[k]
 i1 = idx[k + 1] if k + 1 < len(idx) else len(rows)
