@@ -200,7 +200,7 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   const size_t Hp = roundup64(H);
   return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ +
          2 * align256(4 * (size_t)B * (T + 2)) /* per-frame totals of the two recursions */ +
-         align256(4 * (size_t)B * T) /* frame totals to check */ + align256(4 * (size_t)B) /* final dot products */ + 256;
+         align256(4 * (size_t)B * T) /* frame totals to check */ + align256(8 * (size_t)B) /* final dot products; den_finish_kernel's per-sequence side of the check */ + 256;
 }
 
 namespace {
@@ -243,7 +243,7 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.progress = (int32_t*)((char*)a.seq_progress + align256(8 * (size_t)B));
   a.stream_next = a.progress + 32;
   a.finish_count = a.progress + 40;
-  a.occ_done = a.progress + 41; a.occ_done_target = 0;
+  a.occ_done = a.progress + 24; a.occ_done_target = 0;     // (a cache line of its own: polled while the queue head is drawn from)
   a.loss_out = nullptr; a.loss_num_objf = nullptr; a.loss_scale = 1.f; a.loss_norm_dev = nullptr; a.bad_words = 1;
   a.stream = 0;
   a.tot_a = (float*)((char*)a.progress + 256);

@@ -42,7 +42,7 @@ struct DenArgs {
   // No log, no fp64 and no serial sum sits in a recursion's frame loop.
   float* tot_a;              // [B,T+2]  alpha: tot(t), t = 0 .. L (lazy rows: t < L)
   float* tot_b;              // [B,T+2]  beta:  n(t),   t = L .. 1
-  float* fin_dot;            // [B]      sum_i alpha'(L,i) final(i) in the scale of the last alpha row (NaN: a NaN network output was seen)
+  float* fin_dot;            // [2][B]   [0]: sum_i alpha'(L,i) final(i) in the scale of the last alpha row (NaN: a NaN network output was seen)
   float* gtot;               // [B,T]  G(t) of the frames to check, written by the occupancy kernels
   int check;                 // the occupancy launches of this call record G(t) and den_finish_kernel checks
   int check_all;             // 0: frame 0 only; 1: every frame (verbose level >= 1)
@@ -140,23 +140,31 @@ hipError_t launch_den_finish(const DenArgs& a, hipStream_t st);
 
 // Rings of the streamed occupancy pass by the step count `need` = max(t, L-1-t) that makes a frame computable:
 // kStreamWidth frames wide (= steps between two progress reports of a recursion) up to kStreamFineSpan steps before the end
-// of the longest possible sequence (T), kStreamFineWidth from there on - what is left to evaluate when the recursions end
-// is the last ring of the longest sequences, so those rings are thin.
-constexpr int kStreamWidth = 16, kStreamFineWidth = 4, kStreamFineSpan = 64;
+// of the longest possible sequence (T), kStreamFineWidth from there on, kStreamLastWidth - ONE pair of frames of the two-frame
+// kernel - over the last kStreamLastSpan steps: what is left to evaluate when the recursions end is the last ring of the
+// longest sequences, so those rings are thin (C2: the occupancy launch ends 25 -> 18 us after the recursion).
+constexpr int kStreamWidth = 16, kStreamFineWidth = 4, kStreamFineSpan = 64, kStreamLastWidth = 2, kStreamLastSpan = 8;
 __host__ __device__ inline int stream_fine_begin(int T) { const int f = (T - kStreamFineSpan) / kStreamWidth * kStreamWidth; return f > 0 ? f : 0; }
+__host__ __device__ inline int stream_last_begin(int T) {      // a multiple of kStreamFineWidth, >= stream_fine_begin(T)
+  const int f = stream_fine_begin(T), l = (T - kStreamLastSpan) / kStreamFineWidth * kStreamFineWidth;
+  return l > f ? l : f;
+}
 __host__ __device__ inline int stream_ring_count(int T) {
-  const int f = stream_fine_begin(T);
-  return f / kStreamWidth + (T - f + kStreamFineWidth - 1) / kStreamFineWidth;
+  const int f = stream_fine_begin(T), l = stream_last_begin(T);
+  return f / kStreamWidth + (l - f) / kStreamFineWidth + (T - l + kStreamLastWidth - 1) / kStreamLastWidth;
 }
 // ring r covers need in [lo, hi)
 __host__ __device__ inline void stream_ring(int T, int r, int& lo, int& hi) {
-  const int f = stream_fine_begin(T), nc = f / kStreamWidth;
+  const int f = stream_fine_begin(T), l = stream_last_begin(T), nc = f / kStreamWidth, nf = (l - f) / kStreamFineWidth;
   if (r < nc) { lo = r * kStreamWidth; hi = lo + kStreamWidth; }
-  else { lo = f + (r - nc) * kStreamFineWidth; hi = lo + kStreamFineWidth; }
+  else if (r < nc + nf) { lo = f + (r - nc) * kStreamFineWidth; hi = lo + kStreamFineWidth; }
+  else { lo = l + (r - nc - nf) * kStreamLastWidth; hi = lo + kStreamLastWidth; }
 }
 // a recursion reports after `done` steps if that is a ring boundary
 __host__ __device__ inline bool stream_report_due(int T, int done) {
-  return done < stream_fine_begin(T) ? (done & (kStreamWidth - 1)) == 0 : (done & (kStreamFineWidth - 1)) == 0;
+  if (done < stream_fine_begin(T)) return (done & (kStreamWidth - 1)) == 0;
+  if (done < stream_last_begin(T)) return (done & (kStreamFineWidth - 1)) == 0;
+  return (done & (kStreamLastWidth - 1)) == 0;
 }
 
 // One wave that waits until *progress >= target (set by the recursion workgroups), so that what follows

@@ -86,84 +86,90 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
     }
     return log(m) + (double)ex * 0.69314718055994530942;
   };
-  if (a.occ_done_target) {                                 // the streamed occupancy launch is still running (DenArgs::occ_done)
-    if (tid == 0) {
-      const unsigned long long t0 = wall_clock64();        // 100 MHz
-      while (__hip_atomic_load(a.occ_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.occ_done_target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 2000000000ull) { atomicAdd(a.bad, 1); break; }   // 20 s
-      }
-    }
-    __syncthreads();
-  }
   // (what thread 0 needs after the sums: requested before them)
   const float fin_dot = a.fin_dot[b];
-  const float g0 = a.check && L >= 1 ? __hip_atomic_load(a.gtot + (size_t)b * a.T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1.f;
   const float ta0 = ta[0], tb1 = L >= 1 ? tb[1] : 1.f;
   double sh_total_a = log_of_product(ta, tid, na), sh_total_b = log_of_product(tb, tid + 1, L + 1);
   fin_block_sum2(sh_total_a, sh_total_b, part, tid);
   const double logp = sh_total_a + log((double)fin_dot);
   const float objf = (float)logp;
+  // (frame 0's side of the check, below)   lazy: PA(0) = 0, SB(0) = sum_{tau>=2} log n(tau);   else: log tot(0), sum_{tau>=1}
+  const double pa_sb0 = (a.lazy ? 0.0 : log((double)ta0)) + sh_total_b - (a.lazy && L >= 1 ? log((double)tb1) : 0.0);
+  // Everything above needs the recursions only; frame 0's occupancy total - the other side of the check - comes from the
+  // occupancy launch, which may still be running (DenArgs::occ_done): the sequence's side is left for the last workgroup.
   int bad = 0;
   if (tid == 0) {
-    __hip_atomic_store(a.objf + b, objf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the last workgroup: loss_out)
+    __hip_atomic_store(a.objf + b, objf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read by the last workgroup)
+    __hip_atomic_store(a.fin_dot + a.B + b, (float)(pa_sb0 - logp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!(objf - objf == 0.f)) bad = 1;                    // -inf (the graph cannot end), NaN
   }
-  if (a.check) {
-    // frame t: PA(t) = log-scale of its alpha row, SB(t) = log-scale of the beta row it reads
+  if (a.check && a.check_all) {
+    // every frame (verbose level >= 1; never with an overlapped schedule): thread `tid` walks frames tid*per .. with running
+    // sums started from its chunk's prefix
+    //   frame t: PA(t) = log-scale of its alpha row, SB(t) = log-scale of the beta row it reads
     //   lazy: PA(t) = sum_{tau<t} log tot(tau),  SB(t) = sum_{tau>=t+2} log n(tau)
     //   else: PA(t) = sum_{tau<=t},              SB(t) = sum_{tau>=t+1}
     const float* g = a.gtot + (size_t)b * a.T;
-    if (!a.check_all) {
-      if (tid == 0) {
-        const double pa = a.lazy ? 0.0 : log((double)ta0);
-        const double sbt = sh_total_b - (a.lazy && L >= 1 ? log((double)tb1) : 0.0);   // lazy: tau >= 2; else tau >= 1
-        const double est = log((double)(L >= 1 ? g0 : g[0])) + pa + sbt;
-        if (!(fabs(est - logp) <= 0.0487901642)) bad = 1;  // log(1.05); NaN counts
-      }
-    } else {
-      // every frame: thread `tid` walks frames tid*per .. with running sums started from its chunk's prefix
-      const int per = (L + kFinNT - 1) / kFinNT;
-      const int t0 = tid * per, t1 = min(t0 + per, L);
-      double ca = 0.0, cb = 0.0;                            // sum_{tau<t0} log tot(tau), sum_{tau<=t0} log n(tau) (tau >= 1)
-      for (int t = 0; t < t0; t++) ca += log((double)ta[t]);
-      for (int t = 1; t <= t0 && t <= L; t++) cb += log((double)tb[t]);
-      for (int t = t0; t < t1; t++) {
-        const double lt = log((double)ta[t]);
-        // cb = sum_{1<=tau<=t} log n(tau)
-        const double pa = a.lazy ? ca : ca + lt;
-        const double upto = a.lazy ? cb + (t + 1 <= L ? log((double)tb[t + 1]) : 0.0) : cb;   // sum_{tau<=t+1} / sum_{tau<=t}
-        const double est = log((double)g[t]) + pa + (sh_total_b - upto);
-        if (!(fabs(est - logp) <= 0.0487901642)) bad = 1;
-        ca += lt;
-        if (t + 1 <= L) cb += log((double)tb[t + 1]);
-      }
+    const int per = (L + kFinNT - 1) / kFinNT;
+    const int t0 = tid * per, t1 = min(t0 + per, L);
+    double ca = 0.0, cb = 0.0;                            // sum_{tau<t0} log tot(tau), sum_{tau<=t0} log n(tau) (tau >= 1)
+    for (int t = 0; t < t0; t++) ca += log((double)ta[t]);
+    for (int t = 1; t <= t0 && t <= L; t++) cb += log((double)tb[t]);
+    for (int t = t0; t < t1; t++) {
+      const double lt = log((double)ta[t]);
+      // cb = sum_{1<=tau<=t} log n(tau)
+      const double pa = a.lazy ? ca : ca + lt;
+      const double upto = a.lazy ? cb + (t + 1 <= L ? log((double)tb[t + 1]) : 0.0) : cb;   // sum_{tau<=t+1} / sum_{tau<=t}
+      const double est = log((double)g[t]) + pa + (sh_total_b - upto);
+      if (!(fabs(est - logp) <= 0.0487901642)) bad = 1;   // log(1.05); NaN counts
+      ca += lt;
+      if (t + 1 <= L) cb += log((double)tb[t + 1]);
     }
   }
   if (bad) atomicAdd(a.bad, 1);
-  if (a.loss_out == nullptr) return;
-  // ---- step totals by the workgroup that finishes last (DenArgs::loss_out).  Every workgroup publishes its sequence's
-  // objective and its `bad` increment with the release half of the counter increment; the last one acquires them all.
+  // ---- the workgroup that finishes last: the frame-0 check of every sequence and the step totals (DenArgs::loss_out).  Every
+  // workgroup publishes its sequence's values and its `bad` increment with the release half of the counter increment.
   __shared__ int s_last;
   __syncthreads();                                           // (tid 0 wrote objf[b] and counted into bad above)
   if (tid == 0)
     s_last = __hip_atomic_fetch_add(a.finish_count, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   __syncthreads();
   if (!s_last) return;
-  double acc = 0.0, frames = 0.0;
+  if (a.occ_done_target) {                                   // ONE thread of the call waits for the occupancy launch
+    if (tid == 0) {
+      const unsigned long long t0 = wall_clock64();          // 100 MHz
+      while (__hip_atomic_load(a.occ_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.occ_done_target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 2000000000ull) { atomicAdd(a.bad, 1); break; }   // 20 s
+      }
+    }
+    __syncthreads();
+  }
+  double acc = 0.0, frames = 0.0, nfail = 0.0, unused = 0.0;
   for (int i = tid; i < a.B; i += kFinNT) {
-    acc += (double)__hip_atomic_load(a.objf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float oi = __hip_atomic_load(a.objf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.check && !a.check_all) {
+      // log G(0) + PA(0) + SB(0) = log P within log(1.05) (NaN counts; a sequence whose objective is not finite is counted already)
+      const float g0 = __hip_atomic_load(a.gtot + (size_t)i * a.T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float di = __hip_atomic_load(a.fin_dot + a.B + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (oi - oi == 0.f && !(fabs(log((double)g0) + (double)di) <= 0.0487901642)) nfail += 1.0;
+    }
+    acc += (double)oi;
     if (a.loss_num_objf) acc -= (double)a.loss_num_objf[i];
     frames += (double)seq_len(a.lengths, i, a.T);
   }
   fin_block_sum2(acc, frames, part2, tid);
-  const double total = acc;
+  __syncthreads();
+  fin_block_sum2(nfail, unused, part2, tid);
   if (tid == 0) {
-    double t = total * (double)a.loss_scale;                 // -(num - den) [* 1/frames], pychain/loss.py:100-104, rounded once
-    if (a.loss_norm_dev) t /= (double)*a.loss_norm_dev;
-    int nbad = 0;
-    for (int i = 0; i < a.bad_words; i++) nbad += __hip_atomic_load(a.bad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.loss_out[0] = (float)t; a.loss_out[1] = (float)frames; a.loss_out[2] = (float)nbad; a.loss_out[3] = (float)total;
+    if (nfail > 0.0) atomicAdd(a.bad, (int)nfail);
+    if (a.loss_out) {
+      double t = acc * (double)a.loss_scale;                 // -(num - den) [* 1/frames], pychain/loss.py:100-104, rounded once
+      if (a.loss_norm_dev) t /= (double)*a.loss_norm_dev;
+      int nbad = 0;
+      for (int i = 0; i < a.bad_words; i++) nbad += __hip_atomic_load(a.bad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.loss_out[0] = (float)t; a.loss_out[1] = (float)frames; a.loss_out[2] = (float)nbad; a.loss_out[3] = (float)acc;
+    }
   }
 }
 

@@ -100,11 +100,14 @@ typedef __attribute__((address_space(3))) void lz_lds_void;
 #ifndef PYCHAIN_GATHER_ORDER
 #define PYCHAIN_GATHER_ORDER 1                         /* split arcs, a pair of rows: 1 = both states, then both rows (C3 recursion -0.7 %); 0 = state, row, state, row */
 #endif
-#ifndef PYCHAIN_BATCH_PROW
-#define PYCHAIN_BATCH_PROW 1                           /* 0: the previous row's values are read back and stored group by group (ablation) */
-#endif
 #ifndef PYCHAIN_SUMS_AT_GROUP_END
 #define PYCHAIN_SUMS_AT_GROUP_END 1                    /* a wave adds up its rows' new values where it forms them (two live registers); 0: re-read from LDS after the arc phase - C3 recursion 3.03 -> 2.96 ms, C4 4.71 -> 4.54, C2 0.176 -> 0.167: profiles/r04_j_time_matrix*.txt */
+#endif
+#ifndef PYCHAIN_LK_REGS
+#define PYCHAIN_LK_REGS 0                              /* 1: beta keeps the leaky probabilities of its lane's rows in four registers instead of reading them from LDS at the group ends */
+#endif
+#ifndef PYCHAIN_EXP_NO_ROWSTORE
+#define PYCHAIN_EXP_NO_ROWSTORE 0                      /* timing experiments (WRONG RESULTS): 1 = the rows do not leave for HBM, 2 = they do, but are not re-read from LDS first */
 #endif
 #ifndef PYCHAIN_LATE_FINISH
 #define PYCHAIN_LATE_FINISH 1                          /* 0: the in-place clamp / exp of an LDS-direct row after the arc phase (ablation) */
@@ -231,6 +234,9 @@ template <typename MAP> struct LazyArcsOf<24, MAP> { typedef LazyArcsSplit<24, M
 struct LazyWave {
   float inv, c;                 // 1 / total of the previous frame; beta: coef * leaky-weighted sum of the previous frame
   float sprev;                  // the scalar that completes the row in the gather buffer: alpha tot(t), beta c(t)
+#if PYCHAIN_LK_REGS
+  float lk[4];                  // beta: leaky probability of the lane's row in each of the wave's groups
+#endif
 };
 
 // A group end inside the arc loop does the least it can: the row's new value into the state buffer the
@@ -303,7 +309,13 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
           const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
           if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
             s0 += val;
-            if constexpr (!FWD) s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+            if constexpr (!FWD) {
+#if PYCHAIN_LK_REGS
+              s1 = __builtin_fmaf(val, g == 0 ? w.lk[0] : (g == 1 ? w.lk[1] : (g == 2 ? w.lk[2] : w.lk[3])), s1);
+#else
+              s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+#endif
+            }
           }
           nacc = lz_v2f{0.f, 0.f};
         }
@@ -365,7 +377,13 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
           const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
           if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
             s0 += val;
-            if constexpr (!FWD) s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+            if constexpr (!FWD) {
+#if PYCHAIN_LK_REGS
+              s1 = __builtin_fmaf(val, g == 0 ? w.lk[0] : (g == 1 ? w.lk[1] : (g == 2 ? w.lk[2] : w.lk[3])), s1);
+#else
+              s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+#endif
+            }
           }
           nacc = lz_v2f{0.f, 0.f};
         }
@@ -463,6 +481,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();                                                 // red is rewritten by the first frame (its first 4 NW entries per sum)
   }
 
+#if PYCHAIN_LK_REGS
+  if constexpr (!fwd) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) w.lk[g] = g < MG && g < groups.ngroups ? *reinterpret_cast<const float*>(smem_raw + MAP::kLk + 4 * (gbase[g] + lane)) : 0.f;
+  }
+#endif
   float last_tot = 1.f;
   int next_sig = 0;
   int next_bound = a.sig_n > 0 ? a.seg_bound[0] : 0x7fffffff;
@@ -481,19 +505,21 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   unsigned long long lzph[6] = {0, 0, 0, 0, 0, 0}, lzt = 0;
 #define LZ_PH0() lzt = PH_T()
 #define LZ_PH(i) do { const unsigned long long t_ = PH_T(); lzph[i] += t_ - lzt; lzt = t_; } while (0)
+#define LZ_VMWAIT() do { const unsigned long long t_ = PH_T(); PYCHAIN_WAIT_VM0(); lzph[5] += PH_T() - t_; } while (0)   /* (inside the arc phase) */
 #else
+#define LZ_VMWAIT() (void)0
 #define LZ_PH0() (void)0
 #define LZ_PH(i) (void)0
 #endif
   // Totals of frame step JP (partial sums in red[PARP]): the normaliser of the next frame, the scalar that completes the
   // row JP produced, the total den_finish_kernel reads.  tstore = the row step JP produced (alpha: L is written, never read).
-#define PYCHAIN_LZ_TOTALS(PARP, JP, FWDC, LQ, TQ)                                                           \
+#define PYCHAIN_LZ_TOTALS(R0, R1, JP, FWDC, TQ)                                                              \
   do {                                                                                                      \
-    const float tot = wave_sum(red[(PARP) * 128 + (LQ)]);                                                   \
+    const float tot = wave_sum(R0);                                                                         \
     w.inv = __builtin_amdgcn_rcpf(tot);                                                                     \
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad |= 1;                                                           \
     if (FWDC) w.sprev = tot;                                                                                \
-    else { w.c = coef * wave_sum(red[(PARP) * 128 + 64 + (LQ)]); w.sprev = w.c; }                           \
+    else { w.c = coef * wave_sum(R1); w.sprev = w.c; }                                                      \
     if ((TQ) == 0) totv[(FWDC) ? (JP) + 1 : L - 1 - (JP)] = tot;                                            \
     last_tot = tot;                                                                                         \
   } while (0)
@@ -515,34 +541,36 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
       if (have_next) lz_dma_row<NW, kDmaCh>(xbuf, tn, D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1);            \
     } else if (have_next) xq.load_row(xbuf, tn, D, tq);      /* in flight during the arc work */             \
+    /* What the hook behind the first gathers needs from LDS - the previous step's partial sums and the row it produced (it */ \
+    /* sits in the buffer this step gathers from) - is requested HERE, ahead of the gathers: behind them the reads queue up */ \
+    /* after sixteen waves' first two chunks, and a wave that waits for them issues nothing meanwhile (C3 recursion -4 %: */ \
+    /* profiles/r04_n_*; registers: live exactly as long as in the hook before) */                          \
+    float pre0 = 0.f, pre1 = 0.f;                                                                           \
+    if (j > 0) { pre0 = red[((PAR) ^ 1) * 128 + lq]; if (!(FWDC)) pre1 = red[((PAR) ^ 1) * 128 + 64 + lq]; } \
+    constexpr bool kPreRows = MAP::kMaxPdfs <= 4096;         /* (the map of C4 has no registers to spare: the rows are read in the hook) */ \
+    lz_v2f prow[MG];                                                                                        \
+    if constexpr (kPreRows) {                                                                               \
+      _Pragma("unroll") for (int g = 0; g < MG; g++) prow[g] = lz_ld2(UCUR + gbase[g] * 8 + lq * 8);   /* (gbase = 0 beyond ngroups) */ \
+    }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
     float s0 = 0.f, s1 = 0.f;                                                                               \
     lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, s0, s1, [&]() {                        \
-      if (j > 0) PYCHAIN_LZ_TOTALS((PAR) ^ 1, j - 1, (FWDC), lq, tq);   /* (step 0: the start vector's, above) */ \
-      /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) - it sits in the buffer this */ \
-      /* frame gathers from - is completed and leaves for HBM, also behind the first gathers */              \
+      if (j > 0) PYCHAIN_LZ_TOTALS(pre0, pre1, j - 1, (FWDC), tq);   /* (step 0: the start vector's, above) */ \
+      /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) is completed and leaves for HBM */ \
       const int trow = (FWDC) ? j : L - j;                                                                  \
       const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
-      const int lane4 = lq * 4, lane8 = lq * 8;              /* one VGPR of addresses, the group in the SGPR offset */ \
-      if constexpr (PYCHAIN_BATCH_PROW && MAP::kDma && MAP::kMaxPdfs <= 4096 && R == 32) {  /* all reads, ONE wait, then the */ \
-        /* stores (gbase = 0 beyond ngroups) instead of a round trip per group: C3 -0.6 %; the maps with less room would spill */ \
-        lz_v2f prow[MG];                                                                                    \
-        _Pragma("unroll") for (int g = 0; g < MG; g++) prow[g] = lz_ld2(UCUR + gbase[g] * 8 + lane8);       \
-        _Pragma("unroll") for (int g = 0; g < MG; g++)                                                      \
-          if (g < groups.ngroups)                                                                           \
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow[g].y, prow[g].x)), sbuf, lane4, \
-                                                  row_off + gbase[g] * 4, kStoreDeviceScope);               \
-      } else {                                                                                              \
+      const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
       _Pragma("unroll") for (int g = 0; g < MG; g++)                                                        \
-        if (g < groups.ngroups) {                                                                           \
-          const lz_v2f prow = lz_ld2(UCUR + gbase[g] * 8 + lane8);                                          \
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, prow.y, prow.x)), sbuf, lane4, \
+        if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1) {                                           \
+          const lz_v2f pr = kPreRows ? prow[g] : lz_ld2(UCUR + gbase[g] * 8 + lq * 8);                      \
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, pr.y, pr.x)), sbuf, lane4, \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
         }                                                                                                   \
-      }                                                                                                     \
     }, [&]() {                                                                                              \
       /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
       /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
       if constexpr (MAP::kDma && PYCHAIN_LATE_FINISH) {                                                     \
+        LZ_VMWAIT();                                                                                        \
         if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
       }                                                                                                     \
     });                                                                                                     \
@@ -603,7 +631,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     // step j stores the row of the frame before it (alpha row j, beta row L - j): after steps 0 .. jj + 1, jj + 2 rows
     if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
   }
-  if (nsteps > 0) PYCHAIN_LZ_TOTALS((nsteps - 1) & 1, nsteps - 1, fwd, lane, tid);   // the last step's
+  if (nsteps > 0) {                                                                  // the last step's
+    const float r0 = red[((nsteps - 1) & 1) * 128 + lane], r1 = fwd ? 0.f : red[((nsteps - 1) & 1) * 128 + 64 + lane];
+    PYCHAIN_LZ_TOTALS(r0, r1, nsteps - 1, fwd, tid);
+  }
   if constexpr (!fwd) {
     // the last beta row (row L - nsteps: row 1, or the start row if the sequence has one frame) never saw a next frame
     const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
@@ -624,11 +655,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 #ifdef PYCHAIN_PROFILE_PHASES
   if (lane == 0 && b == 0) {
     const unsigned long long n = (unsigned long long)max(1, nsteps);
-    printf("lazy dir %d wave %2d rows %2d steps %d cycles/step: arcs %llu rereads+x %llu rowstore+sums %llu barrier %llu totals %llu\n",
-           (int)fwd, wave, groups.nslots, nsteps, lzph[0] / n, lzph[1] / n, lzph[2] / n, lzph[3] / n, lzph[4] / n);
+    printf("lazy dir %d wave %2d rows %2d steps %d cycles/step: arcs %llu rereads+x %llu rowstore+sums %llu barrier %llu totals %llu vmwait-in-arcs %llu\n",
+           (int)fwd, wave, groups.nslots, nsteps, lzph[0] / n, lzph[1] / n, lzph[2] / n, lzph[3] / n, lzph[4] / n, lzph[5] / n);
   }
 #endif
 #undef LZ_PH
+#undef LZ_VMWAIT
 #undef LZ_PH0
 
   if constexpr (fwd) {
