@@ -103,8 +103,8 @@ typedef __attribute__((address_space(3))) void lz_lds_void;
 #ifndef PYCHAIN_SUMS_AT_GROUP_END
 #define PYCHAIN_SUMS_AT_GROUP_END 1                    /* a wave adds up its rows' new values where it forms them (two live registers); 0: re-read from LDS after the arc phase - C3 recursion 3.03 -> 2.96 ms, C4 4.71 -> 4.54, C2 0.176 -> 0.167: profiles/r04_j_time_matrix*.txt */
 #endif
-#ifndef PYCHAIN_LK_REGS
-#define PYCHAIN_LK_REGS 0                              /* 1: beta keeps the leaky probabilities of its lane's rows in four registers instead of reading them from LDS at the group ends */
+#ifndef PYCHAIN_LK_NEXT
+#define PYCHAIN_LK_NEXT 1                              /* beta requests the leaky probability of a group end's row one group end ahead (one live register; maps with room for it: C3 recursion -0.5 .. 1 %, the map of C4 +3 %: r04_q_*) */
 #endif
 #ifndef PYCHAIN_EXP_NO_ROWSTORE
 #define PYCHAIN_EXP_NO_ROWSTORE 0                      /* timing experiments (WRONG RESULTS): 1 = the rows do not leave for HBM, 2 = they do, but are not re-read from LDS first */
@@ -138,6 +138,9 @@ template <int NW, int NCH>
 __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_t xbase, int is_exp) {
   bool nan = false;
   PYCHAIN_WAIT_VM0();                                   // this wave's loads have landed
+#ifdef PYCHAIN_EXP_NO_FINISH                            /* timing experiment (WRONG RESULTS): the rows are gathered as they arrived */
+  return false;
+#endif
 #pragma unroll
   for (int c = 0; c < NCH; c++) {
     const int ch = wave + c * NW;
@@ -234,9 +237,7 @@ template <typename MAP> struct LazyArcsOf<24, MAP> { typedef LazyArcsSplit<24, M
 struct LazyWave {
   float inv, c;                 // 1 / total of the previous frame; beta: coef * leaky-weighted sum of the previous frame
   float sprev;                  // the scalar that completes the row in the gather buffer: alpha tot(t), beta c(t)
-#if PYCHAIN_LK_REGS
-  float lk[4];                  // beta: leaky probability of the lane's row in each of the wave's groups
-#endif
+  float lk_next;                // beta (PYCHAIN_LK_NEXT): leaky probability of the lane's row in the group whose end comes next
 };
 
 // A group end inside the arc loop does the least it can: the row's new value into the state buffer the
@@ -309,12 +310,14 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
           const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
           if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
             s0 += val;
+            // (beta's leaky probabilities in four registers instead of this LDS read: two spills, recursion +6 %: r04_p_*)
             if constexpr (!FWD) {
-#if PYCHAIN_LK_REGS
-              s1 = __builtin_fmaf(val, g == 0 ? w.lk[0] : (g == 1 ? w.lk[1] : (g == 2 ? w.lk[2] : w.lk[3])), s1);
-#else
-              s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
-#endif
+              if constexpr (PYCHAIN_LK_NEXT && MAP::kMaxPdfs <= 4096) {
+                s1 = __builtin_fmaf(val, w.lk_next, s1);
+                w.lk_next = lds_abs(MAP::kLk + (uint32_t)(__builtin_amdgcn_readlane(gr.base, (g + 1) & 63) + lane) * 4u);
+              } else {
+                s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+              }
             }
           }
           nacc = lz_v2f{0.f, 0.f};
@@ -377,12 +380,14 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
           const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
           if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
             s0 += val;
+            // (beta's leaky probabilities in four registers instead of this LDS read: two spills, recursion +6 %: r04_p_*)
             if constexpr (!FWD) {
-#if PYCHAIN_LK_REGS
-              s1 = __builtin_fmaf(val, g == 0 ? w.lk[0] : (g == 1 ? w.lk[1] : (g == 2 ? w.lk[2] : w.lk[3])), s1);
-#else
-              s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
-#endif
+              if constexpr (PYCHAIN_LK_NEXT && MAP::kMaxPdfs <= 4096) {
+                s1 = __builtin_fmaf(val, w.lk_next, s1);
+                w.lk_next = lds_abs(MAP::kLk + (uint32_t)(__builtin_amdgcn_readlane(gr.base, (g + 1) & 63) + lane) * 4u);
+              } else {
+                s1 = __builtin_fmaf(val, lds_abs(MAP::kLk + pos * 4u), s1);
+              }
             }
           }
           nacc = lz_v2f{0.f, 0.f};
@@ -481,12 +486,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();                                                 // red is rewritten by the first frame (its first 4 NW entries per sum)
   }
 
-#if PYCHAIN_LK_REGS
-  if constexpr (!fwd) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) w.lk[g] = g < MG && g < groups.ngroups ? *reinterpret_cast<const float*>(smem_raw + MAP::kLk + 4 * (gbase[g] + lane)) : 0.f;
-  }
-#endif
   float last_tot = 1.f;
   int next_sig = 0;
   int next_bound = a.sig_n > 0 ? a.seg_bound[0] : 0x7fffffff;
@@ -547,6 +546,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* profiles/r04_n_*; registers: live exactly as long as in the hook before) */                          \
     float pre0 = 0.f, pre1 = 0.f;                                                                           \
     if (j > 0) { pre0 = red[((PAR) ^ 1) * 128 + lq]; if (!(FWDC)) pre1 = red[((PAR) ^ 1) * 128 + 64 + lq]; } \
+    if constexpr (PYCHAIN_LK_NEXT && MAP::kMaxPdfs <= 4096 && !(FWDC)) w.lk_next = lds_abs(MAP::kLk + gbase[0] * 4 + lq * 4);          \
     constexpr bool kPreRows = MAP::kMaxPdfs <= 4096;         /* (the map of C4 has no registers to spare: the rows are read in the hook) */ \
     lz_v2f prow[MG];                                                                                        \
     if constexpr (kPreRows) {                                                                               \
