@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 12
+#define PYCHAIN_HIP_ABI_VERSION 13
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -93,7 +93,9 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "verbose"        base.h:34-42: >= 1 checks the reference's invariant on every frame instead of frame 0
  *   "den_phase_mask" bit 0 recursion launch, bit 1 occupancy launch (measurement aid)
  *   "den_lazy"       "0": the two-barrier recursion (den_recursion_kernel) instead of the lazy-normalisation one
- *   "den_dma"        "0": nnet-output rows of the lazy recursion through registers instead of LDS-direct loads
+ *   "den_dma"        "0": nnet-output rows of the lazy recursion through registers instead of LDS-direct loads; "2": LDS-direct,
+ *                    and the recursions clamp / exp every row themselves instead of gathering from rows den_exp_rows_kernel
+ *                    exp'd ahead of them on the side stream (bit-identical)
  *   "den_segments"   n >= 1: the occupancy pass in n gated time segments (1 = after the recursions, no overlap) instead of
  *                    the streamed persistent launch
  *   "den_pair"       "1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of
@@ -188,9 +190,15 @@ int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t 
  *   launch-bound scalar kernels behind it (the reference: `tot_log_prob.sum()`, chain-computation.cc:229):
  *   totals[0] = totals[3] = sum_b objf_per_seq[b] (fp64 accumulation, rounded once), totals[1] = sum_b len_b,
  *   totals[2] = bad_count as a float.
+ * workspace: the stored alpha' / beta rows (4 B T roundup64(num_states) bytes each), per-frame totals, counters, and - in a
+ *   call of the denominator alone - a [B,T,D] buffer for the rows exp'd ahead of the recursions (den_exp_rows_kernel: C4
+ *   4.80 -> 4.57 ms): pychain_hip_den_workspace_bytes; pychain_hip_den_workspace_min_bytes is the size without it.
  */
 #define PYCHAIN_HIP_TOTALS 4
 size_t pychain_hip_den_workspace_bytes(int B, int T, int num_states, int num_pdfs);
+/* ... without the [B,T,D] buffer: a workspace of at least this size is accepted everywhere; the rows are then never exp'd
+ * ahead (the fused loss never does: its callers pass this size). */
+size_t pychain_hip_den_workspace_min_bytes(int B, int T, int num_states, int num_pdfs);
 int pychain_hip_den_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows,
     int num_states, int num_pdfs,

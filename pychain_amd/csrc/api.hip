@@ -194,13 +194,17 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   return PYCHAIN_HIP_OK;
 }
 
-extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
-  (void)D;
-  if (B <= 0 || T <= 0 || H <= 0) return 0;
+extern "C" size_t pychain_hip_den_workspace_min_bytes(int B, int T, int H, int D) {
+  if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
   const size_t Hp = roundup64(H);
-  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) + align256(8 * (size_t)B) + 256 /* progress counters */ +
+  return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) +
+         align256(8 * (size_t)B) + 256 + align256(36 * (size_t)B) /* progress counters (zeroed by every call) */ +
          2 * align256(4 * (size_t)B * (T + 2)) /* per-frame totals of the two recursions */ +
          align256(4 * (size_t)B * T) /* frame totals to check */ + align256(8 * (size_t)B) /* final dot products; den_finish_kernel's per-sequence side of the check */ + 256;
+}
+extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
+  const size_t base = pychain_hip_den_workspace_min_bytes(B, T, H, D);
+  return base ? base + align256(4 * (size_t)B * T * D) /* rows exp'd ahead of the recursions (DenArgs::ex) */ : 0;
 }
 
 namespace {
@@ -224,9 +228,9 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
     return fail(PYCHAIN_HIP_EINVAL, "%s: plan stride must be a non-negative multiple of 16", who);
   if (((uintptr_t)plans_dev | (uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)workspace) & 15)
     return fail(PYCHAIN_HIP_EINVAL, "%s: plan, nnet_output, grad and workspace must be 16-byte aligned", who);
-  if (workspace_bytes < pychain_hip_den_workspace_bytes(B, T, H, D))
+  if (workspace_bytes < pychain_hip_den_workspace_min_bytes(B, T, H, D))
     return fail(PYCHAIN_HIP_EWORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
-                pychain_hip_den_workspace_bytes(B, T, H, D));
+                pychain_hip_den_workspace_min_bytes(B, T, H, D));
   memset(&a, 0, sizeof(a));
   a.plans = (const char*)plans_dev; a.plan_stride = plan_stride_bytes;
   a.x = nnet_output; a.lengths = seq_lengths; a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
@@ -246,10 +250,16 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.occ_done = a.progress + 24; a.occ_done_target = 0;     // (a cache line of its own: polled while the queue head is drawn from)
   a.loss_out = nullptr; a.loss_num_objf = nullptr; a.loss_scale = 1.f; a.loss_norm_dev = nullptr; a.bad_words = 1;
   a.stream = 0;
-  a.tot_a = (float*)((char*)a.progress + 256);
+  a.xprog = (int32_t*)((char*)a.progress + 256);           // [2][B][kExMaxQ], then xnan [B]
+  a.xnan = a.xprog + 2 * (size_t)B * kExMaxQ;
+  a.ex_nr = 0; a.ex_q = 0;
+  a.use_ex = 0;
+  a.tot_a = (float*)((char*)a.xprog + align256(36 * (size_t)B));
   a.tot_b = (float*)((char*)a.tot_a + align256(4 * (size_t)B * (T + 2)));
   a.gtot = (float*)((char*)a.tot_b + align256(4 * (size_t)B * (T + 2)));
   a.fin_dot = (float*)((char*)a.gtot + align256(4 * (size_t)B * T));
+  // (behind everything else, and only in a workspace of the full size: DenArgs::ex)
+  a.ex = workspace_bytes >= pychain_hip_den_workspace_bytes(B, T, H, D) ? (float*)((char*)a.fin_dot + align256(8 * (size_t)B) + 256) : nullptr;
   a.lazy = 0;
   a.check = 0; a.check_all = a.knobs.verbose >= 1 ? 1 : 0;
   a.sig_n = 0;
@@ -279,10 +289,11 @@ SideStream* side_streams_for(hipStream_t caller) {
   SideStream& s = table[std::make_pair(dev, caller)];
   if (!s.ready) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    // the occupancy launches only fill idle CUs: lowest priority
+    // stream2: den_exp_rows_kernel, whose rows the recursions wait for (dispatched first: highest priority), then the gate(s)
+    // and the occupancy launches that overlap the recursions
     int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    if (hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+    if (hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join2, hipEventDisableTiming | hipEventReleaseToDevice) != hipSuccess) return nullptr;
@@ -381,7 +392,7 @@ hipError_t launch_zero_words(int32_t* p0, int n0, int32_t* p1, int n1, hipStream
   hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, p0, n0, p1, n1);
   return hipGetLastError();
 }
-int den_counter_words(const DenArgs& a) { return (int)((align256(8 * (size_t)a.B) + 256) / 4); }
+int den_counter_words(const DenArgs& a) { return (int)((align256(8 * (size_t)a.B) + 256 + align256(36 * (size_t)a.B)) / 4); }
 
 // recursion + occupancy launches of one denominator call; `occupancy` = false: recursion only
 // `gamma_wait`: event every occupancy launch has to wait for (the numerator rows it folds in), or null
@@ -422,6 +433,32 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   // the invariant check (DenArgs::tot_a) needs the recursions and the occupancy launches of ONE call
   a.check = (occupancy && user_mask == 3) ? 1 : 0;
   hipError_t e = hipSuccess;
+  // Rows exp'd ahead of the lazy recursions by a launch of its own on the side stream (DenArgs::ex), whichever schedule
+  // follows (option den_dma = 2: the recursions clamp / exp their rows themselves, as they do for short sequences, rows
+  // that are not a multiple of four pdfs and callers that hand in exp'd rows) - in a call of the denominator alone and a
+  // workspace that holds the buffer.  NOT in the fused loss (`zeroed`): there the CUs the recursions leave idle are booked - the
+  // numerator until T/2, the occupancy launch from there to the end - and the launch's registers and HBM traffic held the
+  // numerator back by 1 ms (C3: 3.02 -> 3.31 ms per step with it, although the recursion itself ran 4 % faster:
+  // profiles/r04_u_C3_step_timeline_rows_exp_ahead_in_the_fused_step.txt).
+  const bool exp_ahead = a.ex != nullptr && zeroed == nullptr &&
+                         a.lazy && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && !a.input_is_exp &&
+                         a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && (user_mask & 1) != 0;
+  SideStream* const side_pre = exp_ahead ? side_streams_for(st) : nullptr;
+  if (exp_ahead && !side_pre) { *why = "cannot create the side streams"; return hipErrorInvalidValue; }
+  bool forked = false;                                      // stream2 waits for the zeroed counters (and the caller's x)
+  auto fork_stream2 = [&](SideStream* side) -> hipError_t {
+    if (forked) return hipSuccess;
+    forked = true;
+    hipError_t ef = zeroed ? hipSuccess : hipEventRecord(side->seg[0], st);
+    if (ef == hipSuccess) ef = hipStreamWaitEvent(side->stream2, zeroed ? zeroed : side->seg[0], 0);
+    return ef;
+  };
+  if (exp_ahead) {
+    e = fork_stream2(side_pre);
+    den_exp_rows_shape(a, device_cu_count(), &a.ex_nr, &a.ex_q);
+    if (e == hipSuccess) e = launch_den_exp_rows(a, side_pre->stream2);
+    a.use_ex = 1;
+  }
   if (nseg <= 1) {
     const int mask = occupancy ? user_mask : (user_mask & 1);
     if ((gamma_wait || corrupt) && (mask & 2)) {
@@ -437,6 +474,11 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
       e = launch_den(a, gmax, resident_slot_rows, st, why);
     }
     a.phase_mask = user_mask;
+    if (exp_ahead) {                                        // (long done: the recursions have read every row of it)
+      a.use_ex = 0;
+      if (e == hipSuccess) e = hipEventRecord(side_pre->join2, side_pre->stream2);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st, side_pre->join2, 0);
+    }
     return e;
   }
   SideStream* side = side_streams_for(st);
@@ -460,8 +502,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     // launch that ends last is followed in queue order - was measured: the wake-up of a queue that waits for another queue's
     // event costs 11-19 us wherever it sits, and there the recursion paid it at the head of the step:
     // profiles/r04_i_C3_step_timeline_recursion_on_side_stream.txt.)
-    if (e == hipSuccess && !zeroed) e = hipEventRecord(side->seg[0], st);      // (the occupancy launch must see the zeroed counters)
-    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, zeroed ? zeroed : side->seg[0], 0);
+    if (e == hipSuccess) e = fork_stream2(side);              // (the occupancy launch must see the zeroed counters)
     a.phase_mask = 1;
     if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
     if (e == hipSuccess) e = launch_den_gate(a.progress, den_recursion_blocks(a), a.bad, side->stream2);
@@ -470,7 +511,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     a.occ_done_target = may_finish ? a.stream_blocks : 0;
     if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, side->stream2, why);
     if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
-    a.phase_mask = user_mask; a.sig_n = 0; a.stream = 0;
+    a.phase_mask = user_mask; a.sig_n = 0; a.stream = 0; a.use_ex = 0;
     if (e == hipSuccess && may_finish) { e = launch_den_finish(a, st); *finish_early = true; }   // (DenArgs::occ_done)
     a.occ_done_target = 0;
     if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
@@ -482,8 +523,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   // of them.  (One recursion launch per segment with stream events in between - the first form of this schedule - measured
   // 2 % slower and is gone: profiles/r01_*.)
   a.sig_n = nseg - 1;
-  if (e == hipSuccess && !zeroed) e = hipEventRecord(side->seg[0], st);      // the gates must see the zeroed counters
-  if (e == hipSuccess) e = hipStreamWaitEvent(side->stream2, zeroed ? zeroed : side->seg[0], 0);
+  if (e == hipSuccess) e = fork_stream2(side);                // the gates must see the zeroed counters
   a.phase_mask = 1;
   if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
   a.phase_mask = 2; a.gam_nseg = nseg;
@@ -499,7 +539,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
   if (e == hipSuccess) e = hipEventRecord(side->join2, side->stream2);
   if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join2, 0);
-  a.phase_mask = user_mask; a.gam_nseg = 0; a.sig_n = 0;
+  a.phase_mask = user_mask; a.gam_nseg = 0; a.sig_n = 0; a.use_ex = 0;
   return e;
 }
 // ... and, behind all of them on the caller's stream, den_finish_kernel: objf from the per-frame totals and

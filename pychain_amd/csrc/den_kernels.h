@@ -94,6 +94,17 @@ struct DenArgs {
   // (The caller's stream still waits for the event behind it: what comes next needs the gradient.)  0: no waiting.
   int32_t* occ_done;             // [1], zeroed with the progress counters
   int occ_done_target;
+  // Rows exp'd ahead of the recursions (den_exp_rows_kernel, run_den_launches): ex[b,t,:] = exp(clamp(x[b,t,:])), written from
+  // both ends of every sequence towards its middle (end 0: rows 0 .., end 1: rows L-1 .. downwards) in rounds of ex_nr rows by
+  // ex_q workgroups per (sequence, end) on the side stream while the recursions run; xprog[(end * B + b) * kExMaxQ + q] = rounds
+  // workgroup q (which takes the rounds q, q + ex_q, ...) has complete and visible device-wide; xnan[b] != 0: a NaN was seen.  The lazy recursions then bring their rows in ready to gather - no pass over the row in LDS, which
+  // costs a frame of C3 216 of its ~3500 LDS-busy cycles and a frame of C4 twice that (recursion -4 % / -12 %).  Null: the
+  // recursions clamp / exp their rows themselves.
+  float* ex;                     // [B,T,D] (workspace)
+  int32_t* xprog;                // [2][B][kExMaxQ], zeroed with the progress counters
+  int ex_nr, ex_q;               // rows per round, workgroups per end
+  int32_t* xnan;                 // [B], zeroed with the progress counters
+  int use_ex;                    // this launch reads ex / xprog / xnan
   CallKnobs knobs;               // this call's snapshot of the library settings (host side only)
 };
 
@@ -133,6 +144,11 @@ int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, co
 
 // The kernels for plans in the general format (den_general.hip): the launches a.phase_mask selects, on `st`.
 hipError_t launch_den_general(const DenArgs& a, hipStream_t st);
+
+// ex = exp(clamp(x)) from both ends of every sequence towards the middle (DenArgs::ex)
+constexpr int kExMaxQ = 4;
+void den_exp_rows_shape(const DenArgs& a, int cus, int* nr, int* q);
+hipError_t launch_den_exp_rows(const DenArgs& a, hipStream_t st);
 
 // After the last launch of a call: objf from the stored totals + the invariant check (DenArgs::tot_a).
 // One workgroup per sequence.

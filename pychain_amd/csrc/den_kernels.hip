@@ -945,6 +945,85 @@ int den_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg, co
   return LaunchFrames(a).has(t, L) && t < L ? 1 : 0;
 }
 
+namespace {
+// ---- nnet-output rows exp'd ahead of the recursions (DenArgs::ex) --------------------------------------------------
+// Workgroup (sequence b, end e, q) walks the half of the sequence at that end from the end towards the middle in ROUNDS of NR
+// rows, taking the rounds q, q + Q, q + 2Q, ...: loads, clamp / exp (the recursions' own clamp_exp: bit-identical rows),
+// device-scope stores and - once those are acknowledged - the count of its complete rounds.  A round is an HBM round trip each
+// way (~10 us measured); Q workgroups x NR rows per round keep an end 3x ahead of a recursion that consumes a row per ~2 us
+// (one workgroup per end, 4 rows per round: 2.5 us per row, and the recursions waited for it: profiles/r04_t_*).
+constexpr int kExNT = 512;
+template <int CH>
+__global__ __launch_bounds__(kExNT) void den_exp_rows_kernel(const DenArgs a) {
+  constexpr int NR = CH <= 2 ? 8 : 4;
+  const int tid = threadIdx.x;
+  const int Q = a.ex_q;
+  const int b = blockIdx.x % a.B, end = (blockIdx.x / a.B) & 1, qi = blockIdx.x / (2 * a.B);
+  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T)), D = a.D;
+  const int Lh = (L + 1) / 2, n = end ? L - Lh : Lh;             // end 0 owns rows [0, Lh), end 1 rows [Lh, L) from L-1 down
+  const XBuf xin = make_xbuf(a.x + (size_t)b * a.T * D, (size_t)a.T * D * sizeof(float));
+  const XBuf xout = make_xbuf(a.ex + (size_t)b * a.T * D, (size_t)a.T * D * sizeof(float));
+  int32_t* prog = a.xprog + ((size_t)end * a.B + b) * kExMaxQ + qi;
+  bool nan = false;
+  int done = 0;
+  for (int r0 = qi * NR; r0 < n; r0 += Q * NR) {
+    u32x4 q[NR][CH];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const int t = end ? L - 1 - (r0 + k) : r0 + k;
+      const int soff = __builtin_amdgcn_readfirstlane(t * D * 4);
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const int e = (c * kExNT + tid) * 4;
+        if (r0 + k < n && e < D) q[k][c] = __builtin_amdgcn_raw_buffer_load_b128(xin, e * 4, soff, 0);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      const int t = end ? L - 1 - (r0 + k) : r0 + k;
+      const int soff = __builtin_amdgcn_readfirstlane(t * D * 4);
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const int e = (c * kExNT + tid) * 4;
+        if (r0 + k < n && e < D) {
+          const float x0 = __uint_as_float(q[k][c].x), x1 = __uint_as_float(q[k][c].y), x2 = __uint_as_float(q[k][c].z), x3 = __uint_as_float(q[k][c].w);
+          nan = nan || __builtin_isunordered(x0, x1) || __builtin_isunordered(x2, x3);
+          u32x4 o;
+          o.x = __float_as_uint(clamp_exp(x0, kXExpClamp)); o.y = __float_as_uint(clamp_exp(x1, kXExpClamp));
+          o.z = __float_as_uint(clamp_exp(x2, kXExpClamp)); o.w = __float_as_uint(clamp_exp(x3, kXExpClamp));
+          __builtin_amdgcn_raw_buffer_store_b128(o, xout, e * 4, soff, kStoreDeviceScope);
+        }
+      }
+    }
+    if (nan) __hip_atomic_store(a.xnan + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);                       // this wave's stores are acknowledged
+    __syncthreads();
+    done++;
+    if (tid == 0) __hip_atomic_store(prog, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace
+// rounds of the rows exp'd ahead: rows per round and workgroups per end of a sequence (DenArgs::ex_nr, ex_q)
+void den_exp_rows_shape(const DenArgs& a, int cus, int* nr, int* q) {
+  const int ch = (a.D / 4 + kExNT - 1) / kExNT;
+  *nr = ch <= 2 ? 8 : 4;
+  const int per_end = cus / (2 * a.B);                  // as many workgroups as the chip has CUs
+  *q = per_end < 1 ? 1 : (per_end > kExMaxQ ? kExMaxQ : per_end);
+}
+hipError_t launch_den_exp_rows(const DenArgs& a, hipStream_t st) {
+  const dim3 grid(2 * a.B * a.ex_q), block(kExNT);
+  const int ch = (a.D / 4 + kExNT - 1) / kExNT;
+  switch (ch) {
+    case 1: hipLaunchKernelGGL(den_exp_rows_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(den_exp_rows_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(den_exp_rows_kernel<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(den_exp_rows_kernel<4>, grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL(den_exp_rows_kernel<5>, grid, block, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 hipError_t launch_den_finish(const DenArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(den_finish_kernel, dim3(a.B), dim3(kFinNT), 0, st, a);
   return hipGetLastError();

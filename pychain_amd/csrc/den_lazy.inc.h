@@ -116,7 +116,7 @@ typedef float lz_v4 __attribute__((ext_vector_type(4)));
 #define PYCHAIN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)     /* vmcnt(0) only (gfx9 encoding) */
 // row t of the sequence behind `buf` -> LDS at byte address xbase, 1 KiB chunks dealt to the NW waves; lanes past the
 // row's end re-read its last 16 bytes (a chunk may run past the end of the whole slab otherwise)
-template <int NW, int NCH>
+template <int NW, int NCH, int AUX = 0>
 __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int lane, uint32_t xbase) {
   const int row_bytes = D * 4;
   const int soff = __builtin_amdgcn_readfirstlane(t * row_bytes);
@@ -129,7 +129,7 @@ __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int
       // the row's end re-reads the row's last 16 bytes
       const int voff = ch * 1024 + lane * 16 < row_bytes ? lane * 16 : max(0, row_bytes - 16 - ch * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(buf, (lz_lds_void*)(xbase + (uint32_t)ch * 1024u), 16, voff,
-                                               soff + ch * 1024, 0, 0);
+                                               soff + ch * 1024, 0, AUX);
     }
   }
 }
@@ -401,7 +401,7 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
 // One (sequence, direction).  The direction is a template parameter and the kernel branches ONCE, at its
 // top: with both directions in one body the register allocator keeps a second copy of every arc register
 // across the (uniform) direction branches.
-template <int R, typename MAP, bool fwd>
+template <int R, typename MAP, bool fwd, bool PRE>
 __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b) {
   constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
   const int tid = threadIdx.x;
@@ -437,7 +437,37 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
   float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2);  // per-frame totals for den_finish_kernel (DenArgs::tot_a)
   const float coef = a.coef;
-  const XBuf xbuf = make_xbuf(xseq, (size_t)a.T * D * sizeof(float));
+  constexpr int kDmaCh = ((int)MAP::kMaxPdfs / 256 + NW - 1) / NW;   // 1 KiB chunks of a row one wave may own
+  // rows exp'd ahead of this kernel (DenArgs::ex): they arrive ready to gather; a row is requested once its end of the
+  // sequence reports it (xprog), which after the first microseconds of a call it always has
+  constexpr bool pre = PRE;                             // (a template parameter: the kernel has no register to spare for both forms)
+  static_assert(!PRE || MAP::kDma, "rows exp'd ahead arrive by LDS-direct loads");
+  const XBuf xbuf = make_xbuf(pre ? a.ex + (size_t)b * a.T * D : xseq, (size_t)a.T * D * sizeof(float));
+  int ready_lo = 0, ready_hi = 0;                       // ex rows [0, ready_lo) and [L - ready_hi, L) are complete
+  // rows an end has complete: its workgroup q has done c_q of the rounds q, q + Q, ...: the first round missing is min_q (q + c_q Q)
+  auto rows_of_end = [&](int end) {
+    const int32_t* c = a.xprog + ((size_t)end * a.B + b) * kExMaxQ;
+    int lead = 0x7fffffff;
+    for (int q = 0; q < a.ex_q; q++)
+      lead = min(lead, q + a.ex_q * __builtin_amdgcn_readfirstlane(__hip_atomic_load(c + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    return min(lead, 0x00ffffff) * a.ex_nr;              // (clamped to the end's rows by the comparison below: L - Lh <= Lh <= L)
+  };
+  auto wait_row = [&](int t) {
+    if (t < ready_lo || t >= L - ready_hi) return;
+    const int Lh = (L + 1) / 2;                           // end 0 owns rows [0, Lh), end 1 rows [Lh, L)
+    const unsigned long long t0 = wall_clock64();         // 100 MHz
+    for (;;) {
+      ready_lo = min(rows_of_end(0), Lh); ready_hi = min(rows_of_end(1), L - Lh);
+      if (t < ready_lo || t >= L - ready_hi) break;
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > 2000000000ull) { bad |= 1; break; }   // 20 s: den_exp_rows_kernel died
+    }
+  };
+  // row t -> the buffer at xbase (LDS-direct); device-scope loads for rows another kernel is writing meanwhile
+  auto dma_row = [&](int t, int ln, uint32_t xbase) {
+    if constexpr (pre) { wait_row(t); lz_dma_row<NW, kDmaCh, kStoreDeviceScope>(xbuf, t, D, wave, ln, xbase); }
+    else lz_dma_row<NW, kDmaCh, 0>(xbuf, t, D, wave, ln, xbase);
+  };
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));
 
   LazyWave w;
@@ -449,7 +479,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 
   // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
   XRow<NT, 4, MAP::kXch> xq;
-  constexpr int kDmaCh = ((int)MAP::kMaxPdfs / 256 + NW - 1) / NW;   // 1 KiB chunks of a row one wave may own
   {
     float p0 = 0.f, p1 = 0.f;
     for (int i = tid; i < (int)MAP::kMaxStates; i += NT) {
@@ -462,8 +491,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     }
     const int t0 = fwd ? 0 : L - 1;
     if constexpr (MAP::kDma) {
-      lz_dma_row<NW, kDmaCh>(xbuf, t0, D, wave, lane, MAP::kX0);
-      if (lz_dma_finish<NW, kDmaCh>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
+      dma_row(t0, lane, MAP::kX0);
+      if constexpr (pre) PYCHAIN_WAIT_VM0();
+      else if (lz_dma_finish<NW, kDmaCh>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
     } else {
       xq.load(xseq + (size_t)t0 * D, D, tid);
       if (fwd && xq.has_nan()) bad |= 2;
@@ -538,7 +568,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
     LZ_PH0();                                                                                               \
     if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
-      if (have_next) lz_dma_row<NW, kDmaCh>(xbuf, tn, D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1);            \
+      if (have_next) dma_row(tn, lq, (PAR) ? MAP::kX0 : MAP::kX1);                                          \
     } else if (have_next) xq.load_row(xbuf, tn, D, tq);      /* in flight during the arc work */             \
     /* What the hook behind the first gathers needs from LDS - the previous step's partial sums and the row it produced (it */ \
     /* sits in the buffer this step gathers from) - is requested HERE, ahead of the gathers: behind them the reads queue up */ \
@@ -571,7 +601,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
       if constexpr (MAP::kDma && PYCHAIN_LATE_FINISH) {                                                     \
         LZ_VMWAIT();                                                                                        \
-        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
+        if constexpr (pre) PYCHAIN_WAIT_VM0();               /* (ready to gather: it only has to have landed before the barrier) */ \
+        else if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
       }                                                                                                     \
     });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
@@ -680,6 +711,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();
     if (lane == 0) red[wave] = f;
     __syncthreads();
+    if (PRE && __hip_atomic_load(a.xnan + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) bad |= 2;   // (den_exp_rows_kernel saw it)
     if (bad & 2) red[64] = 1.f;                       // somebody staged a NaN network output
     __syncthreads();
     const float fs = wave_sum(red[lane]);
@@ -691,9 +723,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
-template <int R, typename MAP>
+// PRE: the rows were exp'd ahead by den_exp_rows_kernel (DenArgs::ex)
+template <int R, typename MAP, bool PRE = false>
 __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true>(a, smem_raw, blockIdx.x);
-  else lazy_recursion<R, MAP, false>(a, smem_raw, blockIdx.x - a.B);
+  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, PRE>(a, smem_raw, blockIdx.x);
+  else lazy_recursion<R, MAP, false, PRE>(a, smem_raw, blockIdx.x - a.B);
 }

@@ -147,7 +147,7 @@ def chain_loss_forward_backward(plan, gt, graph_stride, num_states_num, x, lengt
         num_objf = torch.empty(B, dtype=torch.float32, device=dev)
         grad = torch.empty_like(x)
         bad = torch.empty(2, dtype=torch.int32, device=dev)
-        dws = _workspace(L.pychain_hip_den_workspace_bytes(B, T, plan.num_states, D), dev, "den")
+        dws = _workspace(L.pychain_hip_den_workspace_min_bytes(B, T, plan.num_states, D), dev, "den")   # (the fused loss never exp's rows ahead)
         nws = _workspace(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dev, "num")
         _lib.check(L.pychain_hip_chain_loss_forward_backward(
             plan.blob.data_ptr(), plan.stride, plan.slot_rows, plan.num_states, float(leaky_coefficient),
@@ -195,7 +195,7 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
         if norm_dev is not None:
             norm_dev = norm_dev.detach().to(device=dev, dtype=torch.float32).contiguous()
         # per-call workspaces (they must survive until backward); the caching allocator makes this cheap
-        dws = torch.empty(L.pychain_hip_den_workspace_bytes(B, T, plan.num_states, D), dtype=torch.uint8, device=dev)
+        dws = torch.empty(L.pychain_hip_den_workspace_min_bytes(B, T, plan.num_states, D), dtype=torch.uint8, device=dev)
         nws = torch.empty(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dtype=torch.uint8,
                           device=dev)
         grad = torch.empty_like(x) if with_grad else None

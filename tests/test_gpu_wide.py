@@ -117,6 +117,38 @@ def test_dma_rows_on_the_narrow_map_match_the_register_path_bit_for_bit():
     assert int(ChainFunction.last_bad_count.sum()) > 0 and np.isnan(float(o.detach()))
 
 
+@pytest.mark.parametrize("name,H,K,D,T,lens", [
+    ("C3", 3000, 30000, 3456, 301, [301, 288, 130, 1, 2, 65]),       # 16 waves, rows of <= 4096 pdfs
+    ("C4", 3000, 30000, 8408, 160, [160, 159, 64, 3]),               # rows of up to 9216 pdfs
+    ("C2", 200, 2000, 1000, 150, [150, 149, 75, 1, 64, 150]),        # four-wave workgroups
+])
+def test_rows_exp_ahead_of_the_recursions_are_the_same_rows(name, H, K, D, T, lens):
+    """den_exp_rows_kernel (DenArgs::ex) writes exp(clamp(x)) from both ends of every sequence towards its middle while
+    the recursions run, and they gather from those rows as they arrive instead of passing over each row in LDS (option
+    den_dma = 2: the old way).  Same clamp_exp, same recursion: objf and gradient bit for bit, for every length (one
+    frame, even / odd middles), streamed, gated and without overlap; a NaN network output is still seen
+    (loss.py:30,43: it reaches the loss) wherever it sits."""
+    den = syn.make_den_graph(H, K, D, seed=0)
+    L = torch.tensor(lens)
+    x = syn.make_input(len(lens), T, D, seed=29, device=DEV)
+    for extra in ({}, {"den_segments": 3}, {"den_segments": 1}):
+        o, g = _den(x, L, den, den_dma=2, **extra)
+        o2, g2 = _den(x, L, den, **extra)
+        assert o == o2 and torch.equal(g, g2), extra
+    for (b, t, d) in ((0, 0, 5), (0, lens[0] // 2, D - 1), (1, lens[1] - 1, 0), (2, 7, 33)):
+        xn = x.clone()
+        xn[b, t, d] = float("nan")
+        xx = xn.requires_grad_(True)
+        o = ChainFunction.apply(xx, L, ChainGraphBatch(den, len(lens)), 1e-5)
+        torch.cuda.synchronize()
+        assert int(ChainFunction.last_bad_count.sum()) > 0 and np.isnan(float(o.detach())), (b, t, d)
+    # a NaN past the end of its sequence is nobody's business
+    xn = x.clone()
+    xn[2, lens[2], 3] = float("nan")
+    o3, g3 = _den(xn, L, den)
+    assert o3 == o2 and torch.equal(g3, g2)
+
+
 def test_which_kernel_each_shape_gets():
     """The kernel a shape selects is pinned (a silent drop to a slower kernel is a performance bug nobody sees):
     pychain_hip_den_kernel_names answers from the same predicates the launcher uses."""
