@@ -103,12 +103,17 @@ def kernel_rooflines(w, dev, iters, d2d=True):
     frames = int(w["lengths"].sum())
     call = lambda: native.den_forward_backward(plan, w["x"], w["lengths_dev"], 1e-5)
     out = {}
+    # the launches as the TIMED step runs them: a call of the denominator alone has its rows exp'd ahead of the recursions
+    # (den_exp_rows_kernel), the fused loss has not - option den_dma = 2 is that form
+    import contextlib
+    as_in_step = _lib.option("den_dma", 2) if w.get("num_graphs") is not None else contextlib.nullcontext()
     try:
-        call(); torch.cuda.synchronize()
-        for name, mask in (("den_recursion_kernel", 1), ("den_gamma_kernel", 2), ("den_call", 3)):
-            L.pychain_hip_set_den_phase_mask(mask)
+        with as_in_step:
             call(); torch.cuda.synchronize()
-            out[name] = event_time_ms(call, iters, stream)
+            for name, mask in (("den_recursion_kernel", 1), ("den_gamma_kernel", 2), ("den_call", 3)):
+                L.pychain_hip_set_den_phase_mask(mask)
+                call(); torch.cuda.synchronize()
+                out[name] = event_time_ms(call, iters, stream)
     finally:
         L.pychain_hip_set_den_phase_mask(3)
     # algorithmic bytes per live sequence-frame (DESIGN.md §4 / SURVEY.md §8(d)):
@@ -256,8 +261,10 @@ def other_workloads(dev, steps=6, warmup=3):
             stream = torch.cuda.current_stream(dev)
             call = lambda: native.den_forward_backward(plan, w["x"].detach(), w["lengths_dev"], 1e-5)
             parts = {}
+            import contextlib
             for key, mask in (("recursion_ms", 1), ("occupancy_ms", 2), ("den_ms", 3)):
-                with _lib.option("den_phase_mask", mask):
+                # (as the step runs them: kernel_rooflines)
+                with _lib.option("den_phase_mask", mask), (_lib.option("den_dma", 2) if cfg["num"] else contextlib.nullcontext()):
                     call(); torch.cuda.synchronize()
                     parts[key] = event_time_ms(call, 3, stream)
             den_bytes = (12 * cfg["D"] + 8 * (cfg["H"] + 1)) * frames

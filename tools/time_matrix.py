@@ -80,8 +80,16 @@ for cell in cells:
         if parts:
             call = lambda: native.den_forward_backward(plan, w["x"].detach(), w["Ld"], 1e-5)
             for label, mask in (("rec", 1), ("occ", 2), ("den", 3)):
-                with _lib.option("den_phase_mask", mask):
-                    line += "  %s %.4f" % (label, timed(call, 3, 3))
+                # (the launches as the step above runs them: the fused loss never has its rows exp'd ahead - den_dma = 2)
+                extra = [_lib.option("den_dma", 2)] if w["num_graphs"] is not None and "den_dma" not in opts else []
+                for c in extra:
+                    c.__enter__()
+                try:
+                    with _lib.option("den_phase_mask", mask):
+                        line += "  %s %.4f" % (label, timed(call, 3, 3))
+                finally:
+                    for c in extra:
+                        c.__exit__()
         bad = int(ChainFunction.last_bad_count.sum())
         print(line + ("  BAD=%d" % bad if bad else ""), flush=True)
     finally:
