@@ -97,20 +97,8 @@ typedef __attribute__((address_space(3))) void lz_lds_void;
 #ifndef PYCHAIN_LATE_BACK
 #define PYCHAIN_LATE_BACK 2                            /* the late hook of lazy_tile runs this many chunks before the end of the arc phase */
 #endif
-#ifndef PYCHAIN_GATHER_ORDER
-#define PYCHAIN_GATHER_ORDER 1                         /* split arcs, a pair of rows: 1 = both states, then both rows (C3 recursion -0.7 %); 0 = state, row, state, row */
-#endif
-#ifndef PYCHAIN_SUMS_AT_GROUP_END
-#define PYCHAIN_SUMS_AT_GROUP_END 1                    /* a wave adds up its rows' new values where it forms them (two live registers); 0: re-read from LDS after the arc phase - C3 recursion 3.03 -> 2.96 ms, C4 4.71 -> 4.54, C2 0.176 -> 0.167: profiles/r04_j_time_matrix*.txt */
-#endif
-#ifndef PYCHAIN_LK_NEXT
-#define PYCHAIN_LK_NEXT 1                              /* beta requests the leaky probability of a group end's row one group end ahead (one live register; maps with room for it: C3 recursion -0.5 .. 1 %, the map of C4 +3 %: r04_q_*) */
-#endif
 #ifndef PYCHAIN_EXP_NO_ROWSTORE
 #define PYCHAIN_EXP_NO_ROWSTORE 0                      /* timing experiments (WRONG RESULTS): 1 = the rows do not leave for HBM, 2 = they do, but are not re-read from LDS first */
-#endif
-#ifndef PYCHAIN_LATE_FINISH
-#define PYCHAIN_LATE_FINISH 1                          /* 0: the in-place clamp / exp of an LDS-direct row after the arc phase (ablation) */
 #endif
 typedef float lz_v4 __attribute__((ext_vector_type(4)));
 #define PYCHAIN_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)     /* vmcnt(0) only (gfx9 encoding) */
@@ -213,17 +201,11 @@ struct LazyArcsSplit {
   // rows s, s + 1 (s even)
   template <uint32_t UOFF, uint32_t VOFF>
   __device__ __forceinline__ void gather2(int s, lz_v2f& u0, lz_v2f& u1, lz_v2f& v) {
-#if PYCHAIN_GATHER_ORDER == 0
-    u0 = lz_ld2(ua[s] + UOFF);
-    v.x = lds_abs((xp[s / 2] & 0xffffu) + VOFF);
-    u1 = lz_ld2(ua[s + 1] + UOFF);
-    v.y = lds_abs((xp[s / 2] >> 16) + VOFF);
-#else
+    // (both states, then both rows: the C3 recursion is 0.7 % faster than with state, row, state, row)
     u0 = lz_ld2(ua[s] + UOFF);
     u1 = lz_ld2(ua[s + 1] + UOFF);
     v.x = lds_abs((xp[s / 2] & 0xffffu) + VOFF);
     v.y = lds_abs((xp[s / 2] >> 16) + VOFF);
-#endif
   }
 };
 template <int R, typename MAP> struct LazyArcsOf { typedef LazyArcs<R, MAP> type; };
@@ -237,7 +219,7 @@ template <typename MAP> struct LazyArcsOf<24, MAP> { typedef LazyArcsSplit<24, M
 struct LazyWave {
   float inv, c;                 // 1 / total of the previous frame; beta: coef * leaky-weighted sum of the previous frame
   float sprev;                  // the scalar that completes the row in the gather buffer: alpha tot(t), beta c(t)
-  float lk_next;                // beta (PYCHAIN_LK_NEXT): leaky probability of the lane's row in the group whose end comes next
+  float lk_next;                // beta: leaky probability of the lane's row in the group whose end comes next
 };
 
 // A group end inside the arc loop does the least it can: the row's new value into the state buffer the
@@ -308,11 +290,11 @@ __device__ __forceinline__ void lazy_tile(LazyArcs<R, MAP>& ar, const GroupRegs&
           if constexpr (R > 64) if (sidx >= 64) g += __builtin_popcount(m_2 & below);
           const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
           const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
-          if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
+          {                                              // the wave's share of the frame's totals, where the value is formed
             s0 += val;
             // (beta's leaky probabilities in four registers instead of this LDS read: two spills, recursion +6 %: r04_p_*)
             if constexpr (!FWD) {
-              if constexpr (PYCHAIN_LK_NEXT && MAP::kMaxPdfs <= 4096) {
+              if constexpr (MAP::kMaxPdfs <= 4096) {                 // (requested one group end ahead: LazyWave::lk_next)
                 s1 = __builtin_fmaf(val, w.lk_next, s1);
                 w.lk_next = lds_abs(MAP::kLk + (uint32_t)(__builtin_amdgcn_readlane(gr.base, (g + 1) & 63) + lane) * 4u);
               } else {
@@ -378,11 +360,11 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
           const int g = __builtin_popcount(m_lo & ((1u << sidx) - 1u));
           const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
           const float val = lazy_group_end<FWD>(w, nacc, UNEXT + pos * 8u);
-          if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {
+          {                                              // the wave's share of the frame's totals, where the value is formed
             s0 += val;
             // (beta's leaky probabilities in four registers instead of this LDS read: two spills, recursion +6 %: r04_p_*)
             if constexpr (!FWD) {
-              if constexpr (PYCHAIN_LK_NEXT && MAP::kMaxPdfs <= 4096) {
+              if constexpr (MAP::kMaxPdfs <= 4096) {                 // (requested one group end ahead: LazyWave::lk_next)
                 s1 = __builtin_fmaf(val, w.lk_next, s1);
                 w.lk_next = lds_abs(MAP::kLk + (uint32_t)(__builtin_amdgcn_readlane(gr.base, (g + 1) & 63) + lane) * 4u);
               } else {
@@ -576,7 +558,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* profiles/r04_n_*; registers: live exactly as long as in the hook before) */                          \
     float pre0 = 0.f, pre1 = 0.f;                                                                           \
     if (j > 0) { pre0 = red[((PAR) ^ 1) * 128 + lq]; if (!(FWDC)) pre1 = red[((PAR) ^ 1) * 128 + 64 + lq]; } \
-    if constexpr (PYCHAIN_LK_NEXT && MAP::kMaxPdfs <= 4096 && !(FWDC)) w.lk_next = lds_abs(MAP::kLk + gbase[0] * 4 + lq * 4);          \
+    if constexpr (MAP::kMaxPdfs <= 4096 && !(FWDC)) w.lk_next = lds_abs(MAP::kLk + gbase[0] * 4 + lq * 4);          \
     constexpr bool kPreRows = MAP::kMaxPdfs <= 4096;         /* (the map of C4 has no registers to spare: the rows are read in the hook) */ \
     lz_v2f prow[MG];                                                                                        \
     if constexpr (kPreRows) {                                                                               \
@@ -599,42 +581,21 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     }, [&]() {                                                                                              \
       /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
       /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
-      if constexpr (MAP::kDma && PYCHAIN_LATE_FINISH) {                                                     \
+      if constexpr (MAP::kDma) {                                                                            \
         LZ_VMWAIT();                                                                                        \
         if constexpr (pre) PYCHAIN_WAIT_VM0();               /* (ready to gather: it only has to have landed before the barrier) */ \
         else if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
       }                                                                                                     \
     });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
-    /* back from LDS, in flight during the exp of the nnet-output row below: this frame's new values of the */ \
-    /* lane's rows (and, beta, their leaky probs) for the totals */                                         \
-    float val[MG], lkv[MG];                                                                                 \
-    if constexpr (!PYCHAIN_SUMS_AT_GROUP_END) {                                                             \
-      const int lane8 = lq * 8;                                                                             \
-      _Pragma("unroll") for (int g = 0; g < MG; g++) {                                                      \
-        val[g] = 0.f; lkv[g] = 0.f;                                                                         \
-        if (g < groups.ngroups) {                                                                           \
-          val[g] = lds_abs(UNEXT + gbase[g] * 8 + lane8);                                                   \
-          if (!(FWDC)) lkv[g] = lds_abs(MAP::kLk + gbase[g] * 4 + (lane8 >> 1));                            \
-        }                                                                                                   \
+    /* rows through registers: the next step's nnet-output row into the other buffer (last read in the previous step) */ \
+    if constexpr (!MAP::kDma) {                                                                             \
+      if (have_next) {                                                                                      \
+        if ((FWDC) && xq.has_nan()) bad |= 2;                /* a NaN network output: not ok, NaN log-probability */ \
+        xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \
       }                                                                                                     \
     }                                                                                                       \
-    /* the next step's nnet-output row into the other buffer (last read in the previous step) */            \
-    if constexpr (MAP::kDma) {                                                                              \
-      if constexpr (!PYCHAIN_LATE_FINISH)                                                                   \
-        if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
-    } else if (have_next) {                                                                                 \
-      if ((FWDC) && xq.has_nan()) bad |= 2;                  /* a NaN network output: not ok, NaN log-probability */ \
-      xq.store(reinterpret_cast<float*>(smem_raw + ((PAR) ? MAP::kX0 : MAP::kX1)), xseq, D, tq, a.input_is_exp); \
-    }                                                                                                       \
-    LZ_PH(1);                                                /* LDS re-reads issued, nnet-output row clamped / exp'd / stored */ \
-    if constexpr (PYCHAIN_SUMS_AT_GROUP_END) {                                                              \
-    } else if constexpr (MG == 4) {                                                                         \
-      s0 = (val[0] + val[1]) + (val[2] + val[3]);                                                           \
-      if (!(FWDC)) s1 = __builtin_fmaf(val[0], lkv[0], val[1] * lkv[1]) + __builtin_fmaf(val[2], lkv[2], val[3] * lkv[3]); \
-    } else {                                                                                                \
-      _Pragma("unroll") for (int g = 0; g < MG; g++) { s0 += val[g]; if (!(FWDC)) s1 = __builtin_fmaf(val[g], lkv[g], s1); } \
-    }                                                                                                       \
+    LZ_PH(1);                                                /* (rows through registers: nnet-output row clamped / exp'd / stored) */ \
     /* totals: four row sums per wave before the barrier, the rest of the reduction after it */             \
     {                                                                                                       \
       const float r0 = dpp_row_sum(s0);                                                                     \

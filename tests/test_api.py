@@ -130,6 +130,14 @@ def test_alias_package_and_exports():
     _lib.lib().pychain_hip_set_verbose_level(2)
     assert _lib.lib().pychain_hip_get_verbose_level() == 2
     _lib.lib().pychain_hip_set_verbose_level(0)
+    # the two workspace sizes of the denominator (include/pychain_hip.h): the full one holds the [B,T,D] buffer of the rows
+    # exp'd ahead of the recursions on top of the other (256-byte granules), and both reject empty shapes
+    L = _lib.lib()
+    for (B, T, H, D) in ((64, 1500, 3000, 3456), (32, 2000, 3000, 8408), (3, 7, 5, 9)):
+        full, least = L.pychain_hip_den_workspace_bytes(B, T, H, D), L.pychain_hip_den_workspace_min_bytes(B, T, H, D)
+        assert 0 < least < full and full - least == (4 * B * T * D + 255) // 256 * 256
+        assert least >= 4 * B * (2 * T + 1) * ((H + 63) // 64 * 64)          # the stored alpha' / beta rows
+    assert L.pychain_hip_den_workspace_bytes(0, 7, 5, 9) == 0 and L.pychain_hip_den_workspace_min_bytes(3, 7, 5, 0) == 0
 
 
 def test_no_cpu_fallback():
