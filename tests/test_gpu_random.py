@@ -54,3 +54,44 @@ def test_random_shapes_all_recursion_kernels(seed):
         results[name] = (o, g)
     if B >= 2:                                                     # (B = 1 never pairs: the same kernel ran twice)
         assert results["pair"][0] == results["two-barrier"][0] and np.array_equal(results["pair"][1], results["two-barrier"][1])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_rows_exp_ahead(seed):
+    """den_exp_rows_kernel (rows exp'd ahead of the lazy recursions from both ends of every sequence) against
+    the recursions exp'ing their rows themselves (option den_dma = 2), bit for bit: random batch sizes (1 .. 2 workgroups per
+    end up to 4), lengths from one frame to T with T from 64 up, pdf counts of every chunk count of the launch, repeated calls
+    on one workspace (the counters of the previous call must be gone)."""
+    rng = np.random.RandomState(7000 + seed)
+    H, K = [(200, 2000), (640, 6000), (3000, 30000)][seed % 3]
+    D = int(rng.choice([512, 1000, 2048, 3456, 4100, 6144, 8408]))
+    if (H, D) == (200, 8408):
+        D = 1000
+    B = int(rng.choice([1, 2, 3, 5, 8, 33, 64]))
+    T = int(rng.choice([64, 65, 97, 130, 257]))
+    if B * T * D > 40e6:
+        B = max(1, int(40e6 // (T * D)))
+    lengths = [int(rng.randint(1, T + 1)) for _ in range(B)]
+    lengths[0] = T
+    den = syn.make_den_graph(H, K, D, seed=seed)
+    x = syn.make_input(B, T, D, seed=90 + seed, device=DEV)
+    L = torch.tensor(lengths)
+
+    def run(**opts):
+        xx = x.clone().requires_grad_(True)
+        ctx = [_lib.option(k, v) for k, v in opts.items()]
+        for c in ctx:
+            c.__enter__()
+        try:
+            o = ChainFunction.apply(xx, L, ChainGraphBatch(den, B), 1e-5)
+            o.backward()
+            torch.cuda.synchronize()
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+        assert int(ChainFunction.last_bad_count.sum()) == 0
+        return float(o.detach()), xx.grad
+    o0, g0 = run(den_dma=2)
+    for _ in range(3):
+        o, g = run()
+        assert o == o0 and torch.equal(g, g0), (H, K, D, B, T, lengths[:8])
