@@ -63,6 +63,11 @@ int         pychain_hip_get_verbose_level(void);
  * launch, 0 if not, negative on bad arguments.  nseg = 0: the unsegmented launch. */
 int         pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg,
                                          const int32_t* seg_bound, int seg, int32_t* out, int out_len);
+/* Test hook (host only, no GPU): the rings of the STREAMED occupancy pass for sequences of up to T frames:
+ * ring r covers the frames whose step count need = max(t, L-1-t) lies in [out[2r], out[2r+1]); returns the number of rings
+ * (pairs beyond out_len / 2 are not written).  report_due (may be NULL): report_due[d] = 1 if a recursion workgroup reports its
+ * progress after d steps, d < due_len. */
+int         pychain_hip_debug_stream_rings(int T, int32_t* out, int out_len, int32_t* report_due, int due_len);
 /* Measurement aid (bench.py): restrict pychain_hip_den_forward_backward to a subset of
  * its launches so each kernel can be bracketed by events on the caller's stream.
  * bit 0 = alpha/beta recursion launch, bit 1 = occupancy launch; default 3 = both.

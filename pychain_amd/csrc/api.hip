@@ -553,6 +553,19 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
 }
 }  // namespace
 
+extern "C" int pychain_hip_debug_stream_rings(int T, int32_t* out, int out_len, int32_t* report_due, int due_len) {
+  if (T <= 0 || out_len < 0 || due_len < 0 || (out_len && !out) || (due_len && !report_due))
+    return fail(PYCHAIN_HIP_EINVAL, "debug_stream_rings: bad arguments");
+  const int n = stream_ring_count(T);
+  for (int r = 0; r < n && 2 * r + 1 < out_len; r++) {
+    int lo, hi;
+    stream_ring(T, r, lo, hi);
+    out[2 * r] = lo; out[2 * r + 1] = hi;
+  }
+  for (int d = 0; d < due_len; d++) report_due[d] = stream_report_due(T, d) ? 1 : 0;
+  return n;
+}
+
 extern "C" int pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_block, int nseg,
                                             const int32_t* seg_bound, int seg, int32_t* out, int out_len) {
   if (T <= 0 || L <= 0 || L > T || frames_per_block <= 0 || nseg < 0 || nseg > 16 || (nseg && !seg_bound) || seg < 0 || (nseg && seg >= nseg))

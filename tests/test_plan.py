@@ -286,3 +286,40 @@ def test_general_plan_format(monkeypatch):
     assert _plan.plan_info(_blob(small, 40))["slot_rows"] != _plan.HINT_GENERAL
     # state vector + nnet-output row beyond the LDS of one CU: general too
     assert _plan.plan_info(_blob(syn.make_den_graph(300, 1200, 40000, seed=1), 40000))["slot_rows"] == _plan.HINT_GENERAL
+
+
+def test_rings_of_the_streamed_occupancy_pass():
+    """The streamed occupancy launch hands out, per sequence, rings of frames by the step count that makes them computable
+    (den_kernels.h: stream_ring): the rings tile [0, T) without gaps, 16 steps wide, 4 over the last 64 steps and
+    ONE frame pair over the last 8; every ring end is a step count at which the recursions report (else the ring would wait
+    for a later report) and every report falls on an even step count (the recursion loop reports every second step); a
+    sequence of length L <= T gets every one of its frames from exactly one (ring, side) item (den_kernels.hip: stream_take)."""
+    import ctypes
+    from pychain_amd import _lib
+    L_ = _lib.lib()
+    out = (ctypes.c_int32 * 8192)()
+    due = (ctypes.c_int32 * 4200)()
+    for T in list(range(1, 140)) + [150, 255, 256, 257, 751, 1500, 2000, 4097]:
+        n = L_.pychain_hip_debug_stream_rings(T, out, 8192, due, T + 2)
+        assert n > 0 and 2 * n <= 8192
+        rings = [(out[2 * r], out[2 * r + 1]) for r in range(n)]
+        assert rings[0][0] == 0 and rings[-1][1] >= T
+        for (lo, hi), (lo2, _hi2) in zip(rings, rings[1:]):
+            assert lo < hi and hi == lo2
+        widths = [hi - lo for lo, hi in rings]
+        assert set(widths) <= {16, 4, 2} and widths == sorted(widths, reverse=True)
+        assert all(hi - lo == 2 for lo, hi in rings if lo >= max(0, T - 8))          # the end: one frame pair per ring
+        assert all(hi - lo <= 4 for lo, hi in rings if lo >= max(0, T - 48))
+        for lo, hi in rings:
+            if hi < T:
+                assert due[hi] == 1 and hi % 2 == 0, (T, lo, hi)
+        assert all(d % 2 == 0 for d in range(1, T + 1) if due[d]), T
+        # the items of a sequence: ring r, side 0 (left of the middle: need = L-1-t) and side 1 (right: need = t)
+        for L in {1, 2, T, max(1, T // 2), max(1, T - 1), max(1, T // 3)}:
+            half = L // 2
+            seen = []
+            for lo, hi in rings:
+                seen += list(range(max(lo, half), min(hi, L)))                         # side 1
+                seen += list(range(max(0, L - hi), min(half, L - lo)))                 # side 0
+            assert sorted(seen) == list(range(L)), (T, L)
+    assert L_.pychain_hip_debug_stream_rings(0, out, 8192, None, 0) < 0
