@@ -323,7 +323,7 @@ def _ref_batch_from(gb):
     return rb
 
 
-def gen_long():
+def gen_long(names=None, fixture="g6_long"):
     """G6: the long cases of tests/helpers.py:long_case through the REAL reference binary - at
     T >= 700 its fp32 log-domain numerator (LogAdd with the -15.94 cut-off, base.h:14-32, chained through
     chain-log-domain-computation.cc:137-158,256-266) is itself > 1e-4 from the same equations in fp64.  Stored per case:
@@ -333,7 +333,7 @@ def gen_long():
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import helpers
     out = {}
-    for name in helpers.LONG_CASES:
+    for name in (names or helpers.LONG_CASES):
         c = helpers.long_case(name)
         x, L, B = c["x"], c["lengths"], c["x"].shape[0]
         if c["kind"] == "den":
@@ -377,17 +377,25 @@ def gen_long():
         print("%-16s objf %.6f (f64 %.6f, restatement-f32 %.6f)  grad: reference vs f64 %.3e, restatement-f32 vs reference %.3e,"
               " restatement-f32 vs f64 %.3e; %d rows" % (name, float(objf), o64, o32, ref_vs_f64, out[p + "restatement_f32_vs_ref"],
                                                          np.abs(g32 - g64).max() / np.abs(g64).max(), len(rows)))
-    save("g6_long", **out)
+    save(fixture, **out)
 
 
 if __name__ == "__main__":
     if "--only-g6" in sys.argv:
         gen_long()
         sys.exit(0)
+    if "--only-g7" in sys.argv:                    # (round 4: the C4 shape through the real binary; G6 is left as it is)
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import helpers as _h
+        gen_long(_h.LONG_CASES_G7, "g7_c4_slice")
+        sys.exit(0)
     gen_chaingraph_init()
     if "--only-a4" in sys.argv:
         sys.exit(0)
     gen_long()
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import helpers as _h
+    gen_long(_h.LONG_CASES_G7, "g7_c4_slice")
     gen_c1()
     gen_variants()
     gen_medium()

@@ -173,6 +173,7 @@ def oracle_fanout(x_cpu, lengths, den_graph, num_graphs, grad_hip, flavours=("f3
 # reference's outputs.  Lengths where the reference's fp32 log-domain recursion (chain-log-domain-computation.cc:137-158,
 # 256-266 over base.h:14-32) is itself > 1e-4 from the same equations in fp64.
 LONG_CASES = ("c3_slice_den", "c3_slice_num", "num_shared_T720", "fold_T751")
+LONG_CASES_G7 = ("c4_slice_den",)             # fixture g7_c4_slice.npz (round 4): rows of 8408 pdfs
 
 
 def _rand_num_fst(rs, H, extra, D, finals):
@@ -200,6 +201,12 @@ def long_case(name):
                         num=None, num_list=None, leaky=1e-5)
         return dict(x=x, lengths=L, kind="num", den=None, num=syn.make_num_graphs(L.tolist(), cfg["D"], seed=100),
                     num_list=None, leaky=1e-5)
+    if name == "c4_slice_den":
+        # the C4 graph and pdf count (BASELINE.json configs[3]: rows of 8408 pdfs - the 16-wave map for rows beyond 4096 pdfs and
+        # the rows exp'd ahead of the recursions), two utterances of 400 and 333 frames
+        cfg = syn.CONFIGS["C4"]
+        return dict(x=syn.make_input(2, 400, cfg["D"], seed=4), lengths=torch.tensor([400, 333]), kind="den",
+                    den=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0), num=None, num_list=None, leaky=1e-5)
     if name == "num_shared_T720":
         # one 700-state branching numerator graph shared by both utterances (graph stride 0), D = 48
         rs = np.random.RandomState(5)

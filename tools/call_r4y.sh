@@ -1,4 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 120 python -m pytest tests/test_gpu_robust.py -m gpu -q -x 2>&1 | tail -2
+timeout 150 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "c4_shape_slice or c3_shape_slice" 2>&1 | tail -4
