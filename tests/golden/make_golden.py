@@ -358,7 +358,7 @@ def gen_long(names=None, fixture="g6_long"):
         absmax = float(np.abs(ref).max())
         dist = np.abs(ref - g64).max(-1)                              # [B, T]
         ref_vs_f64 = float(dist.max() / np.abs(g64).max())
-        nrows = 12 if c["kind"] != "num" and x.shape[2] > 1024 else 160     # (dense rows of 8 - 14 KB)
+        nrows = (12 if x.shape[2] > 1024 else 24) if c["kind"] == "den" else (12 if c["kind"] != "num" and x.shape[2] > 1024 else 160)   # (dense rows of 4 - 34 KB)
         worst = np.dstack(np.unravel_index(np.argsort(dist, axis=None)[::-1][:nrows // 2], dist.shape))[0]
         live = [(b, t) for b in range(B) for t in range(int(L[b]))]
         spread = np.array(live)[np.linspace(0, len(live) - 1, nrows - len(worst)).astype(int)]

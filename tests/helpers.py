@@ -173,7 +173,7 @@ def oracle_fanout(x_cpu, lengths, den_graph, num_graphs, grad_hip, flavours=("f3
 # reference's outputs.  Lengths where the reference's fp32 log-domain recursion (chain-log-domain-computation.cc:137-158,
 # 256-266 over base.h:14-32) is itself > 1e-4 from the same equations in fp64.
 LONG_CASES = ("c3_slice_den", "c3_slice_num", "num_shared_T720", "fold_T751")
-LONG_CASES_G7 = ("c4_slice_den",)             # fixture g7_c4_slice.npz (round 4): rows of 8408 pdfs
+LONG_CASES_G7 = ("c4_slice_den", "c2_slice_den")     # fixture g7_c4_slice.npz (round 4): rows of 8408 pdfs; a small graph
 
 
 def _rand_num_fst(rs, H, extra, D, finals):
@@ -206,6 +206,11 @@ def long_case(name):
         # the rows exp'd ahead of the recursions), two utterances of 400 and 333 frames
         cfg = syn.CONFIGS["C4"]
         return dict(x=syn.make_input(2, 400, cfg["D"], seed=4), lengths=torch.tensor([400, 333]), kind="den",
+                    den=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0), num=None, num_list=None, leaky=1e-5)
+    if name == "c2_slice_den":
+        # the C2 graph (BASELINE.json configs[1]: 200 states - four-wave workgroups), three ragged utterances of the benchmark length
+        cfg = syn.CONFIGS["C2"]
+        return dict(x=syn.make_input(3, 150, cfg["D"], seed=6), lengths=torch.tensor([150, 149, 64]), kind="den",
                     den=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0), num=None, num_list=None, leaky=1e-5)
     if name == "num_shared_T720":
         # one 700-state branching numerator graph shared by both utterances (graph stride 0), D = 48

@@ -115,7 +115,8 @@ G6_RESTATEMENT_BOUND = {"c3_slice_den": 1e-5,        # measured 1.1e-6
                         "c3_slice_num": 1e-4,        # measured 9.2e-5 (1.33e-4 before log_add used the float log1pf / expf of base.h:26)
                         "num_shared_T720": 1e-4,     # measured 6.1e-5
                         "fold_T751": 1e-4,           # measured 3.0e-5
-                        "c4_slice_den": 2e-6}        # G7 (rows of 8408 pdfs): measured 3.7e-7
+                        "c4_slice_den": 2e-6,        # G7 (rows of 8408 pdfs): measured 3.7e-7
+                        "c2_slice_den": 3e-6}        # G7 (a 200-state graph): measured 9.8e-7
 
 
 @pytest.mark.parametrize("name", list(G6_RESTATEMENT_BOUND))
@@ -127,7 +128,7 @@ def test_g6_long_sequences(golden, name):
       fp64 flavour: reproduces the fixture's fp64 rows (they were produced by it: guards the checker itself);
       the fixture's own claim `ref_vs_f64` is re-measured on the stored rows (the worst rows are among them)."""
     from helpers import G6Case, long_case, long_case_oracle
-    g6 = G6Case(golden("g7_c4_slice" if name == "c4_slice_den" else "g6_long"), name)
+    g6 = G6Case(golden("g7_c4_slice" if name in ("c4_slice_den", "c2_slice_den") else "g6_long"), name)
     case = long_case(name)
     g6.check_input(case)
     o32, g32 = long_case_oracle(case, "f32")
@@ -139,7 +140,7 @@ def test_g6_long_sequences(golden, name):
     assert g6.dist_f64(g64) <= 1e-7                       # (the fixture keeps the fp64 rows rounded to float)
     own_rows = float(np.abs(g6.ref_rows - g6.f64_rows).max() / np.abs(g64).max())
     assert abs(own_rows - g6.ref_vs_f64) <= 1e-7 + 1e-3 * g6.ref_vs_f64, (own_rows, g6.ref_vs_f64)
-    if name not in ("c3_slice_den", "c4_slice_den"):      # the point of G6: the reference itself is not within 1e-4 of exact math
+    if name not in ("c3_slice_den", "c4_slice_den", "c2_slice_den"):      # the point of G6: the reference itself is not within 1e-4 of exact math
         assert 1e-4 < g6.ref_vs_f64 < 2.5e-4, g6.ref_vs_f64
     else:
         assert g6.ref_vs_f64 < 2e-6

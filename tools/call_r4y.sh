@@ -1,3 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 150 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "c4_shape_slice or c3_shape_slice" 2>&1 | tail -4
+timeout 150 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "c4_shape_slice or c2_shape_slice" 2>&1 | tail -4
