@@ -91,7 +91,7 @@ def test_training_example_two_ranks_ddp_on_gloo():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     seen = dict((int(m.group(1)), (float(m.group(2)), float(m.group(3))))
-                for m in re.finditer(r"rank (\d) of 2: global loss (\S+) -> (\S+)", r.stdout))
+                for m in re.finditer(r"rank (\d) of 2: global loss (-?\d+\.\d+(?:e-?\d+)?) -> (-?\d+\.\d+(?:e-?\d+)?)", r.stdout))   # (the two ranks' lines may interleave)
     assert sorted(seen) == [0, 1], r.stdout
     assert seen[0] == seen[1]                         # the value every rank holds is the global one
     assert seen[0][1] < seen[0][0]                    # and it fell
