@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 13
+#define PYCHAIN_HIP_ABI_VERSION 14
 
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
@@ -191,19 +191,26 @@ int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t 
  * bad_count: dev int32[1]; zeroed by the call, incremented by every frame or
  *   sequence whose normaliser is not finite-positive (the reference's `ok`
  *   flag, chain-computation.cc:367-390, without a host sync).
- * totals: dev float[4] or NULL.  The call's last kernel adds up what a caller otherwise computes in several
+ * totals: dev float[PYCHAIN_HIP_TOTALS = 8] or NULL.  The call's last kernel adds up what a caller otherwise computes in several
  *   launch-bound scalar kernels behind it (the reference: `tot_log_prob.sum()`, chain-computation.cc:229):
  *   totals[0] = totals[3] = sum_b objf_per_seq[b] (fp64 accumulation, rounded once), totals[1] = sum_b len_b,
- *   totals[2] = bad_count as a float.
+ *   totals[2] = bad_count as a float; totals[4] = totals[0] once more (ABI 14: the scalar a host framework hands out as the
+ *   loss, apart from the statistics in [0..3] that it may all-reduce or keep), totals[5..7] = 0.
  * workspace: the stored alpha' / beta rows (4 B T roundup64(num_states) bytes each), per-frame totals, counters, and - in a
  *   call of the denominator alone - a [B,T,D] buffer for the rows exp'd ahead of the recursions (den_exp_rows_kernel: C4
  *   4.80 -> 4.57 ms): pychain_hip_den_workspace_bytes; pychain_hip_den_workspace_min_bytes is the size without it.
  */
-#define PYCHAIN_HIP_TOTALS 4
+#define PYCHAIN_HIP_TOTALS 8
 size_t pychain_hip_den_workspace_bytes(int B, int T, int num_states, int num_pdfs);
 /* ... without the [B,T,D] buffer: a workspace of at least this size is accepted everywhere; the rows are then never exp'd
  * ahead (the fused loss never does: its callers pass this size). */
 size_t pychain_hip_den_workspace_min_bytes(int B, int T, int num_states, int num_pdfs);
+/* 1 if pychain_hip_den_forward_backward with these arguments (and the calling thread's options) would use the [B,T,D] buffer
+ * of the full workspace, else 0: a caller that caches its workspace asks before it allocates as much again as the network
+ * output (1.3 GB at C3) for calls that never touch it (pair / general / two-barrier kernels, T < 64, exp'd input, a recursion
+ * grid that leaves less than a quarter of the chip free). */
+int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int resident_slot_rows, int num_states, int num_pdfs,
+                                    int B, int T, int input_is_exp);
 int pychain_hip_den_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows,
     int num_states, int num_pdfs,
@@ -300,11 +307,12 @@ int pychain_hip_chain_loss_forward_backward(
  *              read on the device: no host sync and no extra pass over [B,T,D] to apply it
  *              (the reference multiplies the stored gradient again, loss.py:85).
  * bad_count: dev int32[2] for _forward, dev int32[2] for _backward (may be the same words).
- * totals (dev float[4] or NULL; _forward and _forward_backward): the scalars of ChainLoss.forward from the call's last
+ * totals (dev float[PYCHAIN_HIP_TOTALS = 8] or NULL; _forward and _forward_backward): the scalars of ChainLoss.forward from the call's last
  *   kernel instead of from half a dozen scalar kernels of the host framework behind it (pychain/loss.py:100-104):
  *   totals[0] = (sum_b den_objf[b] - sum_b num_objf[b]) * loss_scale [/ *loss_norm_dev]  = -(num - den) [/ frames],
  *   totals[1] = sum_b len_b, totals[2] = bad_count[0] + bad_count[1] as a float (what a sharded trainer all-reduces
- *   with the loss), totals[3] = sum den - sum num unscaled.  loss_norm_dev: device float or NULL.
+ *   with the loss), totals[3] = sum den - sum num unscaled, totals[4] = totals[0], totals[5..7] = 0.  loss_norm_dev: device
+ *   float or NULL.
  */
 int pychain_hip_chain_loss_forward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,

@@ -10,7 +10,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 13
+ABI_VERSION = 14
+TOTALS = 8            # floats of a `totals` buffer (include/pychain_hip.h: PYCHAIN_HIP_TOTALS)
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
 
@@ -35,6 +36,7 @@ _SIGNATURES = {
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pychain_hip_den_workspace_min_bytes": (_sz, [_i, _i, _i, _i]),
     "pychain_hip_den_plan_info": (_i, [_vp, _sz, _vp]),
+    "pychain_hip_den_uses_row_buffer": (_i, [_i64, _i, _i, _i, _i, _i, _i]),
     "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _f,
                                               _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pychain_hip_num_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -372,6 +372,15 @@ bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
          (den_lazy_eligible(a, resident_slot_rows) || den_call_is_small(a, resident_slot_rows) || den_call_is_dma(a, resident_slot_rows));
 }
 
+// Would a call of the denominator alone, given a workspace with the [B,T,D] buffer, exp its rows ahead of the recursions (§3.9)?
+// (a.lazy / a.shape / a.pair decided.)  The recursion workgroups spin on rows that launch writes and each takes a whole CU, so the
+// launch must find CUs of its own whatever the order of dispatch: at least a quarter of the chip stays free of recursion
+// workgroups, else the recursions exp their rows themselves (2B >= the CU count with pairing off could hang).
+bool den_would_exp_rows_ahead(const DenArgs& a) {
+  return a.lazy && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && !a.input_is_exp &&
+         a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && 4 * den_recursion_blocks(a) <= 3 * device_cu_count();
+}
+
 // option debug_corrupt_row: row[0..n) *= scale, between the recursion and the occupancy launches
 __global__ void scale_row_kernel(float* row, int n, float scale) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) row[i] *= scale;
@@ -440,9 +449,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   // numerator until T/2, the occupancy launch from there to the end - and the launch's registers and HBM traffic held the
   // numerator back by 1 ms (C3: 3.02 -> 3.31 ms per step with it, although the recursion itself ran 4 % faster:
   // profiles/r04_u_C3_step_timeline_rows_exp_ahead_in_the_fused_step.txt).
-  const bool exp_ahead = a.ex != nullptr && zeroed == nullptr &&
-                         a.lazy && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && !a.input_is_exp &&
-                         a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && (user_mask & 1) != 0;
+  const bool exp_ahead = a.ex != nullptr && zeroed == nullptr && den_would_exp_rows_ahead(a) && (user_mask & 1) != 0;
   SideStream* const side_pre = exp_ahead ? side_streams_for(st) : nullptr;
   if (exp_ahead && !side_pre) { *why = "cannot create the side streams"; return hipErrorInvalidValue; }
   bool forked = false;                                      // stream2 waits for the zeroed counters (and the caller's x)
@@ -552,6 +559,19 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
   return e;
 }
 }  // namespace
+
+extern "C" int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T,
+                                              int input_is_exp) {
+  if (B <= 0 || T <= 0 || H <= 0 || D <= 0 || resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) return 0;
+  DenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.plan_stride = plan_stride_bytes; a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H); a.input_is_exp = input_is_exp ? 1 : 0;
+  a.knobs = call_knobs();
+  a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
+  a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
+  a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
+  return den_would_exp_rows_ahead(a) ? 1 : 0;
+}
 
 extern "C" int pychain_hip_debug_stream_rings(int T, int32_t* out, int out_len, int32_t* report_due, int due_len) {
   if (T <= 0 || out_len < 0 || due_len < 0 || (out_len && !out) || (due_len && !report_due))

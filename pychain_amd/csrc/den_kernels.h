@@ -81,7 +81,7 @@ struct DenArgs {
   // Step totals (include/pychain_hip.h: loss_out): the den_finish_kernel workgroup that finishes LAST adds up what the host
   // framework would otherwise compute in half a dozen launch-bound scalar kernels behind it (sums of the per-sequence
   // objectives, the loss arithmetic of pychain/loss.py:100-104, frame and bad counts).  Null = not wanted.
-  float* loss_out;               // [4]: loss, frames, bad total, sum den - sum num (unscaled)
+  float* loss_out;               // [8]: loss, frames, bad total, sum den - sum num (unscaled), loss again, 0, 0, 0
   const float* loss_num_objf;    // [B] numerator objectives (written by an earlier launch), or null: denominator only
   float loss_scale;              // loss = (sum den - sum num) * loss_scale [/ *loss_norm_dev]
   const float* loss_norm_dev;    // optional device scalar (the frame count of avg = True when the lengths live on the device)

@@ -155,7 +155,8 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
       if (oi - oi == 0.f && !(fabs(log((double)g0) + (double)di) <= 0.0487901642)) nfail += 1.0;
     }
     acc += (double)oi;
-    if (a.loss_num_objf) acc -= (double)a.loss_num_objf[i];
+    if (a.loss_num_objf)                                   // (written by the numerator's kernels on another stream: device-scope read)
+      acc -= (double)__hip_atomic_load(a.loss_num_objf + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     frames += (double)seq_len(a.lengths, i, a.T);
   }
   fin_block_sum2(acc, frames, part2, tid);
@@ -165,10 +166,12 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
     if (nfail > 0.0) atomicAdd(a.bad, (int)nfail);
     if (a.loss_out) {
       double t = acc * (double)a.loss_scale;                 // -(num - den) [* 1/frames], pychain/loss.py:100-104, rounded once
-      if (a.loss_norm_dev) t /= (double)*a.loss_norm_dev;
+      if (a.loss_norm_dev) t /= (double)__hip_atomic_load(a.loss_norm_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int nbad = 0;
       for (int i = 0; i < a.bad_words; i++) nbad += __hip_atomic_load(a.bad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       a.loss_out[0] = (float)t; a.loss_out[1] = (float)frames; a.loss_out[2] = (float)nbad; a.loss_out[3] = (float)acc;
+      a.loss_out[4] = (float)t;                              // (a second copy: the scalar a caller hands out, apart from the statistics)
+      a.loss_out[5] = a.loss_out[6] = a.loss_out[7] = 0.f;
     }
   }
 }

@@ -442,7 +442,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       ready_lo = min(rows_of_end(0), Lh); ready_hi = min(rows_of_end(1), L - Lh);
       if (t < ready_lo || t >= L - ready_hi) break;
       __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > 2000000000ull) { bad |= 1; break; }   // 20 s: den_exp_rows_kernel died
+      if (wall_clock64() - t0 > 2000000000ull) {          // 20 s: den_exp_rows_kernel died; no later row waits again
+        bad |= 1; ready_lo = Lh; ready_hi = L - Lh; break;
+      }
     }
   };
   // row t -> the buffer at xbase (LDS-direct); device-scope loads for rows another kernel is writing meanwhile

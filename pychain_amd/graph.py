@@ -246,7 +246,8 @@ class ChainGraphBatch(object):
                 d.pop(name, None)
             # a pageable copy travels (torch's pickler moves a tensor's storage into shared memory IN PLACE, which would
             # un-pin this batch's buffer and re-stage it); the receiver decides about pinning.  The copy has to outlive the
-            # pickling - the receiver maps its shared-memory file later - so it stays with the batch.
+            # pickling - the receiver maps its shared-memory file later - so it stays with the batch (cost: one more host copy
+            # of the batch's buffer, a few hundred KB at C3, until the next pickle replaces it or the batch dies).
             d["_staging"] = self.__dict__["_pickle_keepalive"] = self._staging.clone()
             d["_repack"] = True
         return d

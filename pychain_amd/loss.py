@@ -63,8 +63,8 @@ class ChainFunction(torch.autograd.Function):
             if totals:
                 objf, input_grad, bad, tot = native.den_forward_backward(
                     plan, x, input_lengths, leaky_coefficient, input_is_exp=False, totals=True)
-                ChainFunction.last_totals = tot
-                objf = tot[0]                  # (a view: no launch)
+                ChainFunction.last_totals = tot[:4]
+                objf = native.totals_scalar(tot)   # (no launch; not a view of the statistics)
             else:
                 objf, input_grad, bad = native.den_forward_backward(
                     plan, x, input_lengths, leaky_coefficient, input_is_exp=False)
@@ -94,7 +94,7 @@ class ChainFunction(torch.autograd.Function):
         ctx.in_dtype = input.dtype   # fp16 / bf16 inputs are evaluated in fp32; the gradient goes back in their dtype
         ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
         ChainFunction.last_bad_count = bad
-        return objf.sum() if objf.dim() else objf              # (0-dim: the sum came with the call, a view of `last_totals`)
+        return objf.sum() if objf.dim() else objf              # (0-dim: the sum came with the call)
 
     retain_grad_buffer = False
     last_totals = None           # device float[4] of the last native call that produced them (include/pychain_hip.h: totals)
@@ -173,8 +173,8 @@ class ChainLossFunction(torch.autograd.Function):
             with_grad=ctx.speculative, grad_scale=ctx.host_scale, loss_scale=ctx.host_scale, norm_dev=ctx.dev_norm)
         # -(num - den) [/ frames], loss.py:100-104, comes with the call (the last workgroup of its last kernel adds the
         # per-sequence objectives up): no reduction / subtraction / scaling launches behind it
-        objf = totals[0]                       # (a view: no launch)
-        ChainFunction.last_totals = totals
+        objf = native.totals_scalar(totals)    # (no launch; not a view of the statistics: `loss /= n` works)
+        ChainFunction.last_totals = totals[:4]
         ctx.state = state
         # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
         spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)
@@ -220,6 +220,9 @@ class ChainLoss(nn.Module):
         den_objf = ChainFunction.apply(x, x_lengths, den_graphs, self.leaky_coefficient)
         num_objf = ChainFunction.apply(x, x_lengths, num_graphs)
         objf = -(num_objf - den_objf)
+        # (two native calls made this loss: the totals of the LAST of them are not the step's - ShardedChainLoss must
+        # not mistake them for [loss, frames, bad] of the step and falls back to all-reducing its own three scalars)
+        ChainFunction.last_totals = None
         if self.avg:
             objf = objf / x_lengths.sum()
         return objf

@@ -79,8 +79,10 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
         objf = torch.empty(B, dtype=torch.float32, device=dev)
         grad = torch.empty_like(x)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
-        tot = torch.empty(4, dtype=torch.float32, device=dev) if totals else None
-        nws = L.pychain_hip_den_workspace_bytes(B, T, int(num_states), D)
+        tot = torch.empty(_lib.TOTALS, dtype=torch.float32, device=dev) if totals else None
+        # (the [B,T,D] buffer of the rows exp'd ahead only where this call will use it: ADVICE r4)
+        full = L.pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, int(num_states), D, B, T, int(bool(input_is_exp)))
+        nws = (L.pychain_hip_den_workspace_bytes if full else L.pychain_hip_den_workspace_min_bytes)(B, T, int(num_states), D)
         ws = _workspace(nws, dev, "den")
         _lib.check(L.pychain_hip_den_forward_backward(
             plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(),
@@ -191,7 +193,7 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
         den_objf = torch.empty(B, dtype=torch.float32, device=dev)
         num_objf = torch.empty(B, dtype=torch.float32, device=dev)
         bad = torch.empty(2, dtype=torch.int32, device=dev)
-        totals = torch.empty(4, dtype=torch.float32, device=dev)
+        totals = torch.empty(_lib.TOTALS, dtype=torch.float32, device=dev)
         if norm_dev is not None:
             norm_dev = norm_dev.detach().to(device=dev, dtype=torch.float32).contiguous()
         # per-call workspaces (they must survive until backward); the caching allocator makes this cheap
@@ -252,6 +254,13 @@ def loss_total(den_objf, num_objf, scale=1.0, norm_dev=None):
             den_objf.data_ptr(), 0 if num_objf is None else num_objf.data_ptr(), den_objf.numel(), float(scale),
             0 if norm_dev is None else norm_dev.data_ptr(), out.data_ptr(), _stream(dev)), "pychain_hip_loss_total")
     return out
+
+
+def totals_scalar(totals):
+    """The call's scalar (totals[4], the second copy of totals[0]: include/pychain_hip.h) as a 0-dim tensor that is NOT an
+    autograd view and shares no element with the statistics totals[:4]: a caller may `loss /= n` in place, as it may with
+    the fresh tensor the reference returns (a view created inside a custom Function refuses in-place ops)."""
+    return torch.empty((), dtype=totals.dtype, device=totals.device).set_(totals.untyped_storage(), totals.storage_offset() + 4, ())
 
 
 def rescale_(t, scale_dev):

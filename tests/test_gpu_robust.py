@@ -295,3 +295,67 @@ def test_streamed_and_gated_schedules_with_a_second_process_on_the_gpu():
     finally:
         hog.kill()                                   # (our own child, by handle)
         hog.wait()
+
+
+def test_the_loss_scalar_takes_inplace_ops_like_the_reference():
+    """the reference returns a fresh tensor (`tot_log_prob.sum()`, pychain/loss.py:78,100-104), and trainers write
+    `loss /= n`.  The scalar that comes with the call (totals[4]) must not be an autograd view of a buffer created inside the
+    Function (in-place ops on such views raise) and must not share an element with the step's statistics."""
+    w = syn.make_workload("C1")
+    for fused in (True, False):
+        x = w["x"].to(DEV).requires_grad_(True)
+        crit = ChainLoss(w["den_graph"], 1e-5, avg=False)
+        crit.fused = fused
+        loss = crit(x, w["lengths"], w["num_graphs"])
+        stats = None if ChainFunction.last_totals is None else ChainFunction.last_totals.clone()
+        ref = float(loss.detach())
+        loss /= 4.0
+        loss *= 2.0
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(float(loss.detach()) - ref / 2.0) <= 1e-6 * abs(ref)
+        if fused:
+            assert stats is not None and torch.equal(stats, ChainFunction.last_totals) and float(stats[0]) == ref
+        else:
+            assert ChainFunction.last_totals is None      # two native calls: no totals of the step (ShardedChainLoss falls back)
+        x2 = w["x"].to(DEV).requires_grad_(True)
+        crit(x2, w["lengths"], w["num_graphs"]).backward()
+        assert torch.allclose(x.grad, x2.grad * 0.5, rtol=1e-6, atol=0)
+    # ChainFunction alone (the denominator)
+    x = w["x"].to(DEV).requires_grad_(True)
+    o = ChainFunction.apply(x, w["lengths"], ChainGraphBatch(w["den_graph"], 2), 1e-5)
+    o += 1.0
+    o.backward()
+    torch.cuda.synchronize()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.timeout(300)
+def test_recursion_grid_that_fills_the_chip_does_not_wait_for_rows_nobody_can_write():
+    """with 2B >= the CU count and pairing off (rows beyond 4096 pdfs, option den_pair = 0) every CU holds a
+    recursion workgroup; if those spin on rows den_exp_rows_kernel has yet to write, that launch would never become
+    resident.  Such a call must exp its rows itself: it ends, and with the same numbers as option den_dma = 2."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B, T, D = max(128, (cus + 1) // 2), 64, 4100
+    den = syn.make_den_graph(1100, 6000, D, seed=4)          # more than 1024 states: 16-wave workgroups, one to a CU
+    L = torch.full((B,), T, dtype=torch.long)
+    L[1::3] = 40
+    x = syn.make_input(B, T, D, seed=5, device=DEV)
+    plan = _plan.graph_plan(den, D, torch.device(DEV))
+    outs = []
+    for opts in ({"den_pair": 0}, {"den_pair": 0, "den_dma": 2}):
+        ctx = [_lib.option(k, v) for k, v in opts.items()]
+        for c in ctx:
+            c.__enter__()
+        try:
+            assert _lib.den_kernel_names(plan.slot_rows, den.num_states, D, B)[0] == "den_recursion_lazy_kernel<dma>"
+            assert _lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, den.num_states, D, B, T, 0) == 0
+            assert _lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, den.num_states, D, 8, T, 0) == (0 if "den_dma" in opts else 1)
+            objf, grad, bad = native.den_forward_backward(plan, x, L)
+            torch.cuda.synchronize()
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+        assert int(bad.sum()) == 0
+        outs.append((objf.clone(), grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
