@@ -28,7 +28,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
-                                     "debug_corrupt_row"};
+                                     "debug_corrupt_row", "num_compat"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -65,6 +65,7 @@ CallKnobs call_knobs() {
   k.gamma16 = option_set("gamma16");
   k.den_pair = option_int("den_pair", -1);
   k.den_dma = option_int("den_dma", -1);
+  k.num_compat = option_int("num_compat", 0) ? 1 : 0;
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
@@ -617,8 +618,8 @@ extern "C" int pychain_hip_den_forward_backward(
 }
 
 namespace {
-struct NumCarve { size_t alpha, beta, logp, rows, upd, ucount, uidx, frac, gacc, total; };
-NumCarve num_carve(int B, int T, int H, int K, int D) {
+struct NumCarve { size_t alpha, beta, logp, rows, upd, ucount, uidx, frac, gacc, compat, total; };
+NumCarve num_carve(int B, int T, int H, int K, int D, bool compat) {
   NumCarve c;
   c.alpha = 0;
   c.beta = c.alpha + align256(8 * (size_t)B * (T + 1) * H);
@@ -629,7 +630,8 @@ NumCarve num_carve(int B, int T, int H, int K, int D) {
   c.uidx = c.ucount + align256(4 * (size_t)B);
   c.frac = c.uidx + align256(4 * (size_t)B * K);
   c.gacc = c.frac + align256(4 * (size_t)B * T * K);           // general kernels only (num_general.hip): accumulator rows
-  c.total = c.gacc + (num_needs_general(H, K, D) ? align256(num_general_acc_bytes(D)) : 0) + 256;
+  c.compat = c.gacc + (num_needs_general(H, K, D) ? align256(num_general_acc_bytes(D)) : 0);
+  c.total = c.compat + (compat ? (size_t)B * num_compat_stride(H, K) : 0) + 256;   // (option num_compat: num_compat.hip)
   return c;
 }
 
@@ -651,7 +653,8 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
     return fail(PYCHAIN_HIP_EINVAL, "%s: unknown grad_mode %d", who, grad_mode);
   if (((uintptr_t)nnet_output | (uintptr_t)grad | (uintptr_t)fi | (uintptr_t)bi) & 15)
     return fail(PYCHAIN_HIP_EINVAL, "%s: nnet_output, grad and index tensors must be 16-byte aligned", who);
-  const NumCarve c = num_carve(B, T, H, K, D);
+  const CallKnobs knobs = call_knobs();
+  const NumCarve c = num_carve(B, T, H, K, D, knobs.num_compat != 0);
   if (workspace_bytes < c.total) return fail(PYCHAIN_HIP_EWORKSPACE, "%s: workspace too small", who);
   memset(&a, 0, sizeof(a));
   a.fwd_trans = ft; a.fwd_idx = fi; a.fwd_probs = fp; a.bwd_trans = bt; a.bwd_idx = bi; a.bwd_probs = bp;
@@ -659,7 +662,6 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
   a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
   a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 32;
-  const CallKnobs knobs = call_knobs();
   a.check_all = knobs.verbose >= 1 ? 1 : 0;
   if (knobs.corrupt_what == 2 && knobs.corrupt_b < B && knobs.corrupt_t < T) {
     a.corrupt_b = knobs.corrupt_b; a.corrupt_t = knobs.corrupt_t; a.corrupt_log = logf(knobs.corrupt_scale);
@@ -671,13 +673,14 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   a.uidx_ws = (int32_t*)(ws + c.uidx); a.frac_ws = (float*)(ws + c.frac);
   a.general = num_needs_general(H, K, D) ? 1 : 0;             // graphs beyond the tile kernels: num_general.hip
   a.gen_acc = ws + c.gacc;
+  a.compat = knobs.num_compat; a.compat_ws = ws + c.compat; a.compat_stride = num_compat_stride(H, K);
   return PYCHAIN_HIP_OK;
 }
 }  // namespace
 
 extern "C" size_t pychain_hip_num_workspace_bytes(int B, int T, int H, int K, int D) {
   if (B <= 0 || T <= 0 || H <= 0 || K <= 0 || D <= 0) return 0;
-  return num_carve(B, T, H, K, D).total;
+  return num_carve(B, T, H, K, D, call_knobs().num_compat != 0).total;   // (the calling thread's options, as the call will read them)
 }
 
 extern "C" int pychain_hip_num_forward_backward(
@@ -697,9 +700,14 @@ extern "C" int pychain_hip_num_forward_backward(
   if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(PYCHAIN_HIP_ELAUNCH, "num_forward_backward: hipMemsetAsync failed");
   const char* why = nullptr;
-  hipError_t e = launch_num_fb(a, st, &why);
-  if (e == hipSuccess && a.corrupt_b >= 0) e = launch_num_corrupt(a, st);
-  if (e == hipSuccess) e = launch_num_occ(a, false, st, &why);
+  hipError_t e = hipSuccess;
+  if (a.compat) {                                        // the reference's own arithmetic, one launch (num_compat.hip)
+    e = launch_num_compat(a, 3, st);
+  } else {
+    e = launch_num_fb(a, st, &why);
+    if (e == hipSuccess && a.corrupt_b >= 0) e = launch_num_corrupt(a, st);
+    if (e == hipSuccess) e = launch_num_occ(a, false, st, &why);
+  }
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "num_forward_backward: %s",
                 why ? why : hipGetErrorString(e));
@@ -739,7 +747,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
-  const bool fold = grad && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL && !na.general &&
+  const bool fold = grad && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL && !na.general && !na.compat &&
                     den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
   if (fold) {
     da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
@@ -748,10 +756,12 @@ extern "C" int pychain_hip_chain_loss_forward(
   // fork: numerator on the side stream, denominator recursion on the caller's stream
   if (e == hipSuccess) e = hipEventRecord(side->fork, st);
   if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
-  if (e == hipSuccess && grad) e = launch_num_prep(na, side->stream, &why);
-  if (e == hipSuccess) e = launch_num_fb(na, side->stream, &why);
-  if (e == hipSuccess && na.corrupt_b >= 0) e = launch_num_corrupt(na, side->stream);
-  if (e == hipSuccess && grad && !na.general) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
+  // (option num_compat: the numerator is ONE launch behind the denominator's occupancy launches - it accumulates into the
+  // gradient they wrote - and in front of den_finish_kernel, which reads its log-probabilities)
+  if (e == hipSuccess && grad && !na.compat) e = launch_num_prep(na, side->stream, &why);
+  if (e == hipSuccess && !na.compat) e = launch_num_fb(na, side->stream, &why);
+  if (e == hipSuccess && na.corrupt_b >= 0 && !na.compat) e = launch_num_corrupt(na, side->stream);
+  if (e == hipSuccess && grad && !na.general && !na.compat) e = launch_num_occ(na, true, side->stream, &why);   // compact rows, off the critical path
   if (e == hipSuccess) e = hipEventRecord(side->join, side->stream);
   da.phase_mask = da.knobs.den_phase_mask == 0 ? 0 : 3;     // (mask 0: only the numerator's launches - a measurement aid, outputs not meaningful)
   // (den_finish_kernel reads the numerator's objectives and its bad count for `totals`: the join precedes it)
@@ -762,8 +772,9 @@ extern "C" int pychain_hip_chain_loss_forward(
   // event and the caller's stream for that launch - one barrier packet less, ~5 us, between it and den_finish_kernel)
   const bool joined = fold && da.phase_mask == 3;     // (every schedule of run_den_launches puts the wait in front of its first occupancy launch)
   if (e == hipSuccess && !joined) e = hipStreamWaitEvent(st, side->join, 0);
+  if (e == hipSuccess && na.compat) e = launch_num_compat(na, grad ? 3 : 1, st);            // grad -= grad_scale * gamma_num, the reference's way
   if (e == hipSuccess && (da.phase_mask & 1) && !finished) e = launch_den_finish(da, st);     // (phase mask 0: the numerator alone - bench.py times it so)
-  if (e == hipSuccess && grad && !fold)                                             // grad -= grad_scale * gamma_num
+  if (e == hipSuccess && grad && !fold && !na.compat)                               // grad -= grad_scale * gamma_num
     e = na.general ? launch_num_occ(na, false, st, &why) : launch_num_scatter(na, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
@@ -855,7 +866,7 @@ int chain_loss_backward_impl(
   da.phase_mask = 2;
   if (e == hipSuccess)
     e = resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL ? launch_den_general(da, st) : launch_den(da, (D + 63) / 64, resident_slot_rows, st, &why);
-  if (e == hipSuccess) e = launch_num_occ(na, false, st, &why);
+  if (e == hipSuccess) e = na.compat ? launch_num_compat(na, 2, st) : launch_num_occ(na, false, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
   return PYCHAIN_HIP_OK;

@@ -27,6 +27,7 @@ struct CallKnobs {
   // debug_corrupt_row = "den|num,b,t,scale": one stored alpha row is scaled before the occupancy pass reads it,
   // so that the reference's 5 % invariant (chain-computation.cc:363-390, chain-log-domain-computation.cc:289-303)
   // can be seen to fire
+  int num_compat;             // 1: the numerator in the reference's own fp32 arithmetic (num_compat.hip) instead of the exact path
   int corrupt_what;           // 0 none, 1 denominator, 2 numerator
   int corrupt_b, corrupt_t;
   float corrupt_scale;

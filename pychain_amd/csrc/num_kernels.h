@@ -46,6 +46,12 @@ struct NumArgs {
   // occupancy launch's accumulator rows in the workspace (kNumGeneralBlocks x D 64-bit words)
   int general;
   void* gen_acc;
+  // option num_compat = 1 (num_compat.hip): the reference's own fp32 arithmetic - LogAdd with its cut-off, per-frame
+  // renormalisation, the reference's term order - instead of the exact fp64 path; compat_ws = per-sequence scratch of
+  // compat_stride bytes (sort keys, per-arc occupation log-probabilities, beta rows)
+  int compat;
+  char* compat_ws;
+  size_t compat_stride;
 };
 
 // Numerator graphs the tile kernels do not take - more than 65 535 states or pdfs, or state vectors + nnet-output rows +
@@ -56,6 +62,11 @@ bool num_needs_general(int H, int K, int D);
 size_t num_general_acc_bytes(int D);
 hipError_t launch_num_general_fb(const NumArgs& a, hipStream_t st);
 hipError_t launch_num_general_occ(const NumArgs& a, void* acc, hipStream_t st);
+
+// the numerator in the reference's arithmetic, one workgroup per sequence (NumArgs::compat); phases bit 0: alpha, the
+// log-probabilities and beta's start row; bit 1: beta and the gradient (from what bit 0 left in the workspace)
+size_t num_compat_stride(int H, int K);
+hipError_t launch_num_compat(const NumArgs& a, int phases, hipStream_t st);
 
 size_t num_fb_lds_bytes(int H, int K, int D);
 // forward and backward recursions (launch 1, 2B workgroups): reads x + graphs, writes objf, logp_ws, alpha_ws, beta_ws

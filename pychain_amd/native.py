@@ -169,7 +169,7 @@ class ChainLossState(object):
     """What `chain_loss_forward` leaves behind for `chain_loss_backward`: the stored
     trajectories (workspaces) and the handles of everything the occupancy passes read."""
     __slots__ = ("plan", "gt", "graph_stride", "num_states_num", "x", "lengths_dev", "den_ws", "num_ws", "shape",
-                 "grad")
+                 "grad", "num_compat")
 
 
 def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky_coefficient=1e-5,
@@ -213,6 +213,8 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
             dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_forward")
     st.grad = grad
+    # (which numerator wrote the stored rows: backward runs on autograd's thread, where the caller's thread options do not reach)
+    st.num_compat = _lib.get_option("num_compat") or "0"
     st.plan, st.gt, st.graph_stride, st.num_states_num = plan, gt, int(graph_stride), int(num_states_num)
     st.x, st.lengths_dev, st.den_ws, st.num_ws, st.shape = x, ld, dws, nws, (B, T, D, K)
     return den_objf, num_objf, bad, st, totals
@@ -231,14 +233,15 @@ def chain_loss_backward(st, grad_scale=1.0, grad_scale_dev=None):
         if grad_scale_dev is not None:
             grad_scale_dev = grad_scale_dev.detach().to(device=dev, dtype=torch.float32).contiguous()
             sptr = grad_scale_dev.data_ptr()
-        _lib.check(L.pychain_hip_chain_loss_backward(
-            st.plan.blob.data_ptr(), st.plan.stride, st.plan.slot_rows, st.plan.num_states,
-            st.gt["forward_transitions"].data_ptr(), st.gt["forward_transition_indices"].data_ptr(),
-            st.gt["forward_transition_probs"].data_ptr(),
-            st.graph_stride, st.num_states_num, K, st.x.data_ptr(), st.lengths_dev.data_ptr(), B, T, D,
-            float(grad_scale), sptr, grad.data_ptr(), bad.data_ptr(),
-            st.den_ws.data_ptr(), st.den_ws.numel(), st.num_ws.data_ptr(), st.num_ws.numel(), _stream(dev)),
-            "pychain_hip_chain_loss_backward")
+        with _lib.option("num_compat", st.num_compat):
+            _lib.check(L.pychain_hip_chain_loss_backward(
+                st.plan.blob.data_ptr(), st.plan.stride, st.plan.slot_rows, st.plan.num_states,
+                st.gt["forward_transitions"].data_ptr(), st.gt["forward_transition_indices"].data_ptr(),
+                st.gt["forward_transition_probs"].data_ptr(),
+                st.graph_stride, st.num_states_num, K, st.x.data_ptr(), st.lengths_dev.data_ptr(), B, T, D,
+                float(grad_scale), sptr, grad.data_ptr(), bad.data_ptr(),
+                st.den_ws.data_ptr(), st.den_ws.numel(), st.num_ws.data_ptr(), st.num_ws.numel(), _stream(dev)),
+                "pychain_hip_chain_loss_backward")
     return grad, bad
 
 

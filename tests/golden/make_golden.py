@@ -380,7 +380,63 @@ def gen_long(names=None, fixture="g6_long"):
     save(fixture, **out)
 
 
+def gen_sensitivity(fixture="g8_sensitivity"):
+    """G8: how far does the REFERENCE move when its input moves by ONE ulp?  The long numerator cases of
+    G6 through the real binary twice - on x and on x with every element moved to a neighbouring float (direction from a fixed
+    random stream) - and the distance between the two reference gradients in the survey's metric.  If that distance is of
+    the order of 1e-4, "within 1e-4 of the reference" is not a property an implementation can have at that length: the
+    reference does not have it with respect to itself."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import helpers
+    out = {}
+
+    def run(c, x):
+        L, B = c["lengths"], x.shape[0]
+        if c["kind"] == "den":
+            return run_function(x, L, RefChainGraphBatch(to_ref_graph(c["den"]), B), c["leaky"])
+        if c["kind"] == "num":
+            if c["num_list"] is not None and len(c["num_list"]) == 1:
+                rb = RefChainGraphBatch(to_ref_graph(c["num_list"][0]), B)
+            else:
+                rb = _ref_batch_from(c["num"])
+            return run_function(x, L, rb)
+        gs = c["num_list"]
+        rb = RefChainGraphBatch([to_ref_graph(g) for g in gs], max_num_transitions=max(g.num_transitions for g in gs),
+                                max_num_states=max(g.num_states for g in gs))
+        xx = x.clone().requires_grad_(True)
+        loss = RefChainLoss(to_ref_graph(c["den"]), c["leaky"], avg=True)(xx, L, rb)
+        loss.backward()
+        return loss.detach().numpy().astype(np.float32), xx.grad.numpy()
+
+    for name in ("c3_slice_num", "num_shared_T720", "fold_T751", "c3_slice_den"):
+        c = helpers.long_case(name)
+        x = c["x"]
+        rs = np.random.RandomState(12345)
+        up = rs.randint(0, 2, size=x.numel()).astype(bool).reshape(x.shape)
+        xn = x.numpy()
+        xp = torch.from_numpy(np.where(up, np.nextafter(xn, np.float32(np.inf)), np.nextafter(xn, np.float32(-np.inf))).astype(np.float32))
+        o0, g0 = run(c, x)
+        o1, g1 = run(c, xp)
+        g0 = g0.astype(np.float64); g1 = g1.astype(np.float64)
+        d = float(np.abs(g0 - g1).max() / np.abs(g0).max())
+        # the same question to the fp64 evaluation: what part of it is the true derivative of the gradient, what part rounding
+        c2 = dict(c); c2["x"] = xp
+        _, h0 = helpers.long_case_oracle(c, "f64")
+        _, h1 = helpers.long_case_oracle(c2, "f64")
+        d64 = float(np.abs(h0 - h1).max() / np.abs(h0).max())
+        p = name + "__"
+        out[p + "ref_vs_ref_1ulp"] = np.float64(d)
+        out[p + "f64_vs_f64_1ulp"] = np.float64(d64)
+        out[p + "objf"] = np.float64(o0); out[p + "objf_1ulp"] = np.float64(o1)
+        print("%-16s reference(x) vs reference(x +- 1 ulp): grad %.3e (fp64 evaluation: %.3e), objf %.9g vs %.9g (rel %.2e)"
+              % (name, d, d64, float(o0), float(o1), abs(float(o0) - float(o1)) / abs(float(o0))))
+    save(fixture, **out)
+
+
 if __name__ == "__main__":
+    if "--only-g8" in sys.argv:
+        gen_sensitivity()
+        sys.exit(0)
     if "--only-g6" in sys.argv:
         gen_long()
         sys.exit(0)
