@@ -38,6 +38,15 @@ extern "C" {
 
 #define PYCHAIN_HIP_ABI_VERSION 14
 
+/* Element type of the network output [B,T,D] - and of the gradient an entry point writes for it (ABI 14).
+ * 2-byte rows are read as they are by the kernels and converted where they land; the gradient is rounded (to nearest even)
+ * to the same type where it is written: no up-cast pass, no fp32 copy of [B,T,D], no cast of the gradient back.  All
+ * arithmetic is fp32 (fp64 for the numerator's log-probabilities) whatever the storage type.  Not every kernel family takes
+ * 2-byte rows: ask pychain_hip_*_half_native first (a call that cannot returns PYCHAIN_HIP_EUNSUPPORTED; up-cast then). */
+#define PYCHAIN_HIP_F32  0
+#define PYCHAIN_HIP_BF16 1
+#define PYCHAIN_HIP_F16  2
+
 #define PYCHAIN_HIP_OK            0
 #define PYCHAIN_HIP_EINVAL      (-1)  /* bad argument (null pointer, size mismatch, index out of range) */
 #define PYCHAIN_HIP_EUNSUPPORTED (-2) /* shape outside what the kernels were built for */
@@ -214,10 +223,14 @@ int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int resident_slot
 int pychain_hip_den_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows,
     int num_states, int num_pdfs,
-    const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+    const void* nnet_output, int nnet_output_dtype, int input_is_exp, const int64_t* seq_lengths,
     int B, int T, float leaky_hmm_coefficient, float grad_scale,
-    float* objf_per_seq, float* grad, int32_t* bad_count, float* totals,
+    float* objf_per_seq, void* grad /* nnet_output_dtype */, int32_t* bad_count, float* totals,
     void* workspace, size_t workspace_bytes, void* stream);
+/* 1 if pychain_hip_den_forward_backward takes 2-byte network outputs for this shape (and the calling thread's options): the
+ * lazy recursions with LDS-direct rows or the pair recursion, an occupancy kernel in its float4-chunk forms, rows of a
+ * multiple of 8 pdfs, a plan that is not in the general format. */
+int pychain_hip_den_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int num_states, int num_pdfs, int B, int T);
 
 /* ------------------------------------------------------------------------
  * Numerator forward-backward, log domain, one graph per sequence (replaces
@@ -249,11 +262,14 @@ int pychain_hip_num_forward_backward(
     const float*   initial_probs,               /* dev [G,H] log */
     const float*   final_probs,                 /* dev [G,H] log */
     int graph_batch_stride,
-    const float* nnet_output, const int64_t* seq_lengths,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths,
     int B, int T, int num_pdfs, int num_states, int num_transitions,
     int grad_mode, float grad_scale,
-    float* objf_per_seq, float* grad, int32_t* bad_count,
+    float* objf_per_seq, float* grad /* fp32 whatever nnet_output_dtype */, int32_t* bad_count,
     void* workspace, size_t workspace_bytes, void* stream);
+/* 1 if the numerator's recursions read 2-byte network outputs for this shape (the tile kernels' float4-chunk forms; not the
+ * general kernels, not option num_compat).  The gradient of pychain_hip_num_forward_backward stays fp32. */
+int pychain_hip_num_half_native(int num_states, int num_transitions, int num_pdfs);
 
 /* ------------------------------------------------------------------------
  * Fused ChainLoss (replaces the two ChainFunction calls + the autograd add of
@@ -284,8 +300,8 @@ int pychain_hip_chain_loss_forward_backward(
     const float* initial_probs, const float* final_probs, int graph_batch_stride,
     int num_num_states, int num_num_transitions,
     /* shared */
-    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs, float grad_scale,
-    float* den_objf_per_seq, float* num_objf_per_seq, float* grad, int32_t* bad_count,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths, int B, int T, int num_pdfs, float grad_scale,
+    float* den_objf_per_seq, float* num_objf_per_seq, void* grad /* nnet_output_dtype */, int32_t* bad_count,
     float loss_scale, const float* loss_norm_dev, float* totals,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
@@ -322,14 +338,20 @@ int pychain_hip_chain_loss_forward(
     const int32_t* backward_transition_indices, const float* backward_transition_probs,
     const float* initial_probs, const float* final_probs, int graph_batch_stride,
     int num_num_states, int num_num_transitions,
-    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths, int B, int T, int num_pdfs,
     float* den_objf_per_seq, float* num_objf_per_seq,
-    float* grad /* may be NULL */, float grad_scale, int32_t* bad_count,
+    void* grad /* may be NULL; nnet_output_dtype */, float grad_scale, int32_t* bad_count,
     float loss_scale, const float* loss_norm_dev, float* totals /* may be NULL */,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
 /* data[0..n) *= *scale_dev, skipped on the device when the scalar is exactly 1. */
-int pychain_hip_rescale(float* data, size_t n, const float* scale_dev, void* stream);
+int pychain_hip_rescale(void* data, int dtype /* PYCHAIN_HIP_F32 / _BF16 / _F16 */, size_t n, const float* scale_dev, void* stream);
+/* 1 if the fused calls (_forward with a gradient or without, _forward_backward) take 2-byte network outputs for this shape:
+ * both sides do (pychain_hip_den_half_native, pychain_hip_num_half_native) and the gradient is written ONCE, by the two-frame
+ * occupancy kernel with the numerator folded in (an accumulation into a 2-byte gradient would round twice).
+ * pychain_hip_chain_loss_backward is fp32 only. */
+int pychain_hip_chain_loss_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states, int num_pdfs,
+                                       int B, int T, int num_num_states, int num_num_transitions);
 /* out[0] = (sum_b den_objf_per_seq[b] - sum_b num_objf_per_seq[b]) * scale, divided by *norm_dev if norm_dev != NULL:
  * the scalar ChainLoss.forward returns, -(num - den) [/ sum of lengths] (pychain/loss.py:100-104), in one launch
  * (fp64 accumulation, rounded once).  num_objf_per_seq may be NULL (denominator only).  All pointers on the device. */
@@ -340,9 +362,9 @@ int pychain_hip_chain_loss_backward(
     const int32_t* forward_transitions, const int32_t* forward_transition_indices,
     const float* forward_transition_probs,
     int graph_batch_stride, int num_num_states, int num_num_transitions,
-    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int num_pdfs,
+    const void* nnet_output, int nnet_output_dtype /* PYCHAIN_HIP_F32 only */, const int64_t* seq_lengths, int B, int T, int num_pdfs,
     float grad_scale, const float* grad_scale_dev,
-    float* grad, int32_t* bad_count,
+    void* grad, int32_t* bad_count,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
 

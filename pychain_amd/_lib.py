@@ -14,6 +14,7 @@ ABI_VERSION = 14
 TOTALS = 8            # floats of a `totals` buffer (include/pychain_hip.h: PYCHAIN_HIP_TOTALS)
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
+F32, BF16, F16 = 0, 1, 2        # include/pychain_hip.h: PYCHAIN_HIP_F32 / _BF16 / _F16
 
 _lib = None
 
@@ -37,20 +38,23 @@ _SIGNATURES = {
     "pychain_hip_den_workspace_min_bytes": (_sz, [_i, _i, _i, _i]),
     "pychain_hip_den_plan_info": (_i, [_vp, _sz, _vp]),
     "pychain_hip_den_uses_row_buffer": (_i, [_i64, _i, _i, _i, _i, _i, _i]),
-    "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _f,
+    "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _f, _f,
                                               _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pychain_hip_den_half_native": (_i, [_i64, _i, _i, _i, _i, _i]),
+    "pychain_hip_num_half_native": (_i, [_i, _i, _i]),
+    "pychain_hip_chain_loss_half_native": (_i, [_i64, _i, _i, _i, _i, _i, _i, _i]),
     "pychain_hip_num_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "pychain_hip_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f,
+    "pychain_hip_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f,
                                               _vp, _vp, _vp, _vp, _sz, _vp]),
     "pychain_hip_chain_loss_forward_backward": (_i, [_vp, _i64, _i, _i, _f] + [_vp] * 8 + [_i, _i, _i]
-                                                + [_vp, _vp, _i, _i, _i, _f] + [_vp] * 4 + [_f, _vp, _vp]
+                                                + [_vp, _i, _vp, _i, _i, _i, _f] + [_vp] * 4 + [_f, _vp, _vp]
                                                 + [_vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_chain_loss_forward": (_i, [_vp, _i64, _i, _i, _f] + [_vp] * 8 + [_i, _i, _i]
-                                       + [_vp, _vp, _i, _i, _i] + [_vp, _vp, _vp, _f, _vp] + [_f, _vp, _vp]
+                                       + [_vp, _i, _vp, _i, _i, _i] + [_vp, _vp, _vp, _f, _vp] + [_f, _vp, _vp]
                                        + [_vp, _sz, _vp, _sz, _vp]),
-    "pychain_hip_rescale": (_i, [_vp, _sz, _vp, _vp]),
+    "pychain_hip_rescale": (_i, [_vp, _i, _sz, _vp, _vp]),
     "pychain_hip_loss_total": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
-    "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i,
+    "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i,
                                              _f, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "pychain_hip_batch_layout": (_i64, [_i, _i, _i, _i, _vp, _vp]),
     "pychain_hip_batch_pack": (_i, [_i, _i, _i, _i, _vp, _vp, _sz]),

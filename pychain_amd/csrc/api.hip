@@ -13,6 +13,7 @@
 #include "../../include/pychain_hip.h"
 #include "common.h"
 #include "den_kernels.h"
+#include "device_utils.h"
 #include "num_kernels.h"
 #include "plan_format.h"
 
@@ -210,10 +211,12 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
 
 namespace {
 int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, int hint, int H, int D,
-                  const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+                  const void* nnet_output, int x_dtype, int input_is_exp, const int64_t* seq_lengths,
                   int B, int T, float leaky_hmm_coefficient, float grad_scale,
-                  float* objf_per_seq, float* grad, int32_t* bad_count,
+                  float* objf_per_seq, void* grad, int32_t* bad_count,
                   void* workspace, size_t workspace_bytes, const char* who) {
+  if (x_dtype < PYCHAIN_HIP_F32 || x_dtype > PYCHAIN_HIP_F16)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: unknown nnet_output_dtype %d", who, x_dtype);
   if (!plans_dev || !nnet_output || !seq_lengths || !objf_per_seq || !grad || !bad_count || !workspace)
     return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
   if (B <= 0 || T <= 0 || H <= 0 || D <= 0)
@@ -234,7 +237,7 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
                 pychain_hip_den_workspace_min_bytes(B, T, H, D));
   memset(&a, 0, sizeof(a));
   a.plans = (const char*)plans_dev; a.plan_stride = plan_stride_bytes;
-  a.x = nnet_output; a.lengths = seq_lengths; a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
+  a.x = (const float*)nnet_output; a.x_half = x_dtype; a.lengths = seq_lengths; a.objf = objf_per_seq; a.grad = (float*)grad; a.bad = bad_count;
   a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H);
   a.input_is_exp = input_is_exp ? 1 : 0;
   a.frames_per_block = 32;      // measured at C3: 16 and 64 are both 1-3 % slower
@@ -380,6 +383,26 @@ bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
 bool den_would_exp_rows_ahead(const DenArgs& a) {
   return a.lazy && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && !a.input_is_exp &&
          a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && 4 * den_recursion_blocks(a) <= 3 * device_cu_count();
+}
+
+// 2-byte network outputs (DenArgs::x_half) are read as they are - and the gradient written in the same type - by the lazy
+// recursions with LDS-direct rows, the pair recursion and both occupancy kernels in their float4-chunk forms; rows of a
+// multiple of 8 pdfs (a lane's 16 raw bytes are 8 elements: all inside the row or all past it).  Every other kernel family
+// (general plans, the two-barrier recursion, rows through registers, per-sequence plans of the gated schedule included)
+// reads fp32: the caller up-casts (pychain_amd/native.py does).
+bool den_call_half_native(const DenArgs& a0, int hint) {
+  if (hint == PYCHAIN_HIP_HINT_GENERAL || a0.D % 8 != 0) return false;
+  DenArgs a = a0;
+  a.lazy = den_call_is_lazy(a, hint) ? 1 : 0;
+  a.shape = a.lazy ? den_call_shape(a, hint) : 0;
+  a.pair = den_call_is_pair(a, hint) ? 1 : 0;
+  const bool rec_ok = a.pair || (a.lazy && (a.shape == kShapeDma || a.shape == kShapeSmall));
+  return rec_ok && den_occupancy_half_ok(a, (a.D + 63) / 64, hint);
+}
+// the numerator's tile recursions stage 2-byte rows in their float4-chunk forms (num_fb_kernel); the general and the
+// reference-arithmetic kernels read fp32
+bool num_half_native(const NumArgs& a) {
+  return !a.general && !a.compat && a.D % 4 == 0 && a.D <= 4 * 8 * 512;
 }
 
 // option debug_corrupt_row: row[0..n) *= scale, between the recursion and the occupancy launches
@@ -574,6 +597,32 @@ extern "C" int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int re
   return den_would_exp_rows_ahead(a) ? 1 : 0;
 }
 
+extern "C" int pychain_hip_den_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T) {
+  if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
+  DenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.plan_stride = plan_stride_bytes; a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H); a.frames_per_block = 32;
+  a.knobs = call_knobs();
+  return den_call_half_native(a, resident_slot_rows) ? 1 : 0;
+}
+extern "C" int pychain_hip_num_half_native(int H, int K, int D) {
+  if (H <= 0 || K <= 0 || D <= 0) return 0;
+  NumArgs n;
+  memset(&n, 0, sizeof(n));
+  n.H = H; n.K = K; n.D = D; n.general = num_needs_general(H, K, D) ? 1 : 0; n.compat = call_knobs().num_compat;
+  return num_half_native(n) ? 1 : 0;
+}
+extern "C" int pychain_hip_chain_loss_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int den_H, int D, int B, int T,
+                                                  int num_H, int num_K) {
+  if (!pychain_hip_den_half_native(plan_stride_bytes, resident_slot_rows, den_H, D, B, T) || !pychain_hip_num_half_native(num_H, num_K, D)) return 0;
+  DenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.plan_stride = plan_stride_bytes; a.B = B; a.T = T; a.D = D; a.H = den_H; a.Hp = roundup64(den_H); a.frames_per_block = 32;
+  a.knobs = call_knobs();
+  a.fold_rows = (const float*)1;                          // (the fold's extra LDS counts: gamma2_lds_bytes)
+  return den_uses_gamma2(a, (D + 63) / 64, resident_slot_rows) ? 1 : 0;
+}
+
 extern "C" int pychain_hip_debug_stream_rings(int T, int32_t* out, int out_len, int32_t* report_due, int due_len) {
   if (T <= 0 || out_len < 0 || due_len < 0 || (out_len && !out) || (due_len && !report_due))
     return fail(PYCHAIN_HIP_EINVAL, "debug_stream_rings: bad arguments");
@@ -596,16 +645,18 @@ extern "C" int pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_
 
 extern "C" int pychain_hip_den_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int H, int D,
-    const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+    const void* nnet_output, int nnet_output_dtype, int input_is_exp, const int64_t* seq_lengths,
     int B, int T, float leaky_hmm_coefficient, float grad_scale,
-    float* objf_per_seq, float* grad, int32_t* bad_count, float* totals,
+    float* objf_per_seq, void* grad, int32_t* bad_count, float* totals,
     void* workspace, size_t workspace_bytes, void* stream) {
   DenArgs a;
-  int rc = fill_den_args(a, plans_dev, plan_stride_bytes, resident_slot_rows, H, D, nnet_output, input_is_exp, seq_lengths, B, T,
+  int rc = fill_den_args(a, plans_dev, plan_stride_bytes, resident_slot_rows, H, D, nnet_output, nnet_output_dtype, input_is_exp, seq_lengths, B, T,
                          leaky_hmm_coefficient, grad_scale, objf_per_seq, grad, bad_count, workspace,
                          workspace_bytes, "den_forward_backward");
   if (rc != PYCHAIN_HIP_OK) return rc;
   a.loss_out = totals;                                 // (sum of the per-sequence objectives, frames, bad count: den_finish_kernel)
+  if (a.x_half && !den_call_half_native(a, resident_slot_rows))
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "den_forward_backward: this shape does not take 2-byte network outputs (pychain_hip_den_half_native)");
   hipStream_t st = (hipStream_t)stream;
   if (launch_zero_words(bad_count, 1, a.seq_progress, den_counter_words(a), st) != hipSuccess)
     return fail(PYCHAIN_HIP_ELAUNCH, "den_forward_backward: cannot zero the counters");
@@ -638,10 +689,12 @@ NumCarve num_carve(int B, int T, int H, int K, int D, bool compat) {
 int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float* fp,
                   const int32_t* bt, const int32_t* bi, const float* bp,
                   const float* initial, const float* final_, int graph_batch_stride,
-                  const float* nnet_output, const int64_t* seq_lengths,
+                  const void* nnet_output, int x_dtype, const int64_t* seq_lengths,
                   int B, int T, int D, int H, int K, int grad_mode, float grad_scale,
-                  float* objf_per_seq, float* grad, int32_t* bad_count,
+                  float* objf_per_seq, void* grad, int32_t* bad_count,
                   void* workspace, size_t workspace_bytes, const char* who) {
+  if (x_dtype < PYCHAIN_HIP_F32 || x_dtype > PYCHAIN_HIP_F16)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: unknown nnet_output_dtype %d", who, x_dtype);
   if (!ft || !fi || !fp || !bt || !bi || !bp || !initial || !final_ || !nnet_output || !seq_lengths ||
       !objf_per_seq || !grad || !bad_count || !workspace)
     return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
@@ -658,8 +711,8 @@ int fill_num_args(NumArgs& a, const int32_t* ft, const int32_t* fi, const float*
   if (workspace_bytes < c.total) return fail(PYCHAIN_HIP_EWORKSPACE, "%s: workspace too small", who);
   memset(&a, 0, sizeof(a));
   a.fwd_trans = ft; a.fwd_idx = fi; a.fwd_probs = fp; a.bwd_trans = bt; a.bwd_idx = bi; a.bwd_probs = bp;
-  a.initial = initial; a.final_ = final_; a.x = nnet_output; a.lengths = seq_lengths;
-  a.objf = objf_per_seq; a.grad = grad; a.bad = bad_count;
+  a.initial = initial; a.final_ = final_; a.x = (const float*)nnet_output; a.x_half = x_dtype; a.lengths = seq_lengths;
+  a.objf = objf_per_seq; a.grad = (float*)grad; a.bad = bad_count;
   a.graph_stride = graph_batch_stride; a.B = B; a.T = T; a.D = D; a.H = H; a.K = K;
   a.grad_mode = grad_mode; a.grad_scale = grad_scale; a.frames_per_block = 32;
   a.check_all = knobs.verbose >= 1 ? 1 : 0;
@@ -687,15 +740,18 @@ extern "C" int pychain_hip_num_forward_backward(
     const int32_t* ft, const int32_t* fi, const float* fp,
     const int32_t* bt, const int32_t* bi, const float* bp,
     const float* initial, const float* final_, int graph_batch_stride,
-    const float* nnet_output, const int64_t* seq_lengths,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths,
     int B, int T, int D, int H, int K, int grad_mode, float grad_scale,
     float* objf_per_seq, float* grad, int32_t* bad_count,
     void* workspace, size_t workspace_bytes, void* stream) {
   NumArgs a;
-  int rc = fill_num_args(a, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, seq_lengths,
+  int rc = fill_num_args(a, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, nnet_output_dtype, seq_lengths,
                          B, T, D, H, K, grad_mode, grad_scale, objf_per_seq, grad, bad_count, workspace,
                          workspace_bytes, "num_forward_backward");
   if (rc != PYCHAIN_HIP_OK) return rc;
+  // (2-byte network outputs are READ as they are by the tile recursions; the gradient of this entry point stays fp32)
+  if (a.x_half && !num_half_native(a))
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "num_forward_backward: this shape does not take 2-byte network outputs (pychain_hip_num_half_native)");
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(bad_count, 0, sizeof(int32_t), st) != hipSuccess)
     return fail(PYCHAIN_HIP_ELAUNCH, "num_forward_backward: hipMemsetAsync failed");
@@ -720,22 +776,23 @@ extern "C" int pychain_hip_chain_loss_forward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
     const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
     const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
-    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
-    float* den_objf, float* num_objf, float* grad, float grad_scale, int32_t* bad_count,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths, int B, int T, int D,
+    float* den_objf, float* num_objf, void* grad, float grad_scale, int32_t* bad_count,
     float loss_scale, const float* loss_norm_dev, float* totals,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
   const char* who = "chain_loss_forward";
   if (!bad_count) return fail(PYCHAIN_HIP_EINVAL, "%s: null bad_count", who);
   DenArgs da;
   // without `grad` only the recursions run; any non-null aligned pointer then passes the checks
-  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, resident_slot_rows, den_H, D, nnet_output, 0, seq_lengths, B, T, leaky,
-                         grad_scale, den_objf, grad ? grad : (float*)den_ws, bad_count, den_ws, den_ws_bytes, who);
+  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, resident_slot_rows, den_H, D, nnet_output, nnet_output_dtype, 0, seq_lengths, B, T, leaky,
+                         grad_scale, den_objf, grad ? grad : den_ws, bad_count, den_ws, den_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   NumArgs na;
-  rc = fill_num_args(na, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, seq_lengths,
+  rc = fill_num_args(na, ft, fi, fp, bt, bi, bp, initial, final_, graph_batch_stride, nnet_output, nnet_output_dtype, seq_lengths,
                      B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM, -grad_scale, num_objf,
-                     grad ? grad : (float*)num_ws, bad_count + 1, num_ws, num_ws_bytes, who);
+                     grad ? grad : num_ws, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
+
   na.watch_nan = 0;              // the denominator's alpha workgroups watch every element of every row (NumArgs::watch_nan)
   // the scalars of ChainLoss.forward from den_finish_kernel's last workgroup (DenArgs::loss_out)
   da.loss_out = totals; da.loss_num_objf = num_objf; da.loss_scale = loss_scale; da.loss_norm_dev = loss_norm_dev; da.bad_words = 2;
@@ -747,12 +804,17 @@ extern "C" int pychain_hip_chain_loss_forward(
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.
+  // (decided with the fold's own LDS rows counted in: gamma2_lds_bytes)
+  da.fold_rows = na.rows_ws;
   const bool fold = grad && resident_slot_rows != PYCHAIN_HIP_HINT_GENERAL && !na.general && !na.compat &&
                     den_uses_gamma2(da, (D + 63) / 64, resident_slot_rows);
   if (fold) {
-    da.fold_rows = na.rows_ws; da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
+    da.fold_upd = na.upd_ws; da.fold_ucount = na.ucount_ws; da.fold_K = num_K;
     da.fold_scale = -grad_scale;
-  }
+  } else da.fold_rows = nullptr;
+  // 2-byte network outputs: both sides take them and the gradient is written once, by the fold (chain_loss_half_native)
+  if (nnet_output_dtype != PYCHAIN_HIP_F32 && !(den_call_half_native(da, resident_slot_rows) && num_half_native(na) && (fold || !grad)))
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: this shape does not take 2-byte network outputs (pychain_hip_chain_loss_half_native)", who);
   // fork: numerator on the side stream, denominator recursion on the caller's stream
   if (e == hipSuccess) e = hipEventRecord(side->fork, st);
   if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
@@ -794,11 +856,29 @@ __global__ void rescale_kernel(float4* data, size_t n4, float* tail, int ntail, 
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] *= g;
 }
+__global__ void rescale_half_kernel(uint32_t* data, size_t n2, uint16_t* tail, const float* scale_dev, int bf16) {
+  const float g = *scale_dev;
+  if (g == 1.0f) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) {
+    float lo, hi;
+    half2_to_f32(data[i], bf16 != 0, lo, hi);
+    data[i] = pack_half2(lo * g, hi * g, bf16 != 0);
+  }
+  if (tail && blockIdx.x == 0 && threadIdx.x == 0) *tail = (uint16_t)f32_to_half_bits(half_bits_to_f32(*tail, bf16 != 0) * g, bf16 != 0);
+}
 }  // namespace
 
-extern "C" int pychain_hip_rescale(float* data, size_t n, const float* scale_dev, void* stream) {
-  if (!data || !scale_dev || ((uintptr_t)data & 15))
-    return fail(PYCHAIN_HIP_EINVAL, "rescale: null or unaligned argument");
+extern "C" int pychain_hip_rescale(void* data_, int dtype, size_t n, const float* scale_dev, void* stream) {
+  if (!data_ || !scale_dev || ((uintptr_t)data_ & 15) || dtype < PYCHAIN_HIP_F32 || dtype > PYCHAIN_HIP_F16)
+    return fail(PYCHAIN_HIP_EINVAL, "rescale: null or unaligned argument, or unknown dtype");
+  if (dtype != PYCHAIN_HIP_F32) {                        // 2-byte gradients: value * scale in fp32, rounded to nearest even
+    hipLaunchKernelGGL(rescale_half_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (uint32_t*)data_, n / 2,
+                       (n & 1) ? (uint16_t*)data_ + (n - 1) : nullptr, scale_dev, dtype == PYCHAIN_HIP_BF16 ? 1 : 0);
+    hipError_t eh = hipGetLastError();
+    if (eh != hipSuccess) return fail(PYCHAIN_HIP_ELAUNCH, "rescale: %s", hipGetErrorString(eh));
+    return PYCHAIN_HIP_OK;
+  }
+  float* data = (float*)data_;
   const size_t n4 = n / 4;
   hipLaunchKernelGGL(rescale_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (float4*)data, n4,
                      data + 4 * n4, (int)(n - 4 * n4), scale_dev);
@@ -840,14 +920,16 @@ namespace {
 int chain_loss_backward_impl(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H,
     const int32_t* ft, const int32_t* fi, const float* fp, int graph_batch_stride, int num_H, int num_K,
-    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
-    float grad_scale, const float* grad_scale_dev, float* grad, int32_t* bad_count,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths, int B, int T, int D,
+    float grad_scale, const float* grad_scale_dev, void* grad, int32_t* bad_count,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream, bool zero_bad) {
   const char* who = "chain_loss_backward";
   if (!bad_count || !ft || !fi || !fp) return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
   DenArgs da;
   float dummy_coef = 0.5f;       // the occupancy launch does not use the leaky coefficient
-  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, resident_slot_rows, den_H, D, nnet_output, 0, seq_lengths, B, T, dummy_coef,
+  if (nnet_output_dtype != PYCHAIN_HIP_F32)              // (the numerator's occupancy launch accumulates into an fp32 gradient)
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: 2-byte network outputs are taken by the forward call that also writes the gradient", who);
+  int rc = fill_den_args(da, plans_dev, plan_stride_bytes, resident_slot_rows, den_H, D, nnet_output, nnet_output_dtype, 0, seq_lengths, B, T, dummy_coef,
                          grad_scale, (float*)den_ws, grad, bad_count, den_ws, den_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
@@ -856,7 +938,7 @@ int chain_loss_backward_impl(
   NumArgs na;
   // the occupancy launch reads only the forward transitions / indices / log-probs of the graphs
   rc = fill_num_args(na, ft, fi, fp, ft, fi, fp, fp, fp,
-                     graph_batch_stride, nnet_output, seq_lengths, B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM,
+                     graph_batch_stride, nnet_output, nnet_output_dtype, seq_lengths, B, T, D, num_H, num_K, PYCHAIN_HIP_GRAD_ACCUM,
                      -grad_scale, (float*)num_ws, grad, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   na.grad_scale_dev = grad_scale_dev;
@@ -877,11 +959,11 @@ int chain_loss_backward_impl(
 extern "C" int pychain_hip_chain_loss_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H,
     const int32_t* ft, const int32_t* fi, const float* fp, int graph_batch_stride, int num_H, int num_K,
-    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D,
-    float grad_scale, const float* grad_scale_dev, float* grad, int32_t* bad_count,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths, int B, int T, int D,
+    float grad_scale, const float* grad_scale_dev, void* grad, int32_t* bad_count,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
   return chain_loss_backward_impl(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, ft, fi, fp, graph_batch_stride,
-                                  num_H, num_K, nnet_output, seq_lengths, B, T, D, grad_scale, grad_scale_dev, grad,
+                                  num_H, num_K, nnet_output, nnet_output_dtype, seq_lengths, B, T, D, grad_scale, grad_scale_dev, grad,
                                   bad_count, den_ws, den_ws_bytes, num_ws, num_ws_bytes, stream, true);
 }
 
@@ -889,13 +971,13 @@ extern "C" int pychain_hip_chain_loss_forward_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
     const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
     const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
-    const float* nnet_output, const int64_t* seq_lengths, int B, int T, int D, float grad_scale,
-    float* den_objf, float* num_objf, float* grad, int32_t* bad_count,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths, int B, int T, int D, float grad_scale,
+    float* den_objf, float* num_objf, void* grad, int32_t* bad_count,
     float loss_scale, const float* loss_norm_dev, float* totals,
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
   if (!grad) return fail(PYCHAIN_HIP_EINVAL, "chain_loss_forward_backward: null grad");
   return pychain_hip_chain_loss_forward(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky, ft, fi, fp, bt,
-                                        bi, bp, initial, final_, graph_batch_stride, num_H, num_K, nnet_output,
+                                        bi, bp, initial, final_, graph_batch_stride, num_H, num_K, nnet_output, nnet_output_dtype,
                                         seq_lengths, B, T, D, den_objf, num_objf, grad, grad_scale, bad_count, loss_scale,
                                         loss_norm_dev, totals, den_ws, den_ws_bytes, num_ws, num_ws_bytes, stream);
 }

@@ -14,10 +14,14 @@ enum { kShapeRegs = 0, kShapeDma = 2, kShapeSmall = 3 };
 struct DenArgs {
   const char* plans;         // device plan(s)
   int64_t plan_stride;       // bytes between per-sequence plans, 0 = shared
-  const float* x;            // [B,T,D]
+  const float* x;            // [B,T,D]   (x_half: 2-byte elements behind this pointer)
   const int64_t* lengths;    // [B]
   float* objf;               // [B]
-  float* grad;               // [B,T,D]
+  float* grad;               // [B,T,D]   (x_half: written in the network output's type)
+  // 0: fp32 network output and gradient; kXBf16 / kXF16 (device_utils.h): 2-byte rows read as they are by the kernels that
+  // take them (den_call_half_native: lazy recursions with LDS-direct rows, pair recursion, both occupancy kernels, the rows
+  // exp'd ahead) and the gradient rounded to the same type where it is written - no up-cast pass, no fp32 copy of [B,T,D]
+  int x_half;
   int32_t* bad;              // [1]
   float* alpha_store;        // [B,T,Hp]    alpha'(t,.)/tot(t), alpha numbering
   float* beta_store;         // [B,T+1,Hp]  beta(t,.) (unit sum), beta numbering; row 0 unused
@@ -124,6 +128,7 @@ const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, in
 // ... as den_recursion_pair_kernel (DenArgs::pair); den_pair_blocks: its grid = what a progress counter reaches
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows);
 int den_recursion_blocks(const DenArgs& a);
+bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
 
 // true if launch_den would run the two-frame occupancy kernel (the only one that can fold the numerator in)
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);

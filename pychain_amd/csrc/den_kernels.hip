@@ -292,8 +292,22 @@ constexpr int kLoadDeviceScope = 16;     // cache-policy operand of a buffer loa
 // ------------------------------------------------------------------------------------
 // STREAM = false: one workgroup per (chunk of frames_per_block frames, sequence), the frames of occupancy launch gam_seg.
 // STREAM = true:  persistent workgroups drawing frame ranges from the queue above (one plan for all sequences).
-template <int VEC, int XCH, int R, bool STREAM>
+// XH: 2-byte network output and gradient (DenArgs::x_half; float4 chunks only: VEC == 4, XCH > 0)
+// `n` elements of a gradient slab from element i0 on -> exact zeros, whatever the element size (2-byte: n and i0 even - D % 4 == 0)
+template <bool XH>
+__device__ __forceinline__ void grad_zero(float* gseq, size_t i0, size_t i1, int tid, int nthreads) {
+  if constexpr (XH) {
+    uint32_t* g32 = reinterpret_cast<uint32_t*>(gseq);
+    for (size_t i = i0 / 2 + tid; i < i1 / 2; i += nthreads) g32[i] = 0u;
+  } else {
+    for (size_t i = i0 + tid; i < i1; i += nthreads) gseq[i] = 0.f;
+  }
+}
+template <int VEC, int XCH, int R, bool STREAM, bool XH = false>
 __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
+  static_assert(!XH || (VEC == 4 && XCH > 0), "2-byte rows: chunks of four elements through registers");
+  constexpr size_t kXe = XH ? 2 : 4;                   // bytes per nnet-output / gradient element
+  const bool bf16 = a.x_half == kXBf16;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ int stream_slot[8];
   const int tid = threadIdx.x;
@@ -310,16 +324,14 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     if (chunk < 0) return;
     const int t_begin = chunk * a.frames_per_block;
     const int t_end = min(t_begin + a.frames_per_block, a.T);
-    float* gseq0 = a.grad + (size_t)b * a.T * D;
+    float* gseq0 = reinterpret_cast<float*>(reinterpret_cast<char*>(a.grad) + (size_t)b * a.T * D * kXe);
     if (t_begin >= L) {                               // whole chunk is padding: exact zeros (zeros_like, :58)
-      if (first_launch)
-        for (size_t i = (size_t)t_begin * D + tid; i < (size_t)t_end * D; i += kNT) gseq0[i] = 0.f;
+      if (first_launch) grad_zero<XH>(gseq0, (size_t)t_begin * D, (size_t)t_end * D, tid, kNT);
       return;
     }
     t_live_end = min(t_end, L);
     // padded tail of a chunk that straddles the sequence end
-    if (first_launch && t_live_end < t_end)
-      for (size_t i = (size_t)t_live_end * D + tid; i < (size_t)t_end * D; i += kNT) gseq0[i] = 0.f;
+    if (first_launch && t_live_end < t_end) grad_zero<XH>(gseq0, (size_t)t_live_end * D, (size_t)t_end * D, tid, kNT);
     t_first = den_next_frame(t_begin, t_live_end, L, lf);
     if (t_first >= t_live_end) return;                // none of this chunk's frames belongs to this launch
   }
@@ -362,14 +374,14 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
       if (!stream_take(a, stream_slot, it)) break;
       b = it.b; L = it.L;
       if (it.pad) {
-        float* gz = a.grad + (size_t)b * a.T * D;
-        for (size_t i = (size_t)it.lo * D + tid; i < (size_t)it.hi * D; i += kNT) gz[i] = 0.f;
+        grad_zero<XH>(reinterpret_cast<float*>(reinterpret_cast<char*>(a.grad) + (size_t)b * a.T * D * kXe), (size_t)it.lo * D,
+                      (size_t)it.hi * D, tid, kNT);
         continue;
       }
       t_first = it.lo; t_live_end = it.hi;
     }
-    float* gseq = a.grad + (size_t)b * a.T * D;
-    const float* xseq = a.x + (size_t)b * a.T * D;
+    float* gseq = reinterpret_cast<float*>(reinterpret_cast<char*>(a.grad) + (size_t)b * a.T * D * kXe);
+    const float* xseq = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)b * a.T * D * kXe);
     const float* aseq = a.alpha_store + (size_t)b * a.T * Hp;
     const float* bseq = a.beta_store + (size_t)b * (a.T + 1) * Hp;
     const XBuf abuf = make_xbuf(aseq, (size_t)a.T * Hp * sizeof(float)), bbuf = make_xbuf(bseq, (size_t)(a.T + 1) * Hp * sizeof(float));
@@ -380,7 +392,8 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     //  STREAM: the state rows may have been written by another XCD while this kernel runs: device-scope loads)
 #define GAMMA_PREFETCH(t)                                                                     \
   do {                                                                                        \
-    xq.load(xseq + (size_t)(t) * D, D, tid);                                                  \
+    if constexpr (XH) xq.load_h(reinterpret_cast<const char*>(xseq) + (size_t)(t) * D * 2, D, tid, bf16);                \
+    else xq.load(xseq + (size_t)(t) * D, D, tid);                                             \
     if (uv_in_regs) {                                                                         \
       const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
       const float* br_ = bseq + (size_t)((t) + 1) * Hp;                                       \
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   } while (0)
 #define GAMMA_COMMIT(t)                                                                       \
   do {                                                                                        \
-    xq.store(xr, xseq + (size_t)(t) * D, D, tid, a.input_is_exp);                             \
+    xq.store(xr, XH ? nullptr : xseq + (size_t)(t) * D, D, tid, a.input_is_exp);              \
     if (uv_in_regs) {                                                                         \
       _Pragma("unroll") for (int c = 0; c < kUV; c++) {                                       \
         const int i = (c * kNT + tid) * 4;                                                    \
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     GAMMA_COMMIT(t_first);
     __syncthreads();
     for (int t = t_first; t < t_live_end;) {
-      float* grow = gseq + (size_t)t * D;
+      float* grow = reinterpret_cast<float*>(reinterpret_cast<char*>(gseq) + (size_t)t * D * kXe);
       const int t_next = STREAM ? t + 1 : den_next_frame(t + 1, t_live_end, L, lf);
       const bool have_next = t_next < t_live_end;
       if (have_next) GAMMA_PREFETCH(t_next);
@@ -454,7 +467,10 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
         for (int c = 0; c < XCH; c++) {
           const int e = (c * kNT + tid) * VEC;
           if (e < D) {
-            if constexpr (VEC == 4) {
+            if constexpr (XH) {
+              *reinterpret_cast<uint2*>(reinterpret_cast<char*>(grow) + (size_t)e * 2) =
+                  make_uint2(pack_half2(g[c * 4] * sc, g[c * 4 + 1] * sc, bf16), pack_half2(g[c * 4 + 2] * sc, g[c * 4 + 3] * sc, bf16));
+            } else if constexpr (VEC == 4) {
               *reinterpret_cast<float4*>(grow + e) =
                   make_float4(g[c * 4] * sc, g[c * 4 + 1] * sc, g[c * 4 + 2] * sc, g[c * 4 + 3] * sc);
             } else {
@@ -612,8 +628,10 @@ __device__ __forceinline__ bool den_frame_in_launch(int t, int t_live_end, int L
 }
 
 // STREAM as in den_gamma_kernel: persistent workgroups drawing frame ranges from the queue (one plan for all sequences).
-template <int XCH, int R, bool STREAM>
+template <int XCH, int R, bool STREAM, bool XH = false>
 __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
+  constexpr size_t kXe = XH ? 2 : 4;                   // bytes per nnet-output / gradient element (DenArgs::x_half)
+  const bool bf16 = a.x_half == kXBf16;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ int stream_slot[8];
   constexpr int UVC = 2;                              // float4 chunks of a state row per thread: Hp <= 4 * UVC * kNT2
@@ -631,14 +649,14 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     if (chunk < 0) return;
     const int t_begin = chunk * a.frames_per_block;               // frames_per_block is even
     const int t_end = min(t_begin + a.frames_per_block, T);
-    float* gseq0 = a.grad + (size_t)b * T * D;
+    float* gseq0 = reinterpret_cast<float*>(reinterpret_cast<char*>(a.grad) + (size_t)b * T * D * kXe);
     t_live_end = min(t_end, L);
     // pairs (t0, t0+1), t0 even, with at least one frame of this launch
     t0 = t_begin;
     while (t0 < t_live_end && !den_frame_in_launch(t0, t_live_end, L, lf) && !den_frame_in_launch(t0 + 1, t_live_end, L, lf)) t0 += 2;
     // padding of the first launch is exact zeros: a whole chunk past the end, or the tail of one that straddles it
     if (first_launch && max(t_begin, t_live_end) < t_end)
-      for (size_t i = (size_t)max(t_begin, t_live_end) * D + tid; i < (size_t)t_end * D; i += kNT2) gseq0[i] = 0.f;
+      grad_zero<XH>(gseq0, (size_t)max(t_begin, t_live_end) * D, (size_t)t_end * D, tid, kNT2);
     if (t0 >= t_live_end) return;                     // nothing to evaluate
   }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
@@ -689,14 +707,14 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       if (!stream_take(a, stream_slot, it)) break;
       b = it.b; L = it.L;
       if (it.pad) {
-        float* gz = a.grad + (size_t)b * T * D;
-        for (size_t i = (size_t)it.lo * D + tid; i < (size_t)it.hi * D; i += kNT2) gz[i] = 0.f;
+        grad_zero<XH>(reinterpret_cast<float*>(reinterpret_cast<char*>(a.grad) + (size_t)b * T * D * kXe), (size_t)it.lo * D,
+                      (size_t)it.hi * D, tid, kNT2);
         continue;
       }
       t_lo = it.lo; t_live_end = it.hi; t0 = t_lo & ~1;
     }
-    float* gseq = a.grad + (size_t)b * T * D;
-    const float* xseq = a.x + (size_t)b * T * D;
+    float* gseq = reinterpret_cast<float*>(reinterpret_cast<char*>(a.grad) + (size_t)b * T * D * kXe);
+    const float* xseq = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)b * T * D * kXe);
     const float* aseq = a.alpha_store + (size_t)b * T * Hp;
     const float* bseq = a.beta_store + (size_t)b * (T + 1) * Hp;
     const XBuf abuf = make_xbuf(aseq, (size_t)T * Hp * sizeof(float)), bbuf = make_xbuf(bseq, (size_t)(T + 1) * Hp * sizeof(float));
@@ -764,8 +782,13 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       while (tn < t_live_end && !wanted(tn) && !wanted(tn + 1)) tn += 2;
       const bool have_next = tn < t_live_end;
       // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
-      x0.load(xseq + (size_t)t0 * D, D, tid);
-      x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
+      if constexpr (XH) {
+        x0.load_h(reinterpret_cast<const char*>(xseq) + (size_t)t0 * D * 2, D, tid, bf16);
+        x1.load_h(reinterpret_cast<const char*>(xseq) + (size_t)min(t0 + 1, T - 1) * D * 2, D, tid, bf16);
+      } else {
+        x0.load(xseq + (size_t)t0 * D, D, tid);
+        x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
+      }
       float r00 = 0.f, r01 = 0.f, r10 = 0.f, r11 = 0.f;  // numerator rows of this pair (in flight during the arc work)
       const float* fr0 = frows + (size_t)t0 * a.fold_K;
       const float* fr1 = frows + (size_t)min(t0 + 1, T - 1) * a.fold_K;
@@ -828,8 +851,8 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
         if (valid0 && (t0 == 0 || a.check_all)) den_record_frame_total(a, b, t0, tot0);
         if (valid1 && a.check_all) den_record_frame_total(a, b, t0 + 1, tot1);
       }
-      float* grow0 = gseq + (size_t)t0 * D;
-      float* grow1 = grow0 + D;
+      float* grow0 = reinterpret_cast<float*>(reinterpret_cast<char*>(gseq) + (size_t)t0 * D * kXe);
+      float* grow1 = reinterpret_cast<float*>(reinterpret_cast<char*>(grow0) + (size_t)D * kXe);
 #pragma unroll
       for (int c = 0; c < XCH; c++) {
         const int e = (c * kNT2 + tid) * 4;
@@ -839,10 +862,19 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
           // (g * sc) rounded, then + numerator: bit-identical to the unfused order (occupancy pass, then
           // the numerator accumulated into the stored gradient)
 #define G2(gv, scv, nv) mul_add_mul_rn((gv), (scv), (nv), nscale)
+          if constexpr (XH) {                            // the same fp32 values, rounded once to the network output's type
+            if (valid0) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(grow0) + (size_t)e * 2) =
+                make_uint2(pack_half2(G2(g0[c * 4], sc0, na.x), G2(g0[c * 4 + 1], sc0, na.z), bf16),
+                           pack_half2(G2(g0[c * 4 + 2], sc0, nb.x), G2(g0[c * 4 + 3], sc0, nb.z), bf16));
+            if (valid1) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(grow1) + (size_t)e * 2) =
+                make_uint2(pack_half2(G2(g1[c * 4], sc1, na.y), G2(g1[c * 4 + 1], sc1, na.w), bf16),
+                           pack_half2(G2(g1[c * 4 + 2], sc1, nb.y), G2(g1[c * 4 + 3], sc1, nb.w), bf16));
+          } else {
           if (valid0) *reinterpret_cast<float4*>(grow0 + e) = make_float4(G2(g0[c * 4], sc0, na.x), G2(g0[c * 4 + 1], sc0, na.z),
                                                                              G2(g0[c * 4 + 2], sc0, nb.x), G2(g0[c * 4 + 3], sc0, nb.z));
           if (valid1) *reinterpret_cast<float4*>(grow1 + e) = make_float4(G2(g1[c * 4], sc1, na.y), G2(g1[c * 4 + 1], sc1, na.w),
                                                                              G2(g1[c * 4 + 2], sc1, nb.y), G2(g1[c * 4 + 3], sc1, nb.w));
+          }
 #undef G2
         }
       }
@@ -881,18 +913,26 @@ inline bool gamma2_eligible(const DenArgs& a, int rows2, int gamma_max_groups) {
   return !off && rows2 > 0 && a.D % 4 == 0 && a.D <= 4 * 2 * kNT2 && a.Hp <= 4032 /* packed 16-bit addresses of float2 */ &&
          a.frames_per_block % 2 == 0 && gamma2_lds_bytes(a, gamma_max_groups) + kStaticLds <= 160 * 1024;
 }
+template <int XCH, bool STREAM, bool XH>
+hipError_t launch_gamma2_x(const DenArgs& a, int rows2, size_t lds, dim3 grid, hipStream_t st) {
+  if (rows2 <= 16) return launch_one(den_gamma2_kernel<XCH, 16, STREAM, XH>, a, grid, lds, st, kNT2);
+  if (rows2 <= 32) return launch_one(den_gamma2_kernel<XCH, 32, STREAM, XH>, a, grid, lds, st, kNT2);
+  return launch_one(den_gamma2_kernel<XCH, 64, STREAM, XH>, a, grid, lds, st, kNT2);
+}
 template <int XCH, bool STREAM>
 hipError_t launch_gamma2(const DenArgs& a, int rows2, size_t lds, dim3 grid, hipStream_t st) {
-  if (rows2 <= 16) return launch_one(den_gamma2_kernel<XCH, 16, STREAM>, a, grid, lds, st, kNT2);
-  if (rows2 <= 32) return launch_one(den_gamma2_kernel<XCH, 32, STREAM>, a, grid, lds, st, kNT2);
-  return launch_one(den_gamma2_kernel<XCH, 64, STREAM>, a, grid, lds, st, kNT2);
+  return a.x_half ? launch_gamma2_x<XCH, STREAM, true>(a, rows2, lds, grid, st) : launch_gamma2_x<XCH, STREAM, false>(a, rows2, lds, grid, st);
 }
 // the streamed form of the one-frame kernel: float4 rows, every arc of a wave in registers
+template <int XCH, bool XH>
+hipError_t launch_gamma_stream_x(const DenArgs& a, int r, size_t lds, dim3 grid, hipStream_t st) {
+  if (r <= 16) return launch_one(den_gamma_kernel<4, XCH, 16, true, XH>, a, grid, lds, st);
+  if (r <= 32) return launch_one(den_gamma_kernel<4, XCH, 32, true, XH>, a, grid, lds, st);
+  return launch_one(den_gamma_kernel<4, XCH, kMaxResident, true, XH>, a, grid, lds, st);
+}
 template <int XCH>
 hipError_t launch_gamma_stream(const DenArgs& a, int r, size_t lds, dim3 grid, hipStream_t st) {
-  if (r <= 16) return launch_one(den_gamma_kernel<4, XCH, 16, true>, a, grid, lds, st);
-  if (r <= 32) return launch_one(den_gamma_kernel<4, XCH, 32, true>, a, grid, lds, st);
-  return launch_one(den_gamma_kernel<4, XCH, kMaxResident, true>, a, grid, lds, st);
+  return a.x_half ? launch_gamma_stream_x<XCH, true>(a, r, lds, grid, st) : launch_gamma_stream_x<XCH, false>(a, r, lds, grid, st);
 }
 inline bool gamma_stream_shape_ok(const DenArgs& a, int hint, int gamma_max_groups) {
   if (a.plan_stride != 0) return false;
@@ -921,6 +961,16 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
     if (stream) {
       if constexpr (VEC == 4 && XCH > 0) return launch_gamma_stream<XCH>(a, r, lds_gam, grid, st);
       else return hipErrorInvalidValue;                 // (den_stream_eligible said no)
+    }
+    if (a.x_half) {                                      // 2-byte rows: the float4-chunk forms only (den_call_half_native)
+      if constexpr (VEC == 4 && XCH > 0) {
+        switch (r) {
+          case 0: return hipErrorInvalidValue;
+          case 16: return launch_one(den_gamma_kernel<4, XCH, 16, false, true>, a, grid, lds_gam, st);
+          case 32: return launch_one(den_gamma_kernel<4, XCH, 32, false, true>, a, grid, lds_gam, st);
+          default: return launch_one(den_gamma_kernel<4, XCH, kMaxResident, false, true>, a, grid, lds_gam, st);
+        }
+      } else return hipErrorInvalidValue;
     }
     switch (r) {
       case 0: e = launch_one(den_gamma_kernel<VEC, XCH, 0, false>, a, grid, lds_gam, st); break;
@@ -956,15 +1006,17 @@ namespace {
 // way (~10 us measured); Q workgroups x NR rows per round keep an end 3x ahead of a recursion that consumes a row per ~2 us
 // (one workgroup per end, 4 rows per round: 2.5 us per row, and the recursions waited for it: profiles/r04_t_*).
 constexpr int kExNT = 512;
-template <int CH>
+template <int CH, bool XH = false>                     // XH: 2-byte network output (DenArgs::x_half); the rows written are fp32 either way
 __global__ __launch_bounds__(kExNT) void den_exp_rows_kernel(const DenArgs a) {
+  const bool bf16 = a.x_half == kXBf16;
   constexpr int NR = CH <= 2 ? 8 : 4;
   const int tid = threadIdx.x;
   const int Q = a.ex_q;
   const int b = blockIdx.x % a.B, end = (blockIdx.x / a.B) & 1, qi = blockIdx.x / (2 * a.B);
   const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T)), D = a.D;
   const int Lh = (L + 1) / 2, n = end ? L - Lh : Lh;             // end 0 owns rows [0, Lh), end 1 rows [Lh, L) from L-1 down
-  const XBuf xin = make_xbuf(a.x + (size_t)b * a.T * D, (size_t)a.T * D * sizeof(float));
+  const XBuf xin = XH ? make_xbuf(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)b * a.T * D * 2), (size_t)a.T * D * 2)
+                      : make_xbuf(a.x + (size_t)b * a.T * D, (size_t)a.T * D * sizeof(float));
   const XBuf xout = make_xbuf(a.ex + (size_t)b * a.T * D, (size_t)a.T * D * sizeof(float));
   int32_t* prog = a.xprog + ((size_t)end * a.B + b) * kExMaxQ + qi;
   bool nan = false;
@@ -974,11 +1026,17 @@ __global__ __launch_bounds__(kExNT) void den_exp_rows_kernel(const DenArgs a) {
 #pragma unroll
     for (int k = 0; k < NR; k++) {
       const int t = end ? L - 1 - (r0 + k) : r0 + k;
-      const int soff = __builtin_amdgcn_readfirstlane(t * D * 4);
+      const int soff = __builtin_amdgcn_readfirstlane(t * D * (XH ? 2 : 4));
 #pragma unroll
       for (int c = 0; c < CH; c++) {
         const int e = (c * kExNT + tid) * 4;
-        if (r0 + k < n && e < D) q[k][c] = __builtin_amdgcn_raw_buffer_load_b128(xin, e * 4, soff, 0);
+        if (r0 + k < n && e < D) {
+          if constexpr (XH) {
+            typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+            const u32x2_ h = __builtin_amdgcn_raw_buffer_load_b64(xin, e * 2, soff, 0);
+            q[k][c].x = h.x; q[k][c].y = h.y;
+          } else q[k][c] = __builtin_amdgcn_raw_buffer_load_b128(xin, e * 4, soff, 0);
+        }
       }
     }
 #pragma unroll
@@ -989,7 +1047,9 @@ __global__ __launch_bounds__(kExNT) void den_exp_rows_kernel(const DenArgs a) {
       for (int c = 0; c < CH; c++) {
         const int e = (c * kExNT + tid) * 4;
         if (r0 + k < n && e < D) {
-          const float x0 = __uint_as_float(q[k][c].x), x1 = __uint_as_float(q[k][c].y), x2 = __uint_as_float(q[k][c].z), x3 = __uint_as_float(q[k][c].w);
+          float x0, x1, x2, x3;
+          if constexpr (XH) { half2_to_f32(q[k][c].x, bf16, x0, x1); half2_to_f32(q[k][c].y, bf16, x2, x3); }
+          else { x0 = __uint_as_float(q[k][c].x); x1 = __uint_as_float(q[k][c].y); x2 = __uint_as_float(q[k][c].z); x3 = __uint_as_float(q[k][c].w); }
           nan = nan || __builtin_isunordered(x0, x1) || __builtin_isunordered(x2, x3);
           u32x4 o;
           o.x = __float_as_uint(clamp_exp(x0, kXExpClamp)); o.y = __float_as_uint(clamp_exp(x1, kXExpClamp));
@@ -1017,6 +1077,17 @@ void den_exp_rows_shape(const DenArgs& a, int cus, int* nr, int* q) {
 hipError_t launch_den_exp_rows(const DenArgs& a, hipStream_t st) {
   const dim3 grid(2 * a.B * a.ex_q), block(kExNT);
   const int ch = (a.D / 4 + kExNT - 1) / kExNT;
+  if (a.x_half) {
+    switch (ch) {
+      case 1: hipLaunchKernelGGL((den_exp_rows_kernel<1, true>), grid, block, 0, st, a); break;
+      case 2: hipLaunchKernelGGL((den_exp_rows_kernel<2, true>), grid, block, 0, st, a); break;
+      case 3: hipLaunchKernelGGL((den_exp_rows_kernel<3, true>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((den_exp_rows_kernel<4, true>), grid, block, 0, st, a); break;
+      case 5: hipLaunchKernelGGL((den_exp_rows_kernel<5, true>), grid, block, 0, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (ch) {
     case 1: hipLaunchKernelGGL(den_exp_rows_kernel<1>, grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL(den_exp_rows_kernel<2>, grid, block, 0, st, a); break;
@@ -1053,6 +1124,11 @@ int den_recursion_blocks(const DenArgs& a) { return a.pair ? 2 * ((a.B + 1) / 2)
 
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
   return gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups);
+}
+// 2-byte network output and gradient (DenArgs::x_half): the two-frame kernel, or the one-frame kernel in its float4-chunk forms
+bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
+  if (gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups)) return true;
+  return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && pick_r(a, (resident_slot_rows >> 10) & 1023, 2 * a.Hp) > 0;
 }
 
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,

@@ -41,17 +41,23 @@ inline bool dma_shape_ok(const DenArgs& a, int hint) {
   return ((hint >> 30) & 1) && a.D <= (int)LzDma::kMaxPdfs && a.Hp <= (int)LzDma::kMaxStates && rows > 0 &&
          rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
 }
-template <typename M, bool PRE>
+template <typename M, int XM>
 hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
   const dim3 grid(2 * a.B);
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M, XM>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M, XM>, a, grid, M::kBytes, st, M::kWaves * 64);
+  return launch_one(den_recursion_lazy_kernel<kMaxResident, M, XM>, a, grid, M::kBytes, st, M::kWaves * 64);
+}
+// how the rows of this call arrive (lazy_recursion: XM): exp'd ahead (fp32 whatever the input's type), 2-byte, fp32
+template <typename M>
+hipError_t launch_dma_x(const DenArgs& a, int rows, hipStream_t st) {
+  if (a.use_ex) return launch_dma_m<M, kLzRowsPre>(a, rows, st);
+  return a.x_half ? launch_dma_m<M, kLzRowsHalf>(a, rows, st) : launch_dma_m<M, kLzRowsF32>(a, rows, st);
 }
 hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
-  // the map of C3 where the shape fits it, else the one for rows of up to 9216 pdfs; rows exp'd ahead or not (DenArgs::use_ex)
-  if (lazy_shape_ok(a, hint, true)) return a.use_ex ? launch_dma_m<LzNarrowDma, true>(a, hint & 1023, st) : launch_dma_m<LzNarrowDma, false>(a, hint & 1023, st);
-  return a.use_ex ? launch_dma_m<LzDma, true>(a, hint & 1023, st) : launch_dma_m<LzDma, false>(a, hint & 1023, st);
+  // the map of C3 where the shape fits it, else the one for rows of up to 9216 pdfs
+  if (lazy_shape_ok(a, hint, true)) return launch_dma_x<LzNarrowDma>(a, hint & 1023, st);
+  return launch_dma_x<LzDma>(a, hint & 1023, st);
 }
 // Four-wave workgroups over the plan's four-wave dealing (hint bit 29: every plan of the call holds alpha4 / beta4, and the
 // hint's row count is that dealing's): small graphs, LDS-direct rows.
@@ -62,7 +68,7 @@ inline bool small_shape_ok(const DenArgs& a, int hint) {
 }
 // A frame of a small graph is the arc loop's chunks, one dependent LDS round trip each with one wave per SIMD, whatever the
 // wave gathers (profiles/r04_c2_small_phase_timers_ring4.txt): the loop is as long as the longest wave's rows, in steps of 8 from 16 on.
-template <bool PRE>
+template <int PRE>
 hipError_t launch_small_p(const DenArgs& a, int hint, hipStream_t st) {
   const dim3 grid(2 * a.B);
   const int rows = hint & 1023;
@@ -72,7 +78,10 @@ hipError_t launch_small_p(const DenArgs& a, int hint, hipStream_t st) {
   if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
   return launch_one(den_recursion_lazy_kernel<kMaxResident, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
 }
-hipError_t launch_small(const DenArgs& a, int hint, hipStream_t st) { return a.use_ex ? launch_small_p<true>(a, hint, st) : launch_small_p<false>(a, hint, st); }
+hipError_t launch_small(const DenArgs& a, int hint, hipStream_t st) {
+  if (a.use_ex) return launch_small_p<kLzRowsPre>(a, hint, st);
+  return a.x_half ? launch_small_p<kLzRowsHalf>(a, hint, st) : launch_small_p<kLzRowsF32>(a, hint, st);
+}
 
 // Two sequences per workgroup (den_pair.inc.h): one plan for all sequences, nnet-output rows and state vectors
 // within its fixed LDS map, every arc of a plan wave in registers, the whole sequence in one launch.
@@ -84,6 +93,11 @@ inline bool pair_shape_ok(const DenArgs& a, int hint) {
 hipError_t launch_pair(const DenArgs& a, int hint, hipStream_t st) {
   const dim3 grid(2 * ((a.B + 1) / 2));
   const int rows = hint & 1023;
+  if (a.x_half) {                                        // 2-byte nnet-output rows (DenArgs::x_half)
+    if (rows <= 16) return launch_one(den_recursion_pair_kernel<16, true>, a, grid, kPrBytes, st, kPrNT);
+    if (rows <= 32) return launch_one(den_recursion_pair_kernel<32, true>, a, grid, kPrBytes, st, kPrNT);
+    return launch_one(den_recursion_pair_kernel<kMaxResident, true>, a, grid, kPrBytes, st, kPrNT);
+  }
   if (rows <= 16) return launch_one(den_recursion_pair_kernel<16>, a, grid, kPrBytes, st, kPrNT);
   if (rows <= 32) return launch_one(den_recursion_pair_kernel<32>, a, grid, kPrBytes, st, kPrNT);
   return launch_one(den_recursion_pair_kernel<kMaxResident>, a, grid, kPrBytes, st, kPrNT);

@@ -147,6 +147,49 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
   }
   return nan;
 }
+// 2-byte rows (DenArgs::x_half): the unit a wave owns is 2 KiB of the fp32 row buffer = 512 elements = 1 KiB of raw row,
+// which ONE LDS-direct load per wave brings into the UPPER half of the unit; the finish reads a lane's 16 raw bytes (8
+// elements) from there and writes its 32 bytes of fp32 over the unit from the bottom - every read of a wave is issued before
+// its first write, and no other wave touches the unit.  D % 8 == 0 (a lane's 8 elements are all inside the row or all past it).
+template <int NW, int NU, int AUX = 0>
+__device__ __forceinline__ void lz_dma_row_h(XBuf buf, int t, int D, int wave, int lane, uint32_t xbase) {
+  const int row_bytes = D * 2;
+  const int soff = __builtin_amdgcn_readfirstlane(t * row_bytes);
+#pragma unroll
+  for (int c = 0; c < NU; c++) {
+    const int u = wave + c * NW;                        // (uniform)
+    if (u * 1024 < row_bytes) {
+      const int voff = u * 1024 + lane * 16 < row_bytes ? lane * 16 : max(0, row_bytes - 16 - u * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(buf, (lz_lds_void*)(xbase + (uint32_t)u * 2048u + 1024u), 16, voff,
+                                               soff + u * 1024, 0, AUX);
+    }
+  }
+}
+template <int NW, int NU>
+__device__ __forceinline__ bool lz_dma_finish_h(int D, int wave, int lane, uint32_t xbase, int is_exp, bool bf16) {
+  bool nan = false;
+  PYCHAIN_WAIT_VM0();                                   // this wave's loads have landed
+#pragma unroll
+  for (int c = 0; c < NU; c++) {
+    const int u = wave + c * NW;
+    if (u * 1024 < D * 2) {
+      const uint32_t ubase = xbase + (uint32_t)u * 2048u;
+      const u32x4 r = *(const __attribute__((address_space(3))) u32x4*)(ubase + 1024u + (uint32_t)lane * 16u);
+      // (four elements at a time: the raw words are all in registers before the first write, and no more than four converted
+      // values are live beside them - the kernel runs at its register limit)
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        float f0, f1, f2, f3;
+        half2_to_f32(hf ? r.z : r.x, bf16, f0, f1); half2_to_f32(hf ? r.w : r.y, bf16, f2, f3);
+        nan = nan || __builtin_isunordered(f0, f1) || __builtin_isunordered(f2, f3);
+        if (is_exp == kXExpClamp) { f0 = clamp_exp(f0, kXExpClamp); f1 = clamp_exp(f1, kXExpClamp); f2 = clamp_exp(f2, kXExpClamp); f3 = clamp_exp(f3, kXExpClamp); }
+        *(__attribute__((address_space(3))) lz_v4*)(ubase + (uint32_t)lane * 32u + 16u * hf) = lz_v4{f0, f1, f2, f3};
+        if (hf == 0) asm volatile("" ::: "memory");
+      }
+    }
+  }
+  return nan;
+}
 #pragma clang diagnostic pop
 
 template <int R, typename MAP>
@@ -383,8 +426,13 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
 // One (sequence, direction).  The direction is a template parameter and the kernel branches ONCE, at its
 // top: with both directions in one body the register allocator keeps a second copy of every arc register
 // across the (uniform) direction branches.
-template <int R, typename MAP, bool fwd, bool PRE>
+// XM: how the nnet-output rows arrive - kLzRowsF32: fp32, clamped / exp'd here; kLzRowsPre: exp'd ahead by den_exp_rows_kernel
+// (DenArgs::ex); kLzRowsHalf: 2-byte rows (DenArgs::x_half), converted, clamped / exp'd here.  A template parameter: the
+// kernel has no register to spare for more than one form.
+enum { kLzRowsF32 = 0, kLzRowsPre = 1, kLzRowsHalf = 2 };
+template <int R, typename MAP, bool fwd, int XM>
 __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b) {
+  constexpr bool PRE = XM == kLzRowsPre, XH = XM == kLzRowsHalf;
   constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -424,7 +472,11 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // sequence reports it (xprog), which after the first microseconds of a call it always has
   constexpr bool pre = PRE;                             // (a template parameter: the kernel has no register to spare for both forms)
   static_assert(!PRE || MAP::kDma, "rows exp'd ahead arrive by LDS-direct loads");
-  const XBuf xbuf = make_xbuf(pre ? a.ex + (size_t)b * a.T * D : xseq, (size_t)a.T * D * sizeof(float));
+  static_assert(!XH || MAP::kDma, "2-byte rows arrive by LDS-direct loads");
+  constexpr int kDmaUn = ((int)MAP::kMaxPdfs / 512 + NW - 1) / NW;   // 2 KiB units of a row buffer one wave may own (2-byte rows)
+  const bool bf16 = a.x_half == kXBf16;
+  const XBuf xbuf = XH ? make_xbuf(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)b * a.T * D * 2), (size_t)a.T * D * 2)
+                       : make_xbuf(pre ? a.ex + (size_t)b * a.T * D : xseq, (size_t)a.T * D * sizeof(float));
   int ready_lo = 0, ready_hi = 0;                       // ex rows [0, ready_lo) and [L - ready_hi, L) are complete
   // rows an end has complete: its workgroup q has done c_q of the rounds q, q + Q, ...: the first round missing is min_q (q + c_q Q)
   auto rows_of_end = [&](int end) {
@@ -450,7 +502,13 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // row t -> the buffer at xbase (LDS-direct); device-scope loads for rows another kernel is writing meanwhile
   auto dma_row = [&](int t, int ln, uint32_t xbase) {
     if constexpr (pre) { wait_row(t); lz_dma_row<NW, kDmaCh, kStoreDeviceScope>(xbuf, t, D, wave, ln, xbase); }
+    else if constexpr (XH) lz_dma_row_h<NW, kDmaUn, 0>(xbuf, t, D, wave, ln, xbase);
     else lz_dma_row<NW, kDmaCh, 0>(xbuf, t, D, wave, ln, xbase);
+  };
+  // this wave's share of the row at xbase: raw -> fp32, clamped / exp'd; true if a NaN was seen
+  auto dma_finish = [&](int ln, uint32_t xbase) {
+    if constexpr (XH) return lz_dma_finish_h<NW, kDmaUn>(D, wave, ln, xbase, a.input_is_exp, bf16);
+    else return lz_dma_finish<NW, kDmaCh>(D, wave, ln, xbase, a.input_is_exp);
   };
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));
 
@@ -477,7 +535,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if constexpr (MAP::kDma) {
       dma_row(t0, lane, MAP::kX0);
       if constexpr (pre) PYCHAIN_WAIT_VM0();
-      else if (lz_dma_finish<NW, kDmaCh>(D, wave, lane, MAP::kX0, a.input_is_exp) && fwd) bad |= 2;
+      else if (dma_finish(lane, MAP::kX0) && fwd) bad |= 2;
     } else {
       xq.load(xseq + (size_t)t0 * D, D, tid);
       if (fwd && xq.has_nan()) bad |= 2;
@@ -586,7 +644,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       if constexpr (MAP::kDma) {                                                                            \
         LZ_VMWAIT();                                                                                        \
         if constexpr (pre) PYCHAIN_WAIT_VM0();               /* (ready to gather: it only has to have landed before the barrier) */ \
-        else if (have_next && lz_dma_finish<NW, kDmaCh>(D, wave, lq, (PAR) ? MAP::kX0 : MAP::kX1, a.input_is_exp) && (FWDC)) bad |= 2; \
+        else if (have_next && dma_finish(lq, (PAR) ? MAP::kX0 : MAP::kX1) && (FWDC)) bad |= 2; \
       }                                                                                                     \
     });                                                                                                     \
     LZ_PH(0);                                                /* arc phase */                                 \
@@ -686,10 +744,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   if (bad && lane == 0) atomicAdd(a.bad, 1);
 }
 
-// PRE: the rows were exp'd ahead by den_exp_rows_kernel (DenArgs::ex)
-template <int R, typename MAP, bool PRE = false>
+// XM: kLzRowsPre - the rows were exp'd ahead by den_exp_rows_kernel (DenArgs::ex); kLzRowsHalf - 2-byte rows (DenArgs::x_half)
+template <int R, typename MAP, int XM = kLzRowsF32>
 __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, PRE>(a, smem_raw, blockIdx.x);
-  else lazy_recursion<R, MAP, false, PRE>(a, smem_raw, blockIdx.x - a.B);
+  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM>(a, smem_raw, blockIdx.x);
+  else lazy_recursion<R, MAP, false, XM>(a, smem_raw, blockIdx.x - a.B);
 }

@@ -132,7 +132,8 @@ __device__ __forceinline__ void pair_tile(PairArcs<R>& ar, const GroupRegs& gr, 
     lz_st2(kPrRaw + (uint32_t)(__builtin_amdgcn_readlane(gr.base, g & 63) + lane) * 8u, lz_v2f{0.f, 0.f});
 }
 
-template <int R, bool fwd>
+// XH: 2-byte nnet-output rows (DenArgs::x_half): four elements = 8 bytes per thread and row, converted as they arrive
+template <int R, bool fwd, bool XH>
 __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw, const int p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -166,15 +167,21 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
   const float* start_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_init_a : hd->off_final_b));
-  const float* xA = a.x + (size_t)bA * a.T * D;
-  const float* xB = a.x + (size_t)bB * a.T * D;
+  constexpr size_t kXe = XH ? 2 : 4;                                // bytes per nnet-output element
+  const bool bf16 = a.x_half == kXBf16;
+  const float* xA = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)bA * a.T * D * kXe);
+  const float* xB = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)bB * a.T * D * kXe);
   const size_t rows_per_seq = fwd ? (size_t)a.T : (size_t)a.T + 1;
   float* storeA = (fwd ? a.alpha_store : a.beta_store) + (size_t)bA * rows_per_seq * Hp;
   float* storeB = (fwd ? a.alpha_store : a.beta_store) + (size_t)bB * rows_per_seq * Hp;
   float* totA = (fwd ? a.tot_a : a.tot_b) + (size_t)bA * (a.T + 2);
   float* totB = (fwd ? a.tot_a : a.tot_b) + (size_t)bB * (a.T + 2);
   const float coef = a.coef;
-  const XBuf xbufA = make_xbuf(xA, (size_t)a.T * D * sizeof(float)), xbufB = make_xbuf(xB, (size_t)a.T * D * sizeof(float));
+  const XBuf xbufA = make_xbuf(xA, (size_t)a.T * D * kXe), xbufB = make_xbuf(xB, (size_t)a.T * D * kXe);
+  auto load_rows = [&](XRow<kPrNT, 4, 1>& qa, XRow<kPrNT, 4, 1>& qb, int ta, int tb, int t) {
+    if constexpr (XH) { qa.load_row_h(xbufA, ta, D, t, bf16); qb.load_row_h(xbufB, tb, D, t, bf16); }
+    else { qa.load_row(xbufA, ta, D, t); qb.load_row(xbufB, tb, D, t); }
+  };
   const XBuf sbufA = make_xbuf(storeA, (size_t)(a.T + 1) * Hp * sizeof(float));
   const XBuf sbufB = make_xbuf(storeB, (size_t)(a.T + 1) * Hp * sizeof(float));
 
@@ -252,8 +259,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
       p0 += s; p1 += s * l;
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
-    xqA.load_row(xbufA, fwd ? 0 : LA - 1, D, tid);
-    xqB.load_row(xbufB, fwd ? 0 : LB - 1, D, tid);
+    load_rows(xqA, xqB, fwd ? 0 : LA - 1, fwd ? 0 : LB - 1, tid);
     if (fwd) { nanA = xqA.has_nan(); nanB = haveB && xqB.has_nan(); }
     stage_rows(kPrX0, tid);
     __syncthreads();                                   // red zeroed
@@ -327,8 +333,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     /* nnet-output rows of the NEXT step (a sequence that has none re-reads a row that exists) */            \
     const int tnA = fwd ? j + 1 : LA - 2 - j, tnB = fwd ? j + 1 : LB - 2 - j;                               \
     const bool nextA = fwd ? tnA < LA : tnA >= 1, nextB = haveB && (fwd ? tnB < LB : tnB >= 1);             \
-    xqA.load_row(xbufA, min(max(tnA, 0), a.T - 1), D, tq);                                                  \
-    xqB.load_row(xbufB, min(max(tnB, 0), a.T - 1), D, tq);                                                  \
+    load_rows(xqA, xqB, min(max(tnA, 0), a.T - 1), min(max(tnB, 0), a.T - 1), tq);                          \
     lz_v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f};                                                                \
     pair_tile<R, fwd, VOFF>(arcs, groups, pairmask, lq, s0, s1);                                            \
     PR_PH(0);                                          /* arc phase */                                       \
@@ -401,10 +406,10 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
   if ((bad || nanA || nanB) && lane == 0) atomicAdd(a.bad, 1);
 }
 
-template <int R>
+template <int R, bool XH = false>
 __global__ __launch_bounds__(kPrNT) void den_recursion_pair_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int P = (a.B + 1) / 2;
-  if (blockIdx.x < (unsigned)P) pair_recursion<R, true>(a, smem_raw, blockIdx.x);
-  else pair_recursion<R, false>(a, smem_raw, blockIdx.x - P);
+  if (blockIdx.x < (unsigned)P) pair_recursion<R, true, XH>(a, smem_raw, blockIdx.x);
+  else pair_recursion<R, false, XH>(a, smem_raw, blockIdx.x - P);
 }

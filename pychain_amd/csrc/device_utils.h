@@ -3,6 +3,7 @@
 #define PYCHAIN_HIP_DEVICE_UTILS_H_
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 namespace pychain_hip {
@@ -109,6 +110,33 @@ __device__ __forceinline__ float mul_add_rn(float a, float b, float c) {
   return p + c;
 }
 
+// ---- 2-byte network outputs (bf16 / fp16: SURVEY.md row f4, DenArgs::x_half) -----------------------------------------------
+// The kernels that read the [B,T,D] network output take it as it is - 2-byte elements converted where they land, the
+// gradient rounded to the same type where it is written - instead of a host-side up-cast pass, a second [B,T,D] fp32
+// buffer and a cast of the gradient back (pychain_amd/native.py).  fmt: 1 = bf16, 2 = fp16 (uniform per call).
+enum { kXF32 = 0, kXBf16 = 1, kXF16 = 2 };
+__device__ __forceinline__ float half_bits_to_f32(uint32_t h /* low 16 bits */, bool bf16) {
+  if (bf16) return __uint_as_float(h << 16);
+  return __half2float(__ushort_as_half((unsigned short)h));
+}
+// the two elements of one dword (element 2i in the low half)
+__device__ __forceinline__ void half2_to_f32(uint32_t w, bool bf16, float& lo, float& hi) {
+  if (bf16) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+  else { lo = __half2float(__ushort_as_half((unsigned short)(w & 0xffffu))); hi = __half2float(__ushort_as_half((unsigned short)(w >> 16))); }
+}
+// round to nearest even, as torch's .to(dtype) does (a NaN stays a NaN)
+__device__ __forceinline__ uint32_t f32_to_half_bits(float f, bool bf16) {
+  if (bf16) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  }
+  return (uint32_t)__half_as_ushort(__float2half_rn(f));
+}
+__device__ __forceinline__ uint32_t pack_half2(float lo, float hi, bool bf16) {
+  return f32_to_half_bits(lo, bf16) | (f32_to_half_bits(hi, bf16) << 16);
+}
+
 // ---- buffer descriptor of one sequence's nnet-output [T, D] -------------------------------------
 // Rows are fetched with `buffer_load_dwordx4 vdst, voffset, srsrc, soffset offen`: the row is selected by
 // the SGPR soffset, the lane by a loop-invariant 32-bit voffset, so a frame's load writes NO address
@@ -138,6 +166,30 @@ struct XRow {
       const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(buf, min(e, D - 4) * 4, soff, 0);   // lanes past the row re-read its end
       v[c * 4 + 0] = __uint_as_float(q.x); v[c * 4 + 1] = __uint_as_float(q.y);
       v[c * 4 + 2] = __uint_as_float(q.z); v[c * 4 + 3] = __uint_as_float(q.w);
+    }
+  }
+  // the same two loads for 2-byte rows (VEC == 4: four elements = 8 bytes per thread and chunk); `row` / `buf` address
+  // 2-byte elements, the values arrive converted to fp32
+  __device__ __forceinline__ void load_row_h(XBuf buf, int t, int D, int tid, bool bf16) {
+    static_assert(VEC == 4 && XCH > 0, "buffer form: chunks of four elements");
+    const int soff = __builtin_amdgcn_readfirstlane(t * D * 2);
+#pragma unroll
+    for (int c = 0; c < XCH; c++) {
+      const int e = (c * NT + tid) * 4;
+      typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+      const u32x2_ q = __builtin_amdgcn_raw_buffer_load_b64(buf, min(e, D - 4) * 2, soff, 0);
+      half2_to_f32(q.x, bf16, v[c * 4 + 0], v[c * 4 + 1]);
+      half2_to_f32(q.y, bf16, v[c * 4 + 2], v[c * 4 + 3]);
+    }
+  }
+  __device__ __forceinline__ void load_h(const void* __restrict__ row, int D, int tid, bool bf16) {
+    static_assert(VEC == 4 && XCH > 0, "2-byte rows: chunks of four elements (D % 4 == 0)");
+#pragma unroll
+    for (int c = 0; c < XCH; c++) {
+      const int e = (c * NT + tid) * 4;
+      const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(row) + (size_t)min(e, D - 4) * 2);
+      half2_to_f32(q.x, bf16, v[c * 4 + 0], v[c * 4 + 1]);
+      half2_to_f32(q.y, bf16, v[c * 4 + 2], v[c * 4 + 3]);
     }
   }
   __device__ __forceinline__ void load(const float* __restrict__ row, int D, int tid) {

@@ -11,7 +11,8 @@ struct NumArgs {
   const int32_t* fwd_trans; const int32_t* fwd_idx; const float* fwd_probs;
   const int32_t* bwd_trans; const int32_t* bwd_idx; const float* bwd_probs;
   const float* initial; const float* final_;
-  const float* x;            // [B,T,D] raw
+  const float* x;            // [B,T,D] raw   (x_half: 2-byte elements behind this pointer)
+  int x_half;                // 0 fp32; kXBf16 / kXF16 (device_utils.h): the recursions read 2-byte rows as they are (num_fb_kernel)
   const int64_t* lengths;    // [B]
   float* objf;               // [B]
   float* grad;               // [B,T,D]

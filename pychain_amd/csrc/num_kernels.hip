@@ -70,8 +70,13 @@ __device__ __forceinline__ double wave_max(double v) {
 // log-share stores under divergent branches, every wait degenerates to vmcnt(0), and each step lasts a
 // round trip to HBM (1461 us for T = 1500; XCH then counts chunks of kFbNT threads).
 constexpr int kFbLd = 128;
-template <int VEC, int XCH, int LD>
+// XH: 2-byte network output (NumArgs::x_half; float4-chunk forms only): four elements = 8 bytes per thread and chunk, converted
+// as they arrive
+template <int VEC, int XCH, int LD, bool XH = false>
 __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
+  static_assert(!XH || (VEC == 4 && XCH > 0), "2-byte rows: chunks of four elements through registers");
+  constexpr size_t kXe = XH ? 2 : 4;
+  const bool bf16 = a.x_half == kXBf16;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,8 +102,17 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
     for (int k = tid; k < K; k += kFbNT + LD)
       arc[k] = ArcW{(uint32_t)tr[3 * k + (fwd ? 0 : 1)] | ((uint32_t)tr[3 * k + 2] << 16), pr[k]};
   }
-  const float* xseq = a.x + (size_t)b * T * D;
-  const XBuf xbuf = make_xbuf(xseq, (size_t)T * D * sizeof(float));
+  const float* xseq = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)b * T * D * kXe);
+  const XBuf xbuf = make_xbuf(xseq, (size_t)T * D * kXe);
+  // row `t` of the sequence into a staging register set (by pointer / through the buffer descriptor)
+  auto xload = [&](auto& xr, int t, int ti) {
+    if constexpr (XH) xr.load_h(reinterpret_cast<const char*>(xseq) + (size_t)t * D * 2, D, ti, bf16);
+    else xr.load(xseq + (size_t)t * D, D, ti);
+  };
+  auto xload_row = [&](auto& xr, int t, int ti) {
+    if constexpr (XH) xr.load_row_h(xbuf, t, D, ti, bf16);
+    else xr.load_row(xbuf, t, D, ti);
+  };
   double* rows = (fwd ? a.alpha_ws : a.beta_ws) + (size_t)b * (T + 1) * H;     // row t = alpha(t,.) / beta(t,.), fp64 log-prob
   const int2* idx = reinterpret_cast<const int2*>((fwd ? a.bwd_idx : a.fwd_idx) + g * H * 2);
 
@@ -120,8 +134,8 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
     }
   };
   {
-    const float* xrow = xseq + (size_t)(fwd ? 0 : L - 1) * D;
-    if (!LD || tid >= kFbNT) xq.load(xrow, D, xt);
+    const float* xrow = XH ? nullptr : xseq + (size_t)(fwd ? 0 : L - 1) * D;    // (only the register-less form reads it again)
+    if (!LD || tid >= kFbNT) xload(xq, fwd ? 0 : L - 1, xt);
     // AlphaFirstFrame :84-90 / BetaLastFrame :192-202 (unnormalised: beta(L,i) = final(i); 1/P enters the occupancy)
     if (tid < kFbNT)
       for (int h = tid; h < H; h += kFbNT) {
@@ -138,13 +152,13 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
       static_assert(VEC == 4 && XCH > 0, "row-staging waves use the float4 buffer-load form");
       XRow<LD, VEC, XCH> xq2;
       auto row_of_step = [&](int s) { return fwd ? min(s, L) - 1 : max(L - s, 0); };
-      xq.load_row(xbuf, row_of_step(2), D, xt);
+      xload_row(xq, row_of_step(2), xt);
       for (int s = 1; s <= L; s += 2) {
-        xq2.load_row(xbuf, row_of_step(s + 2), D, xt);
+        xload_row(xq2, row_of_step(s + 2), xt);
         stage(xq, xr1, nullptr, xt);                 // row of step s+1
         __syncthreads();
         if (s + 1 <= L) {
-          xq.load_row(xbuf, row_of_step(s + 3), D, xt);
+          xload_row(xq, row_of_step(s + 3), xt);
           stage(xq2, xr0, nullptr, xt);              // row of step s+2
           __syncthreads();
         }
@@ -168,11 +182,11 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
     float* xnext = (s & 1) ? xr1 : xr0;
     const bool have_next = s < L;
     const int t_next = have_next ? (fwd ? s : L - 1 - s) : 0;
-    const float* xrow_next = xseq + (size_t)t_next * D;
+    const float* xrow_next = XH ? nullptr : xseq + (size_t)t_next * D;
     const size_t trow = (size_t)(fwd ? s : L - s) * H;
     if (!LD && have_next) {
       // buffer form: no address VGPR is written per step, so the load does not wait for this step's row stores
-      if constexpr (VEC == 4 && XCH > 0) xq.load_row(xbuf, t_next, D, tid);
+      if constexpr (VEC == 4 && XCH > 0) xload_row(xq, t_next, tid);
       else xq.load(xrow_next, D, tid);
     }
     // bwd also writes, per arc, its log-share of its source state's beta:  r_k(t) = term_k - beta(t,h) <= 0.
@@ -572,13 +586,21 @@ __global__ __launch_bounds__(kOcNT) void num_scatter_kernel(const NumArgs a) {
   }
 }
 
-template <int VEC, int XCH, int LD = 0>
-hipError_t launch_fb(const NumArgs& a, size_t lds, hipStream_t st) {
-  auto k = num_fb_kernel<VEC, XCH, LD>;
+template <int VEC, int XCH, int LD, bool XH>
+hipError_t launch_fb_x(const NumArgs& a, size_t lds, hipStream_t st) {
+  auto k = num_fb_kernel<VEC, XCH, LD, XH>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(2 * a.B), dim3(kFbNT + LD), lds, st, a);
   return hipGetLastError();
+}
+template <int VEC, int XCH, int LD = 0>
+hipError_t launch_fb(const NumArgs& a, size_t lds, hipStream_t st) {
+  if (a.x_half) {                                      // 2-byte rows: the float4-chunk forms only (num_half_native)
+    if constexpr (VEC == 4 && XCH > 0) return launch_fb_x<VEC, XCH, LD, true>(a, lds, st);
+    else return hipErrorInvalidValue;
+  }
+  return launch_fb_x<VEC, XCH, LD, false>(a, lds, st);
 }
 
 }  // namespace
@@ -597,6 +619,10 @@ hipError_t launch_num_fb(const NumArgs& a, hipStream_t st, const char** why) {
   const size_t lds = num_fb_lds_bytes(a.H, a.K, a.D);
   if (lds > 160 * 1024) {
     *why = "numerator graph + nnet-output rows do not fit the 160 KiB LDS of one CU";
+    return hipErrorInvalidValue;
+  }
+  if (a.x_half && (a.D % 4 != 0 || a.D > 4 * 8 * kFbNT)) {
+    *why = "2-byte network outputs need rows of a multiple of four pdfs within the register-staged forms";
     return hipErrorInvalidValue;
   }
   if ((size_t)a.T * a.D * 4 >= (size_t)1 << 31) {      // rows are addressed as 32-bit byte offsets (buffer loads)

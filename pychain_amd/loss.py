@@ -11,8 +11,9 @@ error behaviour).  What differs is underneath:
     chain-computation.cc:77-89);
   * lengths may be given in any order and on any device (the reference needs
     them sorted descending on the CPU for pack_padded_sequence, loss.py:37-40);
-  * fp16 / bf16 network outputs are accepted (evaluated in fp32, gradient returned in the
-    input's dtype); the reference's C++ accessors take float32 only.
+  * fp16 / bf16 network outputs are accepted and read by the kernels AS THEY ARE (converted where they land, all
+    arithmetic in fp32; the gradient is rounded to the input's dtype where it is written: no fp32 copy of [B,T,D]);
+    the reference's C++ accessors take float32 only.
 
 There is no CPU implementation here: CPU tensors raise.
 """
@@ -168,9 +169,12 @@ class ChainLossFunction(torch.autograd.Function):
         # with the recursions, for an upstream gradient of 1 (what `loss.backward()` sends);
         # backward then only rescales if the upstream gradient turns out to differ.
         ctx.speculative = bool(ctx.needs_input_grad[0]) and ChainLossFunction.overlap
+        # (2-byte network outputs go to the kernels as they are when the gradient is written here, or never)
+        half_ok = ctx.speculative or not bool(ctx.needs_input_grad[0])
         den_objf, num_objf, bad, state, totals = native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
-            with_grad=ctx.speculative, grad_scale=ctx.host_scale, loss_scale=ctx.host_scale, norm_dev=ctx.dev_norm)
+            with_grad=ctx.speculative, grad_scale=ctx.host_scale, loss_scale=ctx.host_scale, norm_dev=ctx.dev_norm,
+            half_ok=half_ok)
         # -(num - den) [/ frames], loss.py:100-104, comes with the call (the last workgroup of its last kernel adds the
         # per-sequence objectives up): no reduction / subtraction / scaling launches behind it
         objf = native.totals_scalar(totals)    # (no launch; not a view of the statistics: `loss /= n` works)
@@ -180,7 +184,7 @@ class ChainLossFunction(torch.autograd.Function):
         spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)
         ctx.again = _recompute(x, lambda: native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
-            with_grad=spec, grad_scale=hscale), lambda r: (r[3], r[2]))      # (state, bad)
+            with_grad=spec, grad_scale=hscale, half_ok=half_ok), lambda r: (r[3], r[2]))      # (state, bad)
         ctx.in_dtype = input.dtype
         ChainFunction.last_bad_count = bad       # int32[2]: denominator, numerator; never synced here
         return objf

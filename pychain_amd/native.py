@@ -61,6 +61,22 @@ def _check_lengths(lengths, B, T):
             raise ValueError("sequence lengths must be in [1, %d]" % T)
 
 
+HALF_ROWS = True        # False: bf16 / fp16 network outputs are up-cast on the host side of the ABI (the tests compare the two ways)
+_DTYPE_CODE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+
+
+def _rows_as_given(x, native):
+    """(tensor the kernels read, its PYCHAIN_HIP_* element code): a bf16 / fp16 network output goes to the kernels as it is
+    where the call's kernel family takes 2-byte rows (`native`: the library's own answer, include/pychain_hip.h:
+    pychain_hip_*_half_native) - no fp32 copy of [B,T,D], and the gradient comes back in the same type; otherwise it is
+    up-cast here, once (general plans, the two-barrier recursion, rows that are not a multiple of 8 pdfs, ...)."""
+    if x.dtype == torch.float32:
+        return x, _lib.F32
+    if HALF_ROWS and x.dtype in _DTYPE_CODE and native():
+        return x, _DTYPE_CODE[x.dtype]
+    return x.float(), _lib.F32
+
+
 def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=False, grad_scale=1.0, totals=False):
     """Denominator on the GPU.  `plan`: _plan.DevicePlan.
     Returns (objf_per_seq[B], grad[B,T,D], bad_count[1]) and, `totals`, the device float[4] of
@@ -68,16 +84,15 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
     num_states = plan.num_states
     _require_device(x, "nnet_output")
     x = x.contiguous()
-    if x.dtype != torch.float32:
-        x = x.float()
     B, T, D = x.shape
     _check_lengths(lengths, B, T)
     L = _lib.lib()
     dev = x.device
     with torch.cuda.device(dev):
+        x, xcode = _rows_as_given(x, lambda: L.pychain_hip_den_half_native(plan.stride, plan.slot_rows, int(num_states), D, B, T))
         ld = _lengths_dev(lengths, dev)
         objf = torch.empty(B, dtype=torch.float32, device=dev)
-        grad = torch.empty_like(x)
+        grad = torch.empty_like(x)                 # (in the type the kernels read: the gradient is rounded where it is written)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
         tot = torch.empty(_lib.TOTALS, dtype=torch.float32, device=dev) if totals else None
         # (the [B,T,D] buffer of the rows exp'd ahead only where this call will use it: ADVICE r4)
@@ -85,7 +100,7 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
         nws = (L.pychain_hip_den_workspace_bytes if full else L.pychain_hip_den_workspace_min_bytes)(B, T, int(num_states), D)
         ws = _workspace(nws, dev, "den")
         _lib.check(L.pychain_hip_den_forward_backward(
-            plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(),
+            plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(), xcode,
             int(bool(input_is_exp)),
             ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
             objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), tot.data_ptr() if totals else 0,
@@ -100,14 +115,13 @@ def num_forward_backward(gt, graph_stride, num_states, x, lengths, grad_mode=_li
     (objf_per_seq[B], grad[B,T,D], bad_count[1])."""
     _require_device(x, "nnet_output")
     x = x.contiguous()
-    if x.dtype != torch.float32:
-        x = x.float()
     B, T, D = x.shape
     _check_lengths(lengths, B, T)
     K = gt["forward_transitions"].shape[1]
     L = _lib.lib()
     dev = x.device
     with torch.cuda.device(dev):
+        x, xcode = _rows_as_given(x, lambda: L.pychain_hip_num_half_native(int(num_states), K, D))
         ld = _lengths_dev(lengths, dev)
         objf = torch.empty(B, dtype=torch.float32, device=dev)
         if grad_mode == _lib.GRAD_ACCUM:
@@ -115,7 +129,7 @@ def num_forward_backward(gt, graph_stride, num_states, x, lengths, grad_mode=_li
                 raise ValueError("GRAD_ACCUM needs grad_out")
             grad = grad_out
         else:
-            grad = torch.empty_like(x)
+            grad = torch.empty(x.shape, dtype=torch.float32, device=dev)     # (this entry point's gradient is fp32 whatever it read)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
         nws = L.pychain_hip_num_workspace_bytes(B, T, int(num_states), K, D)
         ws = _workspace(nws, dev, "num")
@@ -124,7 +138,7 @@ def num_forward_backward(gt, graph_stride, num_states, x, lengths, grad_mode=_li
             gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
             gt["backward_transition_indices"].data_ptr(), gt["backward_transition_probs"].data_ptr(),
             gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
-            x.data_ptr(), ld.data_ptr(), B, T, D, int(num_states), K, int(grad_mode), float(grad_scale),
+            x.data_ptr(), xcode, ld.data_ptr(), B, T, D, int(num_states), K, int(grad_mode), float(grad_scale),
             objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
             "pychain_hip_num_forward_backward")
     return objf, grad, bad
@@ -136,14 +150,14 @@ def chain_loss_forward_backward(plan, gt, graph_stride, num_states_num, x, lengt
     bad_count[2]).  The numerator recursion overlaps the denominator on a side stream."""
     _require_device(x, "nnet_output")
     x = x.contiguous()
-    if x.dtype != torch.float32:
-        x = x.float()
     B, T, D = x.shape
     _check_lengths(lengths, B, T)
     K = gt["forward_transitions"].shape[1]
     L = _lib.lib()
     dev = x.device
     with torch.cuda.device(dev):
+        x, xcode = _rows_as_given(x, lambda: L.pychain_hip_chain_loss_half_native(
+            plan.stride, plan.slot_rows, plan.num_states, D, B, T, int(num_states_num), K))
         ld = _lengths_dev(lengths, dev)
         den_objf = torch.empty(B, dtype=torch.float32, device=dev)
         num_objf = torch.empty(B, dtype=torch.float32, device=dev)
@@ -158,7 +172,7 @@ def chain_loss_forward_backward(plan, gt, graph_stride, num_states_num, x, lengt
             gt["backward_transition_indices"].data_ptr(), gt["backward_transition_probs"].data_ptr(),
             gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
             int(num_states_num), K,
-            x.data_ptr(), ld.data_ptr(), B, T, D, float(grad_scale),
+            x.data_ptr(), xcode, ld.data_ptr(), B, T, D, float(grad_scale),
             den_objf.data_ptr(), num_objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), 1.0, 0, 0,
             dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_forward_backward")
@@ -173,15 +187,13 @@ class ChainLossState(object):
 
 
 def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky_coefficient=1e-5,
-                       with_grad=False, grad_scale=1.0, loss_scale=1.0, norm_dev=None):
+                       with_grad=False, grad_scale=1.0, loss_scale=1.0, norm_dev=None, half_ok=True):
     """Recursions (and, `with_grad`, the occupancy passes overlapped with them: state.grad =
     grad_scale * (gamma_den - gamma_num)).  Returns (den_objf[B], num_objf[B], bad_count[2], state, totals) with
     totals = device float[4] [(sum den - sum num) * loss_scale [/ norm_dev], frames, bad count, sum den - sum num]
     written by the call's last kernel (include/pychain_hip.h)."""
     _require_device(x, "nnet_output")
     x = x.contiguous()
-    if x.dtype != torch.float32:
-        x = x.float()
     B, T, D = x.shape
     _check_lengths(lengths, B, T)
     K = gt["forward_transitions"].shape[1]
@@ -189,6 +201,9 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
     dev = x.device
     st = ChainLossState()
     with torch.cuda.device(dev):
+        # (`half_ok` False: a later chain_loss_backward on this state - it accumulates the numerator into an fp32 gradient)
+        x, xcode = _rows_as_given(x, lambda: half_ok and L.pychain_hip_chain_loss_half_native(
+            plan.stride, plan.slot_rows, plan.num_states, D, B, T, int(num_states_num), K))
         ld = _lengths_dev(lengths, dev)
         den_objf = torch.empty(B, dtype=torch.float32, device=dev)
         num_objf = torch.empty(B, dtype=torch.float32, device=dev)
@@ -207,7 +222,7 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
             gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
             gt["backward_transition_indices"].data_ptr(), gt["backward_transition_probs"].data_ptr(),
             gt["initial_probs"].data_ptr(), gt["final_probs"].data_ptr(), int(graph_stride),
-            int(num_states_num), K, x.data_ptr(), ld.data_ptr(), B, T, D,
+            int(num_states_num), K, x.data_ptr(), xcode, ld.data_ptr(), B, T, D,
             den_objf.data_ptr(), num_objf.data_ptr(), grad.data_ptr() if with_grad else 0, float(grad_scale),
             bad.data_ptr(), float(loss_scale), 0 if norm_dev is None else norm_dev.data_ptr(), totals.data_ptr(),
             dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
@@ -238,7 +253,7 @@ def chain_loss_backward(st, grad_scale=1.0, grad_scale_dev=None):
                 st.plan.blob.data_ptr(), st.plan.stride, st.plan.slot_rows, st.plan.num_states,
                 st.gt["forward_transitions"].data_ptr(), st.gt["forward_transition_indices"].data_ptr(),
                 st.gt["forward_transition_probs"].data_ptr(),
-                st.graph_stride, st.num_states_num, K, st.x.data_ptr(), st.lengths_dev.data_ptr(), B, T, D,
+                st.graph_stride, st.num_states_num, K, st.x.data_ptr(), _DTYPE_CODE[st.x.dtype], st.lengths_dev.data_ptr(), B, T, D,
                 float(grad_scale), sptr, grad.data_ptr(), bad.data_ptr(),
                 st.den_ws.data_ptr(), st.den_ws.numel(), st.num_ws.data_ptr(), st.num_ws.numel(), _stream(dev)),
                 "pychain_hip_chain_loss_backward")
@@ -270,7 +285,7 @@ def rescale_(t, scale_dev):
     """t *= scale_dev (0-dim device tensor), skipped on the device when the scalar is exactly 1."""
     scale_dev = scale_dev.detach().to(device=t.device, dtype=torch.float32).contiguous()
     with torch.cuda.device(t.device):
-        _lib.check(_lib.lib().pychain_hip_rescale(t.data_ptr(), t.numel(), scale_dev.data_ptr(), _stream(t.device)),
+        _lib.check(_lib.lib().pychain_hip_rescale(t.data_ptr(), _DTYPE_CODE[t.dtype], t.numel(), scale_dev.data_ptr(), _stream(t.device)),
                    "pychain_hip_rescale")
     return t
 
