@@ -139,6 +139,12 @@ def kernel_rooflines(w, dev, iters, d2d=True):
                 break
         except Exception:
             continue
+    call_traffic = None
+    try:
+        if traffic_source is not None and "den_call_hbm_bytes" in tj:
+            call_traffic = int(tj["den_call_hbm_bytes"])
+    except Exception:
+        pass
     roof = {
         "bound": "hbm", "kernel": rec_name,
         "achieved": round(bytes_rec / (ms_rec * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -155,7 +161,11 @@ def kernel_rooflines(w, dev, iters, d2d=True):
         "den_forward_backward": {
             "algorithmic_bytes": bytes_rec + bytes_gam, "ms": round(out["den_call"], 4),
             "achieved": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9, 2),
-            "frac": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "frac": round((bytes_rec + bytes_gam) / (out["den_call"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            # PMC bytes of every launch of the call (recursion + occupancy + finish [+ rows exp'd ahead]) from the same committed
+            # file, and their ratio to the algorithmic bytes: what is re-read
+            "traffic": call_traffic,
+            "traffic_over_algorithmic": round(call_traffic / (bytes_rec + bytes_gam), 3) if call_traffic else None},
     }
     # the numerator's launches (side stream, hidden beside the first half of the recursion at B = 64, CU time from B = 128
     # on): the fused call with the denominator's launches masked out - recursions only (num_fb_kernel), then with the
@@ -212,20 +222,44 @@ def numerator_rooflines(w, plan, dev, iters, stream):
             "numerator_forward_backward": mk(ms_all, bytes_fb + bytes_occ)}
 
 
-def _adhoc_workload(name, B, dev):
-    """BASELINE config `name`, optionally at another batch size (same graph, ragged lengths drawn for B)."""
+def _adhoc_workload(name, B, dev, equal=False, den_only=False, dtype=None):
+    """BASELINE config `name`, optionally at another batch size (same graph, ragged lengths drawn for B), with all
+    sequences of the full length (`equal`), without numerators (`den_only`), with a 2-byte network output (`dtype`)."""
     from pychain_amd import synthetic as syn
-    if B is None:
+    if B is None and not equal and not den_only:
         w = syn.make_workload(name, device=dev)
     else:
         cfg = dict(syn.CONFIGS[name])
-        cfg["B"] = B
+        cfg["B"] = B = B or cfg["B"]
+        if equal:
+            cfg["lengths"] = "equal"
+        if den_only:
+            cfg["num"] = False
         lengths = syn.make_lengths(B, cfg["T"], cfg["lengths"], seed=2)
         w = dict(cfg=cfg, lengths=lengths, den_graph=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0),
                  num_graphs=syn.make_num_graphs(lengths.tolist(), cfg["D"], seed=100) if cfg["num"] else None,
                  x=syn.make_input(B, cfg["T"], cfg["D"], seed=1, device=dev))
+    if dtype is not None:
+        w["x"] = w["x"].to(dtype)
     w["lengths_dev"] = w["lengths"].to(dev)
     return w
+
+
+def _committed_call_traffic(workload, frames, algorithmic):
+    """PMC bytes of the whole denominator call (every launch: recursion, occupancy, finish, the rows exp'd ahead) from the
+    newest committed profiles/r*_<workload>_hbm_traffic.json measured on this very workload - labelled, not re-measured."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+            if tj.get("workload") == workload and tj.get("frames") == frames and "den_call_hbm_bytes" in tj:
+                t = int(tj["den_call_hbm_bytes"])
+                return {"traffic": t, "traffic_over_algorithmic": round(t / algorithmic, 3),
+                        "traffic_source": "profiles/" + os.path.basename(path) + " (PMC passes of the same call; not re-measured in this run)"}
+        except Exception:
+            continue
+    return {"traffic": None}
 
 
 def other_workloads(dev, steps=6, warmup=3):
@@ -233,10 +267,15 @@ def other_workloads(dev, steps=6, warmup=3):
     reported BESIDE the metric (`other_workloads`), never in `value`.  C4 is BASELINE.json's "HBM-roofline run"."""
     from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, _lib, _plan, native
     out = {}
-    for label, name, B in (("C4", "C4", None), ("C2", "C2", None), ("C3@B=128", "C3", 128), ("C3@B=256", "C3", 256)):
+    # "C3-equal": B = 64, every sequence 1500 frames, denominator only - the exact configuration BASELINE.md §3 states the
+    # 40 % target on (VERDICT r4 item 5); "C3-bf16": the bench batch with a bf16 network output read by the kernels as it is
+    for label, name, B, kw in (("C4", "C4", None, {}), ("C2", "C2", None, {}), ("C3-equal", "C3", None, dict(equal=True, den_only=True)),
+                               ("C3-bf16", "C3", None, dict(dtype=torch.bfloat16)),
+                               ("C3@B=128", "C3", 128, {}), ("C3@B=256", "C3", 256, {})):
         try:
-            w = _adhoc_workload(name, B, dev)
+            w = _adhoc_workload(name, B, dev, **kw)
             cfg = w["cfg"]
+            half = w["x"].dtype != torch.float32
             x = w["x"].requires_grad_(True)
             crit = ChainLoss(w["den_graph"], 1e-5, avg=False)
             gb = ChainGraphBatch(w["den_graph"], cfg["B"])
@@ -267,15 +306,21 @@ def other_workloads(dev, steps=6, warmup=3):
                 with _lib.option("den_phase_mask", mask), (_lib.option("den_dma", 2) if cfg["num"] else contextlib.nullcontext()):
                     call(); torch.cuda.synchronize()
                     parts[key] = event_time_ms(call, 3, stream)
-            den_bytes = (12 * cfg["D"] + 8 * (cfg["H"] + 1)) * frames
+            # (2-byte rows: x read twice at 2 B, the gradient written at 2 B: 6 D instead of 12 D per frame)
+            den_bytes = ((6 if half else 12) * cfg["D"] + 8 * (cfg["H"] + 1)) * frames
+            uses_rows = bool(_lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, cfg["H"], cfg["D"], cfg["B"], cfg["T"], 0)) and not cfg["num"]
             out[label] = {
-                "workload": "%s: B=%d T<=%d (%d frames), %d pdfs, den %d states/%d arcs%s"
-                            % (name, cfg["B"], cfg["T"], frames, cfg["D"], cfg["H"], cfg["K"], " + numerators" if cfg["num"] else ", denominator only"),
+                "workload": "%s: B=%d T<=%d (%d frames), %d pdfs, den %d states/%d arcs%s%s"
+                            % (name, cfg["B"], cfg["T"], frames, cfg["D"], cfg["H"], cfg["K"], " + numerators" if cfg["num"] else ", denominator only",
+                               ", %s network output and gradient" % str(w["x"].dtype).replace("torch.", "") if half else ""),
+                # the [B,T,D] fp32 buffer of the rows exp'd ahead of the recursions: only calls of the denominator alone
+                "rows_exp_ahead_workspace_bytes": 4 * cfg["B"] * cfg["T"] * cfg["D"] if uses_rows else 0,
                 "ms_per_step": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1), "steps": steps,
                 "recursion_kernel": rec, "occupancy_kernel": occ,
                 "recursion_ms": round(parts["recursion_ms"], 4), "occupancy_ms": round(parts["occupancy_ms"], 4),
-                "den_forward_backward": {"algorithmic_bytes": den_bytes, "ms": round(parts["den_ms"], 4),
-                                         "frac": round(den_bytes / (parts["den_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "den_forward_backward": dict({"algorithmic_bytes": den_bytes, "ms": round(parts["den_ms"], 4),
+                                              "frac": round(den_bytes / (parts["den_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                                             **_committed_call_traffic(name if not kw else label, frames, den_bytes)),
                 "n_bad": int(ChainFunction.last_bad_count.sum()),
             }
             del w, x, crit, gb
@@ -458,9 +503,10 @@ def _cpu_all_cores(w, order, sec_per_utt):
         p_.join()
     tmax = max(g[1] for g in got)
     frames = sum(g[2] for g in got)
-    return {"value": round(frames / tmax, 1), "unit": "frames/s", "cores": cores, "workers": nw, "kind": got[0][3],
-            "sample": "all %d utterances of the batch dealt to %d single-threaded worker processes, "
-                      "%d repetitions each, slowest worker %.1f s" % (int(order.numel()), nw, reps, tmax)}
+    # (`cores` = the threads that did work: one utterance per worker leaves the other host cores idle - said in the line)
+    return {"value": round(frames / tmax, 1), "unit": "frames/s", "cores": nw, "host_cores": cores, "workers": nw, "kind": got[0][3],
+            "sample": "all %d utterances of the batch dealt to %d single-threaded worker processes (%d of the %d host cores used), "
+                      "%d repetitions each, slowest worker %.1f s" % (int(order.numel()), nw, nw, cores, reps, tmax)}
 
 
 class _DenOnlyLoss(torch.nn.Module):

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     //  STREAM: the state rows may have been written by another XCD while this kernel runs: device-scope loads)
 #define GAMMA_PREFETCH(t)                                                                     \
   do {                                                                                        \
-    if constexpr (XH) xq.load_h(reinterpret_cast<const char*>(xseq) + (size_t)(t) * D * 2, D, tid, bf16);                \
+    if constexpr (XH) xq.load_h(reinterpret_cast<const char*>(xseq) + (size_t)(t) * D * 2, D, tid);   /* (raw) */        \
     else xq.load(xseq + (size_t)(t) * D, D, tid);                                             \
     if (uv_in_regs) {                                                                         \
       const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   } while (0)
 #define GAMMA_COMMIT(t)                                                                       \
   do {                                                                                        \
+    if constexpr (XH) xq.convert_h(bf16);                                                     \
     xq.store(xr, XH ? nullptr : xseq + (size_t)(t) * D, D, tid, a.input_is_exp);              \
     if (uv_in_regs) {                                                                         \
       _Pragma("unroll") for (int c = 0; c < kUV; c++) {                                       \
@@ -783,8 +784,8 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       const bool have_next = tn < t_live_end;
       // this pair's nnet-output rows (used after the arc work) and the next pair's state rows
       if constexpr (XH) {
-        x0.load_h(reinterpret_cast<const char*>(xseq) + (size_t)t0 * D * 2, D, tid, bf16);
-        x1.load_h(reinterpret_cast<const char*>(xseq) + (size_t)min(t0 + 1, T - 1) * D * 2, D, tid, bf16);
+        x0.load_h(reinterpret_cast<const char*>(xseq) + (size_t)t0 * D * 2, D, tid);            // (raw: converted behind the arc work)
+        x1.load_h(reinterpret_cast<const char*>(xseq) + (size_t)min(t0 + 1, T - 1) * D * 2, D, tid);
       } else {
         x0.load(xseq + (size_t)t0 * D, D, tid);
         x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
@@ -833,6 +834,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
           }
         }
       };
+      if constexpr (XH) { x0.convert_h(bf16); x1.convert_h(bf16); }
       if (a.input_is_exp == kXExpClamp) products(std::integral_constant<int, kXExpClamp>{});
       else if (a.input_is_exp == kXIdentity) products(std::integral_constant<int, kXIdentity>{});
       else products(std::integral_constant<int, kXClamp>{});

@@ -147,45 +147,42 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
   }
   return nan;
 }
-// 2-byte rows (DenArgs::x_half): the unit a wave owns is 2 KiB of the fp32 row buffer = 512 elements = 1 KiB of raw row,
-// which ONE LDS-direct load per wave brings into the UPPER half of the unit; the finish reads a lane's 16 raw bytes (8
-// elements) from there and writes its 32 bytes of fp32 over the unit from the bottom - every read of a wave is issued before
-// its first write, and no other wave touches the unit.  D % 8 == 0 (a lane's 8 elements are all inside the row or all past it).
-template <int NW, int NU, int AUX = 0>
+// 2-byte rows (DenArgs::x_half): the chunk a wave owns is the same 1 KiB of the fp32 row buffer = 256 elements = 512 bytes of
+// raw row, which lanes 0 .. 31 bring into the UPPER half of the chunk with one LDS-direct load (16 bytes each; the other lanes
+// are masked off and write nothing); the finish then has every lane read ITS 8 raw bytes (4 elements) from there and write
+// its 16 bytes of fp32 over the chunk from the bottom - the reads of a wave are all issued before its first write, and no
+// other wave touches the chunk.  Same chunk-to-wave dealing and the same four elements per lane as the fp32 rows.
+// D % 8 == 0 (a loading lane's 8 elements are all inside the row or all past it).
+template <int NW, int NCH, int AUX = 0>
 __device__ __forceinline__ void lz_dma_row_h(XBuf buf, int t, int D, int wave, int lane, uint32_t xbase) {
   const int row_bytes = D * 2;
   const int soff = __builtin_amdgcn_readfirstlane(t * row_bytes);
 #pragma unroll
-  for (int c = 0; c < NU; c++) {
-    const int u = wave + c * NW;                        // (uniform)
-    if (u * 1024 < row_bytes) {
-      const int voff = u * 1024 + lane * 16 < row_bytes ? lane * 16 : max(0, row_bytes - 16 - u * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(buf, (lz_lds_void*)(xbase + (uint32_t)u * 2048u + 1024u), 16, voff,
-                                               soff + u * 1024, 0, AUX);
+  for (int c = 0; c < NCH; c++) {
+    const int ch = wave + c * NW;                       // (uniform)
+    if (ch * 512 < row_bytes && lane < 32) {
+      const int voff = ch * 512 + lane * 16 < row_bytes ? lane * 16 : max(0, row_bytes - 16 - ch * 512);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(buf, (lz_lds_void*)(xbase + (uint32_t)ch * 1024u + 512u), 16, voff,
+                                               soff + ch * 512, 0, AUX);
     }
   }
 }
-template <int NW, int NU>
+template <int NW, int NCH>
 __device__ __forceinline__ bool lz_dma_finish_h(int D, int wave, int lane, uint32_t xbase, int is_exp, bool bf16) {
   bool nan = false;
   PYCHAIN_WAIT_VM0();                                   // this wave's loads have landed
 #pragma unroll
-  for (int c = 0; c < NU; c++) {
-    const int u = wave + c * NW;
-    if (u * 1024 < D * 2) {
-      const uint32_t ubase = xbase + (uint32_t)u * 2048u;
-      const u32x4 r = *(const __attribute__((address_space(3))) u32x4*)(ubase + 1024u + (uint32_t)lane * 16u);
-      // (four elements at a time: the raw words are all in registers before the first write, and no more than four converted
-      // values are live beside them - the kernel runs at its register limit)
-#pragma unroll
-      for (int hf = 0; hf < 2; hf++) {
-        float f0, f1, f2, f3;
-        half2_to_f32(hf ? r.z : r.x, bf16, f0, f1); half2_to_f32(hf ? r.w : r.y, bf16, f2, f3);
-        nan = nan || __builtin_isunordered(f0, f1) || __builtin_isunordered(f2, f3);
-        if (is_exp == kXExpClamp) { f0 = clamp_exp(f0, kXExpClamp); f1 = clamp_exp(f1, kXExpClamp); f2 = clamp_exp(f2, kXExpClamp); f3 = clamp_exp(f3, kXExpClamp); }
-        *(__attribute__((address_space(3))) lz_v4*)(ubase + (uint32_t)lane * 32u + 16u * hf) = lz_v4{f0, f1, f2, f3};
-        if (hf == 0) asm volatile("" ::: "memory");
-      }
+  for (int c = 0; c < NCH; c++) {
+    const int ch = wave + c * NW;
+    if (ch * 512 < D * 2) {
+      const uint32_t cbase = xbase + (uint32_t)ch * 1024u;
+      typedef unsigned int lz_u2 __attribute__((ext_vector_type(2)));
+      const lz_u2 r = *(const __attribute__((address_space(3))) lz_u2*)(cbase + 512u + (uint32_t)lane * 8u);
+      float f0, f1, f2, f3;
+      half2_to_f32(r.x, bf16, f0, f1); half2_to_f32(r.y, bf16, f2, f3);
+      nan = nan || __builtin_isunordered(f0, f1) || __builtin_isunordered(f2, f3);
+      if (is_exp == kXExpClamp) { f0 = clamp_exp(f0, kXExpClamp); f1 = clamp_exp(f1, kXExpClamp); f2 = clamp_exp(f2, kXExpClamp); f3 = clamp_exp(f3, kXExpClamp); }
+      *(__attribute__((address_space(3))) lz_v4*)(cbase + (uint32_t)lane * 16u) = lz_v4{f0, f1, f2, f3};
     }
   }
   return nan;
@@ -473,7 +470,6 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   constexpr bool pre = PRE;                             // (a template parameter: the kernel has no register to spare for both forms)
   static_assert(!PRE || MAP::kDma, "rows exp'd ahead arrive by LDS-direct loads");
   static_assert(!XH || MAP::kDma, "2-byte rows arrive by LDS-direct loads");
-  constexpr int kDmaUn = ((int)MAP::kMaxPdfs / 512 + NW - 1) / NW;   // 2 KiB units of a row buffer one wave may own (2-byte rows)
   const bool bf16 = a.x_half == kXBf16;
   const XBuf xbuf = XH ? make_xbuf(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)b * a.T * D * 2), (size_t)a.T * D * 2)
                        : make_xbuf(pre ? a.ex + (size_t)b * a.T * D : xseq, (size_t)a.T * D * sizeof(float));
@@ -502,12 +498,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // row t -> the buffer at xbase (LDS-direct); device-scope loads for rows another kernel is writing meanwhile
   auto dma_row = [&](int t, int ln, uint32_t xbase) {
     if constexpr (pre) { wait_row(t); lz_dma_row<NW, kDmaCh, kStoreDeviceScope>(xbuf, t, D, wave, ln, xbase); }
-    else if constexpr (XH) lz_dma_row_h<NW, kDmaUn, 0>(xbuf, t, D, wave, ln, xbase);
+    else if constexpr (XH) lz_dma_row_h<NW, kDmaCh, 0>(xbuf, t, D, wave, ln, xbase);
     else lz_dma_row<NW, kDmaCh, 0>(xbuf, t, D, wave, ln, xbase);
   };
   // this wave's share of the row at xbase: raw -> fp32, clamped / exp'd; true if a NaN was seen
   auto dma_finish = [&](int ln, uint32_t xbase) {
-    if constexpr (XH) return lz_dma_finish_h<NW, kDmaUn>(D, wave, ln, xbase, a.input_is_exp, bf16);
+    if constexpr (XH) return lz_dma_finish_h<NW, kDmaCh>(D, wave, ln, xbase, a.input_is_exp, bf16);
     else return lz_dma_finish<NW, kDmaCh>(D, wave, ln, xbase, a.input_is_exp);
   };
   const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));

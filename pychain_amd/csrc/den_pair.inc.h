@@ -179,7 +179,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
   const float coef = a.coef;
   const XBuf xbufA = make_xbuf(xA, (size_t)a.T * D * kXe), xbufB = make_xbuf(xB, (size_t)a.T * D * kXe);
   auto load_rows = [&](XRow<kPrNT, 4, 1>& qa, XRow<kPrNT, 4, 1>& qb, int ta, int tb, int t) {
-    if constexpr (XH) { qa.load_row_h(xbufA, ta, D, t, bf16); qb.load_row_h(xbufB, tb, D, t, bf16); }
+    if constexpr (XH) { qa.load_row_h(xbufA, ta, D, t); qb.load_row_h(xbufB, tb, D, t); }   // (raw: converted where they are used)
     else { qa.load_row(xbufA, ta, D, t); qb.load_row(xbufB, tb, D, t); }
   };
   const XBuf sbufA = make_xbuf(storeA, (size_t)(a.T + 1) * Hp * sizeof(float));
@@ -260,6 +260,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     load_rows(xqA, xqB, fwd ? 0 : LA - 1, fwd ? 0 : LB - 1, tid);
+    if constexpr (XH) { xqA.convert_h(bf16); xqB.convert_h(bf16); }
     if (fwd) { nanA = xqA.has_nan(); nanB = haveB && xqB.has_nan(); }
     stage_rows(kPrX0, tid);
     __syncthreads();                                   // red zeroed
@@ -338,6 +339,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     pair_tile<R, fwd, VOFF>(arcs, groups, pairmask, lq, s0, s1);                                            \
     PR_PH(0);                                          /* arc phase */                                       \
     /* the other buffer was last read in the previous step, which every wave has left */                    \
+    if constexpr (XH) { xqA.convert_h(bf16); xqB.convert_h(bf16); }   /* (2-byte rows: raw until here) */      \
     if (fwd) { if (nextA && xqA.has_nan()) nanA = true; if (nextB && xqB.has_nan()) nanB = true; }          \
     stage_rows((VOFF) ? kPrX0 : kPrX1, tq);                                                                 \
     PR_PH(1);                                          /* nnet-output rows clamped / exp'd / stored */       \

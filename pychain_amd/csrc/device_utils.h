@@ -168,9 +168,11 @@ struct XRow {
       v[c * 4 + 2] = __uint_as_float(q.z); v[c * 4 + 3] = __uint_as_float(q.w);
     }
   }
-  // the same two loads for 2-byte rows (VEC == 4: four elements = 8 bytes per thread and chunk); `row` / `buf` address
-  // 2-byte elements, the values arrive converted to fp32
-  __device__ __forceinline__ void load_row_h(XBuf buf, int t, int D, int tid, bool bf16) {
+  // The same two loads for 2-byte rows (VEC == 4: four elements = 8 bytes per thread and chunk): `row` / `buf` address 2-byte
+  // elements.  The RAW words stay in v[4c], v[4c + 1] as loaded - converting them on the spot would make the wave wait for
+  // the data where it asked for it, and every caller asks a frame ahead of the use - and convert_h() expands them in place
+  // right before the values are used (exactly once per load).
+  __device__ __forceinline__ void load_row_h(XBuf buf, int t, int D, int tid) {
     static_assert(VEC == 4 && XCH > 0, "buffer form: chunks of four elements");
     const int soff = __builtin_amdgcn_readfirstlane(t * D * 2);
 #pragma unroll
@@ -178,18 +180,25 @@ struct XRow {
       const int e = (c * NT + tid) * 4;
       typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
       const u32x2_ q = __builtin_amdgcn_raw_buffer_load_b64(buf, min(e, D - 4) * 2, soff, 0);
-      half2_to_f32(q.x, bf16, v[c * 4 + 0], v[c * 4 + 1]);
-      half2_to_f32(q.y, bf16, v[c * 4 + 2], v[c * 4 + 3]);
+      v[c * 4 + 0] = __uint_as_float(q.x); v[c * 4 + 1] = __uint_as_float(q.y);
     }
   }
-  __device__ __forceinline__ void load_h(const void* __restrict__ row, int D, int tid, bool bf16) {
+  __device__ __forceinline__ void load_h(const void* __restrict__ row, int D, int tid) {
     static_assert(VEC == 4 && XCH > 0, "2-byte rows: chunks of four elements (D % 4 == 0)");
 #pragma unroll
     for (int c = 0; c < XCH; c++) {
       const int e = (c * NT + tid) * 4;
       const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(row) + (size_t)min(e, D - 4) * 2);
-      half2_to_f32(q.x, bf16, v[c * 4 + 0], v[c * 4 + 1]);
-      half2_to_f32(q.y, bf16, v[c * 4 + 2], v[c * 4 + 3]);
+      v[c * 4 + 0] = __uint_as_float(q.x); v[c * 4 + 1] = __uint_as_float(q.y);
+    }
+  }
+  __device__ __forceinline__ void convert_h(bool bf16) {
+    static_assert(VEC == 4 && XCH > 0, "2-byte rows: chunks of four elements");
+#pragma unroll
+    for (int c = 0; c < XCH; c++) {
+      const uint32_t w0 = __float_as_uint(v[c * 4 + 0]), w1 = __float_as_uint(v[c * 4 + 1]);
+      half2_to_f32(w0, bf16, v[c * 4 + 0], v[c * 4 + 1]);
+      half2_to_f32(w1, bf16, v[c * 4 + 2], v[c * 4 + 3]);
     }
   }
   __device__ __forceinline__ void load(const float* __restrict__ row, int D, int tid) {

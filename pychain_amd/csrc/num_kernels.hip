@@ -106,11 +106,11 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
   const XBuf xbuf = make_xbuf(xseq, (size_t)T * D * kXe);
   // row `t` of the sequence into a staging register set (by pointer / through the buffer descriptor)
   auto xload = [&](auto& xr, int t, int ti) {
-    if constexpr (XH) xr.load_h(reinterpret_cast<const char*>(xseq) + (size_t)t * D * 2, D, ti, bf16);
+    if constexpr (XH) xr.load_h(reinterpret_cast<const char*>(xseq) + (size_t)t * D * 2, D, ti);      // (raw: converted in stage())
     else xr.load(xseq + (size_t)t * D, D, ti);
   };
   auto xload_row = [&](auto& xr, int t, int ti) {
-    if constexpr (XH) xr.load_row_h(xbuf, t, D, ti, bf16);
+    if constexpr (XH) xr.load_row_h(xbuf, t, D, ti);
     else xr.load_row(xbuf, t, D, ti);
   };
   double* rows = (fwd ? a.alpha_ws : a.beta_ws) + (size_t)b * (T + 1) * H;     // row t = alpha(t,.) / beta(t,.), fp64 log-prob
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kFbNT + LD) void num_fb_kernel(const NumArgs a) {
   // a row, clamped, into LDS; NaNs kept only where nobody else watches for them (NumArgs::watch_nan)
   const bool watch_nan = a.watch_nan != 0;
   auto stage = [&](auto& xr, float* lds, const float* row, int t) {
+    if constexpr (XH) xr.convert_h(bf16);            // (2-byte rows stay raw in their registers until they are used: here)
     if constexpr (XCH > 0) {
       if (watch_nan) xr.store(lds, row, D, t, kXClamp);
       else xr.template store_mode<kXClamp>(lds, D, t);

@@ -25,7 +25,7 @@ def per_kernel(path, counter):
 
 def short(k):
     for n in ("den_recursion_lazy_kernel", "den_recursion_pair_kernel", "den_recursion_kernel", "den_gamma2_kernel", "den_gamma_kernel",
-              "den_finish_kernel"):
+              "den_finish_kernel", "den_exp_rows_kernel"):
         if n in k:
             return n
     return None
@@ -45,6 +45,9 @@ for k in set(fetch) | set(write):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     out[n] = {"FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1), "dispatches": nf.get(k, 0),
               "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+# the whole denominator call (one launch of each kernel under PYCHAIN_DEN_SEGMENTS=1): recursion + occupancy + finish
+# [+ the rows exp'd ahead: den_exp_rows_kernel, calls of the denominator alone]
+out["den_call_hbm_bytes"] = int(sum(v["hbm_bytes_per_launch"] for k, v in out.items() if isinstance(v, dict)))
 with open(sys.argv[5], "w") as fo:
     json.dump(out, fo, indent=1)
 print(json.dumps(out, indent=1))
