@@ -222,11 +222,11 @@ def numerator_rooflines(w, plan, dev, iters, stream):
             "numerator_forward_backward": mk(ms_all, bytes_fb + bytes_occ)}
 
 
-def _adhoc_workload(name, B, dev, equal=False, den_only=False, dtype=None):
+def _adhoc_workload(name, B, dev, equal=False, den_only=False, dtype=None, structured=False):
     """BASELINE config `name`, optionally at another batch size (same graph, ragged lengths drawn for B), with all
     sequences of the full length (`equal`), without numerators (`den_only`), with a 2-byte network output (`dtype`)."""
     from pychain_amd import synthetic as syn
-    if B is None and not equal and not den_only:
+    if B is None and not equal and not den_only and not structured:
         w = syn.make_workload(name, device=dev)
     else:
         cfg = dict(syn.CONFIGS[name])
@@ -236,7 +236,10 @@ def _adhoc_workload(name, B, dev, equal=False, den_only=False, dtype=None):
         if den_only:
             cfg["num"] = False
         lengths = syn.make_lengths(B, cfg["T"], cfg["lengths"], seed=2)
-        w = dict(cfg=cfg, lengths=lengths, den_graph=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0),
+        # (`structured`: a phone-LM-like graph of the same size - arcs entering a state share its pdf, strong self-loops)
+        den = syn.make_structured_den_graph(cfg["H"] // 2, (cfg["K"] // (cfg["H"] // 2) - 2) // 2, cfg["D"]) if structured else \
+            syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+        w = dict(cfg=cfg, lengths=lengths, den_graph=den,
                  num_graphs=syn.make_num_graphs(lengths.tolist(), cfg["D"], seed=100) if cfg["num"] else None,
                  x=syn.make_input(B, cfg["T"], cfg["D"], seed=1, device=dev))
     if dtype is not None:
@@ -271,6 +274,7 @@ def other_workloads(dev, steps=6, warmup=3):
     # 40 % target on; "C3-bf16": the bench batch with a bf16 network output read by the kernels as it is
     for label, name, B, kw in (("C4", "C4", None, {}), ("C2", "C2", None, {}), ("C3-equal", "C3", None, dict(equal=True, den_only=True)),
                                ("C3-bf16", "C3", None, dict(dtype=torch.bfloat16)),
+                               ("C3-structured", "C3", None, dict(structured=True)),
                                ("C3@B=128", "C3", 128, {}), ("C3@B=256", "C3", 256, {})):
         try:
             w = _adhoc_workload(name, B, dev, **kw)
@@ -576,6 +580,9 @@ def workload_label(args, cfg, world, local_frames, global_frames):
 
 def main():
     args = parse()
+    # fewer visible devices than ranks: one clear line instead of N ranks dying in set_device / RCCL init
+    if not args.dry_run and torch.cuda.is_available() and args.gpus > torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible on this node" % (args.gpus, torch.cuda.device_count()))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)
     rank = int(os.environ.get("RANK", "0"))

@@ -77,6 +77,9 @@ int         pychain_hip_debug_launch_map(int T, int L, int t, int frames_per_blo
  * (pairs beyond out_len / 2 are not written).  report_due (may be NULL): report_due[d] = 1 if a recursion workgroup reports its
  * progress after d steps, d < due_len. */
 int         pychain_hip_debug_stream_rings(int T, int32_t* out, int out_len, int32_t* report_due, int due_len);
+/* Test hook: `workgroups` workgroups of 1024 threads and 100 KB of LDS (one to a CU) that sleep for `microseconds` on `stream` -
+ * a stand-in for the long-lived kernels of an overlapped RCCL all-reduce beside a loss step (tests/test_gpu_robust.py). */
+int         pychain_hip_debug_occupy(int workgroups, int microseconds, void* stream);
 /* Measurement aid (bench.py): restrict pychain_hip_den_forward_backward to a subset of
  * its launches so each kernel can be bracketed by events on the caller's stream.
  * bit 0 = alpha/beta recursion launch, bit 1 = occupancy launch; default 3 = both.

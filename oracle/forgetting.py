@@ -39,31 +39,11 @@ def graph_arrays(g):
                 leaky=g.leaky_probs.numpy().astype(np.float64), H=int(g.num_states))
 
 
-def structured_graph(n_phone_inst=1500, fanout=9, D=3456, seed=7, loop_lp=-0.35):
-    """A phone-LM-like denominator: every 'phone instance' is the two-state chain topology (entry state a: forward pdf;
-    loop state b: self-loop pdf), both leave to the entry states of `fanout` successor instances.  Every arc ENTERING a
-    state carries that state's pdf (what composing a phone LM with the chain topology gives); self-loops are strong
-    (log-prob loop_lp), so the filter mixes slower than on the random benchmark graph.  H = 2*n, K = n*(2 + 2*fanout)."""
+def structured_graph(**kw):
+    """pychain_amd.synthetic.make_structured_den_graph: a phone-LM-like denominator (arcs entering a state share its pdf,
+    strong self-loops) - the filter mixes slower on it than on the random benchmark graph."""
     from pychain_amd import synthetic as syn
-    from pychain_amd.graph import ChainGraph
-    from pychain_amd.simplefst import StdVectorFst
-    n = n_phone_inst
-    succ = syn.randint(seed * 10 + 1, n * fanout, n).reshape(n, fanout)
-    pdf_fwd = syn.randint(seed * 10 + 2, n, D)
-    pdf_loop = syn.randint(seed * 10 + 3, n, D)
-    lp_exit = -2.1 + 2.0 * syn.uniform(seed * 10 + 4, n * fanout).reshape(n, fanout)
-    src, dst, pdf, lp = [], [], [], []
-    for i in range(n):
-        a, b = 2 * i, 2 * i + 1
-        src += [a, b]; dst += [b, b]; pdf += [int(pdf_loop[i])] * 2; lp += [loop_lp, loop_lp]
-        for j in range(fanout):
-            s = int(succ[i, j])
-            for u in (a, b):
-                src.append(u); dst.append(2 * s); pdf.append(int(pdf_fwd[s])); lp.append(float(lp_exit[i, j]) - 1.2)
-    src, dst, pdf, lp = map(np.asarray, (src, dst, pdf, lp))
-    order = np.argsort(src, kind="stable")
-    fst = StdVectorFst.from_arrays(2 * n, 0, src[order], dst[order], pdf[order], lp[order], np.zeros(2 * n))
-    return ChainGraph(fst, initial_mode="leaky", final_mode="ones", log_domain=False)
+    return syn.make_structured_den_graph(**kw)
 
 
 def frames(G, x, coef):

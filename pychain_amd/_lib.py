@@ -33,6 +33,7 @@ _SIGNATURES = {
     "pychain_hip_get_option": (_i, [ctypes.c_char_p, ctypes.c_char_p, _sz]),
     "pychain_hip_debug_launch_map": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i]),
     "pychain_hip_debug_stream_rings": (_i, [_i, _vp, _i, _vp, _i]),
+    "pychain_hip_debug_occupy": (_i, [_i, _i, _vp]),
     "pychain_hip_den_plan_build": (_i64, [_vp] * 9 + [_i, _i, _i, _vp, _sz]),
     "pychain_hip_den_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pychain_hip_den_workspace_min_bytes": (_sz, [_i, _i, _i, _i]),

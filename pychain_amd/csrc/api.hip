@@ -623,6 +623,28 @@ extern "C" int pychain_hip_chain_loss_half_native(int64_t plan_stride_bytes, int
   return den_uses_gamma2(a, (D + 63) / 64, resident_slot_rows) ? 1 : 0;
 }
 
+// ---- test hook: a long-lived kernel that pins CUs on another stream of the same process, as the channels of an overlapped
+// RCCL bucket all-reduce do during DDP's backward: `workgroups` workgroups of 1024 threads and 100 KB of LDS
+// (one to a CU), each sleeping for `microseconds`
+namespace {
+__global__ __launch_bounds__(1024) void occupy_kernel(unsigned long long ticks, int* sink) {
+  extern __shared__ char occ_lds[];
+  const unsigned long long t0 = wall_clock64();                   // 100 MHz
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (sink && threadIdx.x == 0 && occ_lds[threadIdx.x] == 77) *sink = 1;
+}
+}  // namespace
+extern "C" int pychain_hip_debug_occupy(int workgroups, int microseconds, void* stream) {
+  if (workgroups <= 0 || microseconds < 0 || microseconds > 2000000) return fail(PYCHAIN_HIP_EINVAL, "debug_occupy: bad arguments");
+  const int lds = 100 * 1024;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return fail(PYCHAIN_HIP_ELAUNCH, "debug_occupy: cannot set the LDS size");
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(1024), lds, (hipStream_t)stream, (unsigned long long)microseconds * 100ull, (int*)nullptr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PYCHAIN_HIP_ELAUNCH, "debug_occupy: %s", hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
 extern "C" int pychain_hip_debug_stream_rings(int T, int32_t* out, int out_len, int32_t* report_due, int due_len) {
   if (T <= 0 || out_len < 0 || due_len < 0 || (out_len && !out) || (due_len && !report_due))
     return fail(PYCHAIN_HIP_EINVAL, "debug_stream_rings: bad arguments");

@@ -16,7 +16,7 @@ import torch
 from .graph import ChainGraph, ChainGraphBatch
 from .simplefst import StdVectorFst
 
-__all__ = ["CONFIGS", "uniform", "normal", "make_den_fst", "make_den_graph", "make_num_fst",
+__all__ = ["CONFIGS", "uniform", "normal", "make_den_fst", "make_den_graph", "make_structured_den_graph", "make_num_fst",
            "make_num_graphs", "make_lengths", "make_input", "make_input_utterances", "make_global_workload",
            "make_workload"]
 
@@ -78,6 +78,28 @@ def make_den_fst(H, K, D, seed=0):
 def make_den_graph(H, K, D, seed=0, initial_mode="leaky", final_mode="ones"):
     return ChainGraph(make_den_fst(H, K, D, seed), initial_mode=initial_mode,
                       final_mode=final_mode, log_domain=False)
+
+
+def make_structured_den_graph(n_phone_inst=1500, fanout=9, D=3456, seed=7, loop_lp=-0.35, initial_mode="leaky", final_mode="ones"):
+    """A phone-LM-like denominator (what composing a phone LM with the two-state chain topology gives; the benchmark graph
+    of make_den_fst is random): every 'phone instance' is an entry state a (forward pdf) and a loop state b (self-loop
+    pdf); both leave to the entry states of `fanout` successor instances.  EVERY ARC ENTERING A STATE CARRIES THAT STATE'S
+    PDF, self-loops are strong (log-prob `loop_lp`).  H = 2 n states, K = n (2 + 2 fanout) arcs: 3000 / 30 000 by default."""
+    n = n_phone_inst
+    succ = randint(seed * 10 + 1, n * fanout, n).reshape(n, fanout)
+    pdf_fwd = randint(seed * 10 + 2, n, D)
+    pdf_loop = randint(seed * 10 + 3, n, D)
+    lp_exit = -2.1 + 2.0 * uniform(seed * 10 + 4, n * fanout).reshape(n, fanout)
+    a = 2 * np.arange(n, dtype=np.int64)
+    b = a + 1
+    # per instance: a -> b and b -> b (loop pdf), then a -> entry(s_j), b -> entry(s_j) for its successors (forward pdf of s_j)
+    src = np.concatenate([a, b, np.repeat(a, fanout), np.repeat(b, fanout)])
+    dst = np.concatenate([b, b, 2 * succ.reshape(-1), 2 * succ.reshape(-1)])
+    pdf = np.concatenate([pdf_loop, pdf_loop, pdf_fwd[succ.reshape(-1)], pdf_fwd[succ.reshape(-1)]])
+    lp = np.concatenate([np.full(n, loop_lp), np.full(n, loop_lp), lp_exit.reshape(-1) - 1.2, lp_exit.reshape(-1) - 1.2])
+    order = np.argsort(src, kind="stable")
+    fst = StdVectorFst.from_arrays(2 * n, 0, src[order], dst[order], pdf[order], lp[order], np.zeros(2 * n))
+    return ChainGraph(fst, initial_mode=initial_mode, final_mode=final_mode, log_domain=False)
 
 
 def make_num_fst(num_states, D, seed):

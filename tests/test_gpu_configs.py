@@ -105,3 +105,15 @@ def test_training_example_two_ranks_over_rccl():
                         "--frames", "120"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "on 2 GPU(s)" in r.stdout
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a box with ONE visible GPU")
+def test_bench_with_more_ranks_than_devices_fails_fast():
+    """`bench.py --gpus 2` on a one-GPU box: one clear line, at once - not two ranks dying in RCCL's initialisation."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode != 0 and "only 1 HIP device" in (r.stderr + r.stdout), (r.stdout[-300:], r.stderr[-300:])
+    assert time.time() - t0 < 120

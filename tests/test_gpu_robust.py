@@ -359,3 +359,54 @@ def test_recursion_grid_that_fills_the_chip_does_not_wait_for_rows_nobody_can_wr
         assert int(bad.sum()) == 0
         outs.append((objf.clone(), grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.timeout(600)
+def test_a_long_lived_kernel_on_another_stream_of_the_process():
+    """in a DDP step the channels of the previous bucket's RCCL all-reduce hold CUs while the loss runs.
+    The recursion workgroups, the gate and the streamed occupancy launch wait for one another only in ways that end when
+    that kernel ends: with 32, 64 and 224 of the CUs pinned for 30 ms by a kernel on another stream of this process
+    (pychain_hip_debug_occupy) the fused step gives the SAME BITS as alone, nothing gives up into `bad`, and it ends within
+    the pinned time plus a few steps (no 20 s time-out anywhere).  The timeline is written to gpurun_out/."""
+    import json, os, time
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    B, T = 64, 400
+    L = syn.make_lengths(B, T, "ragged", seed=5)
+    num = syn.make_num_graphs(L.tolist(), cfg["D"], seed=700)
+    x = syn.make_input(B, T, cfg["D"], seed=71, device=DEV)
+    crit = ChainLoss(den, 1e-5)
+    Ld = L.to(DEV)
+
+    def step():
+        xx = x.clone().requires_grad_(True)
+        loss = crit(xx, Ld, num)
+        loss.backward()
+        return loss.detach(), xx.grad, ChainFunction.last_bad_count
+    ref = step(); ref = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); step(); torch.cuda.synchronize()
+    alone_ms = (time.perf_counter() - t0) * 1e3
+    side = torch.cuda.Stream()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rows = [dict(pinned_cus=0, step_ms=round(alone_ms, 3))]
+    for pinned in (32, 64, cus - 32):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().pychain_hip_debug_occupy(pinned, 30000, side.cuda_stream), "debug_occupy")
+        out = step()
+        torch.cuda.current_stream().synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        assert int(out[2].sum()) == 0, pinned
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), pinned
+        assert ms < 30 + 25 * max(alone_ms, 1.0), (pinned, ms, alone_ms)
+        rows.append(dict(pinned_cus=pinned, step_ms=round(ms, 3)))
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "co_resident_kernel.json"), "w") as f:
+            json.dump(dict(workload="C3 graph, B=64, T<=400 ragged, fused ChainLoss step; a 30 ms kernel pins CUs on another stream",
+                           cus=cus, rows=rows), f, indent=1)
+    except OSError:
+        pass

@@ -174,3 +174,16 @@ def test_which_kernel_each_shape_gets():
         assert got[0] == rec, (H, K, D, B, got)
         if occ is not None:
             assert got[1] == occ, (H, K, D, B, got)
+
+
+def test_structured_phone_lm_like_graph_vs_oracle():
+    """synthetic.make_structured_den_graph (arcs entering a state share its pdf, strong self-loops - what a phone LM composed
+    with the chain topology looks like; the benchmark graph is random): the C3-size one through the default kernels against
+    the oracle, and a small one through the four-wave shape."""
+    for n, fan, D, T, lens in ((1500, 9, 3456, 200, [200, 150, 64, 1]), (90, 5, 1000, 80, [80, 33, 2])):
+        den = syn.make_structured_den_graph(n, fan, D)
+        L = torch.tensor(lens)
+        x = syn.make_input(len(lens), T, D, seed=61, device=DEV)
+        o, g = _den(x, L, den)
+        ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, len(lens)), 1e-5)
+        assert abs(o - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4, (n, rel_err(g.cpu().numpy(), rg))
