@@ -347,6 +347,33 @@ int pychain_hip_chain_loss_forward(
     float loss_scale, const float* loss_norm_dev, float* totals /* may be NULL */,
     void* den_workspace, size_t den_workspace_bytes, void* num_workspace, size_t num_workspace_bytes,
     void* stream);
+/* ------------------------------------------------------------------------
+ * Host twins (ABI 14): the same two computations on HOST pointers in the reference layout, for callers
+ * whose tensors live on the CPU - the reference serves those from its own CPU loops (chain-computation.cc:113-176,247-311;
+ * chain-log-domain-computation.cc:123-159,231-271) and code written against it unit-tests its criterion there.  The sequences
+ * of the minibatch are dealt to `num_threads` host threads (0 = one per hardware thread); graph_batch_stride 0 = one graph
+ * for every sequence, 1 = per-sequence graphs [B,...].  Denominator: fp32 state vectors and gradient, fp64 totals and
+ * log-probability; numerator: fp64 log-probabilities, exact log-sum-exp (as the device path; the reference's fp32 LogAdd chain
+ * is the device's option num_compat).  bad_count: host int32[1], the reference's `ok` (sequences whose log-probability is not
+ * finite or whose frame-0 occupancies do not sum to one within 5 %).  These functions never touch a device, and the device
+ * entry points never fall back to them.  pychain_hip_cpu_calls: how many host calls this process has made (the GPU tests
+ * check that it stays where it was). */
+long pychain_hip_cpu_calls(void);
+int pychain_hip_cpu_den_forward_backward(
+    const int32_t* forward_transitions, const int32_t* forward_transition_indices, const float* forward_transition_probs,
+    const int32_t* backward_transitions, const int32_t* backward_transition_indices, const float* backward_transition_probs,
+    const float* leaky_probs, const float* initial_probs, const float* final_probs, int graph_batch_stride,
+    const float* nnet_output, int input_is_exp, const int64_t* seq_lengths,
+    int B, int T, int num_pdfs, int num_states, int num_transitions,
+    float leaky_hmm_coefficient, float grad_scale, float* objf_per_seq, float* grad, int32_t* bad_count, int num_threads);
+int pychain_hip_cpu_num_forward_backward(
+    const int32_t* forward_transitions, const int32_t* forward_transition_indices, const float* forward_transition_probs,
+    const int32_t* backward_transitions, const int32_t* backward_transition_indices, const float* backward_transition_probs,
+    const float* initial_probs, const float* final_probs, int graph_batch_stride,
+    const float* nnet_output, const int64_t* seq_lengths,
+    int B, int T, int num_pdfs, int num_states, int num_transitions, int grad_mode, float grad_scale,
+    float* objf_per_seq, float* grad, int32_t* bad_count, int num_threads);
+
 /* data[0..n) *= *scale_dev, skipped on the device when the scalar is exactly 1. */
 int pychain_hip_rescale(void* data, int dtype /* PYCHAIN_HIP_F32 / _BF16 / _F16 */, size_t n, const float* scale_dev, void* stream);
 /* 1 if the fused calls (_forward with a gradient or without, _forward_backward) take 2-byte network outputs for this shape:

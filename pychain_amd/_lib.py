@@ -53,6 +53,9 @@ _SIGNATURES = {
     "pychain_hip_chain_loss_forward": (_i, [_vp, _i64, _i, _i, _f] + [_vp] * 8 + [_i, _i, _i]
                                        + [_vp, _i, _vp, _i, _i, _i] + [_vp, _vp, _vp, _f, _vp] + [_f, _vp, _vp]
                                        + [_vp, _sz, _vp, _sz, _vp]),
+    "pychain_hip_cpu_calls": (ctypes.c_long, []),
+    "pychain_hip_cpu_den_forward_backward": (_i, [_vp] * 9 + [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _i]),
+    "pychain_hip_cpu_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i]),
     "pychain_hip_rescale": (_i, [_vp, _i, _sz, _vp, _vp]),
     "pychain_hip_loss_total": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i,

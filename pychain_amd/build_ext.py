@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(_HERE, "libpychain_hip.so")
 OBJ = os.path.join(os.path.dirname(_HERE), "build", "obj")
-SOURCES = ["den_rec.hip", "den_lazy.hip", "den_kernels.hip", "plan.cpp", "fst.cpp", "pack.cpp", "den_general.hip", "num_kernels.hip", "num_general.hip", "num_compat.hip",
+SOURCES = ["den_rec.hip", "den_lazy.hip", "den_kernels.hip", "plan.cpp", "fst.cpp", "pack.cpp", "cpu.cpp", "den_general.hip", "num_kernels.hip", "num_general.hip", "num_compat.hip",
            "api.hip"]          # (the slowest translation units first: they are compiled side by side)
 HEADERS = ["common.h", "plan_format.h", "den_kernels.h", "num_kernels.h", "device_utils.h", "den_common.inc.h", "den_lazy.inc.h",
            "den_pair.inc.h"]

@@ -15,7 +15,8 @@ error behaviour).  What differs is underneath:
     arithmetic in fp32; the gradient is rounded to the input's dtype where it is written: no fp32 copy of [B,T,D]);
     the reference's C++ accessors take float32 only.
 
-There is no CPU implementation here: CPU tensors raise.
+CPU tensors are served by the library's host twins (csrc/cpu.cpp), device tensors by the HIP kernels - never one for the
+other: a device tensor that cannot reach the kernels raises.
 """
 import torch
 import torch.nn as nn
@@ -44,6 +45,11 @@ class ChainFunction(torch.autograd.Function):
         denominator's last kernel also leaves [sum objf, frames, bad, sum objf] in ChainFunction.last_totals, and the sum
         is returned in place of the per-sequence values (no reduction launch behind the call)."""
         D = x.size(2)
+        if not x.is_cuda:
+            # CPU tensors: the library's host twins (pychain_amd/csrc/cpu.cpp) - what the reference does with them
+            # (chain-computation.cc:40,136-175); device tensors never come here
+            ChainFunction.last_totals = None
+            return native.cpu_forward_backward(graphs, x, input_lengths, leaky_coefficient)
         if not graphs.log_domain:   # usually the denominator
             if graphs.shared_graph is not None:
                 plan = _plan.graph_plan(graphs.shared_graph, D, x.device)
@@ -109,6 +115,8 @@ class ChainFunction(torch.autograd.Function):
         grad = _take_grad_buffer(ctx, "grad_buf")
         if grad is None:
             grad, ChainFunction.last_bad_count = ctx.again()   # second backward over a retained graph: evaluate again
+        if not grad.is_cuda:
+            return torch.mul(grad, objf_grad).to(ctx.in_dtype), None, None, None          # (loss.py:85, as it is)
         return native.rescale_(grad, objf_grad).to(ctx.in_dtype), None, None, None
 
 

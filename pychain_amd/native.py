@@ -17,8 +17,55 @@ _WS_CACHE_ENTRIES = 8   # a training process uses 2 (den, num) per stream; more 
 def _require_device(t, what):
     if not t.is_cuda:
         raise RuntimeError(
-            "pychain_amd: %s must live on a HIP device (got %s). The MI355X path has no CPU "
-            "fallback by design." % (what, t.device))
+            "pychain_amd: %s must live on a HIP device (got %s): the HIP entry points have no CPU fallback "
+            "(CPU tensors are served by cpu_forward_backward, never the other way round)." % (what, t.device))
+
+
+# ---------------------------------------------------------------------------
+# CPU tensors: the library's host twins (include/pychain_hip.h: pychain_hip_cpu_*; pychain_amd/csrc/cpu.cpp).  The reference
+# computes on whatever device its input lives on (chain-computation.cc:40): so does this package - CPU tensors HERE, device
+# tensors in the HIP kernels, and never one for the other (a device tensor that cannot reach the kernels raises).
+# ---------------------------------------------------------------------------
+CPU_THREADS = 0          # host threads the sequences of a minibatch are dealt to (0 = one per hardware thread)
+_GRAPH_INT = ("forward_transitions", "forward_transition_indices", "backward_transitions", "backward_transition_indices")
+
+
+def _cpu_graph(graphs, with_leaky):
+    """(tensors in ABI order, graph_batch_stride): one graph for every sequence (stride 0) or [B,...] tensors."""
+    src, stride = (graphs.shared_graph, 0) if graphs.shared_graph is not None else (graphs, 1)
+    names = ["forward_transitions", "forward_transition_indices", "forward_transition_probs",
+             "backward_transitions", "backward_transition_indices", "backward_transition_probs"]
+    names += (["leaky_probs"] if with_leaky else []) + ["initial_probs", "final_probs"]
+    ts = [getattr(src, n).to(torch.int32 if n in _GRAPH_INT else torch.float32).contiguous() for n in names]
+    return ts, stride
+
+
+def cpu_forward_backward(graphs, x, lengths, leaky_coefficient=1e-5, input_is_exp=False, grad_mode=_lib.GRAD_LINEAR):
+    """ChainFunction's computation on CPU tensors: (objf_per_seq[B], grad[B,T,D] fp32, bad_count int32[1]).  Denominator
+    (probability-domain graphs) or numerator (log-domain graphs) by `graphs.log_domain`."""
+    if x.is_cuda:
+        raise RuntimeError("pychain_amd: cpu_forward_backward is for CPU tensors; device tensors run on the HIP kernels")
+    xf = x.detach().to(torch.float32).contiguous()
+    B, T, D = xf.shape
+    lc = torch.as_tensor(lengths).to(torch.int64).cpu().contiguous()
+    _check_lengths(lc, B, T)
+    ts, stride = _cpu_graph(graphs, not graphs.log_domain)
+    H, K = int(ts[1].shape[-2]), int(ts[0].shape[-2])
+    objf = torch.empty(B, dtype=torch.float32)
+    grad = torch.empty(B, T, D, dtype=torch.float32)
+    bad = torch.zeros(1, dtype=torch.int32)
+    L = _lib.lib()
+    ptrs = [t.data_ptr() for t in ts]
+    if not graphs.log_domain:
+        _lib.check(L.pychain_hip_cpu_den_forward_backward(
+            *ptrs, stride, xf.data_ptr(), int(bool(input_is_exp)), lc.data_ptr(), B, T, D, H, K,
+            float(leaky_coefficient), 1.0, objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), int(CPU_THREADS)),
+            "pychain_hip_cpu_den_forward_backward")
+    else:
+        _lib.check(L.pychain_hip_cpu_num_forward_backward(
+            *ptrs, stride, xf.data_ptr(), lc.data_ptr(), B, T, D, H, K, int(grad_mode), 1.0,
+            objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), int(CPU_THREADS)), "pychain_hip_cpu_num_forward_backward")
+    return objf, grad, bad
 
 
 def _workspace(nbytes, device, tag="a"):
@@ -81,8 +128,8 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
     """Denominator on the GPU.  `plan`: _plan.DevicePlan.
     Returns (objf_per_seq[B], grad[B,T,D], bad_count[1]) and, `totals`, the device float[4] of
     include/pychain_hip.h (sum of the objectives, frames, bad count - from the call's last kernel, no extra launch)."""
-    num_states = plan.num_states
     _require_device(x, "nnet_output")
+    num_states = plan.num_states
     x = x.contiguous()
     B, T, D = x.shape
     _check_lengths(lengths, B, T)
@@ -333,6 +380,15 @@ def _compat_cached(kind, tensors, extra, build):
     return hit[0]
 
 
+class _RawGraphs(object):
+    """The batched graph tensors of a pychain_C-style call as the object cpu_forward_backward reads."""
+    shared_graph = None
+
+    def __init__(self, named, log_domain):
+        self.__dict__.update(named)
+        self.log_domain = log_domain
+
+
 def forward_backward(forward_transitions, forward_transition_indices, forward_transition_probs,
                      backward_transitions, backward_transition_indices, backward_transition_probs,
                      leaky_probs, initial_probs, final_probs, start_state, exp_nnet_output,
@@ -349,6 +405,10 @@ def forward_backward(forward_transitions, forward_transition_indices, forward_tr
     vals = [forward_transitions, forward_transition_indices, forward_transition_probs,
             backward_transitions, backward_transition_indices, backward_transition_probs,
             leaky_probs, initial_probs, final_probs]
+    if not exp_nnet_output.is_cuda:              # the reference's CPU path (chain-computation.cc:136-175,272-310): the host twin
+        gb = _RawGraphs(dict(zip(names, vals)), log_domain=False)
+        objf, grad, bad = cpu_forward_backward(gb, exp_nnet_output, sequence_lengths, leaky_hmm_coefficient, input_is_exp=True)
+        return [objf.sum(), grad, bad == 0]
     D = exp_nnet_output.shape[2]
     dev = exp_nnet_output.device
     plan = _compat_cached("den", vals, (D, str(dev)), lambda: _plan.batch_plans(dict(zip(names, vals)), D, dev))
@@ -373,6 +433,10 @@ def forward_backward_log_domain(forward_transitions, forward_transition_indices,
     vals = [forward_transitions, forward_transition_indices, forward_transition_probs,
             backward_transitions, backward_transition_indices, backward_transition_probs,
             initial_probs, final_probs]
+    if not nnet_output.is_cuda:                   # chain-log-domain-computation.cc:123-159,231-271: the host twin
+        gb = _RawGraphs(dict(zip(_GRAPH6 + ["initial_probs", "final_probs"], vals)), log_domain=True)
+        objf, lgrad, bad = cpu_forward_backward(gb, nnet_output, sequence_lengths, grad_mode=_lib.GRAD_LOG)
+        return [objf.sum(), lgrad, bad == 0]
     gt = _compat_cached("num", vals, (str(dev),), lambda: {
         n: t.contiguous().to(dev) for n, t in zip(_GRAPH6 + ["initial_probs", "final_probs"], vals)})
     objf, lgrad, bad = num_forward_backward(gt, 1, num_states, nnet_output, sequence_lengths,

@@ -141,10 +141,19 @@ def test_alias_package_and_exports():
 
 
 def test_no_cpu_fallback():
-    from pychain_amd import ChainFunction
-    with pytest.raises(RuntimeError, match="no CPU"):
-        ChainFunction.apply(torch.zeros(2, 5, 9), torch.tensor([5, 5]),
-                            ChainGraphBatch(syn.make_den_graph(6, 14, 9, seed=11), 2))
+    """The HIP entry points take device tensors only and raise on anything else; CPU tensors are served by the library's
+    host twins (tests/test_cpu_twins.py) through a door of their own - never one for the other."""
+    from pychain_amd import native
+    den = syn.make_den_graph(6, 14, 9, seed=11)
+    gt = {n: getattr(den, n).unsqueeze(0) for n in ("forward_transitions", "forward_transition_indices", "forward_transition_probs",
+                                                    "backward_transitions", "backward_transition_indices", "backward_transition_probs",
+                                                    "initial_probs", "final_probs")}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native.num_forward_backward(gt, 0, den.num_states, torch.zeros(2, 5, 9), torch.tensor([5, 5]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native.den_forward_backward(None, torch.zeros(2, 5, 9), torch.tensor([5, 5]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native.chain_loss_forward(None, gt, 0, den.num_states, torch.zeros(2, 5, 9), torch.tensor([5, 5]))
     # the product package never imports, links or opens anything under oracle/
     pat = re.compile(r"^\s*(import|from)\s+(oracle|ref_loader|build_ref)\b|oracle[/\\]|chain_oracle|libchain_oracle|_ref/",
                      re.M)
