@@ -192,14 +192,20 @@ struct XRow {
       v[c * 4 + 0] = __uint_as_float(q.x); v[c * 4 + 1] = __uint_as_float(q.y);
     }
   }
-  __device__ __forceinline__ void convert_h(bool bf16) {
-    static_assert(VEC == 4 && XCH > 0, "2-byte rows: chunks of four elements");
+  // (`bf16` is uniform: ONE branch around the whole row, not one per pair of elements - sixteen branch sites in a staging
+  // loop whose pace is its instruction stream made the numerator's step a third longer)
+  template <bool BF16>
+  __device__ __forceinline__ void convert_h_as() {
 #pragma unroll
     for (int c = 0; c < XCH; c++) {
       const uint32_t w0 = __float_as_uint(v[c * 4 + 0]), w1 = __float_as_uint(v[c * 4 + 1]);
-      half2_to_f32(w0, bf16, v[c * 4 + 0], v[c * 4 + 1]);
-      half2_to_f32(w1, bf16, v[c * 4 + 2], v[c * 4 + 3]);
+      half2_to_f32(w0, BF16, v[c * 4 + 0], v[c * 4 + 1]);
+      half2_to_f32(w1, BF16, v[c * 4 + 2], v[c * 4 + 3]);
     }
+  }
+  __device__ __forceinline__ void convert_h(bool bf16) {
+    static_assert(VEC == 4 && XCH > 0, "2-byte rows: chunks of four elements");
+    if (bf16) convert_h_as<true>(); else convert_h_as<false>();
   }
   __device__ __forceinline__ void load(const float* __restrict__ row, int D, int tid) {
     if constexpr (XCH > 0) {
