@@ -95,3 +95,105 @@ def test_random_shapes_rows_exp_ahead(seed):
     for _ in range(3):
         o, g = run()
         assert o == o0 and torch.equal(g, g0), (H, K, D, B, T, lengths[:8])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_shapes_two_byte_rows(seed):
+    """bf16 / fp16 network outputs read by the kernels against the host-side up-cast, BIT FOR BIT, on random
+    shapes: every recursion family that takes 2-byte rows (lazy with LDS-direct rows in its three maps, four-wave, pair), both
+    occupancy kernels, rows exp'd ahead or not, fused loss and numerator alone; pdf counts of every chunk count (multiples of 8),
+    batches of every parity, lengths from one frame up; shapes the library declines are up-cast and still agree."""
+    from pychain_amd import ChainLoss, _plan, native
+    rng = np.random.RandomState(9000 + seed)
+    H, K = [(100, 700), (200, 2000), (640, 6000), (1100, 9000), (3000, 30000)][seed % 5]
+    D = int(rng.choice([40, 136, 1000, 2048, 3456, 4104, 8408]))
+    if H <= 200 and D > 4096:
+        D = 1000
+    B = int(rng.choice([1, 2, 3, 5, 8, 17]))
+    T = int(rng.choice([5, 33, 64, 97, 130]))
+    if B * T * D > 30e6:
+        B = max(1, int(30e6 // (T * D)))
+    lengths = [int(rng.randint(1, T + 1)) for _ in range(B)]
+    lengths[0] = T
+    dtype = torch.bfloat16 if seed % 2 == 0 else torch.float16
+    opts = [{}, {"den_pair": 1}, {"den_dma": 2}, {"den_segments": 2}, {"gamma16": 1}][int(rng.randint(5))]
+    den = syn.make_den_graph(H, K, D, seed=seed)
+    x = syn.make_input(B, T, D, seed=190 + seed, device=DEV).to(dtype)
+    L = torch.tensor(lengths)
+    num = syn.make_num_graphs([max(4, l) for l in lengths], D, seed=800 + seed) if min(lengths) >= 4 else None
+
+    def both(fn):
+        out = []
+        ctx = [_lib.option(k, v) for k, v in opts.items()]
+        for c in ctx:
+            c.__enter__()
+        try:
+            for flag in (True, False):
+                native.HALF_ROWS = flag
+                try:
+                    out.append(fn())
+                finally:
+                    native.HALF_ROWS = True
+                torch.cuda.synchronize()
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+        return out
+
+    def den_step():
+        xx = x.clone().requires_grad_(True)
+        o = ChainFunction.apply(xx, L, ChainGraphBatch(den, B), 1e-5)
+        o.backward()
+        torch.cuda.synchronize()
+        assert int(ChainFunction.last_bad_count.sum()) == 0
+        return float(o.detach()), xx.grad
+    (o1, g1), (o0, g0) = both(den_step)
+    assert g1.dtype == dtype and o1 == o0 and torch.equal(g1, g0), (H, K, D, B, T, opts, str(dtype))
+    if num is not None:
+        def loss_step():
+            xx = x.clone().requires_grad_(True)
+            loss = ChainLoss(den, 1e-5)(xx, L, num)
+            loss.backward()
+            torch.cuda.synchronize()
+            assert int(ChainFunction.last_bad_count.sum()) == 0
+            return float(loss.detach()), xx.grad
+        (l1, h1), (l0, h0) = both(loss_step)
+        assert h1.dtype == dtype and l1 == l0 and torch.equal(h1, h0), (H, K, D, B, T, opts, str(dtype))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_numerators_in_the_reference_arithmetic(seed):
+    """Option num_compat against the fp32 flavour of the oracle - the reference's LogAdd arithmetic - on
+    random branching numerator graphs: padded per-utterance batches and one shared graph, unreachable states, several arcs of
+    one pdf into a state, network outputs far apart (the cut-off at work), ragged lengths; objective and gradient through
+    ChainFunction."""
+    from helpers import _rand_num_fst
+    from pychain_amd import ChainGraph, native
+    rs = np.random.RandomState(4000 + seed)
+    D = int(rs.choice([12, 48, 300, 2048]))
+    B = int(rs.randint(1, 5))
+    T = int(rs.choice([7, 40, 150]))
+    fin = lambda H: {H - 1: 0.0, max(0, H - 2): -0.3}
+    shared = seed % 3 == 0
+    if shared:
+        g = ChainGraph(_rand_num_fst(rs, int(rs.randint(3, min(T, 90))), int(rs.randint(0, 60)), D, fin), log_domain=True)
+        gb = ChainGraphBatch(g, B)
+    else:
+        gs = [ChainGraph(_rand_num_fst(rs, int(rs.randint(3, min(T, 90))), int(rs.randint(0, 60)), D, fin), log_domain=True) for _ in range(B)]
+        gb = ChainGraphBatch(gs, max_num_transitions=max(g.num_transitions for g in gs), max_num_states=max(g.num_states for g in gs))
+    lengths = sorted((int(rs.randint(max(3, gb.num_states), T + 1)) if T > gb.num_states else T for _ in range(B)), reverse=True)
+    lengths[0] = T
+    L = torch.tensor(lengths)
+    x = syn.make_input(B, T, D, seed=300 + seed, scale=float(rs.choice([1.0, 2.5, 5.0])))
+    ro, rlg, _ = orc.num(gb, x.clamp(-30, 30), L, shared=shared, flavour="f32")
+    if not np.isfinite(ro).all():
+        pytest.skip("this draw has an utterance its graph cannot produce")
+    with _lib.option("num_compat", 1):
+        xx = x.to(DEV).requires_grad_(True)
+        o = ChainFunction.apply(xx, L, gb)
+        o.backward()
+        torch.cuda.synchronize()
+        assert int(ChainFunction.last_bad_count.sum()) == 0
+    assert abs(float(o.detach()) - float(ro.sum())) <= 3e-6 * abs(float(ro.sum())) + 1e-5
+    rg = np.exp(rlg.astype(np.float64))
+    assert rel_err(xx.grad.cpu().numpy(), rg) <= 2e-5, rel_err(xx.grad.cpu().numpy(), rg)
