@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--no-rooflines", action="store_true",
                     help="skip the per-kernel roofline measurement on rank 0 (at N > 1 it is a short one: 3 launches per kernel, "
                          "no d2d copy probe - the other ranks wait for it in a barrier)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test mode for boxes with fewer GPUs than ranks: rank r runs on GPU r %% (visible GPUs) and the collectives go "
+                         "over gloo (device tensors through the host) - the sharded GPU path in N processes without N GPUs; never a "
+                         "scaling measurement (tests/test_gpu_configs.py)")
     ap.add_argument("--no-fresh-num-graphs", action="store_true",
                     help="skip the host-side leg: a fresh numerator ChainGraphBatch per step, as a trainer builds it")
     return ap.parse_args()
@@ -581,7 +585,7 @@ def workload_label(args, cfg, world, local_frames, global_frames):
 def main():
     args = parse()
     # fewer visible devices than ranks: one clear line instead of N ranks dying in set_device / RCCL init
-    if not args.dry_run and torch.cuda.is_available() and args.gpus > torch.cuda.device_count():
+    if not args.dry_run and not args.share_gpu and torch.cuda.is_available() and args.gpus > torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) are visible on this node" % (args.gpus, torch.cuda.device_count()))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)
@@ -596,11 +600,12 @@ def main():
     if dry:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        gpu = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
+        torch.cuda.set_device(gpu)
+        dev = torch.device("cuda", gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
+        if dry or args.share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
@@ -625,7 +630,7 @@ def main():
         if not dry:
             torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=None if dry else [local_rank])
+            dist.barrier(device_ids=None if (dry or args.share_gpu) else [local_rank])
         if not dry:
             torch.cuda.synchronize()
 
@@ -729,7 +734,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
             print(json.dumps(out))
     if world > 1:
-        dist.barrier(device_ids=None if dry else [local_rank])
+        dist.barrier(device_ids=None if (dry or args.share_gpu) else [local_rank])
         dist.destroy_process_group()
 
 

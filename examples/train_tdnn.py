@@ -65,13 +65,16 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if args.device == "cuda":
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
+        # (fewer GPUs than ranks: only with gloo, whose collectives copy device tensors through the host - RCCL wants a GPU
+        # per rank; the one-GPU test box runs two ranks on its GPU this way: tests/test_gpu_configs.py)
+        gpu = local_rank if (args.backend == "nccl" or local_rank < torch.cuda.device_count()) else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(gpu)
+        dev = torch.device("cuda", gpu)
     else:
         dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.device == "cuda":
+        if args.device == "cuda" and args.backend == "nccl":
             dist.init_process_group(args.backend, device_id=dev)
         else:
             dist.init_process_group(args.backend)
@@ -84,7 +87,7 @@ def main():
     torch.manual_seed(0)
     model = TDNN(args.feat_dim, args.hidden, args.pdfs).to(dev)
     if world > 1:
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank] if args.device == "cuda" else None)
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if args.device == "cuda" else None)
     opt = torch.optim.AdamW(model.parameters(), lr=args.lr)
     den_graph = syn.make_den_graph(args.states, args.arcs, args.pdfs, seed=0)      # the shared "phone LM"
     criterion = ShardedChainLoss(den_graph, leaky_coefficient=1e-5, avg=True, loss_cls=loss_cls)

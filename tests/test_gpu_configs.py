@@ -117,3 +117,41 @@ def test_bench_with_more_ranks_than_devices_fails_fast():
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert r.returncode != 0 and "only 1 HIP device" in (r.stderr + r.stdout), (r.stdout[-300:], r.stderr[-300:])
     assert time.time() - t0 < 120
+
+
+def test_training_example_two_ranks_share_one_gpu_over_gloo():
+    """The sharded step in TWO processes on device tensors where only one GPU is there: both ranks on cuda:0, collectives
+    over gloo (they copy device tensors through the host) - the HIP kernels of two processes beside each other, DDP's bucket
+    all-reduce, ShardedChainLoss's one all-reduce of the loss call's device totals.  (The RCCL flavour of the same run needs
+    two GPUs: the test above, skipped here.)"""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(REPO, "examples", "train_tdnn.py"), "--steps", "8", "--batch", "8",
+                        "--frames", "120", "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "on 2 GPU(s)" in r.stdout
+    import re
+    ends = re.findall(r"rank (\d) of 2: global loss ([-\d.]+) -> ([-\d.]+)", r.stdout)
+    assert len(ends) == 2 and ends[0][1:] == ends[1][1:], r.stdout[-600:]      # both ranks report the same global loss
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """`bench.py --gpus 2 --share-gpu`: the bench's sharded path with the REAL kernels in two processes (both on this box's one
+    GPU, collectives over gloo): every utterance of the global minibatch (128) owned once, frames add up, no `bad`, one line from
+    rank 0 with `n_gpus` = 2 and the per-rank view - what the driver's scaling run exercises with one GPU per rank over RCCL."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1",
+                        "--no-grad-slab", "--no-rooflines"], capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-800:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["n_bad"] == 0 and d["value"] > 0 and d["config"]["global_batch"] == 128
+    assert d["sharding"]["every_utterance_owned_once"] and d["sharding"]["frames_add_up"]
+    assert len(d["per_rank"]["frames"]) == 2 and d["per_rank"]["utterances"] == [64, 64]
