@@ -207,7 +207,9 @@ int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t 
  *   launch-bound scalar kernels behind it (the reference: `tot_log_prob.sum()`, chain-computation.cc:229):
  *   totals[0] = totals[3] = sum_b objf_per_seq[b] (fp64 accumulation, rounded once), totals[1] = sum_b len_b,
  *   totals[2] = bad_count as a float; totals[4] = totals[0] once more (ABI 14: the scalar a host framework hands out as the
- *   loss, apart from the statistics in [0..3] that it may all-reduce or keep), totals[5..7] = 0.
+ *   loss, apart from the statistics in [0..3] that it may all-reduce or keep); totals[5] = speculated rows of a time-segmented
+ *   call that did not verify (0, or the call ran its recursions again unsegmented), totals[6] = its segments per (sequence,
+ *   direction) (1: not segmented), totals[7] = 0.
  * workspace: the stored alpha' / beta rows (4 B T roundup64(num_states) bytes each), per-frame totals, counters, and - in a
  *   call of the denominator alone - a [B,T,D] buffer for the rows exp'd ahead of the recursions (den_exp_rows_kernel: C4
  *   4.80 -> 4.57 ms): pychain_hip_den_workspace_bytes; pychain_hip_den_workspace_min_bytes is the size without it.
@@ -330,7 +332,7 @@ int pychain_hip_chain_loss_forward_backward(
  *   kernel instead of from half a dozen scalar kernels of the host framework behind it (pychain/loss.py:100-104):
  *   totals[0] = (sum_b den_objf[b] - sum_b num_objf[b]) * loss_scale [/ *loss_norm_dev]  = -(num - den) [/ frames],
  *   totals[1] = sum_b len_b, totals[2] = bad_count[0] + bad_count[1] as a float (what a sharded trainer all-reduces
- *   with the loss), totals[3] = sum den - sum num unscaled, totals[4] = totals[0], totals[5..7] = 0.  loss_norm_dev: device
+ *   with the loss), totals[3] = sum den - sum num unscaled, totals[4] = totals[0], totals[5..7] as above.  loss_norm_dev: device
  *   float or NULL.
  */
 int pychain_hip_chain_loss_forward(

@@ -29,7 +29,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
-                                     "debug_corrupt_row", "num_compat"};
+                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -67,6 +67,8 @@ CallKnobs call_knobs() {
   k.den_pair = option_int("den_pair", -1);
   k.den_dma = option_int("den_dma", -1);
   k.num_compat = option_int("num_compat", 0) ? 1 : 0;
+  k.den_tseg = option_int("den_tseg", -1);
+  k.den_tburn = option_int("den_tburn", 256);
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
@@ -202,7 +204,8 @@ extern "C" size_t pychain_hip_den_workspace_min_bytes(int B, int T, int H, int D
   return align256(4 * (size_t)B * T * Hp) + align256(4 * (size_t)B * (T + 1) * Hp) +
          align256(8 * (size_t)B) + 256 + align256(36 * (size_t)B) /* progress counters (zeroed by every call) */ +
          2 * align256(4 * (size_t)B * (T + 2)) /* per-frame totals of the two recursions */ +
-         align256(4 * (size_t)B * T) /* frame totals to check */ + align256(8 * (size_t)B) /* final dot products; den_finish_kernel's per-sequence side of the check */ + 256;
+         align256(4 * (size_t)B * T) /* frame totals to check */ + align256(8 * (size_t)B) /* final dot products; den_finish_kernel's per-sequence side of the check */ + 256 +
+         align256(4 * (size_t)B * 2 * kMaxTimeSegs * 2 * Hp) /* time segments: the speculated rows next to the segments (DenArgs::splice) */;
 }
 extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
   const size_t base = pychain_hip_den_workspace_min_bytes(B, T, H, D);
@@ -263,7 +266,9 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   a.gtot = (float*)((char*)a.tot_b + align256(4 * (size_t)B * (T + 2)));
   a.fin_dot = (float*)((char*)a.gtot + align256(4 * (size_t)B * T));
   // (behind everything else, and only in a workspace of the full size: DenArgs::ex)
-  a.ex = workspace_bytes >= pychain_hip_den_workspace_bytes(B, T, H, D) ? (float*)((char*)a.fin_dot + align256(8 * (size_t)B) + 256) : nullptr;
+  a.splice = (float*)((char*)a.fin_dot + align256(8 * (size_t)B) + 256);
+  a.redo = a.progress + 48; a.redo_if = 0; a.tseg = 0; a.tburn = 0;
+  a.ex = workspace_bytes >= pychain_hip_den_workspace_bytes(B, T, H, D) ? (float*)((char*)a.splice + align256(4 * (size_t)B * 2 * kMaxTimeSegs * 2 * a.Hp)) : nullptr;
   a.lazy = 0;
   a.check = 0; a.check_all = a.knobs.verbose >= 1 ? 1 : 0;
   a.sig_n = 0;
@@ -376,13 +381,40 @@ bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
          (den_lazy_eligible(a, resident_slot_rows) || den_call_is_small(a, resident_slot_rows) || den_call_is_dma(a, resident_slot_rows));
 }
 
+// Time segments (DenArgs::tseg): how many a call's (sequence, direction) recursions are cut into.  With few
+// sequences the chain of T dependent frames IS the step and most CUs idle; S segments started `burn` frames outside
+// themselves run T / S + burn frames each on 2 B S workgroups.  The price: the burn-in frames (CU-time) and the occupancy launch no
+// longer overlapping the recursions (a frame's rows come from four workgroups, not two).  Chosen where the estimate says it
+// pays by more than 10 %: per frame ~1.94 us (2.2 us for rows beyond 4096 pdfs), occupancy ~3.5 ps per frame and pdf of whole-chip
+// time; the grid must leave every workgroup a CU (a fused call: half of the chip stays with the numerator).  At B = 64 it never
+// does (the step is CU-time-bound there: DESIGN.md §4); C4 (B = 32, T = 2000) runs four segments.
+int den_time_segments(const DenArgs& a, bool fused) {
+  const int want = a.knobs.den_tseg;
+  if (want == 0 || want == 1 || !a.lazy || a.shape != kShapeDma || a.check_all) return 1;
+  const int burn = a.knobs.den_tburn;
+  if (burn < 1) return 1;
+  const int cus = device_cu_count() / (fused ? 2 : 1);
+  int best = 1;
+  const double f = a.D > 4096 ? 2.2e-6 : 1.94e-6, occ = 3.5e-12 * (double)a.D * (double)a.B * (double)a.T;
+  double best_t = 0.9 * (double)a.T * f;
+  for (int S = 2; S <= kMaxTimeSegs; S *= 2) {
+    if (2 * a.B * S > cus || a.T < 2 * burn) continue;
+    if (want == S) return S;
+    const double t = ((double)a.T / S + burn) * f + occ;
+    if (want < 0 && t < best_t) { best = S; best_t = t; }
+  }
+  return best;
+}
+
 // Would a call of the denominator alone, given a workspace with the [B,T,D] buffer, exp its rows ahead of the recursions (§3.9)?
 // (a.lazy / a.shape / a.pair decided.)  The recursion workgroups spin on rows that launch writes and each takes a whole CU, so the
 // launch must find CUs of its own whatever the order of dispatch: at least a quarter of the chip stays free of recursion
 // workgroups, else the recursions exp their rows themselves (2B >= the CU count with pairing off could hang).
 bool den_would_exp_rows_ahead(const DenArgs& a) {
+  // (not where the call is cut into time segments: the rows are written from the sequence ends inwards, a segment starts inside)
   return a.lazy && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && !a.input_is_exp &&
-         a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && 4 * den_recursion_blocks(a) <= 3 * device_cu_count();
+         a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && 4 * den_recursion_blocks(a) <= 3 * device_cu_count() &&
+         den_time_segments(a, false) == 1;
 }
 
 // 2-byte network outputs (DenArgs::x_half) are read as they are - and the gradient written in the same type - by the lazy
@@ -489,6 +521,27 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
     den_exp_rows_shape(a, device_cu_count(), &a.ex_nr, &a.ex_q);
     if (e == hipSuccess) e = launch_den_exp_rows(a, side_pre->stream2);
     a.use_ex = 1;
+  }
+  // Time segments: recursion launch over 2 B S workgroups, the check of every speculated row, the ordinary recursion launch as
+  // a fallback that runs only if a row did not verify, then the occupancy launch (no overlap: den_time_segments)
+  const int tseg = exp_ahead ? 1 : den_time_segments(a, zeroed != nullptr);   // (den_would_exp_rows_ahead: false where this says > 1)
+  if (tseg > 1) {
+    const int mask = occupancy ? user_mask : (user_mask & 1);
+    if (mask & 1) {
+      a.phase_mask = 1; a.tseg = tseg; a.tburn = a.knobs.den_tburn;
+      e = launch_den(a, gmax, resident_slot_rows, st, why);
+      if (e == hipSuccess) e = launch_den_splice_check(a, st);
+      const int keep = a.tseg;
+      a.tseg = 0; a.redo_if = 1;
+      if (e == hipSuccess) e = launch_den(a, gmax, resident_slot_rows, st, why);
+      a.redo_if = 0; a.tseg = keep;                       // (den_finish_kernel: an inner segment's NaN report)
+      if (e == hipSuccess && corrupt)
+        e = launch_scale_row(a.alpha_store + ((size_t)a.knobs.corrupt_b * a.T + a.knobs.corrupt_t) * a.Hp, a.Hp, a.knobs.corrupt_scale, st);
+    }
+    if (e == hipSuccess && gamma_wait && (mask & 2)) e = hipStreamWaitEvent(st, gamma_wait, 0);
+    if (e == hipSuccess && (mask & 2)) { a.phase_mask = 2; e = launch_den(a, gmax, resident_slot_rows, st, why); }
+    a.phase_mask = user_mask;
+    return e;
   }
   if (nseg <= 1) {
     const int mask = occupancy ? user_mask : (user_mask & 1);

@@ -10,6 +10,7 @@
 namespace pychain_hip {
 
 enum { kShapeRegs = 0, kShapeDma = 2, kShapeSmall = 3 };
+constexpr int kMaxTimeSegs = 4;
 
 struct DenArgs {
   const char* plans;         // device plan(s)
@@ -109,6 +110,18 @@ struct DenArgs {
   int ex_nr, ex_q;               // rows per round, workgroups per end
   int32_t* xnan;                 // [B], zeroed with the progress counters
   int use_ex;                    // this launch reads ex / xprog / xnan
+  // Time segments (round 5; den_lazy.inc.h: lazy_recursion): with few sequences the T dependent frames of a
+  // (sequence, direction) are the whole step and most CUs idle.  tseg = S > 1: the recursion grid is 2 B S workgroups;
+  // workgroup (b, direction, k) produces the rows of time segment k of sequence b, started `tburn` frames outside the segment
+  // from the ordinary start vector - a forward / backward filter forgets where it started (profiles/r05_forgetting_table.md:
+  // 1e-7 after 192 frames on the benchmark graphs) - with the rows of its burn-in discarded, except the one next to the segment:
+  // that one goes to splice[((b * 2 + dir) * kMaxTimeSegs + k) * 2 * Hp] and den_splice_check_kernel compares it with the TRUE row
+  // the neighbouring segment stored; any mismatch beyond 1e-6 sets *redo (and counts into respec), and the recursion launch that
+  // follows - the ordinary one, launched with redo_if - runs only then.  Sequences shorter than 2 tburn frames run as one segment.
+  int tseg, tburn;
+  float* splice;                 // [B][2][kMaxTimeSegs][2][Hp]: the speculated row next to a segment; a row nobody reads (workspace)
+  int32_t* redo;                 // [2]: [0] != 0: a splice did not verify; [1]: how many (reported; zeroed with the progress counters)
+  int redo_if;                   // this recursion launch is the fallback: its workgroups leave at once unless *redo != 0
   CallKnobs knobs;               // this call's snapshot of the library settings (host side only)
 };
 
@@ -128,6 +141,7 @@ const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, in
 // ... as den_recursion_pair_kernel (DenArgs::pair); den_pair_blocks: its grid = what a progress counter reaches
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows);
 int den_recursion_blocks(const DenArgs& a);
+hipError_t launch_den_splice_check(const DenArgs& a, hipStream_t st);
 bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
 
 // true if launch_den would run the two-frame occupancy kernel (the only one that can fold the numerator in)

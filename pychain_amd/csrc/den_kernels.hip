@@ -87,7 +87,8 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
     return log(m) + (double)ex * 0.69314718055994530942;
   };
   // (what thread 0 needs after the sums: requested before them)
-  const float fin_dot = a.fin_dot[b];
+  // (time segments: an inner alpha segment that staged a NaN network output says so in xnan - the last one owns fin_dot)
+  const float fin_dot = (a.tseg > 1 && __hip_atomic_load(a.xnan + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? __builtin_nanf("") : a.fin_dot[b];
   const float ta0 = ta[0], tb1 = L >= 1 ? tb[1] : 1.f;
   double sh_total_a = log_of_product(ta, tid, na), sh_total_b = log_of_product(tb, tid + 1, L + 1);
   fin_block_sum2(sh_total_a, sh_total_b, part, tid);
@@ -171,7 +172,10 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
       for (int i = 0; i < a.bad_words; i++) nbad += __hip_atomic_load(a.bad + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       a.loss_out[0] = (float)t; a.loss_out[1] = (float)frames; a.loss_out[2] = (float)nbad; a.loss_out[3] = (float)acc;
       a.loss_out[4] = (float)t;                              // (a second copy: the scalar a caller hands out, apart from the statistics)
-      a.loss_out[5] = a.loss_out[6] = a.loss_out[7] = 0.f;
+      // [5]: time segments (DenArgs::tseg) - how many speculated rows did not verify (> 0: the call ran its recursions again, whole)
+      a.loss_out[5] = a.tseg > 1 ? (float)__hip_atomic_load(a.redo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      a.loss_out[6] = (float)(a.tseg > 1 ? a.tseg : 1);
+      a.loss_out[7] = 0.f;
     }
   }
 }
@@ -1098,6 +1102,50 @@ hipError_t launch_den_exp_rows(const DenArgs& a, hipStream_t st) {
     case 5: hipLaunchKernelGGL(den_exp_rows_kernel<5>, grid, block, 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+namespace {
+// ---- time segments (DenArgs::tseg): every speculated row next to a segment against the TRUE row its neighbour stored.
+// alpha segment k > 0 speculated row s_k - 1 (true: segment k-1's last row); beta segment k < S-1 speculated row e_k + 1 (true:
+// segment k+1's last row).  Rows are in per-frame scales of their own: compared as distributions, max |p - q| / max p <= 1e-6 -
+// a filter that agrees that well one frame outside a segment agrees better inside it (it contracts).  A miss sets redo[0] (the
+// fallback recursion launch behind this kernel then runs) and counts into redo[1].
+__global__ __launch_bounds__(256) void den_splice_check_kernel(const DenArgs a) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Lb = seq_len(a.lengths, b, a.T);
+  const int nseg = (a.tseg > 1 && Lb >= 2 * a.tburn) ? a.tseg : 1;
+  int miss = 0;
+  for (int dir = 0; dir < 2; dir++)
+    for (int k = dir == 0 ? 1 : 0; k < (dir == 0 ? nseg : nseg - 1); k++) {
+      const int s = (int)(((long)k * Lb) / nseg), e = k + 1 == nseg ? Lb : (int)(((long)(k + 1) * Lb) / nseg);
+      if (dir == 0 && s - a.tburn <= 0) continue;        // (the segment started at the true start: nothing speculated)
+      if (dir == 1 && e + a.tburn >= Lb) continue;
+      const float* truth = dir == 0 ? a.alpha_store + ((size_t)b * a.T + (s - 1)) * a.Hp : a.beta_store + ((size_t)b * (a.T + 1) + (e + 1)) * a.Hp;
+      const float* spec = a.splice + ((size_t)(b * 2 + dir) * kMaxTimeSegs + k) * 2 * a.Hp;
+      float sp = 0.f, sq = 0.f;
+      for (int i = tid; i < a.H; i += 256) { sp += truth[i]; sq += spec[i]; }
+      sp = wave_sum(sp); sq = wave_sum(sq);
+      __syncthreads();
+      if ((tid & 63) == 0) { red[0][tid >> 6] = sp; red[1][tid >> 6] = sq; }
+      __syncthreads();
+      sp = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]); sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      const float ip = 1.f / sp, iq = 1.f / sq;
+      float dmax = 0.f, pmax = 0.f;
+      for (int i = tid; i < a.H; i += 256) { const float p = truth[i] * ip; dmax = fmaxf(dmax, fabsf(p - spec[i] * iq)); pmax = fmaxf(pmax, p); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); pmax = fmaxf(pmax, __shfl_xor(pmax, o, 64)); }
+      __syncthreads();
+      if ((tid & 63) == 0) { red[0][tid >> 6] = dmax; red[1][tid >> 6] = pmax; }
+      __syncthreads();
+      dmax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])); pmax = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+      if (!(dmax <= 1e-6f * pmax)) miss++;                // (also: NaN, a dead row)
+    }
+  if (tid == 0 && miss) { atomicAdd(a.redo, 1); atomicAdd(a.redo + 1, miss); }
+}
+}  // namespace
+hipError_t launch_den_splice_check(const DenArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(den_splice_check_kernel, dim3(a.B), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_den_finish(const DenArgs& a, hipStream_t st) {

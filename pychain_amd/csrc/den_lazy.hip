@@ -41,16 +41,18 @@ inline bool dma_shape_ok(const DenArgs& a, int hint) {
   return ((hint >> 30) & 1) && a.D <= (int)LzDma::kMaxPdfs && a.Hp <= (int)LzDma::kMaxStates && rows > 0 &&
          rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
 }
-template <typename M, int XM>
+template <typename M, int XM, bool TS = false>
 hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
-  const dim3 grid(2 * a.B);
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M, XM>, a, grid, M::kBytes, st, M::kWaves * 64);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M, XM>, a, grid, M::kBytes, st, M::kWaves * 64);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident, M, XM>, a, grid, M::kBytes, st, M::kWaves * 64);
+  const dim3 grid(2 * a.B * (TS ? a.tseg : 1));
+  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M, XM, TS>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M, XM, TS>, a, grid, M::kBytes, st, M::kWaves * 64);
+  return launch_one(den_recursion_lazy_kernel<kMaxResident, M, XM, TS>, a, grid, M::kBytes, st, M::kWaves * 64);
 }
-// how the rows of this call arrive (lazy_recursion: XM): exp'd ahead (fp32 whatever the input's type), 2-byte, fp32
+// how the rows of this call arrive (lazy_recursion: XM): exp'd ahead (fp32 whatever the input's type), 2-byte, fp32;
+// time segments (DenArgs::tseg: never with rows exp'd ahead - they are written from the sequence ends inwards)
 template <typename M>
 hipError_t launch_dma_x(const DenArgs& a, int rows, hipStream_t st) {
+  if (a.tseg > 1) return a.x_half ? launch_dma_m<M, kLzRowsHalf, true>(a, rows, st) : launch_dma_m<M, kLzRowsF32, true>(a, rows, st);
   if (a.use_ex) return launch_dma_m<M, kLzRowsPre>(a, rows, st);
   return a.x_half ? launch_dma_m<M, kLzRowsHalf>(a, rows, st) : launch_dma_m<M, kLzRowsF32>(a, rows, st);
 }

@@ -427,15 +427,34 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
 // (DenArgs::ex); kLzRowsHalf: 2-byte rows (DenArgs::x_half), converted, clamped / exp'd here.  A template parameter: the
 // kernel has no register to spare for more than one form.
 enum { kLzRowsF32 = 0, kLzRowsPre = 1, kLzRowsHalf = 2 };
-template <int R, typename MAP, bool fwd, int XM>
-__device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b) {
+// TS: time segments (DenArgs::tseg) - a template parameter: the one-segment kernel keeps its registers
+template <int R, typename MAP, bool fwd, int XM, bool TS>
+__device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b, const int seg_in = 0) {
   constexpr bool PRE = XM == kLzRowsPre, XH = XM == kLzRowsHalf;
   constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
-  const int nsteps = fwd ? L : L - 1;
+  // ---- time segments (DenArgs::tseg).  The recursion below runs on a VIRTUAL sequence: alpha segment k on the frames [f0, e)
+  // of the real one (f0 = s - burn: rows, totals and the nnet-output slab are addressed from f0, so that local row j is real
+  // row f0 + j), beta segment k as if the sequence ended at f1 = e + burn and stopping at row s + 1.  Rows / totals outside
+  // [s, e) (beta: rows s+1 .. e) are the burn-in: discarded, but for the row next to the segment (DenArgs::splice).
+  const int Lb = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
+  const int seg = TS ? seg_in : 0;
+  const int nseg = (TS && a.tseg > 1 && Lb >= 2 * a.tburn) ? a.tseg : 1;
+  if (TS && seg >= nseg) return;                         // (a sequence shorter than two burn-ins is not cut: its segment 0 does everything)
+  const int seg_s = TS ? (int)(((long)seg * Lb) / nseg) : 0;
+  const int seg_e = (!TS || seg + 1 == nseg) ? Lb : (int)(((long)(seg + 1) * Lb) / nseg);
+  const bool seg_last = !TS || (fwd ? seg + 1 == nseg : seg == 0);   // the segment that ends where the sequence's recursion ends
+  const int f0 = (TS && fwd && seg > 0) ? max(seg_s - a.tburn, 0) : 0;                 // alpha: first frame of the virtual sequence
+  const int L = !TS ? Lb : (fwd ? seg_e - f0 : (seg + 1 == nseg ? Lb : min(Lb, seg_e + a.tburn)));   // its length (beta: its last frame + 1)
+  const int nsteps = fwd ? L : L - 1 - seg_s;
+  // real rows / totals (local numbering): alpha rows >= row_lo, beta rows <= row_hi; the speculated row next to them
+  const int row_lo = fwd ? seg_s - f0 : 0, row_hi = fwd ? 0x7fffffff : seg_e;
+  const int spec_row = fwd ? row_lo - 1 : seg_e + 1;     // (alpha segment 0 / the last beta segment have none: never met)
+  auto row_real = [&](int r) { return !TS || (fwd ? r >= row_lo : r <= row_hi); };
+  // alpha totals: index i = tot(f0 + i), real for row_lo <= i < L (the last segment: <= L); beta: n(i), real for i <= row_hi
+  auto tot_real = [&](int i) { return !TS || (fwd ? (i >= row_lo && (i < L || seg + 1 == nseg)) : i <= row_hi); };
   const int Hp = a.Hp, D = a.D;
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
@@ -460,9 +479,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
   const float* start_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_init_a : hd->off_final_b));
-  const float* xseq = a.x + (size_t)b * a.T * D;
-  float* store = fwd ? a.alpha_store + (size_t)b * a.T * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
-  float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2);  // per-frame totals for den_finish_kernel (DenArgs::tot_a)
+  const float* xseq = a.x + ((size_t)b * a.T + f0) * D;
+  float* store = fwd ? a.alpha_store + ((size_t)b * a.T + f0) * Hp : a.beta_store + (size_t)b * (a.T + 1) * Hp;
+  float* totv = (fwd ? a.tot_a : a.tot_b) + (size_t)b * (a.T + 2) + f0;  // per-frame totals for den_finish_kernel (DenArgs::tot_a)
   const float coef = a.coef;
   constexpr int kDmaCh = ((int)MAP::kMaxPdfs / 256 + NW - 1) / NW;   // 1 KiB chunks of a row one wave may own
   // rows exp'd ahead of this kernel (DenArgs::ex): they arrive ready to gather; a row is requested once its end of the
@@ -471,8 +490,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   static_assert(!PRE || MAP::kDma, "rows exp'd ahead arrive by LDS-direct loads");
   static_assert(!XH || MAP::kDma, "2-byte rows arrive by LDS-direct loads");
   const bool bf16 = a.x_half == kXBf16;
-  const XBuf xbuf = XH ? make_xbuf(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + (size_t)b * a.T * D * 2), (size_t)a.T * D * 2)
-                       : make_xbuf(pre ? a.ex + (size_t)b * a.T * D : xseq, (size_t)a.T * D * sizeof(float));
+  const XBuf xbuf = XH ? make_xbuf(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x) + ((size_t)b * a.T + f0) * D * 2), (size_t)(a.T - f0) * D * 2)
+                       : make_xbuf(pre ? a.ex + (size_t)b * a.T * D : xseq, (size_t)(a.T - f0) * D * sizeof(float));
   int ready_lo = 0, ready_hi = 0;                       // ex rows [0, ready_lo) and [L - ready_hi, L) are complete
   // rows an end has complete: its workgroup q has done c_q of the rounds q, q + Q, ...: the first round missing is min_q (q + c_q Q)
   auto rows_of_end = [&](int end) {
@@ -506,7 +525,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if constexpr (XH) return lz_dma_finish_h<NW, kDmaCh>(D, wave, ln, xbase, a.input_is_exp, bf16);
     else return lz_dma_finish<NW, kDmaCh>(D, wave, ln, xbase, a.input_is_exp);
   };
-  const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1) * Hp * sizeof(float));
+  const XBuf sbuf = make_xbuf(store, (size_t)(a.T + 1 - f0) * Hp * sizeof(float));
+  // where a burn-in row goes: [0] the speculated row next to the segment, [1] a row nobody reads
+  const XBuf spbuf = TS ? make_xbuf(a.splice + ((size_t)(b * 2 + (fwd ? 0 : 1)) * kMaxTimeSegs + seg) * 2 * Hp, 2 * (size_t)Hp * sizeof(float)) : sbuf;
 
   LazyWave w;
   // group g of this wave: rows base_g .. base_g + 63 (lane l owns row base_g + l)
@@ -550,7 +571,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     w.c = coef * wtot;
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad |= 1;
     w.sprev = fwd ? tot : w.c;                         // the start row (alpha row 0 / beta row L) goes out at the end of frame 0
-    if (tid == 0) totv[fwd ? 0 : L] = tot;
+    if (tid == 0 && tot_real(fwd ? 0 : L)) totv[fwd ? 0 : L] = tot;
     __syncthreads();                                                 // red is rewritten by the first frame (its first 4 NW entries per sum)
   }
 
@@ -587,7 +608,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad |= 1;                                                           \
     if (FWDC) w.sprev = tot;                                                                                \
     else { w.c = coef * wave_sum(R1); w.sprev = w.c; }                                                      \
-    if ((TQ) == 0) totv[(FWDC) ? (JP) + 1 : L - 1 - (JP)] = tot;                                            \
+    if ((TQ) == 0 && tot_real((FWDC) ? (JP) + 1 : L - 1 - (JP))) totv[(FWDC) ? (JP) + 1 : L - 1 - (JP)] = tot;   \
     last_tot = tot;                                                                                         \
   } while (0)
   // One frame step j: alpha produces a(j+1,.) from a(j,.) and x(j); beta produces b(t,.), t = L-1-j, from b(t+1,.) and x(t).
@@ -603,7 +624,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     constexpr uint32_t UOFF = UCUR - MAP::kUField;                                                          \
     constexpr uint32_t VOFF = ((PAR) ? MAP::kX1 : MAP::kX0) - MAP::kXField;   /* nnet-output buffer PAR */   \
     const int tn = (FWDC) ? j + 1 : L - 2 - j;               /* nnet-output row of the NEXT step */          \
-    const bool have_next = (FWDC) ? (tn < L) : (tn >= 1);    /* beta never consumes row 0 */                 \
+    const bool have_next = (FWDC) ? (tn < L) : (tn >= seg_s + 1);   /* beta never consumes row 0 (its segment: row s) */ \
     LZ_PH0();                                                                                               \
     if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
       if (have_next) dma_row(tn, lq, (PAR) ? MAP::kX0 : MAP::kX1);                                          \
@@ -626,12 +647,16 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       if (j > 0) PYCHAIN_LZ_TOTALS(pre0, pre1, j - 1, (FWDC), tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) is completed and leaves for HBM */ \
       const int trow = (FWDC) ? j : L - j;                                                                  \
-      const int row_off = __builtin_amdgcn_readfirstlane(trow * Hp * 4);                                    \
+      /* (time segments: a burn-in row goes to the splice buffer - the one next to the segment to be verified, the others */ \
+      /* to a row nobody reads; both choices are uniform: a descriptor and an offset in SGPRs) */            \
+      const bool real_row = row_real(trow);                                                                 \
+      const XBuf obuf = (!TS || real_row) ? sbuf : spbuf;                                                   \
+      const int row_off = __builtin_amdgcn_readfirstlane((!TS || real_row) ? trow * Hp * 4 : (trow == spec_row ? 0 : Hp * 4)); \
       const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
       _Pragma("unroll") for (int g = 0; g < MG; g++)                                                        \
         if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1) {                                           \
           const lz_v2f pr = kPreRows ? prow[g] : lz_ld2(UCUR + gbase[g] * 8 + lq * 8);                      \
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, pr.y, pr.x)), sbuf, lane4, \
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, pr.y, pr.x)), obuf, lane4, \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
         }                                                                                                   \
     }, [&]() {                                                                                              \
@@ -711,6 +736,11 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 #undef LZ_VMWAIT
 #undef LZ_PH0
 
+  if (TS && fwd && !seg_last) {                            // an inner alpha segment: nothing to total; a NaN it staged is reported
+    if (bad & 2) { if (tid == 0) __hip_atomic_store(a.xnan + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad &= ~2; }
+    if (bad && lane == 0) atomicAdd(a.bad, 1);
+    return;
+  }
   if constexpr (fwd) {
     // ComputeTotLogLike, chain-computation.cc:209-230: log sum_i a'(L,i) final(i) + sum_{t<L} log tot(t),
     // a'(L,i) = a(L,i) + tot(L) cl(i); the vector of step L-1 sits in buffer (L & 1)
@@ -741,9 +771,18 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 }
 
 // XM: kLzRowsPre - the rows were exp'd ahead by den_exp_rows_kernel (DenArgs::ex); kLzRowsHalf - 2-byte rows (DenArgs::x_half)
-template <int R, typename MAP, int XM = kLzRowsF32>
+template <int R, typename MAP, int XM = kLzRowsF32, bool TS = false>
 __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM>(a, smem_raw, blockIdx.x);
-  else lazy_recursion<R, MAP, false, XM>(a, smem_raw, blockIdx.x - a.B);
+  // (the fallback launch behind a segmented one: runs only if a splice did not verify - DenArgs::redo)
+  if (a.redo_if && __hip_atomic_load(a.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  if constexpr (TS) {
+    const unsigned per_dir = (unsigned)a.B * (unsigned)a.tseg;                        // workgroups per direction: segment-major
+    const unsigned r = blockIdx.x < per_dir ? blockIdx.x : blockIdx.x - per_dir;
+    if (blockIdx.x < per_dir) lazy_recursion<R, MAP, true, XM, true>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+    else lazy_recursion<R, MAP, false, XM, true>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+  } else {
+    if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM, false>(a, smem_raw, blockIdx.x);
+    else lazy_recursion<R, MAP, false, XM, false>(a, smem_raw, blockIdx.x - a.B);
+  }
 }

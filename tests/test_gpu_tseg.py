@@ -1,0 +1,113 @@
+"""Time segments of the denominator recursions (VERDICT r4 item 1 where the CU-time accounting lets it pay:
+few sequences).  With B <= 32 the chain of T dependent frames IS the step and most CUs idle: the lazy recursions of a
+(sequence, direction) are cut into 2 or 4 time segments, each started `den_tburn` frames outside itself from the ordinary start
+vector - a forward / backward filter forgets where it started (profiles/r05_forgetting_table.md) - its burn-in rows discarded.
+The row next to every segment is compared on the device with the TRUE row the neighbouring segment stored (1e-6 as distributions);
+a miss makes the call run its recursions again, unsegmented, and is reported (totals[5]).  Replaces the T-long dependent chain of
+chain-computation.cc:196-207,332-342."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from helpers import rel_err
+from pychain_amd import ChainFunction, ChainGraphBatch, ChainLoss, _lib, _plan, native, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _den(plan, x, L, **opts):
+    ctx = [_lib.option(k, v) for k, v in opts.items()]
+    for c in ctx:
+        c.__enter__()
+    try:
+        objf, grad, bad, tot = native.den_forward_backward(plan, x, L, 1e-5, totals=True)
+        torch.cuda.synchronize()
+    finally:
+        for c in reversed(ctx):
+            c.__exit__()
+    return objf, grad, int(bad), tot
+
+
+@pytest.mark.parametrize("name,B,T,lens", [
+    ("C3", 3, 1300, [1300, 1111, 400]),            # (400 < 2 burn-ins: that sequence is not cut)
+    ("C3", 5, 1024, [1024, 1023, 777, 515, 512]),
+    ("C4", 2, 1100, [1100, 901]),                  # rows beyond 4096 pdfs: the LzDma map
+])
+def test_segmented_recursions_agree_with_the_chain(name, B, T, lens):
+    cfg = syn.CONFIGS[name]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    plan = _plan.graph_plan(den, cfg["D"], torch.device(DEV))
+    L = torch.tensor(lens)
+    x = syn.make_input(B, T, cfg["D"], seed=21, device=DEV)
+    o0, g0, b0, t0 = _den(plan, x, L, den_tseg=0)
+    assert b0 == 0 and int(t0[6]) == 1
+    for S in (2, 4):
+        o, g, b, t = _den(plan, x, L, den_tseg=S)
+        assert b == 0 and int(t[6]) == S and int(t[5]) == 0            # nothing had to be redone
+        assert float((o - o0).abs().max()) <= 1e-6 * float(o0.abs().max())
+        assert rel_err(g.cpu().numpy(), g0.cpu().numpy()) <= 1e-6
+        o2, g2, _, _ = _den(plan, x, L, den_tseg=S)                     # and it is a deterministic schedule
+        assert torch.equal(o, o2) and torch.equal(g, g2)
+    # the automatic choice for this shape: four segments (few sequences, a long chain), and against the oracle
+    o, g, b, t = _den(plan, x, L)
+    assert int(t[6]) == 4 and int(t[5]) == 0
+    if name == "C3" and B == 3:
+        ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, B), 1e-5)
+        assert abs(float(o.sum()) - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4
+    # verbose >= 1 checks every frame against per-frame scales chained through the whole sequence: not cut
+    with _lib.option("verbose", 1):
+        assert int(_den(plan, x, L)[3][6]) == 1
+
+
+def test_a_burn_in_that_is_too_short_is_caught_and_redone():
+    """16 frames of burn-in do not forget the start: every speculated row misses, the call runs its recursions again
+    unsegmented - the SAME BITS as the unsegmented call - and says how many rows missed; nothing is `bad`."""
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    plan = _plan.graph_plan(den, cfg["D"], torch.device(DEV))
+    L = torch.tensor([900, 640, 100])
+    x = syn.make_input(3, 900, cfg["D"], seed=23, device=DEV)
+    o0, g0, b0, t0 = _den(plan, x, L, den_tseg=0)
+    o, g, b, t = _den(plan, x, L, den_tseg=4, den_tburn=16)
+    assert int(t[5]) >= 6 and int(t[6]) == 4 and b == 0
+    assert torch.equal(o, o0) and torch.equal(g, g0)
+
+
+def test_segmented_fused_loss_two_byte_rows_and_nan():
+    """The fused loss with few sequences (the numerator beside the segmented recursions), bf16 rows (the 2-byte form of the
+    segmented kernel), a NaN network output inside an inner segment (it must reach the loss)."""
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = torch.tensor([1200, 1100, 800, 600])
+    num = syn.make_num_graphs(L.tolist(), cfg["D"], seed=77)
+    x = syn.make_input(4, 1200, cfg["D"], seed=25, device=DEV)
+
+    def step(xin, **opts):
+        ctx = [_lib.option(k, v) for k, v in opts.items()]
+        for c in ctx:
+            c.__enter__()
+        try:
+            xx = xin.clone().requires_grad_(True)
+            loss = ChainLoss(den, 1e-5)(xx, L, num)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+        return float(loss.detach()), xx.grad, ChainFunction.last_bad_count.clone(), ChainFunction.last_totals.clone()
+    l0, g0, b0, t0 = step(x, den_tseg=0)
+    l1, g1, b1, t1 = step(x)                                   # automatic: 4 sequences -> segments
+    assert int(b1.sum()) == 0 and abs(l1 - l0) <= 1e-6 * abs(l0) and rel_err(g1.cpu().numpy(), g0.cpu().numpy()) <= 1e-6
+    ro, rg = orc.chain_loss(x.cpu(), L, den, num, 1e-5, avg=True, flavour="f64")
+    assert abs(l1 - float(ro)) <= 1e-4 * abs(float(ro)) and rel_err(g1.cpu().numpy(), rg) <= 1e-5
+    xh = x.to(torch.bfloat16)
+    lh0, gh0, _, _ = step(xh, den_tseg=0)
+    lh1, gh1, bh1, _ = step(xh, den_tseg=4)
+    assert int(bh1.sum()) == 0 and abs(lh1 - lh0) <= 1e-6 * abs(lh0)
+    assert rel_err(gh1.float().cpu().numpy(), gh0.float().cpu().numpy()) <= 2.0 ** -8
+    xn = x.clone()
+    xn[0, 700, 11] = float("nan")                              # frame 700 of 1200: an inner segment of sequence 0
+    ln, gn, bn, _ = step(xn, den_tseg=4)
+    assert np.isnan(ln) and int(bn.sum()) > 0
