@@ -110,9 +110,14 @@ def kernel_rooflines(w, dev, iters, d2d=True):
     # the launches as the TIMED step runs them: a call of the denominator alone has its rows exp'd ahead of the recursions
     # (den_exp_rows_kernel), the fused loss has not - option den_dma = 2 is that form
     import contextlib
-    as_in_step = _lib.option("den_dma", 2) if w.get("num_graphs") is not None else contextlib.nullcontext()
+    fused = w.get("num_graphs") is not None
+    as_in_step = _lib.option("den_dma", 2) if fused else contextlib.nullcontext()
+    # ... and cut into as many time segments as the step's call is (a fused call at B = 64 is not cut, a call of
+    # the denominator alone at B = 64 would be)
+    tsegs = int(L.pychain_hip_den_time_segments(plan.stride, plan.slot_rows, H, D, cfg["B"], cfg["T"], int(fused)))
+    as_cut = _lib.option("den_tseg", tsegs if tsegs > 1 else 0)
     try:
-        with as_in_step:
+        with as_in_step, as_cut:
             call(); torch.cuda.synchronize()
             for name, mask in (("den_recursion_kernel", 1), ("den_gamma_kernel", 2), ("den_call", 3)):
                 L.pychain_hip_set_den_phase_mask(mask)
@@ -150,7 +155,7 @@ def kernel_rooflines(w, dev, iters, d2d=True):
     except Exception:
         pass
     roof = {
-        "bound": "hbm", "kernel": rec_name,
+        "bound": "hbm", "kernel": rec_name, "time_segments": tsegs,
         "achieved": round(bytes_rec / (ms_rec * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(bytes_rec / (ms_rec * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "traffic": traffic, "traffic_source": traffic_source,
@@ -279,6 +284,8 @@ def other_workloads(dev, steps=6, warmup=3):
     for label, name, B, kw in (("C4", "C4", None, {}), ("C2", "C2", None, {}), ("C3-equal", "C3", None, dict(equal=True, den_only=True)),
                                ("C3-bf16", "C3", None, dict(dtype=torch.bfloat16)),
                                ("C3-structured", "C3", None, dict(structured=True)),
+                               # few sequences: the recursions are cut into time segments
+                               ("C3@B=16", "C3", 16, {}), ("C3@B=32", "C3", 32, {}),
                                ("C3@B=128", "C3", 128, {}), ("C3@B=256", "C3", 256, {})):
         try:
             w = _adhoc_workload(name, B, dev, **kw)
@@ -306,12 +313,18 @@ def other_workloads(dev, steps=6, warmup=3):
             plan = _plan.graph_plan(w["den_graph"], cfg["D"], dev)
             rec, occ = _lib.den_kernel_names(plan.slot_rows, cfg["H"], cfg["D"], cfg["B"])
             stream = torch.cuda.current_stream(dev)
+            # time segments of the call the step makes (totals[5..7] of include/pychain_hip.h: segments per (sequence, direction),
+            # speculated rows that did not verify, the worst mismatch seen; 1 / 0 / 0 where the call is not cut)
+            fused_call = w["num_graphs"] is not None
+            tsegs = int(_lib.lib().pychain_hip_den_time_segments(plan.stride, plan.slot_rows, cfg["H"], cfg["D"], cfg["B"], cfg["T"], int(fused_call)))
+            tot8 = ChainFunction.last_totals_all.detach().float().cpu().tolist() if getattr(ChainFunction, "last_totals_all", None) is not None else None
             call = lambda: native.den_forward_backward(plan, w["x"].detach(), w["lengths_dev"], 1e-5)
             parts = {}
             import contextlib
             for key, mask in (("recursion_ms", 1), ("occupancy_ms", 2), ("den_ms", 3)):
                 # (as the step runs them: kernel_rooflines)
-                with _lib.option("den_phase_mask", mask), (_lib.option("den_dma", 2) if cfg["num"] else contextlib.nullcontext()):
+                with _lib.option("den_phase_mask", mask), (_lib.option("den_dma", 2) if cfg["num"] else contextlib.nullcontext()), \
+                        _lib.option("den_tseg", tsegs if tsegs > 1 else 0):
                     call(); torch.cuda.synchronize()
                     parts[key] = event_time_ms(call, 3, stream)
             # (2-byte rows: x read twice at 2 B, the gradient written at 2 B: 6 D instead of 12 D per frame)
@@ -325,6 +338,8 @@ def other_workloads(dev, steps=6, warmup=3):
                 "rows_exp_ahead_workspace_bytes": 4 * cfg["B"] * cfg["T"] * cfg["D"] if uses_rows else 0,
                 "ms_per_step": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1), "steps": steps,
                 "recursion_kernel": rec, "occupancy_kernel": occ,
+                "time_segments": tsegs,
+                "splices_redone": None if tot8 is None else int(tot8[5]), "worst_splice_mismatch": None if tot8 is None else tot8[7],
                 "recursion_ms": round(parts["recursion_ms"], 4), "occupancy_ms": round(parts["occupancy_ms"], 4),
                 "den_forward_backward": dict({"algorithmic_bytes": den_bytes, "ms": round(parts["den_ms"], 4),
                                               "frac": round(den_bytes / (parts["den_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},

@@ -209,7 +209,7 @@ int pychain_hip_den_plan_info(const void* host_blob, size_t blob_bytes, int32_t 
  *   totals[2] = bad_count as a float; totals[4] = totals[0] once more (ABI 14: the scalar a host framework hands out as the
  *   loss, apart from the statistics in [0..3] that it may all-reduce or keep); totals[5] = speculated rows of a time-segmented
  *   call that did not verify (0, or the call ran its recursions again unsegmented), totals[6] = its segments per (sequence,
- *   direction) (1: not segmented), totals[7] = 0.
+ *   direction) (1: not segmented), totals[7] = the worst mismatch of a speculated row (max |p - q| / max p; the bound is 4e-6).
  * workspace: the stored alpha' / beta rows (4 B T roundup64(num_states) bytes each), per-frame totals, counters, and - in a
  *   call of the denominator alone - a [B,T,D] buffer for the rows exp'd ahead of the recursions (den_exp_rows_kernel: C4
  *   4.80 -> 4.57 ms): pychain_hip_den_workspace_bytes; pychain_hip_den_workspace_min_bytes is the size without it.
@@ -223,6 +223,10 @@ size_t pychain_hip_den_workspace_min_bytes(int B, int T, int num_states, int num
  * of the full workspace, else 0: a caller that caches its workspace asks before it allocates as much again as the network
  * output (1.3 GB at C3) for calls that never touch it (pair / general / two-barrier kernels, T < 64, exp'd input, a recursion
  * grid that leaves less than a quarter of the chip free). */
+/* How many time segments the recursions of a (sequence, direction) of such a call are cut into (1: not cut; `fused`: the
+ * call is a fused loss - half of the chip stays with the numerator).  totals[5..7] of the call report how the cut went; a
+ * caller that sees totals[5] > 0 repeatedly (its data forgets slowly) should raise option den_tburn or set den_tseg = 0. */
+int pychain_hip_den_time_segments(int64_t plan_stride_bytes, int resident_slot_rows, int num_states, int num_pdfs, int B, int T, int fused);
 int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int resident_slot_rows, int num_states, int num_pdfs,
                                     int B, int T, int input_is_exp);
 int pychain_hip_den_forward_backward(

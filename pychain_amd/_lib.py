@@ -39,6 +39,7 @@ _SIGNATURES = {
     "pychain_hip_den_workspace_min_bytes": (_sz, [_i, _i, _i, _i]),
     "pychain_hip_den_plan_info": (_i, [_vp, _sz, _vp]),
     "pychain_hip_den_uses_row_buffer": (_i, [_i64, _i, _i, _i, _i, _i, _i]),
+    "pychain_hip_den_time_segments": (_i, [_i64, _i, _i, _i, _i, _i, _i]),
     "pychain_hip_den_forward_backward": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _f, _f,
                                               _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pychain_hip_den_half_native": (_i, [_i64, _i, _i, _i, _i, _i]),

@@ -68,7 +68,7 @@ CallKnobs call_knobs() {
   k.den_dma = option_int("den_dma", -1);
   k.num_compat = option_int("num_compat", 0) ? 1 : 0;
   k.den_tseg = option_int("den_tseg", -1);
-  k.den_tburn = option_int("den_tburn", 256);
+  k.den_tburn = option_int("den_tburn", 192);
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
@@ -385,9 +385,9 @@ bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
 // sequences the chain of T dependent frames IS the step and most CUs idle; S segments started `burn` frames outside
 // themselves run T / S + burn frames each on 2 B S workgroups.  The price: the burn-in frames (CU-time) and the occupancy launch no
 // longer overlapping the recursions (a frame's rows come from four workgroups, not two).  Chosen where the estimate says it
-// pays by more than 10 %: per frame ~1.94 us (2.2 us for rows beyond 4096 pdfs), occupancy ~3.5 ps per frame and pdf of whole-chip
-// time; the grid must leave every workgroup a CU (a fused call: half of the chip stays with the numerator).  At B = 64 it never
-// does (the step is CU-time-bound there: DESIGN.md §4); C4 (B = 32, T = 2000) runs four segments.
+// pays by more than 5 %: per frame ~1.94 us (2.2 us for rows beyond 4096 pdfs), occupancy ~3.5 ps per frame and pdf of whole-chip
+// time; the grid must leave every workgroup a CU (a fused call: half of the chip stays with the numerator).  The fused loss at
+// B = 64 is never cut (CU-time-bound: DESIGN.md §4); the denominator alone at B = 64 runs two segments, C4 (B = 32) four.
 int den_time_segments(const DenArgs& a, bool fused) {
   const int want = a.knobs.den_tseg;
   if (want == 0 || want == 1 || !a.lazy || a.shape != kShapeDma || a.check_all) return 1;
@@ -396,11 +396,13 @@ int den_time_segments(const DenArgs& a, bool fused) {
   const int cus = device_cu_count() / (fused ? 2 : 1);
   int best = 1;
   const double f = a.D > 4096 ? 2.2e-6 : 1.94e-6, occ = 3.5e-12 * (double)a.D * (double)a.B * (double)a.T;
-  double best_t = 0.9 * (double)a.T * f;
+  // (not cut: the chain, 5 % of head and tail, and the part of the streamed occupancy launch that is left when the recursions
+  // end - about a third of it with sequences of one length; cut: the occupancy launch follows the recursions, + three launches)
+  double best_t = 0.95 * (1.05 * (double)a.T * f + (fused ? 0.1 : 0.35) * occ);
   for (int S = 2; S <= kMaxTimeSegs; S *= 2) {
     if (2 * a.B * S > cus || a.T < 2 * burn) continue;
     if (want == S) return S;
-    const double t = ((double)a.T / S + burn) * f + occ;
+    const double t = ((double)a.T / S + burn) * f + occ + 6e-5;
     if (want < 0 && t < best_t) { best = S; best_t = t; }
   }
   return best;
@@ -650,6 +652,18 @@ extern "C" int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int re
   return den_would_exp_rows_ahead(a) ? 1 : 0;
 }
 
+extern "C" int pychain_hip_den_time_segments(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T, int fused) {
+  if (B <= 0 || T <= 0 || H <= 0 || D <= 0 || resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) return 1;
+  DenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.plan_stride = plan_stride_bytes; a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H); a.frames_per_block = 32;
+  a.knobs = call_knobs();
+  a.check_all = a.knobs.verbose >= 1 ? 1 : 0;
+  a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
+  a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
+  a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
+  return den_time_segments(a, fused != 0);
+}
 extern "C" int pychain_hip_den_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T) {
   if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
   DenArgs a;

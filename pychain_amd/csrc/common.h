@@ -29,7 +29,7 @@ struct CallKnobs {
   // can be seen to fire
   int num_compat;             // 1: the numerator in the reference's own fp32 arithmetic (num_compat.hip) instead of the exact path
   int den_tseg;               // time segments per (sequence, direction) of the lazy recursions: -1 automatic, 0 / 1 never, 2 or 4 wherever the shape allows
-  int den_tburn;              // frames a segment starts outside itself (its burn-in); default 256
+  int den_tburn;              // frames a segment starts outside itself (its burn-in); default 192
   int corrupt_what;           // 0 none, 1 denominator, 2 numerator
   int corrupt_b, corrupt_t;
   float corrupt_scale;

@@ -116,11 +116,11 @@ struct DenArgs {
   // from the ordinary start vector - a forward / backward filter forgets where it started (profiles/r05_forgetting_table.md:
   // 1e-7 after 192 frames on the benchmark graphs) - with the rows of its burn-in discarded, except the one next to the segment:
   // that one goes to splice[((b * 2 + dir) * kMaxTimeSegs + k) * 2 * Hp] and den_splice_check_kernel compares it with the TRUE row
-  // the neighbouring segment stored; any mismatch beyond 1e-6 sets *redo (and counts into respec), and the recursion launch that
+  // the neighbouring segment stored; any mismatch beyond 4e-6 sets *redo (and counts into respec), and the recursion launch that
   // follows - the ordinary one, launched with redo_if - runs only then.  Sequences shorter than 2 tburn frames run as one segment.
   int tseg, tburn;
   float* splice;                 // [B][2][kMaxTimeSegs][2][Hp]: the speculated row next to a segment; a row nobody reads (workspace)
-  int32_t* redo;                 // [2]: [0] != 0: a splice did not verify; [1]: how many (reported; zeroed with the progress counters)
+  int32_t* redo;                 // [3]: [0] != 0: a splice did not verify; [1]: how many; [2]: the worst mismatch as float bits (reported; zeroed with the progress counters)
   int redo_if;                   // this recursion launch is the fallback: its workgroups leave at once unless *redo != 0
   CallKnobs knobs;               // this call's snapshot of the library settings (host side only)
 };

@@ -737,7 +737,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 #undef LZ_PH0
 
   if (TS && fwd && !seg_last) {                            // an inner alpha segment: nothing to total; a NaN it staged is reported
-    if (bad & 2) { if (tid == 0) __hip_atomic_store(a.xnan + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad &= ~2; }
+    if (bad & 2) { __hip_atomic_store(a.xnan + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad &= ~2; }   // (whichever wave staged it)
     if (bad && lane == 0) atomicAdd(a.bad, 1);
     return;
   }

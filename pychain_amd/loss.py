@@ -70,7 +70,7 @@ class ChainFunction(torch.autograd.Function):
             if totals:
                 objf, input_grad, bad, tot = native.den_forward_backward(
                     plan, x, input_lengths, leaky_coefficient, input_is_exp=False, totals=True)
-                ChainFunction.last_totals = tot[:4]
+                ChainFunction.last_totals, ChainFunction.last_totals_all = tot[:4], tot
                 objf = native.totals_scalar(tot)   # (no launch; not a view of the statistics)
             else:
                 objf, input_grad, bad = native.den_forward_backward(
@@ -105,6 +105,7 @@ class ChainFunction(torch.autograd.Function):
 
     retain_grad_buffer = False
     last_totals = None           # device float[4] of the last native call that produced them (include/pychain_hip.h: totals)
+    last_totals_all = None       # ... all eight: [5..7] say how a time-segmented call went (segments redone, count, worst mismatch)
 
     @staticmethod
     def backward(ctx, objf_grad):
@@ -186,7 +187,7 @@ class ChainLossFunction(torch.autograd.Function):
         # -(num - den) [/ frames], loss.py:100-104, comes with the call (the last workgroup of its last kernel adds the
         # per-sequence objectives up): no reduction / subtraction / scaling launches behind it
         objf = native.totals_scalar(totals)    # (no launch; not a view of the statistics: `loss /= n` works)
-        ChainFunction.last_totals = totals[:4]
+        ChainFunction.last_totals, ChainFunction.last_totals_all = totals[:4], totals
         ctx.state = state
         # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
         spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)

@@ -108,6 +108,72 @@ def _check_lengths(lengths, B, T):
             raise ValueError("sequence lengths must be in [1, %d]" % T)
 
 
+# ---------------------------------------------------------------------------
+# Time segments (include/pychain_hip.h: totals[5..7]): how long a recursion needs to forget where it started
+# depends on the DATA (peaky network outputs forget slowly: N(0,1) x 4 instead of x 2 needs > 256 frames on the benchmark
+# graph; the benchmark's x 2 verifies from 192 on: profiles/r05_time_segments.txt), and a call whose speculated rows do not verify runs its recursions twice.  The library is stateless; this layer
+# watches totals[5] of the calls it made - copied to pinned host memory behind the call and read when the copy's event
+# has fired, never a sync - and, after a miss, lengthens the burn-in for that plan by half (option den_tburn), or stops cutting it
+# for a while when the burn-in would eat the gain.  Options set by the caller (den_tseg / den_tburn) switch this off.
+# ---------------------------------------------------------------------------
+_tseg_ctl = {}
+TSEG_COOLDOWN_CALLS = 500
+TSEG_BURN = 192          # the library's default burn-in (option den_tburn)
+
+
+class _TsegState(object):
+    __slots__ = ("burn", "off", "pending", "misses", "calls", "host")
+
+    def __init__(self):
+        self.burn, self.off, self.pending, self.misses, self.calls, self.host = TSEG_BURN, 0, None, 0, 0, None
+
+
+def _tseg_key(plan, B, T, D, dev, fused):
+    """None where the library would not cut such a call anyway (nothing to watch: B = 64, small graphs, ...)."""
+    if _lib.get_option("den_tseg") is not None or _lib.get_option("den_tburn") is not None:
+        return None
+    if _lib.lib().pychain_hip_den_time_segments(plan.stride, plan.slot_rows, int(plan.num_states), int(D), int(B), int(T), int(fused)) <= 1:
+        return None
+    return (str(dev), plan.blob.data_ptr(), int(B), int(T), bool(fused))
+
+
+def _tseg_options(key, T):
+    """The option overrides of this call ([] = the library's own choice), after looking at what earlier calls reported."""
+    if key is None:
+        return []
+    st = _tseg_ctl.get(key)
+    if st is None:
+        st = _tseg_ctl[key] = _TsegState()
+        while len(_tseg_ctl) > 64:
+            _tseg_ctl.pop(next(iter(_tseg_ctl)))
+    st.calls += 1
+    if st.pending is not None and st.pending[0].query():
+        redone = float(st.pending[1][0])
+        st.pending = None
+        if redone > 0:
+            st.misses += 1
+            grown = int(st.burn * 1.5 + 0.5)
+            if grown * 3 <= T:                       # (a burn-in beyond a third of the sequence: the cut no longer pays)
+                st.burn = grown
+            else:
+                st.off, st.burn = st.calls + TSEG_COOLDOWN_CALLS, TSEG_BURN
+    if st.off > st.calls:
+        return [_lib.option("den_tseg", 0)]
+    return [_lib.option("den_tburn", st.burn)] if st.burn != TSEG_BURN else []
+
+
+def _tseg_observe(key, tot, dev):
+    st = _tseg_ctl.get(key) if key is not None else None
+    if st is None or st.pending is not None:
+        return
+    if st.host is None:
+        st.host = torch.empty(3, dtype=torch.float32, pin_memory=True)
+    st.host.copy_(tot[5:8], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    st.pending = (ev, st.host)
+
+
 HALF_ROWS = True        # False: bf16 / fp16 network outputs are up-cast on the host side of the ABI (the tests compare the two ways)
 _DTYPE_CODE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
@@ -141,18 +207,27 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
         objf = torch.empty(B, dtype=torch.float32, device=dev)
         grad = torch.empty_like(x)                 # (in the type the kernels read: the gradient is rounded where it is written)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
-        tot = torch.empty(_lib.TOTALS, dtype=torch.float32, device=dev) if totals else None
-        # (the [B,T,D] buffer of the rows exp'd ahead only where this call will use it: ADVICE r4)
-        full = L.pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, int(num_states), D, B, T, int(bool(input_is_exp)))
-        nws = (L.pychain_hip_den_workspace_bytes if full else L.pychain_hip_den_workspace_min_bytes)(B, T, int(num_states), D)
-        ws = _workspace(nws, dev, "den")
-        _lib.check(L.pychain_hip_den_forward_backward(
-            plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(), xcode,
-            int(bool(input_is_exp)),
-            ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
-            objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), tot.data_ptr() if totals else 0,
-            ws.data_ptr(), ws.numel(), _stream(dev)),
-            "pychain_hip_den_forward_backward")
+        tot = torch.empty(_lib.TOTALS, dtype=torch.float32, device=dev)
+        key = _tseg_key(plan, B, T, D, dev, False)
+        ctx = _tseg_options(key, T)
+        for c in ctx:
+            c.__enter__()
+        try:
+            # (the [B,T,D] buffer of the rows exp'd ahead only where this call will use it: ADVICE r4)
+            full = L.pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, int(num_states), D, B, T, int(bool(input_is_exp)))
+            nws = (L.pychain_hip_den_workspace_bytes if full else L.pychain_hip_den_workspace_min_bytes)(B, T, int(num_states), D)
+            ws = _workspace(nws, dev, "den")
+            _lib.check(L.pychain_hip_den_forward_backward(
+                plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(), xcode,
+                int(bool(input_is_exp)),
+                ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
+                objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), tot.data_ptr(),
+                ws.data_ptr(), ws.numel(), _stream(dev)),
+                "pychain_hip_den_forward_backward")
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+        _tseg_observe(key, tot, dev)
     return (objf, grad, bad, tot) if totals else (objf, grad, bad)
 
 
@@ -263,7 +338,12 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
         nws = torch.empty(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dtype=torch.uint8,
                           device=dev)
         grad = torch.empty_like(x) if with_grad else None
-        _lib.check(L.pychain_hip_chain_loss_forward(
+        key = _tseg_key(plan, B, T, D, dev, True)
+        tctx = _tseg_options(key, T)
+        for c in tctx:
+            c.__enter__()
+        try:
+          _lib.check(L.pychain_hip_chain_loss_forward(
             plan.blob.data_ptr(), plan.stride, plan.slot_rows, plan.num_states, float(leaky_coefficient),
             gt["forward_transitions"].data_ptr(), gt["forward_transition_indices"].data_ptr(),
             gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
@@ -274,6 +354,10 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
             bad.data_ptr(), float(loss_scale), 0 if norm_dev is None else norm_dev.data_ptr(), totals.data_ptr(),
             dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_forward")
+        finally:
+            for c in reversed(tctx):
+                c.__exit__()
+        _tseg_observe(key, totals, dev)
     st.grad = grad
     # (which numerator wrote the stored rows: backward runs on autograd's thread, where the caller's thread options do not reach)
     st.num_compat = _lib.get_option("num_compat") or "0"

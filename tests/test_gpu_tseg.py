@@ -107,7 +107,39 @@ def test_segmented_fused_loss_two_byte_rows_and_nan():
     lh1, gh1, bh1, _ = step(xh, den_tseg=4)
     assert int(bh1.sum()) == 0 and abs(lh1 - lh0) <= 1e-6 * abs(lh0)
     assert rel_err(gh1.float().cpu().numpy(), gh0.float().cpu().numpy()) <= 2.0 ** -8
-    xn = x.clone()
-    xn[0, 700, 11] = float("nan")                              # frame 700 of 1200: an inner segment of sequence 0
-    ln, gn, bn, _ = step(xn, den_tseg=4)
-    assert np.isnan(ln) and int(bn.sum()) > 0
+    # frame 700 of 1200: only an INNER alpha segment of sequence 0 stages it (the last one starts its burn-in at 708);
+    # frame 100: the first segment; frame 1150: the last one; frame 650 of sequence 1 (1100 frames)
+    for (b, t) in ((0, 700), (0, 100), (0, 1150), (1, 650)):
+        xn = x.clone()
+        xn[b, t, 11] = float("nan")
+        ln, gn, bn, _ = step(xn, den_tseg=4)
+        assert np.isnan(ln) and int(bn.sum()) > 0, (b, t)
+
+
+def test_a_burn_in_that_misses_is_noticed_by_the_host_layer():
+    """How long a recursion needs to forget its start depends on the DATA (network outputs N(0,1) x 4 instead of x 2 need more
+    than 256 frames on the benchmark graph: profiles/r05_time_segments.txt), and a call whose speculated rows do not verify runs
+    its recursions twice.  pychain_amd.native watches totals[5] of its calls - a non-blocking copy to pinned memory, read when
+    its event has fired: no sync - and lengthens the burn-in for that plan by half after a miss (or stops cutting it when the burn-in
+    would eat the gain).  Started here from a burn-in of 57 frames: 57, 86, 129 miss, 194 verifies; every call - also the
+    missing ones, through the fallback - gives the unsegmented call's numbers."""
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    plan = _plan.graph_plan(den, cfg["D"], torch.device(DEV))
+    B, T = 4, 1500
+    L = torch.full((B,), T)
+    x = syn.make_input(B, T, cfg["D"], seed=31, device=DEV)
+    o0, g0, _, _ = _den(plan, x, L, den_tseg=0)
+    native._tseg_ctl.clear()
+    key = native._tseg_key(plan, B, T, cfg["D"], torch.device(DEV), False)
+    assert key is not None
+    st = native._tseg_ctl[key] = native._TsegState()
+    st.burn = 57
+    seen = []
+    for i in range(6):
+        o, g, b, t = native.den_forward_backward(plan, x, L, 1e-5, totals=True)
+        torch.cuda.synchronize()
+        seen.append((int(t[6]), int(t[5]), st.burn))
+        assert int(b) == 0 and rel_err(g.cpu().numpy(), g0.cpu().numpy()) <= 1e-5 and float((o - o0).abs().max()) <= 1e-5 * float(o0.abs().max())
+    assert seen[0][0] == 4 and seen[0][1] > 0 and seen[0][2] == 57, seen               # cut, missed, redone
+    assert seen[-1][1] == 0 and seen[-1][2] == 194 and st.misses == 3, seen           # 57 -> 86 -> 129 -> 194: verifies
