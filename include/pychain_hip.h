@@ -105,7 +105,7 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  * pychain_hip_set_thread_option overrides it for the calling host thread only (value NULL removes the override,
  * "" = unset for this thread); pychain_hip_get_option copies the value in effect for the calling thread into buf and
  * returns its length (0 = unset).  pychain_hip_set_verbose_level / _set_den_phase_mask / _set_den_lazy are the
- * process-wide "verbose" / "den_phase_mask" / "den_lazy".  The eight names - every one selects between SHIPPED kernel
+ * process-wide "verbose" / "den_phase_mask" / "den_lazy".  The eleven names - every one selects between SHIPPED kernel
  * families so that the tests can compare them (all give the same results to rounding; most bit for bit), or is a test hook:
  *   "verbose"        base.h:34-42: >= 1 checks the reference's invariant on every frame instead of frame 0
  *   "den_phase_mask" bit 0 recursion launch, bit 1 occupancy launch (measurement aid)
@@ -122,6 +122,10 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "debug_corrupt_row" "den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the
  *                    recursions and the occupancy pass, so that the 5 % invariant of chain-computation.cc:363-390 /
  *                    chain-log-domain-computation.cc:289-303 can be seen to fire: `ok` false at t = 0, at any t at verbose >= 1
+ *   "num_compat"     "1": the numerator in the reference's own fp32 arithmetic (num_compat.hip) instead of the exact path
+ *   "den_tseg"       time segments per (sequence, direction) of the lazy recursions: unset / "-1" automatic (few sequences
+ *                    only: pychain_hip_den_time_segments), "0": never, "2" / "4": wherever the shape allows
+ *   "den_tburn"      frames a time segment starts outside itself (default 192); see totals[5..7]
  * Unknown name: EINVAL.  (Kernel variants that measured slower - 8 / 12 waves, two copies of the nnet-output row, a
  * recursion relaunched per segment - are not in the library; their measurements are under profiles/r03_*.) */
 int         pychain_hip_set_option(const char* name, const char* value);
