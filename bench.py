@@ -132,7 +132,7 @@ def kernel_rooflines(w, dev, iters, d2d=True):
     bytes_gam = (4 * D + 4 * (H + 1)) * frames
     ms_rec, ms_gam = out["den_recursion_kernel"], out["den_gamma_kernel"]
     # the kernels this shape runs, as the library's own launcher decides (include/pychain_hip.h: pychain_hip_den_kernel_names)
-    rec_name, occ_name = _lib.den_kernel_names(plan.slot_rows, H, D, cfg["B"])
+    rec_name, occ_name = _lib.den_kernel_names(plan.slot_rows, plan.num_states, D, cfg["B"])
     # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, summary committed under
     # profiles/ by tools/profile_round.sh): the newest file measured on this very workload and kernel
     traffic, traffic_source = None, None
@@ -311,12 +311,12 @@ def other_workloads(dev, steps=6, warmup=3):
             ms = (time.perf_counter() - t0) / steps * 1e3
             frames = int(w["lengths"].sum())
             plan = _plan.graph_plan(w["den_graph"], cfg["D"], dev)
-            rec, occ = _lib.den_kernel_names(plan.slot_rows, cfg["H"], cfg["D"], cfg["B"])
+            rec, occ = _lib.den_kernel_names(plan.slot_rows, plan.num_states, cfg["D"], cfg["B"])
             stream = torch.cuda.current_stream(dev)
             # time segments of the call the step makes (totals[5..7] of include/pychain_hip.h: segments per (sequence, direction),
             # speculated rows that did not verify, the worst mismatch seen; 1 / 0 / 0 where the call is not cut)
             fused_call = w["num_graphs"] is not None
-            tsegs = int(_lib.lib().pychain_hip_den_time_segments(plan.stride, plan.slot_rows, cfg["H"], cfg["D"], cfg["B"], cfg["T"], int(fused_call)))
+            tsegs = int(_lib.lib().pychain_hip_den_time_segments(plan.stride, plan.slot_rows, plan.num_states, cfg["D"], cfg["B"], cfg["T"], int(fused_call)))
             tot8 = ChainFunction.last_totals_all.detach().float().cpu().tolist() if getattr(ChainFunction, "last_totals_all", None) is not None else None
             call = lambda: native.den_forward_backward(plan, w["x"].detach(), w["lengths_dev"], 1e-5)
             parts = {}
@@ -329,7 +329,7 @@ def other_workloads(dev, steps=6, warmup=3):
                     parts[key] = event_time_ms(call, 3, stream)
             # (2-byte rows: x read twice at 2 B, the gradient written at 2 B: 6 D instead of 12 D per frame)
             den_bytes = ((6 if half else 12) * cfg["D"] + 8 * (cfg["H"] + 1)) * frames
-            uses_rows = bool(_lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, cfg["H"], cfg["D"], cfg["B"], cfg["T"], 0)) and not cfg["num"]
+            uses_rows = bool(_lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, plan.num_states, cfg["D"], cfg["B"], cfg["T"], 0)) and not cfg["num"]
             out[label] = {
                 "workload": "%s: B=%d T<=%d (%d frames), %d pdfs, den %d states/%d arcs%s%s"
                             % (name, cfg["B"], cfg["T"], frames, cfg["D"], cfg["H"], cfg["K"], " + numerators" if cfg["num"] else ", denominator only",

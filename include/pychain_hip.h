@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 14
+#define PYCHAIN_HIP_ABI_VERSION 15
 
 /* Element type of the network output [B,T,D] - and of the gradient an entry point writes for it (ABI 14).
  * 2-byte rows are read as they are by the kernels and converted where they land; the gradient is rounded (to nearest even)
@@ -105,7 +105,7 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  * pychain_hip_set_thread_option overrides it for the calling host thread only (value NULL removes the override,
  * "" = unset for this thread); pychain_hip_get_option copies the value in effect for the calling thread into buf and
  * returns its length (0 = unset).  pychain_hip_set_verbose_level / _set_den_phase_mask / _set_den_lazy are the
- * process-wide "verbose" / "den_phase_mask" / "den_lazy".  The eleven names - every one selects between SHIPPED kernel
+ * process-wide "verbose" / "den_phase_mask" / "den_lazy".  The twelve names - every one selects between SHIPPED kernel
  * families so that the tests can compare them (all give the same results to rounding; most bit for bit), or is a test hook:
  *   "verbose"        base.h:34-42: >= 1 checks the reference's invariant on every frame instead of frame 0
  *   "den_phase_mask" bit 0 recursion launch, bit 1 occupancy launch (measurement aid)
@@ -126,6 +126,8 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "den_tseg"       time segments per (sequence, direction) of the lazy recursions: unset / "-1" automatic (few sequences
  *                    only: pychain_hip_den_time_segments), "0": never, "2" / "4": wherever the shape allows
  *   "den_tburn"      frames a time segment starts outside itself (default 192); see totals[5..7]
+ *   "plan_split"     read by pychain_hip_den_plan_build: "0": no state on more than one lane; default: where it gains a
+ *                    shorter register-resident loop
  * Unknown name: EINVAL.  (Kernel variants that measured slower - 8 / 12 waves, two copies of the nnet-output row, a
  * recursion relaunched per segment - are not in the library; their measurements are under profiles/r03_*.) */
 int         pychain_hip_set_option(const char* name, const char* value);
@@ -143,6 +145,15 @@ int         pychain_hip_get_option(const char* name, char* buf, size_t buf_bytes
  *   by pdf-id            (occupancy pass;  replaces the reference's atomicAdd
  *                         scatter, chain-kernels.cu:53-87,230-240)
  * plus the permuted leaky / initial / final vectors.
+ *
+ * States on several lanes: a row group of a recursion is as long as its longest row, so one state with many arcs
+ * entering (leaving) it would set the loop length of the whole workgroup.  Where it gains a shorter register-resident loop
+ * the compiler puts such a state on several POSITIONS of a side's numbering, each collecting a share of its arcs; the
+ * arcs that gather the state are repeated once per position (csrc/plan.cpp).  The plan then has more positions than the
+ * graph has states: pychain_hip_den_plan_info reports the position count as info[0] - THE VALUE TO PASS AS num_states
+ * to the workspace and forward-backward calls - and the graph's own count as info[6].  Results are the same to rounding.
+ * Plans passed to one call with a non-zero stride must agree in info[0]: build them with the option "plan_split" = "0"
+ * (no state on more than one lane).
  *
  * Graphs the tile kernels do not take - more than 65 535 states or pdfs (packed 16-bit arc addresses), or a state
  * vector + nnet-output row beyond the 160 KiB LDS of one CU - are compiled into a GENERAL format instead (the reference
@@ -171,14 +182,16 @@ int64_t pychain_hip_den_plan_build(
 
 /* Facts about a filled HOST blob that the launcher needs (the blob itself lives on the
  * device at call time and is never read back):
- *   info[0] num_states  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes, low 31 bits (info[5]: the rest)
+ *   info[0] num_states (positions: see "States on several lanes")  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes, low 31 bits (info[5]: the rest)
  *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers), three
  *           fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
- *           and for 8 waves (20-28); combine several plans by taking the max of each field
+ *           and for 8 waves (20-27); combine several plans by taking the max of each field
+ *           bit 28: a state sits on several positions of the beta numbering: not for den_recursion_pair_kernel (OR)
  *           bit 29: the plan also holds its recursion tiles dealt to FOUR waves (small graphs: 256-thread recursion
  *                   workgroups); the recursion field is then that dealing's row count (AND over several plans)
  *           bit 30: every recursion wave owns few enough row groups for the lazy-normalisation recursions (AND)
- *   info[5] plan bytes >> 31 (general-format plans may exceed 2 GiB)   info[6..7] reserved (0)
+ *   info[5] plan bytes >> 31 (general-format plans may exceed 2 GiB)   info[6] the graph's states, info[7] positions
+ *   added by states on several lanes (0: none)
  * A blob whose header or payload does not match the checksums in its header, or whose header points outside the blob
  * (a damaged or foreign cache file), is EINVAL.
  */

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 14
+ABI_VERSION = 15
 TOTALS = 8            # floats of a `totals` buffer (include/pychain_hip.h: PYCHAIN_HIP_TOTALS)
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
@@ -103,7 +103,7 @@ def lib():
     return _lib
 
 
-OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn")
+OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split")
 
 _thread_values = threading.local()       # what this thread's overrides currently are (for restoring)
 

@@ -58,7 +58,8 @@ def build_plan_blob(forward_transitions, forward_transition_indices, forward_tra
                 rc = L.pychain_hip_den_plan_info(blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes,
                                                  info.ctypes.data_as(ctypes.c_void_p))
                 # (plan_info also verifies the checksum of the payload behind the header)
-                if rc == 0 and (int(info[0]), int(info[1]), int(info[2]), int(info[3]) + (int(info[5]) << 31)) == (H, K, int(num_pdfs), blob.nbytes):
+                # (info[6]: the graph's states where the plan has put some on several lanes - info[0] then counts positions)
+                if rc == 0 and (int(info[6]) or int(info[0]), int(info[1]), int(info[2]), int(info[3]) + (int(info[5]) << 31)) == (H, K, int(num_pdfs), blob.nbytes):
                     return blob
         except (OSError, ValueError):
             pass
@@ -83,8 +84,11 @@ def plan_info(blob):
     info = np.zeros(8, dtype=np.int32)
     _lib.check(_lib.lib().pychain_hip_den_plan_info(blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes,
                                                     info.ctypes.data_as(ctypes.c_void_p)), "den_plan_info")
+    # num_states: what the calls are given as num_states - the plan's POSITIONS (a state with many arcs may sit on several:
+    # csrc/plan.cpp, "states on several lanes"); graph_states: the graph's own count
     return dict(num_states=int(info[0]), num_transitions=int(info[1]), num_pdfs=int(info[2]),
-                bytes=int(info[3]) + (int(info[5]) << 31), slot_rows=int(info[4]))
+                bytes=int(info[3]) + (int(info[5]) << 31), slot_rows=int(info[4]),
+                graph_states=int(info[6]) or int(info[0]), split_positions=int(info[7]))
 
 
 # ---- on-disk cache of compiled plans -------------------------------------------------------------
@@ -94,7 +98,7 @@ def plan_info(blob):
 # ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans, created 0700; "0" / "off" disables).  Writes are
 # atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.  A file is only
 # believed if its header matches the request AND its payload matches the checksum in the header.
-_KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_LINEAR")
+_KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_SPLIT")
 
 
 def _cache_dir():
@@ -126,6 +130,7 @@ def _plan_key(arrays, num_pdfs):
                                                                  _build_id().encode()))
     for k in _KNOBS:
         h.update(("%s=%s;" % (k, os.environ.get(k, ""))).encode())
+    h.update(("plan_split=%s;" % (_lib.get_option("plan_split") or "")).encode())
     for a in arrays:
         h.update(str(a.dtype).encode() + str(a.shape).encode())
         h.update(np.ascontiguousarray(a).tobytes())
@@ -156,14 +161,15 @@ def _tensor_versions(graph):
 def graph_plan(graph, num_pdfs, device):
     """DevicePlan of a ChainGraph (shared denominator), cached on the graph until one of its tensors
     is modified or replaced."""
-    key = (str(device), int(num_pdfs))
+    key = (str(device), int(num_pdfs), _lib.get_option("plan_split"))
     if not hasattr(graph, "_plan_cache"):
         graph._plan_cache = {}
     ver = _tensor_versions(graph)
     hit = graph._plan_cache.get(key)
     if hit is None or hit[0] != ver:
         blob = build_plan_blob(*[getattr(graph, n) for n in _NAMES], num_pdfs)
-        plan = DevicePlan(torch.from_numpy(blob).to(device), 0, plan_info(blob)["slot_rows"], graph.num_states)
+        info = plan_info(blob)
+        plan = DevicePlan(torch.from_numpy(blob).to(device), 0, info["slot_rows"], info["num_states"])
         graph._plan_cache[key] = hit = (ver, plan)
     return hit[1]
 
@@ -178,18 +184,27 @@ def batch_plans(tensors, num_pdfs, device):
     rows = [0] if same else range(B)
     # (the compiler is native code behind ctypes, which releases the GIL: the plans of a list of graphs compile side by side)
     if len(rows) > 1:
+        # (plans passed with a stride share one position count: no state on several lanes - option plan_split is per thread)
+        def build(b):
+            with _lib.option("plan_split", "0"):
+                return build_plan_blob(*[t[b] for t in ts], num_pdfs)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(rows), os.cpu_count() or 1, 16)) as ex:
-            blobs = list(ex.map(lambda b: build_plan_blob(*[t[b] for t in ts], num_pdfs), rows))
+            blobs = list(ex.map(build, rows))
     else:
         blobs = [build_plan_blob(*[t[b] for t in ts], num_pdfs) for b in rows]
-    hints = [plan_info(b)["slot_rows"] for b in blobs]
+    infos = [plan_info(b) for b in blobs]
+    hints = [i["slot_rows"] for i in infos]
+    H = max(i["num_states"] for i in infos)
+    assert all(i["num_states"] == H for i in infos), "plans of one batch must have the same number of positions"
     if any(h == HINT_GENERAL for h in hints):
         # the format follows from the sizes (and PYCHAIN_PLAN_GENERAL): all plans of one batch are alike
         assert all(h == HINT_GENERAL for h in hints)
         slot_rows = HINT_GENERAL
     else:
-        slot_rows = sum(max((h >> sh) & mask for h in hints) << sh for sh, mask in ((0, 1023), (10, 1023), (20, 511)))
+        slot_rows = sum(max((h >> sh) & mask for h in hints) << sh for sh, mask in ((0, 1023), (10, 1023), (20, 255)))
+        if any((h >> 28) & 1 for h in hints):      # a state on several beta positions: not for the pair kernel
+            slot_rows |= 1 << 28
         for bit in (29, 30):                       # every plan holds four-wave tiles / fits the lazy recursion (<= 4 groups per wave)
             if all((h >> bit) & 1 for h in hints):
                 slot_rows |= 1 << bit

@@ -29,7 +29,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
-                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn"};
+                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -69,6 +69,7 @@ CallKnobs call_knobs() {
   k.num_compat = option_int("num_compat", 0) ? 1 : 0;
   k.den_tseg = option_int("den_tseg", -1);
   k.den_tburn = option_int("den_tburn", 192);
+  k.plan_split = option_int("plan_split", -1);
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
@@ -184,8 +185,8 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (m > 1023) m = 1023;
   if (gmm > 1023) gmm = 1023;
   if (gm2 > 1023) gm2 = 1023;
-  // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (10 bits) << 10 | occupancy rows, 8 waves (9 bits) << 20
-  if (gm2 > 511) gm2 = 511;
+  // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (10 bits) << 10 | occupancy rows, 8 waves (8 bits) << 20
+  if (gm2 > 255) gm2 = 255;
   // bit 29: the plan holds the recursion tiles dealt to FOUR waves (small graphs: den_recursion_lazy_kernel<small>); the
   // recursion field is then the row count of THAT dealing (>= the 16-wave one: a kernel sized by it fits either)
   const bool small = hd->alpha4.nwaves == PLAN_REC4_WAVES && hd->beta4.nwaves == PLAN_REC4_WAVES &&
@@ -195,6 +196,11 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (small) info[4] |= 1 << 29;
   // bit 30: every recursion wave owns at most 4 groups (what den_recursion_lazy_kernel keeps in registers)
   if (hd->rec_max_wave_groups >= 1 && hd->rec_max_wave_groups <= 4) info[4] |= 1 << 30;
+  // bit 28: a state sits on several positions of the beta numbering (plan.cpp, "states on several lanes"): not for
+  // den_recursion_pair_kernel, whose normalise pass gives every position the constant c(t)
+  if (hd->reserved[2] > 0) info[4] |= 1 << 28;
+  info[6] = hd->reserved[0];                     // the graph's states (info[0]: positions of the longer side = what calls pass as num_states)
+  info[7] = hd->reserved[1] + hd->reserved[2];   // positions added by states on several lanes
   return PYCHAIN_HIP_OK;
 }
 

@@ -237,7 +237,8 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
             // row sums, updated IN PLACE (tied asm operands): a plain `s0 += nacc` makes s0/s1 loop-carried
             // values of the chunk chain and costs register copies on the common path of every chunk
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(s0) : "v"(nacc));
-            if (wvec) { const float wv = wvec[pos]; asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(s1) : "v"(nacc), "v"(wv)); }
+            // (|wv|: beta's leaky probabilities carry a flag in their sign bit - plan.cpp, "states on several lanes")
+            if (wvec) { const float wv = wvec[pos]; asm volatile("v_fma_f32 %0, %1, |%2|, %0" : "+v"(s1) : "v"(nacc), "v"(wv)); }
           }
           nacc = 0.f;
         }
@@ -257,7 +258,7 @@ __device__ __forceinline__ void tile_rows(ArcRegs<R>& ar, const GroupRegs& gr,
       acc = fmaf(__uint_as_float(a.y) * U[a.x & 0xffffu], V[a.x >> 16], acc);
       if (--remaining == 0) {
         tile_store<MODE>(acc, cur_base + lane, out, row_map);
-        if constexpr (MODE == 0) { s0 += acc; if (wvec) s1 += acc * wvec[cur_base + lane]; }
+        if constexpr (MODE == 0) { s0 += acc; if (wvec) s1 += acc * __builtin_fabsf(wvec[cur_base + lane]); }
         acc = 0.f;
         g++;
         cur_base = __builtin_amdgcn_readlane(gr.base, g & 63);
@@ -294,10 +295,13 @@ __device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const 
       }
       v = make_float4(r.x * inv + cl.x, r.y * inv + cl.y, r.z * inv + cl.z, r.w * inv + cl.w);
     } else {
-      // (positions >= H are padding: nothing gathers them and the occupancy pass skips them, so they are
-      // allowed to carry add * inv instead of zero - masking costs 8 VALU per thread on the critical path)
-      const float ai = add * inv;                     // (r + add) * inv as one fma per element
-      v = make_float4(__builtin_fmaf(r.x, inv, ai), __builtin_fmaf(r.y, inv, ai), __builtin_fmaf(r.z, inv, ai), __builtin_fmaf(r.w, inv, ai));
+      // (r + add) * inv as one fma per element; a position whose leaky probability has the sign bit set takes no constant
+      // (a state's second lane, padding: plan.cpp, "states on several lanes")
+      const float ai = add * inv;
+      const float4 l = *reinterpret_cast<const float4*>(lk + i);
+      auto gate = [&](float lv) { return __uint_as_float(__float_as_uint(ai) & ~(uint32_t)((int32_t)__float_as_uint(lv) >> 31)); };
+      v = make_float4(__builtin_fmaf(r.x, inv, gate(l.x)), __builtin_fmaf(r.y, inv, gate(l.y)), __builtin_fmaf(r.z, inv, gate(l.z)),
+                      __builtin_fmaf(r.w, inv, gate(l.w)));
     }
     *reinterpret_cast<float4*>(cur + i) = v;
     if (row_off >= 0) {

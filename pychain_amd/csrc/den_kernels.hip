@@ -942,7 +942,7 @@ hipError_t launch_gamma_stream(const DenArgs& a, int r, size_t lds, dim3 grid, h
 }
 inline bool gamma_stream_shape_ok(const DenArgs& a, int hint, int gamma_max_groups) {
   if (a.plan_stride != 0) return false;
-  if (gamma2_eligible(a, (hint >> 20) & 511, gamma_max_groups)) return true;
+  if (gamma2_eligible(a, (hint >> 20) & 255, gamma_max_groups)) return true;
   const int r = pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
   return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && r > 0;
 }
@@ -957,9 +957,9 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
   if (a.phase_mask & 2) {
     const bool stream = (a.stream & 2) != 0;            // ONE persistent launch over the whole queue (DenArgs::stream)
     const dim3 grid = stream ? dim3(a.stream_blocks) : dim3(gx, a.B);
-    if (gamma2_eligible(a, (hint >> 20) & 511, gamma_max_groups)) {
+    if (gamma2_eligible(a, (hint >> 20) & 255, gamma_max_groups)) {
       const size_t lds2 = gamma2_lds_bytes(a, gamma_max_groups);
-      const int r2 = (hint >> 20) & 511;
+      const int r2 = (hint >> 20) & 255;
       if (stream) return a.D <= 4 * kNT2 ? launch_gamma2<1, true>(a, r2, lds2, grid, st) : launch_gamma2<2, true>(a, r2, lds2, grid, st);
       return a.D <= 4 * kNT2 ? launch_gamma2<1, false>(a, r2, lds2, grid, st) : launch_gamma2<2, false>(a, r2, lds2, grid, st);
     }
@@ -1175,16 +1175,16 @@ const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) 
   return "den_recursion_kernel";
 }
 const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  return gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 255, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
 }
 int den_recursion_blocks(const DenArgs& a) { return a.pair ? 2 * ((a.B + 1) / 2) : 2 * a.B; }
 
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  return gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups);
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 255, gamma_max_groups);
 }
 // 2-byte network output and gradient (DenArgs::x_half): the two-frame kernel, or the one-frame kernel in its float4-chunk forms
 bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  if (gamma2_eligible(a, (resident_slot_rows >> 20) & 511, gamma_max_groups)) return true;
+  if (gamma2_eligible(a, (resident_slot_rows >> 20) & 255, gamma_max_groups)) return true;
   return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && pick_r(a, (resident_slot_rows >> 10) & 1023, 2 * a.Hp) > 0;
 }
 

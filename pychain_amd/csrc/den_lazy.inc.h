@@ -542,7 +542,13 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     float p0 = 0.f, p1 = 0.f;
     for (int i = tid; i < (int)MAP::kMaxStates; i += NT) {
       float s = 0.f, second = fwd ? 0.f : 1.f, l = 0.f;
-      if (i < Hp) { s = start_g[i]; l = leaky_g[i]; if (fwd) second = coef * l; }
+      if (i < Hp) {
+        s = start_g[i]; l = leaky_g[i];
+        if (fwd) second = coef * l;
+        // (beta: a position that does not take the constant c(t) - a state's second lane, padding - has the sign bit set:
+        // plan.cpp, "states on several lanes")
+        else { second = (__float_as_uint(l) >> 31) ? 0.f : 1.f; l = __builtin_fabsf(l); }
+      }
       *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{s, second};
       *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, second};
       if (!fwd) *reinterpret_cast<float*>(smem_raw + MAP::kLk + 4 * i) = l;

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     float p0 = 0.f, p1 = 0.f;
     for (int i = tid; i < Hp; i += kNT) {
       const float l = leaky_g[i], s = start_g[i];
-      lk[i] = l; raw[i] = s;
-      p0 += s; p1 += s * l;
+      lk[i] = l; raw[i] = s;                           // (beta: the sign bit = "takes no constant c(t)", plan.cpp; read as |l|)
+      p0 += s; p1 += s * __builtin_fabsf(l);
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     {

@@ -361,7 +361,11 @@ struct BuiltTile {
 // Deal groups (slot-row counts `gsl`) to `nwaves` waves: longest-processing-time-first, then single
 // moves / swaps while they lower the heavier wave (the frame time of a workgroup is set by its most
 // loaded wave).  Returns the groups of every wave, in descending slot count.
-std::vector<std::vector<int>> deal_groups(const std::vector<int>& gsl, int nwaves) {
+// `max_groups`: groups a wave may own - the lazy recursions keep the bases of four in registers (den_lazy.inc.h: kMaxGroups),
+// so a recursion tile of at most 4 x nwaves groups is dealt under that limit (rec_group_limit); else a wave keeps its
+// group table in one VGPR pair: <= 64.
+int rec_group_limit(size_t ngroups, int nwaves) { return (int)ngroups <= 4 * nwaves ? 4 : 64; }
+std::vector<std::vector<int>> deal_groups(const std::vector<int>& gsl, int nwaves, int max_groups = 64) {
   const int ngroups = (int)gsl.size();
   std::vector<int> by_size(ngroups);
   std::iota(by_size.begin(), by_size.end(), 0);
@@ -370,9 +374,9 @@ std::vector<std::vector<int>> deal_groups(const std::vector<int>& gsl, int nwave
   std::vector<int> load(nwaves, 0);
   auto cost = [&](int g) { return gsl[g] + 1; };     // +1: the per-group store/bookkeeping cost
   for (int g : by_size) {
-    int w = -1;                     // a wave keeps its group table in one VGPR pair: <= 64 groups
+    int w = -1;
     for (int i = 0; i < nwaves; i++)
-      if (per_wave[i].size() < 64 && (w < 0 || load[i] < load[w])) w = i;
+      if ((int)per_wave[i].size() < max_groups && (w < 0 || load[i] < load[w])) w = i;
     per_wave[w].push_back(g);
     load[w] += cost(g);
   }
@@ -384,7 +388,7 @@ std::vector<std::vector<int>> deal_groups(const std::vector<int>& gsl, int nwave
       const int ga = per_wave[wmax][ia];
       for (int w2 = 0; w2 < nwaves && !improved; w2++) {
         if (w2 == wmax) continue;
-        if (per_wave[w2].size() < 64 && load[w2] + cost(ga) < load[wmax]) {          // move
+        if ((int)per_wave[w2].size() < max_groups && load[w2] + cost(ga) < load[wmax]) {          // move
           per_wave[w2].push_back(ga); per_wave[wmax].erase(per_wave[wmax].begin() + ia);
           load[w2] += cost(ga); load[wmax] -= cost(ga); improved = true; break;
         }
@@ -404,9 +408,9 @@ std::vector<std::vector<int>> deal_groups(const std::vector<int>& gsl, int nwave
     std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return gsl[a] > gsl[b]; });
   return per_wave;
 }
-int max_wave_rows(const std::vector<int>& gsl, int nwaves) {
+int max_wave_rows(const std::vector<int>& gsl, int nwaves, int max_groups = 64) {
   int mx = 0;
-  for (const auto& w : deal_groups(gsl, nwaves)) { int n = 0; for (int g : w) n += gsl[g]; mx = std::max(mx, n); }
+  for (const auto& w : deal_groups(gsl, nwaves, max_groups)) { int n = 0; for (int g : w) n += gsl[g]; mx = std::max(mx, n); }
   return mx;
 }
 
@@ -464,7 +468,7 @@ BuiltTile emit_tile(const Tile& t, const SlotOrder& so, const Layouts& lay, cons
 // Spare slot-rows per group such that no wave exceeds `target` rows: start from the uniform slack that fills
 // the budget, take a row back from the fullest wave's most padded group while a wave is over, then hand rows
 // out again (smallest groups first) where they still fit.  Groups of fewer than 4 rows get none (as with_slack).
-std::vector<int> fit_slack(const std::vector<int>& base, int nwaves, int target) {
+std::vector<int> fit_slack(const std::vector<int>& base, int nwaves, int target, int max_groups = 64) {
   const int ng = (int)base.size();
   long total = 0, elig = 0;
   for (int g = 0; g < ng; g++) { total += base[g]; if (base[g] >= 4) elig++; }
@@ -475,7 +479,7 @@ std::vector<int> fit_slack(const std::vector<int>& base, int nwaves, int target)
   auto rows = [&]() { std::vector<int> v = base; for (int g = 0; g < ng; g++) v[g] += sl[g]; return v; };
   for (int iter = 0; iter < 4 * ng; iter++) {
     const std::vector<int> v = rows();
-    const auto deal = deal_groups(v, nwaves);
+    const auto deal = deal_groups(v, nwaves, max_groups);
     int wmax = 0, mx = -1;
     for (int w = 0; w < nwaves; w++) { int n = 0; for (int g : deal[w]) n += v[g]; if (n > mx) { mx = n; wmax = w; } }
     if (mx <= target) break;
@@ -484,14 +488,14 @@ std::vector<int> fit_slack(const std::vector<int>& base, int nwaves, int target)
     if (pick < 0) break;                                   // nothing left to take back: the caller checks the result
     sl[pick]--;
   }
-  if (max_wave_rows(rows(), nwaves) > target) return base;
+  if (max_wave_rows(rows(), nwaves, max_groups) > target) return base;
   std::vector<int> order(ng);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return base[a] + sl[a] < base[b] + sl[b]; });
   for (int g : order) {
     if (base[g] < 4 || sl[g] >= 4) continue;
     sl[g]++;
-    if (max_wave_rows(rows(), nwaves) > target) sl[g]--;
+    if (max_wave_rows(rows(), nwaves, max_groups) > target) sl[g]--;
   }
   return rows();
 }
@@ -519,7 +523,7 @@ std::vector<int> group_rows(const std::vector<std::vector<Arc>>& rows, const std
 }
 // a dealing to `nwaves` waves in which no wave owns more than `max_rows` slot-rows or `max_groups` groups?
 bool dealing_fits(const std::vector<int>& gsl, int nwaves, int max_rows, int max_groups) {
-  for (const auto& w : deal_groups(gsl, nwaves)) {
+  for (const auto& w : deal_groups(gsl, nwaves, rec_group_limit(gsl.size(), nwaves))) {
     int n = 0;
     for (int g : w) n += gsl[g];
     if (n > max_rows || (int)w.size() > max_groups) return false;
@@ -531,6 +535,8 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
                int lay0, int lay1, int own_layout, int weight, int slack, int nwaves) {
   t.rows = &rows; t.order = order; t.npos = npos; t.lay[0] = lay0; t.lay[1] = lay1; t.own_layout = own_layout; t.weight = weight;
   const int ng = npos / 64;
+  // (a recursion tile is dealt under the lazy kernels' limit of four groups per wave where its groups allow: rec_group_limit)
+  const int lim = own_layout >= 0 ? rec_group_limit((size_t)ng, nwaves) : 64;
   t.gsl = group_rows(rows, order, npos, own_layout >= 0);
   // freedom 2: spare slot-rows per group.  The kernels keep 16, 32 or 40 slot-rows of a wave in
   // registers and walk all of them every frame, so slack is free up to the next of those sizes:
@@ -539,7 +545,7 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
   auto with_slack = [&](int k) { std::vector<int> v = t.gsl; for (int& x : v) if (x >= 4) x += k; return v; };
   if (slack >= 0) { t.gsl = with_slack(slack); return; }
   static const int kResident[3] = {PLAN_RESIDENT_0, PLAN_RESIDENT_1, PLAN_RESIDENT_2};
-  const int base = max_wave_rows(t.gsl, nwaves);
+  const int base = max_wave_rows(t.gsl, nwaves, lim);
   if (base > kResident[2]) return;                                  // the tail is streamed anyway
   // PYCHAIN_PLAN_FIT=n (32 <= n < 40): per-group slack fitted to an n-row wave budget (fit_slack) instead of uniform
   // slack; -1: never.  Default (0): fitted to the 32-row loop where uniform slack >= 2 does not land there but about one
@@ -549,26 +555,143 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
   // 36 and 32 fitted rows measured no faster than 40 with slack.]
   const long fit_target = env_long("PYCHAIN_PLAN_FIT", 0);
   if (fit_target >= kResident[1] && fit_target < kResident[2] && base <= fit_target) {
-    t.gsl = fit_slack(t.gsl, nwaves, (int)fit_target);
+    t.gsl = fit_slack(t.gsl, nwaves, (int)fit_target, lim);
     t.fitted = true;
     return;
   }
   if (fit_target == 0 && own_layout >= 0 && base <= kResident[1] && base > kResident[0] &&
-      max_wave_rows(with_slack(2), nwaves) > kResident[1]) {
-    const std::vector<int> fit = fit_slack(t.gsl, nwaves, kResident[1]);
+      max_wave_rows(with_slack(2), nwaves, lim) > kResident[1]) {
+    const std::vector<int> fit = fit_slack(t.gsl, nwaves, kResident[1], lim);
     long spare = 0, elig = 0;
     for (int g = 0; g < ng; g++) { spare += fit[g] - t.gsl[g]; if (t.gsl[g] >= 4) elig++; }
-    if (getenv("PYCHAIN_PLAN_STATS")) fprintf(stderr, "[plan] fit: base %d, fitted max %d, spare %ld, eligible %ld\n", base, max_wave_rows(fit, nwaves), spare, elig);
-    if (max_wave_rows(fit, nwaves) <= kResident[1] && 2 * spare >= elig) { t.gsl = fit; t.fitted = true; return; }
+    if (getenv("PYCHAIN_PLAN_STATS")) fprintf(stderr, "[plan] fit: base %d, fitted max %d, spare %ld, eligible %ld\n", base, max_wave_rows(fit, nwaves, lim), spare, elig);
+    // (round 5: taken whatever it leaves spare - the alternative is the 40-row loop with packed arcs)
+    if (max_wave_rows(fit, nwaves, lim) <= kResident[1]) { t.gsl = fit; t.fitted = true; return; }
   }
+  // (measured on C2 in round 5 and not kept: the 16-row loop for four-wave workgroups with NO spare row - two states on two
+  // lanes each, rows 21 -> 16 - leaves the recursion where it was, 0.180 ms: the small frame is not waiting for its chunks)
   int chosen = 0;
   for (int ri = 0; ri < 3 && chosen == 0; ri++) {
     if (base > kResident[ri]) continue;
     for (int k = 4; k >= (ri < 2 ? 2 : 1); k--)
-      if (max_wave_rows(with_slack(k), nwaves) <= kResident[ri]) { chosen = k; break; }
+      if (max_wave_rows(with_slack(k), nwaves, lim) <= kResident[ri]) { chosen = k; break; }
   }
   t.gsl = with_slack(chosen);
 }
+
+
+// ---- states on several lanes (round 5) ------------------------------------------------------------------------------
+// A group of 64 rows is as long as its longest row, a group cannot be cut between waves, and a wave keeps at most
+// PLAN_RESIDENT_2 slot-rows in registers: ONE state with many arcs entering it sets the loop length of the whole
+// workgroup (graphs with skewed in-degrees: DESIGN.md §4 "A structured graph").  Such a state is put on several lanes
+// without any kernel knowing: in the numbering of a side (alpha: "pa", beta: "pb") it becomes `parts` positions, each of
+// which collects a share of its arcs; whoever gathers the state gathers every part - its arc is repeated once per part
+// (the recursions are linear in the gathered vector).  What is NOT linear is written into the per-position vectors:
+//   alpha'(t,i) = alpha(t,i) + tot(t) coef leaky(i)   the first part carries leaky(i), initial(i); the others 0;
+//   beta'(t,i)  = beta(t,i) + c(t)                    only the first part takes the constant: the others (and the
+//                                                     padding positions) carry the SIGN BIT in leaky_b - the kernels
+//                                                     use |leaky_b| and drop c(t) where it is set;
+//   final(i) multiplies alpha'(L, i): every part carries it; beta(L,i) = final(i): the first part.
+// parts are chosen per side by a cap on the row length: the largest cap (fewest repeated arcs) that reaches the
+// smallest register-resident loop the tile can reach at all; a side that gains no loop class stays as it is.
+struct SideArcs {                       // the arcs of one side's rows: row = the state that owns the sum, other = the state it gathers
+  const int32_t* tr; const int32_t* idx; int own_col, other_col;
+  int begin(int h) const { return idx[2 * h]; }
+  int end(int h) const { return idx[2 * h + 1]; }
+  int other(int k) const { return tr[3 * k + other_col]; }
+};
+// row length of state h when every state s is on parts[s] positions
+long virtual_len(const SideArcs& sa, const std::vector<int>& parts, int h) {
+  long n = 0;
+  for (int k = sa.begin(h); k < sa.end(h); k++) n += parts[sa.other(k)];
+  return n;
+}
+// parts such that no position collects more than `cap` arcs (a fixed point: a state on more positions lengthens the rows
+// that gather it); false if it does not settle within sane bounds
+bool settle_parts(const SideArcs& sa, int H, int cap, std::vector<int>& parts, long max_arcs) {
+  parts.assign(H, 1);
+  for (int iter = 0; iter < 16; iter++) {
+    bool changed = false;
+    long total = 0;
+    for (int h = 0; h < H; h++) {
+      const long n = virtual_len(sa, parts, h);
+      total += n;
+      const int need = (int)((n + cap - 1) / cap);
+      if (need > parts[h]) { parts[h] = need; changed = true; }
+      if (parts[h] > 64) return false;
+    }
+    if (total > max_arcs) return false;
+    if (!changed) return true;
+  }
+  return false;
+}
+// lengths of the positions (virtual rows) of a side
+std::vector<int> part_lengths(const SideArcs& sa, int H, const std::vector<int>& parts) {
+  std::vector<int> len;
+  for (int h = 0; h < H; h++) {
+    const long n = virtual_len(sa, parts, h);
+    for (int m = 0; m < parts[h]; m++) len.push_back((int)((n + parts[h] - 1 - m) / parts[h]));
+  }
+  return len;
+}
+// the loop class a recursion tile with these row lengths lands in when dealt to `nwaves` waves (as init_tile would lay it
+// out): 0..3 = PLAN_RESIDENT_0 / 24 (four waves only) / _1 / _2 slot-rows in registers, 4 = none of them
+int loop_class(const std::vector<int>& len, int nwaves, int npos, int slack) {
+  if ((int)len.size() > npos) return 4;
+  std::vector<std::vector<Arc>> rows(len.size());
+  for (size_t i = 0; i < len.size(); i++) rows[i].resize(len[i]);
+  std::vector<int> ids(len.size());
+  std::iota(ids.begin(), ids.end(), 0);
+  Tile t;
+  init_tile(t, rows, sort_by_degree(len, ids), npos, kLayA, kLayX, kLayA, 2, slack, nwaves);
+  if (!dealing_fits(t.gsl, nwaves, PLAN_RESIDENT_2, 4)) return 4;
+  const int m = max_wave_rows(t.gsl, nwaves, rec_group_limit(t.gsl.size(), nwaves));
+  if (getenv("PYCHAIN_PLAN_STATS")) {
+    const std::vector<int> g0 = group_rows(rows, t.order, npos, true);
+    long tot0 = 0, tot1 = 0; for (int x : g0) tot0 += x; for (int x : t.gsl) tot1 += x;
+    fprintf(stderr, "[plan]   %d waves: groups %zu, rows without slack %ld (max wave %d), with %ld (max wave %d); first groups %d %d %d %d\n", nwaves, g0.size(), tot0,
+            max_wave_rows(g0, nwaves, rec_group_limit(g0.size(), nwaves)), tot1, m, g0[0], g0.size() > 1 ? g0[1] : 0, g0.size() > 2 ? g0[2] : 0, g0.size() > 3 ? g0[3] : 0);
+  }
+  if (m <= PLAN_RESIDENT_0) return 0;
+  if (m <= 24 && nwaves == PLAN_REC4_WAVES) return 1;
+  return m <= PLAN_RESIDENT_1 ? 2 : 3;
+}
+struct PartsChoice { std::vector<int> parts; int cls = 4; int cap = 0; };
+// candidates: caps from the longest row down; per cap the class at 4 and at 16 waves
+struct SideSearch {
+  std::vector<PartsChoice> c4, c16;          // per candidate cap (descending); index 0 = no state split
+};
+SideSearch search_side(const SideArcs& sa, int H, int K, int D, int slack) {
+  SideSearch out;
+  int maxlen = 0;
+  for (int h = 0; h < H; h++) maxlen = std::max(maxlen, sa.end(h) - sa.begin(h));
+  const int lo = std::max(4, (int)(((long)K + H - 1) / H));         // (the mean row length: below it everything would be on two lanes)
+  std::vector<int> caps{maxlen};
+  for (int c = maxlen - 1; c >= lo; c -= std::max(1, (maxlen - lo) / 32)) caps.push_back(c);
+  for (int cap : caps) {
+    PartsChoice pc;
+    pc.cap = cap;
+    if (!settle_parts(sa, H, cap, pc.parts, K + K / 4 + 64)) {
+      if (getenv("PYCHAIN_PLAN_STATS")) fprintf(stderr, "[plan] cap %d: does not settle within 5/4 of the arcs\n", cap);
+      break;
+    }
+    const std::vector<int> len = part_lengths(sa, H, pc.parts);
+    const int Hv = (int)len.size(), Hp = (Hv + 63) / 64 * 64;
+    if (!pychain_hip::plan_fits_fast_kernels(Hv, D)) break;
+    PartsChoice a = pc, b = pc;
+    a.cls = (Hp <= 64 * 4 * PLAN_REC4_WAVES && D <= 4096) ? loop_class(len, PLAN_REC4_WAVES, Hp, slack) : 4;
+    b.cls = loop_class(len, PLAN_REC_WAVES, Hp, slack);
+    out.c4.push_back(a); out.c16.push_back(b);
+    if (getenv("PYCHAIN_PLAN_STATS")) fprintf(stderr, "[plan] cap %d: %d positions, class at 4 waves %d, at 16 waves %d\n", cap, Hv, a.cls, b.cls);
+  }
+  return out;
+}
+// the largest cap (first candidate) whose class is <= target
+const PartsChoice* first_within(const std::vector<PartsChoice>& v, int target) {
+  for (const PartsChoice& c : v) if (c.cls <= target) return &c;
+  return nullptr;
+}
+int best_class(const std::vector<PartsChoice>& v) { int b = 4; for (const PartsChoice& c : v) b = std::min(b, c.cls); return b; }
 
 size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 
@@ -650,13 +773,13 @@ extern "C" int64_t pychain_hip_den_plan_build(
     return plan_build_impl(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, blob, blob_bytes);   // (reports the error)
   static thread_local LastPlan last;
   uint64_t key = 14695981039346656037ull;
-  const int dims[3] = {H, K, D};
+  const int dims[4] = {H, K, D, pychain_hip::call_knobs().plan_split};
   key = fnv64(key, dims, sizeof(dims));
   key = fnv64(key, ft, (size_t)K * 12); key = fnv64(key, fi, (size_t)H * 8); key = fnv64(key, fp, (size_t)K * 4);
   key = fnv64(key, bt, (size_t)K * 12); key = fnv64(key, bi, (size_t)H * 8); key = fnv64(key, bp, (size_t)K * 4);
   key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
   for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
-                           "PYCHAIN_PLAN_LINEAR"}) {
+                           "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_SPLIT"}) {
     const char* v = getenv(knob);
     key = fnv64(key, knob, strlen(knob));
     if (v) key = fnv64(key, v, strlen(v));
@@ -697,40 +820,82 @@ int64_t plan_build_impl(
         b[0] < 0 || b[0] >= H || b[1] < 0 || b[1] >= H || b[2] < 0 || b[2] >= D)
       return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: transition %d has a state or pdf out of range", k);
   }
-  const int Hp = (H + 63) / 64 * 64;
   // graphs the tile-plan kernels do not take (or PYCHAIN_PLAN_GENERAL=1: the tests): the general format
   if (!pychain_hip::plan_fits_fast_kernels(H, D) || env_long("PYCHAIN_PLAN_GENERAL", 0) != 0)
-    return build_general(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, Hp, blob, blob_bytes, grow);
-  std::vector<int> indeg(H), outdeg(H), ids(H);
-  std::iota(ids.begin(), ids.end(), 0);
-  for (int h = 0; h < H; h++) { indeg[h] = bi[2 * h + 1] - bi[2 * h]; outdeg[h] = fi[2 * h + 1] - fi[2 * h]; }
-
-  // rows by entity ids.  alpha rows: arcs entering h, in the reference's order (fstext.cc:63-76)
-  std::vector<std::vector<Arc>> rows_a(H), rows_b(H), rows_g(D);
+    return build_general(ft, fi, fp, bt, bi, bp, leaky, initial, final_, H, K, D, (H + 63) / 64 * 64, blob, blob_bytes, grow);
   for (int h = 0; h < H; h++) {
-    for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++) {
+    for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++)
       if (bt[3 * k + 1] != h)
         return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: backward transition %d is not grouped under its destination", k);
-      rows_a[h].push_back(Arc{bt[3 * k], bt[3 * k + 2], bp[k]});
-    }
-    for (int k = fi[2 * h]; k < fi[2 * h + 1]; k++) {
+    for (int k = fi[2 * h]; k < fi[2 * h + 1]; k++)
       if (ft[3 * k] != h)
         return pychain_hip::fail(PYCHAIN_HIP_EINVAL, "den_plan_build: forward transition %d is not grouped under its source", k);
-      rows_b[h].push_back(Arc{ft[3 * k + 1], ft[3 * k + 2], fp[k]});
-      // gamma rows keep the (state, arc) order the reference accumulates in (chain-computation.cc:293-305)
-      rows_g[ft[3 * k + 2]].push_back(Arc{h, ft[3 * k + 1], fp[k]});
-    }
   }
-  std::vector<int> gdeg(D), gids;
-  for (int n = 0; n < D; n++) { gdeg[n] = (int)rows_g[n].size(); if (gdeg[n] > 0) gids.push_back(n); }
-  const int gpos = std::max(((int)gids.size() + 63) / 64 * 64, 64);
-
   // tuning knobs (environment): PYCHAIN_PLAN_SLACK spare slot-rows per recursion group (default: automatic), PYCHAIN_PLAN_BALANCE
-  // row-placement moves per transition (0 = rows stay in degree order), PYCHAIN_PLAN_ANNEAL slot moves per cell
+  // row-placement moves per transition (0 = rows stay in degree order), PYCHAIN_PLAN_ANNEAL slot moves per cell,
+  // PYCHAIN_PLAN_SPLIT=0: no state on more than one lane
   const int slack = (int)env_long("PYCHAIN_PLAN_SLACK", -1);
   const long balance_moves = env_long("PYCHAIN_PLAN_BALANCE", 170);
   const long anneal_knob = env_long("PYCHAIN_PLAN_ANNEAL", -1);        // < 0: 200, and 3000 for a recursion tile fitted to the 32-row loop
   const bool stats = env_long("PYCHAIN_PLAN_STATS", 0) != 0;
+
+  // ---- states on several lanes ("states on several lanes" above): parts per state and side
+  const SideArcs side_a{bt, bi, 1, 0}, side_b{ft, fi, 0, 1};
+  std::vector<int> parts_a(H, 1), parts_b(H, 1);
+  const int split_knob = pychain_hip::call_knobs().plan_split;      // (option plan_split, else the environment)
+  if ((split_knob >= 0 ? split_knob : (int)env_long("PYCHAIN_PLAN_SPLIT", 1)) != 0) {
+    const SideSearch sa = search_side(side_a, H, K, D, slack), sb = search_side(side_b, H, K, D, slack);
+    if (!sa.c16.empty() && !sb.c16.empty()) {
+      // four-wave workgroups if both sides can be made to fit them, else sixteen; the loop is as long as the longer side's
+      const bool four = best_class(sa.c4) <= 3 && best_class(sb.c4) <= 3;
+      const std::vector<PartsChoice>& va = four ? sa.c4 : sa.c16;
+      const std::vector<PartsChoice>& vb = four ? sb.c4 : sb.c16;
+      const int target = std::max(best_class(va), best_class(vb));
+      const int unsplit = std::max(va[0].cls, vb[0].cls);
+      if (target < unsplit) {
+        const PartsChoice* ca = first_within(va, target);
+        const PartsChoice* cb = first_within(vb, target);
+        if (ca && cb) { parts_a = ca->parts; parts_b = cb->parts; }
+        if (stats) fprintf(stderr, "[plan] states on several lanes: loop class %d -> %d (%s waves), cap alpha %d beta %d\n", unsplit, target,
+                           four ? "4" : "16", ca ? ca->cap : -1, cb ? cb->cap : -1);
+      }
+    }
+  }
+  // positions ("entities") of a side: state h owns ea0[h] .. ea0[h + 1] - 1 in the alpha numbering, eb0 likewise
+  std::vector<int> ea0(H + 1, 0), eb0(H + 1, 0);
+  for (int h = 0; h < H; h++) { ea0[h + 1] = ea0[h] + parts_a[h]; eb0[h + 1] = eb0[h] + parts_b[h]; }
+  const int HA = ea0[H], HB = eb0[H], HV = std::max(HA, HB);
+  const int Hp = (HV + 63) / 64 * 64;
+  std::vector<int> ids_a(HA), ids_b(HB);
+  std::iota(ids_a.begin(), ids_a.end(), 0);
+  std::iota(ids_b.begin(), ids_b.end(), 0);
+
+  // rows by entity ids.  alpha rows: arcs entering h, in the reference's order (fstext.cc:63-76); an arc is repeated once per
+  // part of the state it gathers, and the arcs of a state on several positions are dealt to them in turn
+  std::vector<std::vector<Arc>> rows_a(HA), rows_b(HB), rows_g(D);
+  for (int h = 0; h < H; h++) {
+    int n = 0;
+    for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++)
+      for (int m = 0; m < parts_a[bt[3 * k]]; m++, n++)
+        rows_a[ea0[h] + n % parts_a[h]].push_back(Arc{ea0[bt[3 * k]] + m, bt[3 * k + 2], bp[k]});
+    n = 0;
+    for (int k = fi[2 * h]; k < fi[2 * h + 1]; k++) {
+      const int dst = ft[3 * k + 1];
+      for (int m = 0; m < parts_b[dst]; m++, n++)
+        rows_b[eb0[h] + n % parts_b[h]].push_back(Arc{eb0[dst] + m, ft[3 * k + 2], fp[k]});
+      // gamma rows keep the (state, arc) order the reference accumulates in (chain-computation.cc:293-305)
+      for (int ma = 0; ma < parts_a[h]; ma++)
+        for (int mb = 0; mb < parts_b[dst]; mb++)
+          rows_g[ft[3 * k + 2]].push_back(Arc{ea0[h] + ma, eb0[dst] + mb, fp[k]});
+    }
+  }
+  std::vector<int> indeg(HA), outdeg(HB);
+  for (int i = 0; i < HA; i++) indeg[i] = (int)rows_a[i].size();
+  for (int i = 0; i < HB; i++) outdeg[i] = (int)rows_b[i].size();
+  std::vector<int> gdeg(D), gids;
+  for (int n = 0; n < D; n++) { gdeg[n] = (int)rows_g[n].size(); if (gdeg[n] > 0) gids.push_back(n); }
+  const int gpos = std::max(((int)gids.size() + 63) / 64 * 64, 64);
+
 
   // The occupancy tiles take no slack: their kernels are not bound by gather cycles and the two-frame
   // kernel keeps exactly 64 slot-rows per wave in registers.
@@ -738,7 +903,7 @@ int64_t plan_build_impl(
   // A graph whose recursion tiles fit FOUR waves (<= PLAN_RESIDENT_2 slot-rows and <= 4 groups per wave: a few hundred states,
   // a few thousand arcs) gets its slack fitted to that dealing and carries it as alpha4 / beta4: its recursions then run in
   // 256-thread workgroups (den_lazy.inc.h: LzSmall) instead of sixteen waves meeting at a barrier for four groups of work.
-  const std::vector<int> order_a = sort_by_degree(indeg, ids), order_b = sort_by_degree(outdeg, ids);
+  const std::vector<int> order_a = sort_by_degree(indeg, ids_a), order_b = sort_by_degree(outdeg, ids_b);
   bool small = Hp <= 64 * 4 * PLAN_REC4_WAVES && D <= 4096 &&
                dealing_fits(group_rows(rows_a, order_a, Hp, true), PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4) &&
                dealing_fits(group_rows(rows_b, order_b, Hp, true), PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4);
@@ -748,8 +913,9 @@ int64_t plan_build_impl(
   small = small && dealing_fits(tiles[0].gsl, PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4) && dealing_fits(tiles[1].gsl, PLAN_REC4_WAVES, PLAN_RESIDENT_2, 4);
   init_tile(tiles[2], rows_g, sort_by_degree(gdeg, gids), gpos, kLayA, kLayB, -1, 1, 0, PLAN_GAM_WAVES);
   Layouts lay;
-  lay.pos[kLayA].assign(H, 0); lay.pos[kLayB].assign(H, 0); lay.pos[kLayX].resize(D);
-  for (int i = 0; i < H; i++) { lay.pos[kLayA][tiles[0].order[i]] = i; lay.pos[kLayB][tiles[1].order[i]] = i; }
+  lay.pos[kLayA].assign(HA, 0); lay.pos[kLayB].assign(HB, 0); lay.pos[kLayX].resize(D);
+  for (int i = 0; i < HA; i++) lay.pos[kLayA][tiles[0].order[i]] = i;
+  for (int i = 0; i < HB; i++) lay.pos[kLayB][tiles[1].order[i]] = i;
   std::iota(lay.pos[kLayX].begin(), lay.pos[kLayX].end(), 0);
   {
     Balancer bal(tiles, lay);
@@ -781,7 +947,8 @@ int64_t plan_build_impl(
             (double)so_a.cycles_op[0] / std::max(1L, so_a.columns.load()), (double)so_a.cycles_op[1] / std::max(1L, so_a.columns.load()),
             (double)so_b.cycles_op[0] / std::max(1L, so_b.columns.load()), (double)so_b.cycles_op[1] / std::max(1L, so_b.columns.load()));
 
-  const auto deal_a = deal_groups(tiles[0].gsl, PLAN_REC_WAVES), deal_b = deal_groups(tiles[1].gsl, PLAN_REC_WAVES);
+  const auto deal_a = deal_groups(tiles[0].gsl, PLAN_REC_WAVES, rec_group_limit(tiles[0].gsl.size(), PLAN_REC_WAVES));
+  const auto deal_b = deal_groups(tiles[1].gsl, PLAN_REC_WAVES, rec_group_limit(tiles[1].gsl.size(), PLAN_REC_WAVES));
   BuiltTile ta = emit_tile(tiles[0], so_a, lay, deal_a);
   BuiltTile tb = emit_tile(tiles[1], so_b, lay, deal_b);
   BuiltTile tg = emit_tile(tiles[2], so_g, lay, deal_groups(tiles[2].gsl, PLAN_GAM_WAVES));
@@ -790,8 +957,8 @@ int64_t plan_build_impl(
   // PLAN_RESIDENT_2 slot-rows in registers and four groups: den_lazy.inc.h, LzSmall)
   BuiltTile ta4, tb4;
   if (small) {
-    ta4 = emit_tile(tiles[0], so_a, lay, deal_groups(tiles[0].gsl, PLAN_REC4_WAVES));
-    tb4 = emit_tile(tiles[1], so_b, lay, deal_groups(tiles[1].gsl, PLAN_REC4_WAVES));
+    ta4 = emit_tile(tiles[0], so_a, lay, deal_groups(tiles[0].gsl, PLAN_REC4_WAVES, rec_group_limit(tiles[0].gsl.size(), PLAN_REC4_WAVES)));
+    tb4 = emit_tile(tiles[1], so_b, lay, deal_groups(tiles[1].gsl, PLAN_REC4_WAVES, rec_group_limit(tiles[1].gsl.size(), PLAN_REC4_WAVES)));
   }
 
   // ---- lay the blob out
@@ -799,7 +966,10 @@ int64_t plan_build_impl(
   PlanHeader hd;
   memset(&hd, 0, sizeof(hd));
   hd.magic = PLAN_MAGIC; hd.version = PLAN_VERSION;
-  hd.H = H; hd.K = K; hd.D = D; hd.Hp = Hp;
+  // H = positions of the longer side (what the caller sizes its workspace by); reserved: the graph's states, states on
+  // several positions per side
+  hd.H = HV; hd.K = K; hd.D = D; hd.Hp = Hp;
+  hd.reserved[0] = H; hd.reserved[1] = HA - H; hd.reserved[2] = HB - H;
   for (const BuiltTile* t : {&ta, &tb})
     for (const WaveEntry& we : t->waves) hd.rec_max_wave_groups = std::max(hd.rec_max_wave_groups, we.ngroups);
   if (small)
@@ -837,10 +1007,17 @@ int64_t plan_build_impl(
   float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);
+  // (beta positions that do not take the constant c(t) - parts after a state's first, padding - carry the sign bit)
+  for (int i = 0; i < Hp; i++) leaky_b[i] = -0.0f;
   for (int h = 0; h < H; h++) {
-    const int pa = lay.pos[kLayA][h], pb = lay.pos[kLayB][h];
-    init_a[pa] = initial[h]; leaky_a[pa] = leaky[h]; final_a[pa] = final_[h];
-    leaky_b[pb] = leaky[h]; final_b[pb] = final_[h];
+    for (int m = 0; m < parts_a[h]; m++) {
+      const int pa = lay.pos[kLayA][ea0[h] + m];
+      init_a[pa] = m == 0 ? initial[h] : 0.f; leaky_a[pa] = m == 0 ? leaky[h] : 0.f; final_a[pa] = final_[h];
+    }
+    for (int m = 0; m < parts_b[h]; m++) {
+      const int pb = lay.pos[kLayB][eb0[h] + m];
+      leaky_b[pb] = m == 0 ? fabsf(leaky[h]) : -fabsf(leaky[h]); final_b[pb] = m == 0 ? final_[h] : 0.f;
+    }
   }
   for (int i = 0; i < gpos; i++) row_pdf[i] = i < (int)tiles[2].order.size() ? tiles[2].order[i] : -1;
   // integrity of everything behind the header: the kernels follow the blob's offsets and packed LDS addresses

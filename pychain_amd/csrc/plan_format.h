@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 11
+#define PLAN_VERSION 12
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan

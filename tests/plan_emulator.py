@@ -7,7 +7,7 @@ against the oracle without a GPU.  Mirrors the kernels step by step.
 """
 import numpy as np
 
-HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 11), in int32 words
+HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 12), in int32 words
 
 
 def parse(blob):
@@ -29,10 +29,15 @@ def parse(blob):
     hd["alpha"], hd["beta"], hd["gamma"] = tile(8), tile(16), tile(24)
     hd["gamma2"], hd["alpha4"], hd["beta4"] = tile(40), tile(48), tile(56)
     hd["rec_max_wave_groups"], hd["rec4_max_wave_groups"], hd["header_hash"], hd["payload_hash"] = int(h[7]), int(h[38]), int(h[39]), int(h[64])
+    # reserved[0..2]: the graph's states, positions added on the alpha / beta side by states on several lanes (plan.cpp)
+    hd["graph_states"], hd["split_a"], hd["split_b"] = int(h[65]), int(h[66]), int(h[67])
     offs = [int(v) for v in h[32:38]]
     Hp = hd["Hp"]
     vec = lambda o: b[o:o + 4 * Hp].view(np.float32).copy()
     hd["init_a"], hd["leaky_a"], hd["final_a"], hd["leaky_b"], hd["final_b"] = [vec(o) for o in offs[:5]]
+    # beta positions that take the constant c(t): the sign bit of leaky_b is clear (a state's first lane); the kernels use |leaky_b|
+    hd["takes_c"] = ~np.signbit(hd["leaky_b"])
+    hd["leaky_b"] = np.abs(hd["leaky_b"])
     ng = max(hd["gamma"]["ngroups"] * 64, 64)
     hd["row_pdf"] = b[offs[5]:offs[5] + 4 * ng].view(np.int32).copy()
     return hd
@@ -62,7 +67,7 @@ def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.fl
     ex = x.astype(dtype) if input_is_exp else np.exp(np.clip(x.astype(dtype), -30, 30))
     objf = np.zeros(B, dtype=dtype)
     grad = np.zeros((B, T, D), dtype=dtype)
-    mask = (np.arange(Hp) < H).astype(dtype)
+    mask = hd["takes_c"].astype(dtype)
     la, lb = hd["leaky_a"].astype(dtype), hd["leaky_b"].astype(dtype)
     for b in range(B):
         L = int(lengths[b])
@@ -79,10 +84,10 @@ def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.fl
             A[t] = v / tot + coef * la
         objf[b] = logsum + np.log((A[L] * hd["final_a"].astype(dtype)).sum())
         v = hd["final_b"].astype(dtype)
-        Bt[L] = (v + coef * (v * lb).sum()) / v.sum() * mask
+        Bt[L] = (v + mask * coef * (v * lb).sum()) / v.sum()
         for t in range(L - 1, 0, -1):
             v = tile_rows(hd["beta"], Bt[t + 1], ex[b, t], Hp, dtype)
-            Bt[t] = (v + coef * (v * lb).sum()) / v.sum() * mask
+            Bt[t] = (v + mask * coef * (v * lb).sum()) / v.sum()
         g = hd["gamma"]
         for t in range(L):
             st = tile_rows(g, A[t], Bt[t + 1], max(g["ngroups"] * 64, 64), dtype)

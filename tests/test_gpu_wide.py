@@ -36,7 +36,7 @@ def _names(den, D, B, **opts):
     for c in ctx:
         c.__enter__()
     try:
-        return _lib.den_kernel_names(plan.slot_rows, den.num_states, D, B)
+        return _lib.den_kernel_names(plan.slot_rows, plan.num_states, D, B)
     finally:
         for c in reversed(ctx):
             c.__exit__()
@@ -187,3 +187,36 @@ def test_structured_phone_lm_like_graph_vs_oracle():
         o, g = _den(x, L, den)
         ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, len(lens)), 1e-5)
         assert abs(o - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4, (n, rel_err(g.cpu().numpy(), rg))
+
+
+@pytest.mark.parametrize("case", ["small_hubs", "hubs", "structured"])
+def test_states_on_several_lanes_on_the_device(case):
+    """Plans that put states with many arcs on several positions (csrc/plan.cpp; tests/test_plan.py holds the CPU side):
+    every recursion family that reads such a plan - lazy with LDS-direct rows, lazy with rows through registers, the
+    two-barrier kernel, two sequences per workgroup, time segments - against the fp64 oracle and against the same graph
+    compiled with every state on one lane."""
+    from test_plan import _hub_graph
+    if case == "small_hubs":
+        (den, D), T = _hub_graph(seed=6, H=200, D=300, extra=1500, hubs=3, fan=45), 120
+    elif case == "hubs":
+        (den, D), T = _hub_graph(), 420
+    else:
+        den, D, T = syn.make_structured_den_graph(), 3456, 420
+    dev = torch.device(DEV)
+    plan = _plan.graph_plan(den, D, dev)
+    with _lib.option("plan_split", "0"):
+        plan0 = _plan.graph_plan(den, D, dev)
+    assert plan.num_states > den.num_states == plan0.num_states and (plan.slot_rows & 1023) < (plan0.slot_rows & 1023)
+    L = torch.tensor([T, T - 7, (2 * T) // 3, 3, 1])
+    x = syn.make_input(5, T, D, seed=71, device=DEV)
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, 5), 1e-5, flavour="f64")
+    with _lib.option("plan_split", "0"):
+        o0, g0 = _den(x, L, den)
+    forms = [{}, {"den_dma": 0}, {"den_lazy": 0}, {"den_pair": 1}, {"den_pair": 1, "den_lazy": 0}]
+    if case != "small_hubs":
+        forms.append({"den_tseg": 2, "den_tburn": 96})          # (T = 420: two segments of 210 frames that start 96 outside)
+    for opts in forms:
+        o, g = _den(x, L, den, **opts)
+        e = rel_err(g.cpu().numpy(), rg)
+        assert abs(o - ro) <= 1e-5 * abs(ro) and e <= 2e-5, (case, opts, o, ro, e)
+        assert abs(o - o0) <= 1e-5 * abs(o0) and rel_err(g.cpu().numpy(), g0.cpu().numpy()) <= 2e-5, (case, opts)

@@ -21,7 +21,8 @@ def _blob(g, D):
 
 def test_plan_structure():
     g = syn.make_den_graph(200, 2000, 1000, seed=3)
-    hd = emu.parse(_blob(g, 1000))
+    with _lib.option("plan_split", "0"):                           # (every state on one lane: test_states_on_several_lanes has the other form)
+        hd = emu.parse(_blob(g, 1000))
     assert hd["H"] == 200 and hd["K"] == 2000 and hd["Hp"] == 256
     for name, nreal in (("alpha", 2000), ("beta", 2000), ("gamma", 2000)):
         t = hd[name]
@@ -323,3 +324,54 @@ def test_rings_of_the_streamed_occupancy_pass():
                 seen += list(range(max(0, L - hi), min(half, L - lo)))                 # side 0
             assert sorted(seen) == list(range(L)), (T, L)
     assert L_.pychain_hip_debug_stream_rings(0, out, 8192, None, 0) < 0
+
+
+def _hub_graph(seed=5, H=1000, D=600, extra=7300, hubs=12, fan=70):
+    """1000 states / 10 000 random arcs plus twelve states with 70 arcs ENTERING them and few leaving, and twelve with 70
+    LEAVING and few entering: one such state makes its group of 64 rows 70+ slot-rows long (nothing fits a register-resident
+    loop) - unless the plan puts it on several lanes."""
+    from pychain_amd import ChainGraph
+    from pychain_amd.simplefst import StdVectorFst
+    rs = np.random.RandomState(seed)
+    lo = H // 10
+    arcs = [(s, (s + 1) % H, int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for s in range(H)]
+    arcs += [(int(rs.randint(lo, H)), int(rs.randint(lo, H)), int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for _ in range(extra)]
+    for hub in range(hubs):
+        arcs += [(int(rs.randint(lo, H)), hub, int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for _ in range(fan)]
+        arcs += [(lo // 2 + hub, int(rs.randint(lo, H)), int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for _ in range(fan)]
+    arcs.sort(key=lambda a: a[0])
+    return ChainGraph(StdVectorFst.from_arcs(H, 0, arcs, {s: 0.0 for s in range(H)}), initial_mode="leaky", final_mode="ones"), D
+
+
+@pytest.mark.parametrize("case", ["small_hubs", "hubs", "structured"])
+def test_states_on_several_lanes(case):
+    """A state with many arcs is put on several POSITIONS of a side's numbering where that gains a shorter register-resident
+    loop (csrc/plan.cpp): every arc still exactly once per (position it belongs to, position it gathers), the loop class
+    falls, and what the kernels compute from such a plan (the emulator, fp64) is the fp64 oracle's result."""
+    if case == "small_hubs":                                       # (a graph of C2's size: four-wave workgroups)
+        (g, D), T = _hub_graph(seed=6, H=200, D=300, extra=1500, hubs=3, fan=45), 14
+    elif case == "hubs":
+        (g, D), T = _hub_graph(), 9
+    else:
+        g, D, T = syn.make_structured_den_graph(), 3456, 5
+    blob = _blob(g, D)
+    info, hd = _plan.plan_info(blob), emu.parse(blob)
+    with _lib.option("plan_split", "0"):
+        blob0 = _blob(g, D)
+    info0 = _plan.plan_info(blob0)
+    assert info0["split_positions"] == 0 and info0["num_states"] == g.num_states
+    assert info["split_positions"] > 0 and info["graph_states"] == g.num_states
+    assert info["num_states"] == g.num_states + max(hd["split_a"], hd["split_b"]) and hd["Hp"] == (info["num_states"] + 63) // 64 * 64
+    assert (info["slot_rows"] & 1023) < (info0["slot_rows"] & 1023)            # a shorter loop: what it is for
+    assert ((info["slot_rows"] >> 28) & 1) == (1 if hd["split_b"] else 0)      # beta positions without the constant: not for the pair kernel
+    assert (info["slot_rows"] >> 30) & 1                                      # four groups per wave at most: the lazy recursions
+    # only first lanes (and no padding position) take beta's constant / carry alpha's leaky and initial probability
+    assert int(hd["takes_c"].sum()) == g.num_states
+    assert abs(hd["leaky_a"].sum() - g.leaky_probs.sum().item()) < 1e-5 and abs(hd["leaky_b"][hd["takes_c"]].sum() - g.leaky_probs.sum().item()) < 1e-5
+    x = syn.make_input(2, T, D, seed=21).numpy()
+    L = np.array([T, T - 3])
+    objf, grad = emu.den_forward_backward(blob, x, L, 1e-3)
+    objf0, grad0 = emu.den_forward_backward(blob0, x, L, 1e-3)                # the same graph, every state on one lane
+    assert np.abs(objf - objf0).max() <= 1e-11 * np.abs(objf0).max() and rel_err(grad, grad0) <= 1e-11
+    ro, rg, ok = orc.den(ChainGraphBatch(g, 2), np.exp(np.clip(x, -30, 30)), L, 1e-3, flavour="f64")   # (exp(x) rounded to fp32 on its way in)
+    assert ok and abs(objf.sum() - ro.sum()) <= 2e-6 * abs(ro.sum()) and rel_err(grad, rg) <= 1e-5
