@@ -105,7 +105,7 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  * pychain_hip_set_thread_option overrides it for the calling host thread only (value NULL removes the override,
  * "" = unset for this thread); pychain_hip_get_option copies the value in effect for the calling thread into buf and
  * returns its length (0 = unset).  pychain_hip_set_verbose_level / _set_den_phase_mask / _set_den_lazy are the
- * process-wide "verbose" / "den_phase_mask" / "den_lazy".  The twelve names - every one selects between SHIPPED kernel
+ * process-wide "verbose" / "den_phase_mask" / "den_lazy".  The thirteen names - every one selects between SHIPPED kernel
  * families so that the tests can compare them (all give the same results to rounding; most bit for bit), or is a test hook:
  *   "verbose"        base.h:34-42: >= 1 checks the reference's invariant on every frame instead of frame 0
  *   "den_phase_mask" bit 0 recursion launch, bit 1 occupancy launch (measurement aid)
@@ -126,6 +126,7 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "den_tseg"       time segments per (sequence, direction) of the lazy recursions: unset / "-1" automatic (few sequences
  *                    only: pychain_hip_den_time_segments), "0": never, "2" / "4": wherever the shape allows
  *   "den_tburn"      frames a time segment starts outside itself (default 192); see totals[5..7]
+ *   "chain_slices"   the fused loss with a gradient over a batch larger than the chip: "0" one call, "n" n slices; default automatic
  *   "plan_split"     read by pychain_hip_den_plan_build: "0": no state on more than one lane; default: where it gains a
  *                    shorter register-resident loop
  * Unknown name: EINVAL.  (Kernel variants that measured slower - 8 / 12 waves, two copies of the nnet-output row, a
@@ -355,7 +356,14 @@ int pychain_hip_chain_loss_forward_backward(
  *   totals[1] = sum_b len_b, totals[2] = bad_count[0] + bad_count[1] as a float (what a sharded trainer all-reduces
  *   with the loss), totals[3] = sum den - sum num unscaled, totals[4] = totals[0], totals[5..7] as above.  loss_norm_dev: device
  *   float or NULL.
+ * A batch larger than the chip (B >= 7/8 of the CU count, one shared denominator plan, `grad` given): the call runs over
+ *   SLICES of at most CUs / 2 sequences, one after the other on `stream` in the same workspaces (their last 4 KiB hold the
+ *   slices' counters), and a last small launch forms bad_count and totals over the whole batch - same per-sequence results,
+ *   same totals (fp64 over the per-sequence values, rounded once).  With every CU holding a recursion workgroup the
+ *   numerator of ONE call only finds room as they end: B = 256 on 256 CUs 11.1 ms, as two slices 10.2.  Option
+ *   "chain_slices": "0" never, "n" that many; pychain_hip_chain_loss_slices says what a call would do.
  */
+int pychain_hip_chain_loss_slices(int64_t plan_stride_bytes, int resident_slot_rows, int B);
 int pychain_hip_chain_loss_forward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
     float leaky_hmm_coefficient,

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "pychain_hip_den_half_native": (_i, [_i64, _i, _i, _i, _i, _i]),
     "pychain_hip_num_half_native": (_i, [_i, _i, _i]),
     "pychain_hip_chain_loss_half_native": (_i, [_i64, _i, _i, _i, _i, _i, _i, _i]),
+    "pychain_hip_chain_loss_slices": (_i, [_i64, _i, _i]),
     "pychain_hip_num_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "pychain_hip_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f,
                                               _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -103,7 +104,7 @@ def lib():
     return _lib
 
 
-OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split")
+OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices")
 
 _thread_values = threading.local()       # what this thread's overrides currently are (for restoring)
 

@@ -29,7 +29,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
-                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split"};
+                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -70,6 +70,7 @@ CallKnobs call_knobs() {
   k.den_tseg = option_int("den_tseg", -1);
   k.den_tburn = option_int("den_tburn", 192);
   k.plan_split = option_int("plan_split", -1);
+  k.chain_slices = option_int("chain_slices", -1);
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
@@ -867,7 +868,9 @@ extern "C" int pychain_hip_num_forward_backward(
 
 // ---- fused ChainLoss ------------------------------------------------------------------
 
-extern "C" int pychain_hip_chain_loss_forward(
+namespace {
+// one fused call over the B sequences it is given (pychain_hip_chain_loss_forward: all of them, or one slice of a large batch)
+int chain_loss_forward_one(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
     const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
     const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
@@ -935,6 +938,106 @@ extern "C" int pychain_hip_chain_loss_forward(
     e = na.general ? launch_num_occ(na, false, st, &why) : launch_num_scatter(na, st, &why);
   if (e != hipSuccess)
     return fail(why ? PYCHAIN_HIP_EUNSUPPORTED : PYCHAIN_HIP_ELAUNCH, "%s: %s", who, why ? why : hipGetErrorString(e));
+  return PYCHAIN_HIP_OK;
+}
+
+// ---- a batch larger than the chip: slices (round 5).  From B = 224 on 256 CUs the recursion workgroups of ONE call (two
+// sequences each: den_recursion_pair_kernel) hold every CU for the whole recursion, the numerator only finds room as they
+// end, and the occupancy launch that folds it in starts late (DESIGN.md §4 "B >= 128": B = 256 11.1 ms against 2 x 5.06 for
+// two calls of 128).  The fused call that also writes the gradient is therefore run over slices of about half the CU count
+// in sequences, one after the other on the caller's stream, in the SAME workspaces; every slice reports into a scratch
+// line at the end of the denominator's workspace, and one small launch sums the bad counts and forms `totals` from the
+// per-sequence log-probabilities of the whole batch exactly as den_finish_kernel does (fp64, rounded once).
+// Option chain_slices: 0 / 1 never, n >= 2 that many (where the batch allows), default automatic.
+struct SliceLine { int32_t bad[2]; int32_t pad[2]; float totals[PYCHAIN_HIP_TOTALS]; };     // 48 bytes per slice
+constexpr int kMaxSlices = 32;
+__global__ void chain_slices_combine_kernel(const SliceLine* lines, int nslices, const float* den_objf, const float* num_objf,
+                                            const int64_t* lengths, int B, int T, float loss_scale, const float* loss_norm_dev,
+                                            int32_t* bad_count, float* totals) {
+  __shared__ double part[2][4];
+  double acc = 0.0, frames = 0.0;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    acc += (double)den_objf[i] - (double)num_objf[i];
+    const int64_t l = lengths[i];
+    frames += (double)(l < 1 ? 1 : (l > T ? T : l));
+  }
+  for (int o = 32; o > 0; o >>= 1) { acc += __shfl_down(acc, o); frames += __shfl_down(frames, o); }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = acc; part[1][threadIdx.x >> 6] = frames; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    acc = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+    frames = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    int b0 = 0, b1 = 0;
+    float redone = 0.f, segs = 1.f, worst = 0.f;
+    for (int c = 0; c < nslices; c++) {
+      b0 += lines[c].bad[0]; b1 += lines[c].bad[1];
+      redone += lines[c].totals[5]; segs = fmaxf(segs, lines[c].totals[6]); worst = fmaxf(worst, lines[c].totals[7]);
+    }
+    bad_count[0] = b0; bad_count[1] = b1;
+    if (totals) {
+      double t = acc * (double)loss_scale;
+      if (loss_norm_dev) t /= (double)*loss_norm_dev;
+      totals[0] = (float)t; totals[1] = (float)frames; totals[2] = (float)(b0 + b1); totals[3] = (float)acc; totals[4] = (float)t;
+      totals[5] = redone; totals[6] = segs; totals[7] = worst;
+    }
+  }
+}
+// slices of a fused call over B sequences (1 = the call as it is)
+int chain_loss_slices(int B, int resident_slot_rows, int64_t plan_stride_bytes, bool with_grad) {
+  const int want = call_knobs().chain_slices;
+  if (!with_grad || want == 0 || want == 1 || resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL || plan_stride_bytes != 0) return 1;
+  const int cus = device_cu_count();
+  int n = 1;
+  if (want >= 2) n = want;
+  else if (8 * B >= 7 * cus) n = (2 * B + cus - 1) / cus;          // automatic: slices of at most CUs / 2 sequences
+  n = std::min(n, std::min(kMaxSlices, B / 2));
+  return std::max(n, 1);
+}
+}  // namespace
+
+extern "C" int pychain_hip_chain_loss_slices(int64_t plan_stride_bytes, int resident_slot_rows, int B) {
+  return chain_loss_slices(B, resident_slot_rows, plan_stride_bytes, true);
+}
+
+extern "C" int pychain_hip_chain_loss_forward(
+    const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_H, float leaky,
+    const int32_t* ft, const int32_t* fi, const float* fp, const int32_t* bt, const int32_t* bi, const float* bp,
+    const float* initial, const float* final_, int graph_batch_stride, int num_H, int num_K,
+    const void* nnet_output, int nnet_output_dtype, const int64_t* seq_lengths, int B, int T, int D,
+    float* den_objf, float* num_objf, void* grad, float grad_scale, int32_t* bad_count,
+    float loss_scale, const float* loss_norm_dev, float* totals,
+    void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream) {
+  const int nsl = (B > 0 && T > 0 && D > 0 && den_ws && bad_count && den_objf && num_objf && seq_lengths && nnet_output && ft && fi && fp &&
+                   bt && bi && bp && initial && final_ && den_ws_bytes > 8192)
+                      ? chain_loss_slices(B, resident_slot_rows, plan_stride_bytes, grad != nullptr) : 1;
+  if (nsl <= 1)
+    return chain_loss_forward_one(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky, ft, fi, fp, bt, bi, bp, initial, final_,
+                                  graph_batch_stride, num_H, num_K, nnet_output, nnet_output_dtype, seq_lengths, B, T, D, den_objf, num_objf,
+                                  grad, grad_scale, bad_count, loss_scale, loss_norm_dev, totals, den_ws, den_ws_bytes, num_ws, num_ws_bytes,
+                                  stream);
+  // the scratch lines: the last 4 KiB of the denominator's workspace (sized by the caller for all B sequences; a slice
+  // needs about 1 / nsl of it)
+  const size_t ws_bytes = (den_ws_bytes - 4096) & ~(size_t)255;
+  SliceLine* lines = reinterpret_cast<SliceLine*>((char*)den_ws + ws_bytes);
+  const size_t esz = nnet_output_dtype == PYCHAIN_HIP_F32 ? 4 : 2;
+  const int per = ((B + nsl - 1) / nsl + 1) & ~1;            // (even: the pair recursion takes its sequences two by two)
+  int c = 0;
+  for (int b0 = 0; b0 < B; b0 += per, c++) {
+    const int nb = std::min(per, B - b0);
+    const size_t g = graph_batch_stride ? (size_t)b0 : 0;     // per-sequence numerator graphs: [G, K, 3] / [G, H, 2] / [G, K] / [G, H]
+    const int rc = chain_loss_forward_one(
+        plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky,
+        ft + g * num_K * 3, fi + g * num_H * 2, fp + g * num_K, bt + g * num_K * 3, bi + g * num_H * 2, bp + g * num_K,
+        initial + g * num_H, final_ + g * num_H, graph_batch_stride, num_H, num_K,
+        (const char*)nnet_output + (size_t)b0 * T * D * esz, nnet_output_dtype, seq_lengths + b0, nb, T, D,
+        den_objf + b0, num_objf + b0, (char*)grad + (size_t)b0 * T * D * esz, grad_scale, lines[c].bad,
+        loss_scale, loss_norm_dev, lines[c].totals, den_ws, ws_bytes, num_ws, num_ws_bytes, stream);
+    if (rc != PYCHAIN_HIP_OK) return rc;
+  }
+  hipLaunchKernelGGL(chain_slices_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lines, c, den_objf, num_objf, seq_lengths,
+                     B, T, loss_scale, loss_norm_dev, bad_count, totals);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PYCHAIN_HIP_ELAUNCH, "chain_loss_forward: %s", hipGetErrorString(e));
   return PYCHAIN_HIP_OK;
 }
 

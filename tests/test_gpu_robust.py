@@ -410,3 +410,40 @@ def test_a_long_lived_kernel_on_another_stream_of_the_process():
                            cus=cus, rows=rows), f, indent=1)
     except OSError:
         pass
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_a_batch_larger_than_the_chip_runs_in_slices(dtype):
+    """The fused loss over B >= 7/8 of the CU count (include/pychain_hip.h: pychain_hip_chain_loss_slices) runs over slices
+    of the batch in the same workspaces: per-sequence results, gradient, totals and bad count are those of the one call,
+    bit for bit - ragged lengths, an odd slice, per-utterance numerator graphs (their tensors are sliced too), a NaN in
+    one slice only, 2-byte rows."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B, T, D = (7 * cus + 7) // 8 + 5, 48, 1000
+    den = syn.make_den_graph(200, 2000, D)
+    L = syn.make_lengths(B, T, "ragged", seed=4)
+    num = syn.make_num_graphs(L.tolist(), D, seed=300)
+    plan = _plan.graph_plan(den, D, torch.device(DEV))
+    assert _lib.lib().pychain_hip_chain_loss_slices(plan.stride, plan.slot_rows, B) == 2
+    assert _lib.lib().pychain_hip_chain_loss_slices(plan.stride, plan.slot_rows, B // 2) == 1
+    x = syn.make_input(B, T, D, seed=5, device=DEV).to(dtype)
+    x[B - 3, 2, 7] = float("nan")                                 # (in the last slice)
+
+    def run(slices):
+        with _lib.option("chain_slices", slices):
+            xx = x.clone().requires_grad_(True)
+            loss = ChainLoss(den, 1e-5, avg=True)(xx, L, num)
+            loss.backward()
+            torch.cuda.synchronize()
+            return (float(loss), xx.grad.clone(), ChainFunction.last_totals.clone(), ChainFunction.last_bad_count.clone(),
+                    ChainLoss.last_objf_per_seq.clone() if hasattr(ChainLoss, "last_objf_per_seq") else None)
+    one, two, three = run("0"), run("-1"), run("3")
+    for got in (two, three):
+        assert (got[0] == one[0]) or (got[0] != got[0] and one[0] != one[0])
+        assert torch.equal(torch.nan_to_num(got[1].float()), torch.nan_to_num(one[1].float()))
+        assert torch.equal(torch.nan_to_num(got[2]), torch.nan_to_num(one[2])) and torch.equal(got[3], one[3])
+    assert int(one[3].sum()) >= 1                                  # the NaN was counted - once
+    # without the NaN: finite, and the slices' loss is the loss
+    x[B - 3, 2, 7] = 0.0
+    one, two = run("0"), run("-1")
+    assert one[0] == one[0] and two[0] == one[0] and torch.equal(two[1], one[1]) and int(two[3].sum()) == 0
