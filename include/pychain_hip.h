@@ -357,7 +357,7 @@ int pychain_hip_chain_loss_forward_backward(
  *   with the loss), totals[3] = sum den - sum num unscaled, totals[4] = totals[0], totals[5..7] as above.  loss_norm_dev: device
  *   float or NULL.
  * A batch larger than the chip (B >= 7/8 of the CU count, one shared denominator plan, `grad` given): the call runs over
- *   SLICES of at most CUs / 2 sequences, one after the other on `stream` in the same workspaces (their last 4 KiB hold the
+ *   SLICES of about CUs / 2 sequences (B = 256: 2 x 128, 320: 2 x 160, 384: 3 x 128), one after the other on `stream` in the same workspaces (their last 4 KiB hold the
  *   slices' counters), and a last small launch forms bad_count and totals over the whole batch - same per-sequence results,
  *   same totals (fp64 over the per-sequence values, rounded once).  With every CU holding a recursion workgroup the
  *   numerator of ONE call only finds room as they end: B = 256 on 256 CUs 11.1 ms, as two slices 10.2.  Option

@@ -989,7 +989,9 @@ int chain_loss_slices(int B, int resident_slot_rows, int64_t plan_stride_bytes, 
   const int cus = device_cu_count();
   int n = 1;
   if (want >= 2) n = want;
-  else if (8 * B >= 7 * cus) n = (2 * B + cus - 1) / cus;          // automatic: slices of at most CUs / 2 sequences
+  // automatic: slices of about CUs / 2 sequences, rather a few more than one slice more (measured on 256 CUs, profiles/r05_slices.txt:
+  // B = 320 as 2 x 160 13.2 ms, as 3 x 107 13.8, one call 13.7; B = 384 as 3 x 128 15.6, as 2 x 192 17.0, one call 16.1)
+  else if (8 * B >= 7 * cus) n = (int)(2.0 * B / cus + 0.25);
   n = std::min(n, std::min(kMaxSlices, B / 2));
   return std::max(n, 1);
 }
