@@ -187,7 +187,8 @@ int64_t pychain_hip_den_plan_build(
  *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers), three
  *           fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
  *           and for 8 waves (20-27); combine several plans by taking the max of each field
- *           bit 28: a state sits on several positions of the beta numbering: not for den_recursion_pair_kernel (OR)
+ *           bit 28: a state sits on several positions of the beta numbering: the lazy recursions' NC form; not for
+ *                   den_recursion_pair_kernel (OR)
  *           bit 29: the plan also holds its recursion tiles dealt to FOUR waves (small graphs: 256-thread recursion
  *                   workgroups); the recursion field is then that dealing's row count (AND over several plans)
  *           bit 30: every recursion wave owns few enough row groups for the lazy-normalisation recursions (AND)

@@ -199,9 +199,9 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (hd->rec_max_wave_groups >= 1 && hd->rec_max_wave_groups <= 4) info[4] |= 1 << 30;
   // bit 28: a state sits on several positions of the beta numbering (plan.cpp, "states on several lanes"): not for
   // den_recursion_pair_kernel, whose normalise pass gives every position the constant c(t)
-  if (hd->reserved[2] > 0) info[4] |= 1 << 28;
-  info[6] = hd->reserved[0];                     // the graph's states (info[0]: positions of the longer side = what calls pass as num_states)
-  info[7] = hd->reserved[1] + hd->reserved[2];   // positions added by states on several lanes
+  if (hd->n_no_const > 0) info[4] |= 1 << 28;
+  info[6] = hd->graph_states;                     // the graph's states (info[0]: positions of the longer side = what calls pass as num_states)
+  info[7] = hd->H - hd->graph_states;            // positions added by states on several lanes (the longer side)
   return PYCHAIN_HIP_OK;
 }
 

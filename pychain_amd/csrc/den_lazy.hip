@@ -27,13 +27,21 @@ inline bool lazy_shape_ok(const DenArgs& a, int hint, bool dma = false) {
   return ((hint >> 30) & 1) && (dma || a.D % 4 == 0) && a.D <= (int)LzNarrow::kMaxPdfs && a.Hp <= (int)LzNarrow::kMaxStates && rows > 0 &&
          rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
 }
+// (launch hint bit 28: the plan has beta positions that take no constant - the kernels' NC form, den_lazy.inc.h)
+inline bool hint_no_const(int hint) { return hint >= 0 && ((hint >> 28) & 1); }   // (negative: PYCHAIN_HIP_HINT_GENERAL)
+template <int R, typename M, int XM, bool TS>
+hipError_t launch_lz(const DenArgs& a, const dim3 grid, hipStream_t st, bool nc) {
+  if (nc) return launch_one(den_recursion_lazy_kernel<R, M, XM, TS, true>, a, grid, M::kBytes, st, M::kWaves * 64);
+  return launch_one(den_recursion_lazy_kernel<R, M, XM, TS, false>, a, grid, M::kBytes, st, M::kWaves * 64);
+}
 hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
   const dim3 grid(2 * a.B);
   const int rows = hint & 1023;
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, LzNarrow>, a, grid, kLzBytes, st);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, LzNarrow>, a, grid, kLzBytes, st);
-  if (rows <= PLAN_RESIDENT_FIT) return launch_one(den_recursion_lazy_kernel<PLAN_RESIDENT_FIT, LzNarrow>, a, grid, kLzBytes, st);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident, LzNarrow>, a, grid, kLzBytes, st);
+  const bool nc = hint_no_const(hint);
+  if (rows <= 16) return launch_lz<16, LzNarrow, kLzRowsF32, false>(a, grid, st, nc);
+  if (rows <= 32) return launch_lz<32, LzNarrow, kLzRowsF32, false>(a, grid, st, nc);
+  if (rows <= PLAN_RESIDENT_FIT) return launch_lz<PLAN_RESIDENT_FIT, LzNarrow, kLzRowsF32, false>(a, grid, st, nc);
+  return launch_lz<kMaxResident, LzNarrow, kLzRowsF32, false>(a, grid, st, nc);
 }
 // the 16-wave shape with LDS-direct nnet-output rows (LzDma): D <= 9216, Hp <= 3072
 inline bool dma_shape_ok(const DenArgs& a, int hint) {
@@ -42,24 +50,24 @@ inline bool dma_shape_ok(const DenArgs& a, int hint) {
          rows <= kMaxResident && PLAN_REC_WAVES == 16 && a.plan_stride >= 0;
 }
 template <typename M, int XM, bool TS = false>
-hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st) {
+hipError_t launch_dma_m(const DenArgs& a, int rows, hipStream_t st, bool nc) {
   const dim3 grid(2 * a.B * (TS ? a.tseg : 1));
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M, XM, TS>, a, grid, M::kBytes, st, M::kWaves * 64);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M, XM, TS>, a, grid, M::kBytes, st, M::kWaves * 64);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident, M, XM, TS>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if (rows <= 16) return launch_lz<16, M, XM, TS>(a, grid, st, nc);
+  if (rows <= 32) return launch_lz<32, M, XM, TS>(a, grid, st, nc);
+  return launch_lz<kMaxResident, M, XM, TS>(a, grid, st, nc);
 }
 // how the rows of this call arrive (lazy_recursion: XM): exp'd ahead (fp32 whatever the input's type), 2-byte, fp32;
 // time segments (DenArgs::tseg: never with rows exp'd ahead - they are written from the sequence ends inwards)
 template <typename M>
-hipError_t launch_dma_x(const DenArgs& a, int rows, hipStream_t st) {
-  if (a.tseg > 1) return a.x_half ? launch_dma_m<M, kLzRowsHalf, true>(a, rows, st) : launch_dma_m<M, kLzRowsF32, true>(a, rows, st);
-  if (a.use_ex) return launch_dma_m<M, kLzRowsPre>(a, rows, st);
-  return a.x_half ? launch_dma_m<M, kLzRowsHalf>(a, rows, st) : launch_dma_m<M, kLzRowsF32>(a, rows, st);
+hipError_t launch_dma_x(const DenArgs& a, int rows, hipStream_t st, bool nc) {
+  if (a.tseg > 1) return a.x_half ? launch_dma_m<M, kLzRowsHalf, true>(a, rows, st, nc) : launch_dma_m<M, kLzRowsF32, true>(a, rows, st, nc);
+  if (a.use_ex) return launch_dma_m<M, kLzRowsPre>(a, rows, st, nc);
+  return a.x_half ? launch_dma_m<M, kLzRowsHalf>(a, rows, st, nc) : launch_dma_m<M, kLzRowsF32>(a, rows, st, nc);
 }
 hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
   // the map of C3 where the shape fits it, else the one for rows of up to 9216 pdfs
-  if (lazy_shape_ok(a, hint, true)) return launch_dma_x<LzNarrowDma>(a, hint & 1023, st);
-  return launch_dma_x<LzDma>(a, hint & 1023, st);
+  if (lazy_shape_ok(a, hint, true)) return launch_dma_x<LzNarrowDma>(a, hint & 1023, st, hint_no_const(hint));
+  return launch_dma_x<LzDma>(a, hint & 1023, st, hint_no_const(hint));
 }
 // Four-wave workgroups over the plan's four-wave dealing (hint bit 29: every plan of the call holds alpha4 / beta4, and the
 // hint's row count is that dealing's): small graphs, LDS-direct rows.
@@ -75,10 +83,11 @@ hipError_t launch_small_p(const DenArgs& a, int hint, hipStream_t st) {
   const dim3 grid(2 * a.B);
   const int rows = hint & 1023;
   typedef LzSmall M;
-  if (rows <= 16) return launch_one(den_recursion_lazy_kernel<16, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
-  if (rows <= 24) return launch_one(den_recursion_lazy_kernel<24, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
-  if (rows <= 32) return launch_one(den_recursion_lazy_kernel<32, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
-  return launch_one(den_recursion_lazy_kernel<kMaxResident, M, PRE>, a, grid, M::kBytes, st, M::kWaves * 64);
+  const bool nc = hint_no_const(hint);
+  if (rows <= 16) return launch_lz<16, M, PRE, false>(a, grid, st, nc);
+  if (rows <= 24) return launch_lz<24, M, PRE, false>(a, grid, st, nc);
+  if (rows <= 32) return launch_lz<32, M, PRE, false>(a, grid, st, nc);
+  return launch_lz<kMaxResident, M, PRE, false>(a, grid, st, nc);
 }
 hipError_t launch_small(const DenArgs& a, int hint, hipStream_t st) {
   if (a.use_ex) return launch_small_p<kLzRowsPre>(a, hint, st);
@@ -90,7 +99,7 @@ hipError_t launch_small(const DenArgs& a, int hint, hipStream_t st) {
 inline bool pair_shape_ok(const DenArgs& a, int hint) {
   const int rows = hint & 1023;
   return a.plan_stride == 0 && a.D % 4 == 0 && a.D <= 4096 && a.Hp <= 4096 && rows > 0 && rows <= kMaxResident &&
-         PLAN_REC_WAVES == 16 && a.B >= 2;
+         PLAN_REC_WAVES == 16 && a.B >= 2 && !hint_no_const(hint);   // (its normalise pass gives every position the constant c(t))
 }
 hipError_t launch_pair(const DenArgs& a, int hint, hipStream_t st) {
   const dim3 grid(2 * ((a.B + 1) / 2));

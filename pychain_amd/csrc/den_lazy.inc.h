@@ -427,8 +427,8 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
 // (DenArgs::ex); kLzRowsHalf: 2-byte rows (DenArgs::x_half), converted, clamped / exp'd here.  A template parameter: the
 // kernel has no register to spare for more than one form.
 enum { kLzRowsF32 = 0, kLzRowsPre = 1, kLzRowsHalf = 2 };
-// TS: time segments (DenArgs::tseg) - a template parameter: the one-segment kernel keeps its registers
-template <int R, typename MAP, bool fwd, int XM, bool TS>
+// TS: time segments (DenArgs::tseg) - a template parameter: the one-segment kernel keeps its registers; NC: see the start vector
+template <int R, typename MAP, bool fwd, int XM, bool TS, bool NC>
 __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b, const int seg_in = 0) {
   constexpr bool PRE = XM == kLzRowsPre, XH = XM == kLzRowsHalf;
   constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
@@ -542,13 +542,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     float p0 = 0.f, p1 = 0.f;
     for (int i = tid; i < (int)MAP::kMaxStates; i += NT) {
       float s = 0.f, second = fwd ? 0.f : 1.f, l = 0.f;
-      if (i < Hp) {
-        s = start_g[i]; l = leaky_g[i];
-        if (fwd) second = coef * l;
-        // (beta: a position that does not take the constant c(t) - a state's second lane, padding - has the sign bit set:
-        // plan.cpp, "states on several lanes")
-        else { second = (__float_as_uint(l) >> 31) ? 0.f : 1.f; l = __builtin_fabsf(l); }
-      }
+      if (i < Hp) { s = start_g[i]; l = leaky_g[i]; if (fwd) second = coef * l; }
       *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{s, second};
       *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, second};
       if (!fwd) *reinterpret_cast<float*>(smem_raw + MAP::kLk + 4 * i) = l;
@@ -572,6 +566,17 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if (lane == 0) { red[wave] = p0; red[64 + wave] = p1; }
     if (tid >= NW && tid < 64) { red[tid] = 0.f; red[64 + tid] = 0.f; }
     __syncthreads();
+    // NC: beta positions that take no constant c(t) - a state's lanes after its first (plan.cpp, "states on several lanes"): the
+    // second word of their {b, 1} pairs is 0, in both buffers, from before the first frame on.  A template parameter (launch
+    // hint bit 28: few plans have such positions): even this loop, outside the frames, moves the register allocation of the
+    // frame loop - the 2-byte-row kernel lost 5 % to it (profiles/r05_ab_no_const.txt)
+    if constexpr (NC && !fwd) {
+      const int32_t* nc = reinterpret_cast<const int32_t*>(plan + hd->off_no_const);
+      for (int j = tid; j < hd->n_no_const; j += NT) {
+        const uint32_t at = 8u * (uint32_t)nc[j] + 4u;
+        lz_st1(MAP::kU0 + at, 0.f); lz_st1(MAP::kU1 + at, 0.f);
+      }
+    }
     const float tot = wave_sum(red[lane]), wtot = wave_sum(red[64 + lane]);
     w.inv = __builtin_amdgcn_rcpf(tot);
     w.c = coef * wtot;
@@ -777,7 +782,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 }
 
 // XM: kLzRowsPre - the rows were exp'd ahead by den_exp_rows_kernel (DenArgs::ex); kLzRowsHalf - 2-byte rows (DenArgs::x_half)
-template <int R, typename MAP, int XM = kLzRowsF32, bool TS = false>
+template <int R, typename MAP, int XM = kLzRowsF32, bool TS = false, bool NC = false>
 __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // (the fallback launch behind a segmented one: runs only if a splice did not verify - DenArgs::redo)
@@ -785,10 +790,10 @@ __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(co
   if constexpr (TS) {
     const unsigned per_dir = (unsigned)a.B * (unsigned)a.tseg;                        // workgroups per direction: segment-major
     const unsigned r = blockIdx.x < per_dir ? blockIdx.x : blockIdx.x - per_dir;
-    if (blockIdx.x < per_dir) lazy_recursion<R, MAP, true, XM, true>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
-    else lazy_recursion<R, MAP, false, XM, true>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+    if (blockIdx.x < per_dir) lazy_recursion<R, MAP, true, XM, true, NC>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+    else lazy_recursion<R, MAP, false, XM, true, NC>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
   } else {
-    if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM, false>(a, smem_raw, blockIdx.x);
-    else lazy_recursion<R, MAP, false, XM, false>(a, smem_raw, blockIdx.x - a.B);
+    if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM, false, NC>(a, smem_raw, blockIdx.x);
+    else lazy_recursion<R, MAP, false, XM, false, NC>(a, smem_raw, blockIdx.x - a.B);
   }
 }

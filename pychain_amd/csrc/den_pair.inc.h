@@ -121,8 +121,7 @@ __device__ __forceinline__ void pair_tile(PairArcs<R>& ar, const GroupRegs& gr, 
 #pragma clang fp contract(off)
             s0 = s0 + nacc;
           }
-          // (|wv|: beta's leaky probabilities carry a flag in their sign bit - plan.cpp, "states on several lanes")
-          if constexpr (!FWD) { const float wv = __builtin_fabsf(lds_abs(kPrLk + (uint32_t)pos * 4u)); s1 = __builtin_elementwise_fma(nacc, lz_v2f{wv, wv}, s1); }
+          if constexpr (!FWD) { const float wv = lds_abs(kPrLk + (uint32_t)pos * 4u); s1 = __builtin_elementwise_fma(nacc, lz_v2f{wv, wv}, s1); }
           nacc = lz_v2f{0.f, 0.f};
         }
       }
@@ -214,7 +213,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
     if (i < Hp) {
       nr01 = lz_ld4(kPrRaw + (uint32_t)i * 8u);
       nr23 = lz_ld4(kPrRaw + (uint32_t)i * 8u + 16u);
-      nlk = lz_ld4(kPrLk + (uint32_t)i * 4u);           // (alpha: coef * leaky; beta: the sign bit = "takes no constant")
+      if (fwd) nlk = lz_ld4(kPrLk + (uint32_t)i * 4u);
     }
   };
   auto normalise = [&](lz_v2f inv, lz_v2f add, int rowA, int rowB, int tq, lz_v4f nr01, lz_v4f nr23, lz_v4f nlk) {
@@ -230,13 +229,8 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
         for (int k = 0; k < 4; k++) { va[k] = ra[k] * inv.x + cl[k]; vb[k] = rb[k] * inv.y + cl[k]; }
       } else {
         const float aiA = add.x * inv.x, aiB = add.y * inv.y;
-        const float lk4[4] = {nlk.x, nlk.y, nlk.z, nlk.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {                  // (normalise_row's gate: a state's second lane and padding take no constant)
-          const uint32_t keep = ~(uint32_t)((int32_t)__float_as_uint(lk4[k]) >> 31);
-          va[k] = __builtin_fmaf(ra[k], inv.x, __uint_as_float(__float_as_uint(aiA) & keep));
-          vb[k] = __builtin_fmaf(rb[k], inv.y, __uint_as_float(__float_as_uint(aiB) & keep));
-        }
+        for (int k = 0; k < 4; k++) { va[k] = __builtin_fmaf(ra[k], inv.x, aiA); vb[k] = __builtin_fmaf(rb[k], inv.y, aiB); }
       }
       lz_st4((uint32_t)i * 8u, lz_v4f{va[0], vb[0], va[1], vb[1]});
       lz_st4((uint32_t)i * 8u + 16u, lz_v4f{va[2], vb[2], va[3], vb[3]});
@@ -262,7 +256,7 @@ __device__ __forceinline__ void pair_recursion(const DenArgs& a, char* smem_raw,
       const float l = leaky_g[i], s = start_g[i];
       lz_st1(kPrLk + (uint32_t)i * 4u, l);
       lz_st2(kPrRaw + (uint32_t)i * 8u, lz_v2f{s, s});
-      p0 += s; p1 += s * __builtin_fabsf(l);
+      p0 += s; p1 += s * l;
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     load_rows(xqA, xqB, fwd ? 0 : LA - 1, fwd ? 0 : LB - 1, tid);

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
     float p0 = 0.f, p1 = 0.f;
     for (int i = tid; i < Hp; i += kNT) {
       const float l = leaky_g[i], s = start_g[i];
-      lk[i] = l; raw[i] = s;                           // (beta: the sign bit = "takes no constant c(t)", plan.cpp; read as |l|)
-      p0 += s; p1 += s * __builtin_fabsf(l);
+      lk[i] = l; raw[i] = s;
+      p0 += s; p1 += s * l;
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1);
     {
@@ -90,6 +90,12 @@ __global__ __launch_bounds__(kNT) void den_recursion_kernel(const DenArgs a) {
       if (xq.store(xr, xseq + (size_t)t0 * D, D, tid, a.input_is_exp) && fwd) bad |= 2;
     }
     __syncthreads();                                   // red zeroed
+    // beta positions that take no constant c(t) (plan.cpp, "states on several lanes"): marked in the sign bit of their leaky
+    // probability, which is read as |l| (tile_rows, normalise_row)
+    if (!fwd) {
+      const int32_t* nc = reinterpret_cast<const int32_t*>(plan + hd->off_no_const);
+      for (int j = tid; j < hd->n_no_const; j += kNT) lk[nc[j]] = __uint_as_float(__float_as_uint(lk[nc[j]]) | 0x80000000u);
+    }
     if (lane == 0) { red[wave] = p0; red[16 + wave] = p1; }
     __syncthreads();
     tot = block_total(red, lane); wtot = block_total(red + 16, lane);

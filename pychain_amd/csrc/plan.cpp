@@ -588,9 +588,10 @@ void init_tile(Tile& t, const std::vector<std::vector<Arc>>& rows, const std::ve
 // which collects a share of its arcs; whoever gathers the state gathers every part - its arc is repeated once per part
 // (the recursions are linear in the gathered vector).  What is NOT linear is written into the per-position vectors:
 //   alpha'(t,i) = alpha(t,i) + tot(t) coef leaky(i)   the first part carries leaky(i), initial(i); the others 0;
-//   beta'(t,i)  = beta(t,i) + c(t)                    only the first part takes the constant: the others (and the
-//                                                     padding positions) carry the SIGN BIT in leaky_b - the kernels
-//                                                     use |leaky_b| and drop c(t) where it is set;
+//   beta'(t,i)  = beta(t,i) + c(t)                    only the first part takes the constant: the others are listed in
+//                                                     the plan (PlanHeader::off_no_const) and the kernels mark them
+//                                                     once, before the first frame (every part carries leaky(i):
+//                                                     c(t) = coef sum_i leaky_i beta(t,i) is linear);
 //   final(i) multiplies alpha'(L, i): every part carries it; beta(L,i) = final(i): the first part.
 // parts are chosen per side by a cap on the row length: the largest cap (fewest repeated arcs) that reaches the
 // smallest register-resident loop the tile can reach at all; a side that gains no loop class stays as it is.
@@ -969,7 +970,7 @@ int64_t plan_build_impl(
   // H = positions of the longer side (what the caller sizes its workspace by); reserved: the graph's states, states on
   // several positions per side
   hd.H = HV; hd.K = K; hd.D = D; hd.Hp = Hp;
-  hd.reserved[0] = H; hd.reserved[1] = HA - H; hd.reserved[2] = HB - H;
+  hd.graph_states = H; hd.n_no_const = HB - H;
   for (const BuiltTile* t : {&ta, &tb})
     for (const WaveEntry& we : t->waves) hd.rec_max_wave_groups = std::max(hd.rec_max_wave_groups, we.ngroups);
   if (small)
@@ -988,6 +989,7 @@ int64_t plan_build_impl(
   place_vec(hd.off_init_a, Hp); place_vec(hd.off_leaky_a, Hp); place_vec(hd.off_final_a, Hp);
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
   place_vec(hd.off_row_pdf, gpos);
+  place_vec(hd.off_no_const, std::max(1, HB - H));
   if (off > (size_t)INT32_MAX)
     return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED, "den_plan_build: plan larger than 2 GiB");
   hd.total_bytes = (int32_t)off;
@@ -1007,8 +1009,8 @@ int64_t plan_build_impl(
   float* init_a = (float*)(base + hd.off_init_a); float* leaky_a = (float*)(base + hd.off_leaky_a);
   float* final_a = (float*)(base + hd.off_final_a); float* leaky_b = (float*)(base + hd.off_leaky_b);
   float* final_b = (float*)(base + hd.off_final_b); int32_t* row_pdf = (int32_t*)(base + hd.off_row_pdf);
-  // (beta positions that do not take the constant c(t) - parts after a state's first, padding - carry the sign bit)
-  for (int i = 0; i < Hp; i++) leaky_b[i] = -0.0f;
+  int32_t* no_const = (int32_t*)(base + hd.off_no_const);
+  int n_nc = 0;
   for (int h = 0; h < H; h++) {
     for (int m = 0; m < parts_a[h]; m++) {
       const int pa = lay.pos[kLayA][ea0[h] + m];
@@ -1016,7 +1018,8 @@ int64_t plan_build_impl(
     }
     for (int m = 0; m < parts_b[h]; m++) {
       const int pb = lay.pos[kLayB][eb0[h] + m];
-      leaky_b[pb] = m == 0 ? fabsf(leaky[h]) : -fabsf(leaky[h]); final_b[pb] = m == 0 ? final_[h] : 0.f;
+      leaky_b[pb] = leaky[h]; final_b[pb] = m == 0 ? final_[h] : 0.f;
+      if (m > 0) no_const[n_nc++] = pb;                  // (beta' = beta + c(t): the constant once per state)
     }
   }
   for (int i = 0; i < gpos; i++) row_pdf[i] = i < (int)tiles[2].order.size() ? tiles[2].order[i] : -1;

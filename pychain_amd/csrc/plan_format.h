@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 12
+#define PLAN_VERSION 13
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -86,7 +86,9 @@ struct PlanHeader {
   // four-wave workgroup (a wave would own more than PLAN_RESIDENT_2 slot-rows or more than four groups) and they are left out
   TilePlan alpha4, beta4;
   int32_t payload_hash;        // FNV-1a over bytes [sizeof(PlanHeader), total_bytes): checked by pychain_hip_den_plan_info
-  int32_t reserved[3];
+  // states on several lanes (plan.cpp): the graph's own state count (H counts POSITIONS of the longer side), and the beta
+  // positions that take no constant c(t) - every position of a state after its first: int32[n_no_const] at off_no_const
+  int32_t graph_states, off_no_const, n_no_const;
 };
 
 // ---- the GENERAL format: graphs the compiled tile plans do not take (more than 65 535 states or pdfs, or vectors that
@@ -162,6 +164,7 @@ inline bool plan_header_in_bounds(const PlanHeader& hd) {
     if (!tile_in_bounds(*tp, n)) return false;
   for (int32_t off : {hd.off_init_a, hd.off_leaky_a, hd.off_final_a, hd.off_leaky_b, hd.off_final_b})
     if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
+  if (hd.n_no_const < 0 || hd.off_no_const < 0 || (size_t)hd.off_no_const + (size_t)hd.n_no_const * 4 > n) return false;
   return hd.off_row_pdf >= 0 && (size_t)hd.off_row_pdf + (size_t)hd.gamma.ngroups * 64 * 4 <= n;
 }
 }  // namespace pychain_hip

@@ -7,7 +7,7 @@ against the oracle without a GPU.  Mirrors the kernels step by step.
 """
 import numpy as np
 
-HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 12), in int32 words
+HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 13), in int32 words
 
 
 def parse(blob):
@@ -29,15 +29,17 @@ def parse(blob):
     hd["alpha"], hd["beta"], hd["gamma"] = tile(8), tile(16), tile(24)
     hd["gamma2"], hd["alpha4"], hd["beta4"] = tile(40), tile(48), tile(56)
     hd["rec_max_wave_groups"], hd["rec4_max_wave_groups"], hd["header_hash"], hd["payload_hash"] = int(h[7]), int(h[38]), int(h[39]), int(h[64])
-    # reserved[0..2]: the graph's states, positions added on the alpha / beta side by states on several lanes (plan.cpp)
-    hd["graph_states"], hd["split_a"], hd["split_b"] = int(h[65]), int(h[66]), int(h[67])
+    # the graph's states (H counts positions), and the beta positions that take no constant c(t) (plan.cpp, "states on several lanes")
+    hd["graph_states"], off_nc, n_nc = int(h[65]), int(h[66]), int(h[67])
+    hd["no_const"] = b[off_nc:off_nc + 4 * n_nc].view(np.int32).copy()
+    hd["split_b"] = n_nc
     offs = [int(v) for v in h[32:38]]
     Hp = hd["Hp"]
     vec = lambda o: b[o:o + 4 * Hp].view(np.float32).copy()
     hd["init_a"], hd["leaky_a"], hd["final_a"], hd["leaky_b"], hd["final_b"] = [vec(o) for o in offs[:5]]
-    # beta positions that take the constant c(t): the sign bit of leaky_b is clear (a state's first lane); the kernels use |leaky_b|
-    hd["takes_c"] = ~np.signbit(hd["leaky_b"])
-    hd["leaky_b"] = np.abs(hd["leaky_b"])
+    # beta positions that take the constant c(t): all but the listed ones (a state's lanes after its first)
+    hd["takes_c"] = np.ones(Hp, dtype=bool)
+    hd["takes_c"][hd["no_const"]] = False
     ng = max(hd["gamma"]["ngroups"] * 64, 64)
     hd["row_pdf"] = b[offs[5]:offs[5] + 4 * ng].view(np.int32).copy()
     return hd

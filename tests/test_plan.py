@@ -361,12 +361,12 @@ def test_states_on_several_lanes(case):
     info0 = _plan.plan_info(blob0)
     assert info0["split_positions"] == 0 and info0["num_states"] == g.num_states
     assert info["split_positions"] > 0 and info["graph_states"] == g.num_states
-    assert info["num_states"] == g.num_states + max(hd["split_a"], hd["split_b"]) and hd["Hp"] == (info["num_states"] + 63) // 64 * 64
+    assert info["num_states"] == g.num_states + info["split_positions"] >= g.num_states + hd["split_b"] and hd["Hp"] == (info["num_states"] + 63) // 64 * 64
     assert (info["slot_rows"] & 1023) < (info0["slot_rows"] & 1023)            # a shorter loop: what it is for
     assert ((info["slot_rows"] >> 28) & 1) == (1 if hd["split_b"] else 0)      # beta positions without the constant: not for the pair kernel
     assert (info["slot_rows"] >> 30) & 1                                      # four groups per wave at most: the lazy recursions
     # only first lanes (and no padding position) take beta's constant / carry alpha's leaky and initial probability
-    assert int(hd["takes_c"].sum()) == g.num_states
+    assert int((~hd["takes_c"]).sum()) == hd["split_b"] and (hd["split_b"] > 0 or case == "structured")
     assert abs(hd["leaky_a"].sum() - g.leaky_probs.sum().item()) < 1e-5 and abs(hd["leaky_b"][hd["takes_c"]].sum() - g.leaky_probs.sum().item()) < 1e-5
     x = syn.make_input(2, T, D, seed=21).numpy()
     L = np.array([T, T - 3])
