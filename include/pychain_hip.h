@@ -356,7 +356,9 @@ int pychain_hip_chain_loss_forward_backward(
  *   totals[0] = (sum_b den_objf[b] - sum_b num_objf[b]) * loss_scale [/ *loss_norm_dev]  = -(num - den) [/ frames],
  *   totals[1] = sum_b len_b, totals[2] = bad_count[0] + bad_count[1] as a float (what a sharded trainer all-reduces
  *   with the loss), totals[3] = sum den - sum num unscaled, totals[4] = totals[0], totals[5..7] as above.  loss_norm_dev: device
- *   float or NULL.
+ *   float or NULL; where it is given, a gradient written by the same call is divided by it too (grad = grad_scale /
+ *   *loss_norm_dev * (gamma_den - gamma_num): the occupancy launches read its reciprocal on the device - ChainLoss(avg=True)
+ *   with the lengths on the device costs no pass over [B,T,D] behind the call).
  * A batch larger than the chip (B >= 7/8 of the CU count, one shared denominator plan, `grad` given): the call runs over
  *   SLICES of about CUs / 2 sequences (B = 256: 2 x 128, 320: 2 x 160, 384: 3 x 128), one after the other on `stream` in the same workspaces (their last 4 KiB hold the
  *   slices' counters), and a last small launch forms bad_count and totals over the whole batch - same per-sequence results,

@@ -458,12 +458,18 @@ hipError_t launch_scale_row(float* row, int n, float scale, hipStream_t st) {
 // Every word a call's launches count in - the caller's bad count(s) and the workspace's counters (per-sequence progress, gate
 // counters, the queue head of the streamed occupancy pass, den_finish_kernel's arrival counter) - zeroed by ONE small launch
 // (two hipMemsetAsync are two fill kernels with a gap between them: 18 us at the head of every step).
-__global__ void zero_words_kernel(int32_t* p0, int n0, int32_t* p1, int n1) {
+// (`norm` / `inv_out`: the fused loss with a device-side normaliser - *inv_out = 1 / *norm for the occupancy launches of the
+// call, which scale the gradient by it; inv_out lies inside p1's range and is written behind its zeroing)
+__global__ void zero_words_kernel(int32_t* p0, int n0, int32_t* p1, int n1, const float* norm, float* inv_out) {
   for (int i = threadIdx.x; i < n0; i += blockDim.x) p0[i] = 0;
   for (int i = threadIdx.x; i < n1; i += blockDim.x) p1[i] = 0;
+  if (inv_out) {
+    __syncthreads();
+    if (threadIdx.x == 0) *inv_out = 1.0f / *norm;
+  }
 }
-hipError_t launch_zero_words(int32_t* p0, int n0, int32_t* p1, int n1, hipStream_t st) {
-  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, p0, n0, p1, n1);
+hipError_t launch_zero_words(int32_t* p0, int n0, int32_t* p1, int n1, hipStream_t st, const float* norm = nullptr, float* inv_out = nullptr) {
+  hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, p0, n0, p1, n1, norm, inv_out);
   return hipGetLastError();
 }
 int den_counter_words(const DenArgs& a) { return (int)((align256(8 * (size_t)a.B) + 256 + align256(36 * (size_t)a.B)) / 4); }
@@ -898,7 +904,12 @@ int chain_loss_forward_one(
   SideStream* side = side_streams_for(st);
   if (!side) return fail(PYCHAIN_HIP_ELAUNCH, "%s: cannot create the side stream", who);
   const char* why = nullptr;
-  hipError_t e = launch_zero_words(bad_count, 2, da.seq_progress, den_counter_words(da), st);
+  // a device-side normaliser of the loss (loss_norm_dev: ChainLoss(avg=True) with the lengths on the device) also divides the
+  // gradient written here: its reciprocal goes into a spare counter word at the head of the call and the occupancy launches
+  // of both sides read it (DenArgs / NumArgs::grad_scale_dev) - not a pass over [B, T, D] behind the call
+  float* inv_norm = (loss_norm_dev && grad) ? reinterpret_cast<float*>(da.progress + 56) : nullptr;
+  if (inv_norm) { da.grad_scale_dev = inv_norm; na.grad_scale_dev = inv_norm; }
+  hipError_t e = launch_zero_words(bad_count, 2, da.seq_progress, den_counter_words(da), st, loss_norm_dev, inv_norm);
   // The two-frame occupancy kernel folds the numerator in (grad = scale * (gamma_den - gamma_num), written
   // once): the numerator then also produces compact occupancy rows on its stream, and the occupancy
   // launches wait for them.  Otherwise the numerator is accumulated into the gradient afterwards.

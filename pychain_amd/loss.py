@@ -190,10 +190,10 @@ class ChainLossFunction(torch.autograd.Function):
         ChainFunction.last_totals, ChainFunction.last_totals_all = totals[:4], totals
         ctx.state = state
         # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
-        spec, hscale = ctx.speculative, ctx.host_scale      # (locals: the closure must not hold ctx)
+        spec, hscale, dnorm = ctx.speculative, ctx.host_scale, ctx.dev_norm      # (locals: the closure must not hold ctx)
         ctx.again = _recompute(x, lambda: native.chain_loss_forward(
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
-            with_grad=spec, grad_scale=hscale, half_ok=half_ok), lambda r: (r[3], r[2]))      # (state, bad)
+            with_grad=spec, grad_scale=hscale, norm_dev=dnorm, half_ok=half_ok), lambda r: (r[3], r[2]))      # (state, bad)
         ctx.in_dtype = input.dtype
         ChainFunction.last_bad_count = bad       # int32[2]: denominator, numerator; never synced here
         return objf
@@ -202,13 +202,15 @@ class ChainLossFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, objf_grad):
-        g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
         state = _take_grad_buffer(ctx, "state")
         if state is None:
             state, ChainFunction.last_bad_count = ctx.again()
         if ctx.speculative:
-            grad = native.rescale_(state.grad, g)
+            # (a device-side normaliser - avg=True with the lengths on the device - was divided into the gradient by the call
+            # that wrote it: include/pychain_hip.h, loss_norm_dev; an upstream gradient of exactly 1 then costs one tiny launch)
+            grad = native.rescale_(state.grad, objf_grad)
         else:
+            g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
             grad, bad = native.chain_loss_backward(state, ctx.host_scale, g)
             ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad
         state.grad = None         # the stored trajectories go with `state`

@@ -156,6 +156,7 @@ def test_step_totals_come_with_the_call():
     w = syn.make_workload("C1")
     x = w["x"].to(DEV)
     for avg in (True, False):
+        grads = []
         for lengths in (w["lengths"], w["lengths"].to(DEV)):
             xx = x.clone().requires_grad_(True)
             loss = ChainLoss(w["den_graph"], 1e-5, avg=avg)(xx, lengths, w["num_graphs"])
@@ -170,6 +171,13 @@ def test_step_totals_come_with_the_call():
             assert abs(raw - want * (float(w["lengths"].sum()) if avg else 1.0)) <= 1e-5 * abs(raw)
             loss.backward()
             assert torch.isfinite(xx.grad).all()
+            grads.append(xx.grad.clone())
+        # lengths on the device: avg's 1 / frames is divided into the gradient by the call itself, read on the device
+        # (include/pychain_hip.h: loss_norm_dev) - the same gradient as with the host-side scalar, to one rounding
+        assert (grads[0] - grads[1]).abs().max() <= 2e-7 * grads[0].abs().max()
+        xr = x.clone().requires_grad_(True)
+        ref(xr, w["lengths"], w["num_graphs"]).backward()
+        assert (grads[1] - xr.grad).abs().max() <= 1e-5 * xr.grad.abs().max()
     # denominator only, B = 300 > 256 threads of the finishing workgroup; unequal lengths
     den = syn.make_den_graph(20, 60, 40, seed=0)
     B = 300
