@@ -30,7 +30,10 @@ def short(k):
             # a call cut into time segments launches the lazy recursion twice: the segmented kernel (last
             # template argument true) and, behind the check, the uncut one, which leaves at once unless a splice missed
             if n == "den_recursion_lazy_kernel":
-                return n + (" [time segments]" if ", true>" in k else "")
+                # (template arguments: rows, LDS map, row form, TS, NC)
+                import re
+                m = re.search(r"den_recursion_lazy_kernel<[^>]*?,\s*(true|false),\s*(true|false)>", k)
+                return n + (" [time segments]" if (m and m.group(1) == "true") else "")
             return n
     return None
 
