@@ -215,8 +215,14 @@ def test_states_on_several_lanes_on_the_device(case):
     forms = [{}, {"den_dma": 0}, {"den_lazy": 0}, {"den_pair": 1}, {"den_pair": 1, "den_lazy": 0}]
     if case != "small_hubs":
         forms.append({"den_tseg": 2, "den_tburn": 96})          # (T = 420: two segments of 210 frames that start 96 outside)
+    from helpers import record_parity
+    worst = {}
     for opts in forms:
         o, g = _den(x, L, den, **opts)
         e = rel_err(g.cpu().numpy(), rg)
         assert abs(o - ro) <= 1e-5 * abs(ro) and e <= 2e-5, (case, opts, o, ro, e)
-        assert abs(o - o0) <= 1e-5 * abs(o0) and rel_err(g.cpu().numpy(), g0.cpu().numpy()) <= 2e-5, (case, opts)
+        e0 = rel_err(g.cpu().numpy(), g0.cpu().numpy())
+        assert abs(o - o0) <= 1e-5 * abs(o0) and e0 <= 2e-5, (case, opts)
+        worst["grad_vs_f64"] = max(worst.get("grad_vs_f64", 0.0), e)
+        worst["grad_vs_every_state_on_one_lane"] = max(worst.get("grad_vs_every_state_on_one_lane", 0.0), e0)
+    record_parity("states_on_several_lanes_" + case, positions=plan.num_states, states=den.num_states, **worst)
