@@ -351,3 +351,22 @@ def test_batch_as_an_argument_of_a_spawned_process():
         got = q.get(timeout=120)
         p.join()
         assert p.exitcode == 0 and got == float(gb.forward_transition_probs.sum())
+
+
+def test_policy_queries_answer_without_a_device():
+    """What a caller asks before it allocates (slices of a fused call, time segments, the [B,T,D] row buffer) is host
+    arithmetic: it answers on a machine without a GPU (256 CUs assumed) and follows the documented rules."""
+    L = _lib.lib()
+    hint = 32 | (1 << 30)
+    assert [L.pychain_hip_chain_loss_slices(0, hint, B) for B in (64, 128, 223, 224, 256, 320, 384, 512)] == [1, 1, 1, 2, 2, 2, 3, 4]
+    assert L.pychain_hip_chain_loss_slices(4096, hint, 512) == 1                       # per-sequence plans: one call
+    with _lib.option("chain_slices", "0"):
+        assert L.pychain_hip_chain_loss_slices(0, hint, 512) == 1
+    with _lib.option("chain_slices", "3"):
+        assert L.pychain_hip_chain_loss_slices(0, hint, 90) == 3
+    # time segments: few sequences only, never the fused step at B = 64, never below two burn-ins
+    ts = lambda B, T, fused: L.pychain_hip_den_time_segments(0, hint, 3000, 3456, B, T, fused)
+    assert ts(64, 1500, 1) == 1 and ts(16, 1500, 1) == 4 and ts(32, 1500, 1) == 2
+    assert ts(32, 1500, 0) == 4 and ts(64, 1500, 0) == 2 and ts(128, 1500, 0) == 1 and ts(8, 300, 0) == 1
+    with _lib.option("den_tseg", "0"):
+        assert ts(16, 1500, 1) == 1
