@@ -1033,7 +1033,9 @@ extern "C" int pychain_hip_chain_loss_forward(
   const size_t ws_bytes = (den_ws_bytes - 4096) & ~(size_t)255;
   SliceLine* lines = reinterpret_cast<SliceLine*>((char*)den_ws + ws_bytes);
   const size_t esz = nnet_output_dtype == PYCHAIN_HIP_F32 ? 4 : 2;
-  const int per = ((B + nsl - 1) / nsl + 1) & ~1;            // (even: the pair recursion takes its sequences two by two)
+  // (a multiple of 8 sequences: every slice's rows, gradient and graph tensors start 16-byte aligned whatever T and D are -
+  // 2-byte rows of odd T x D included -, and the pair recursion takes its sequences two by two)
+  const int per = ((B + nsl - 1) / nsl + 7) & ~7;
   int c = 0;
   for (int b0 = 0; b0 < B; b0 += per, c++) {
     const int nb = std::min(per, B - b0);

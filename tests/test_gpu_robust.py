@@ -420,14 +420,15 @@ def test_a_long_lived_kernel_on_another_stream_of_the_process():
         pass
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_a_batch_larger_than_the_chip_runs_in_slices(dtype):
+@pytest.mark.parametrize("dtype,T,D", [(torch.float32, 48, 1000), (torch.bfloat16, 48, 1000), (torch.float32, 47, 1001)])
+def test_a_batch_larger_than_the_chip_runs_in_slices(dtype, T, D):
     """The fused loss over B >= 7/8 of the CU count (include/pychain_hip.h: pychain_hip_chain_loss_slices) runs over slices
     of the batch in the same workspaces: per-sequence results, gradient, totals and bad count are those of the one call,
     bit for bit - ragged lengths, an odd slice, per-utterance numerator graphs (their tensors are sliced too), a NaN in
-    one slice only, 2-byte rows."""
+    one slice only, 2-byte rows, rows of an odd number of pdfs over an odd number of frames (a slice still starts 16-byte
+    aligned: slices are multiples of 8 sequences)."""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    B, T, D = (7 * cus + 7) // 8 + 5, 48, 1000
+    B = (7 * cus + 7) // 8 + 5
     den = syn.make_den_graph(200, 2000, D)
     L = syn.make_lengths(B, T, "ragged", seed=4)
     num = syn.make_num_graphs(L.tolist(), D, seed=300)
