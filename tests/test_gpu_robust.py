@@ -441,7 +441,7 @@ def test_a_batch_larger_than_the_chip_runs_in_slices(dtype, T, D):
     def run(slices):
         with _lib.option("chain_slices", slices):
             xx = x.clone().requires_grad_(True)
-            loss = ChainLoss(den, 1e-5, avg=True)(xx, L, num)
+            loss = ChainLoss(den, 1e-5, avg=True)(xx, L, num)           # (L: rebound below)
             loss.backward()
             torch.cuda.synchronize()
             return (float(loss), xx.grad.clone(), ChainFunction.last_totals.clone(), ChainFunction.last_bad_count.clone(),
@@ -456,3 +456,8 @@ def test_a_batch_larger_than_the_chip_runs_in_slices(dtype, T, D):
     x[B - 3, 2, 7] = 0.0
     one, two = run("0"), run("-1")
     assert one[0] == one[0] and two[0] == one[0] and torch.equal(two[1], one[1]) and int(two[3].sum()) == 0
+    # the lengths on the device: every slice divides its gradient by the frame count of the WHOLE batch, read on the device
+    Lh, L = L, L.to(DEV)
+    dev_len = run("-1")
+    assert abs(dev_len[0] - one[0]) <= 1e-6 * abs(one[0])
+    assert (dev_len[1].float() - one[1].float()).abs().max() <= (4e-3 if dtype != torch.float32 else 2e-7) * one[1].float().abs().max()
