@@ -683,6 +683,17 @@ SideSearch search_side(const SideArcs& sa, int H, int K, int D, int slack) {
     a.cls = (Hp <= 64 * 4 * PLAN_REC4_WAVES && D <= 4096) ? loop_class(len, PLAN_REC4_WAVES, Hp, slack) : 4;
     b.cls = loop_class(len, PLAN_REC_WAVES, Hp, slack);
     out.c4.push_back(a); out.c16.push_back(b);
+    if (cap == maxlen) {
+      // nothing to gain where the rows as they are already reach the shortest loop K arcs can fit at all (C3: 30 000 arcs on
+      // 16 waves are 29.3 slot-rows per wave - the 32-row loop it has): no candidates, 1.6 s of compile time less
+      auto floor_class = [&](int nwaves) {
+        const long per_wave = ((long)K + 64L * nwaves - 1) / (64L * nwaves);
+        return per_wave <= PLAN_RESIDENT_0 ? 0 : (per_wave <= 24 && nwaves == PLAN_REC4_WAVES ? 1 : (per_wave <= PLAN_RESIDENT_1 ? 2 : (per_wave <= PLAN_RESIDENT_2 ? 3 : 4)));
+      };
+      const bool done16 = b.cls <= floor_class(PLAN_REC_WAVES);
+      const bool done4 = a.cls == 4 ? floor_class(PLAN_REC4_WAVES) == 4 : a.cls <= floor_class(PLAN_REC4_WAVES);
+      if (done16 && done4) break;
+    }
     if (getenv("PYCHAIN_PLAN_STATS")) fprintf(stderr, "[plan] cap %d: %d positions, class at 4 waves %d, at 16 waves %d\n", cap, Hv, a.cls, b.cls);
   }
   return out;
