@@ -115,8 +115,8 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *                    exp'd ahead of them on the side stream (bit-identical)
  *   "den_segments"   n >= 1: the occupancy pass in n gated time segments (1 = after the recursions, no overlap) instead of
  *                    the streamed persistent launch
- *   "den_pair"       "1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 3/8 of
- *                    the CU count in sequences on, i.e. B >= 96 on 256 CUs - bit-identical to den_recursion_kernel
+ *   "den_pair"       "1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 25/64 of
+ *                    the CU count in sequences on, i.e. B >= 100 on 256 CUs - bit-identical to den_recursion_kernel
  *   "gamma16"        the one-frame occupancy kernel (and with it the numerator accumulated into the stored gradient
  *                    instead of folded into the occupancy launch) also where the two-frame kernel fits
  *   "debug_corrupt_row" "den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the

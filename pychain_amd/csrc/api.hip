@@ -368,9 +368,10 @@ bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
   if (a.knobs.den_pair >= 0) return a.knobs.den_pair != 0;
   // small graphs run in four-wave workgroups, several to a CU: nothing to gain from pairing sequences
   if (a.knobs.den_lazy && den_call_is_small(a, resident_slot_rows)) return false;
-  // measured on the C3 graph (tools/time_step.py B 1500): B = 96 +3.5 %, B = 128 +27 %, B = 256 +13 %; below 3/4 of the
-  // CUs the one-sequence workgroups leave enough of the chip to the occupancy launches and their chain is shorter
-  return 8 * a.B >= 3 * device_cu_count();
+  // measured on the C3 graph, fused step (round 5, 256 CUs): B = 96 one-sequence workgroups 4.40 ms, pairs 4.58; B = 104:
+  // 5.36 / 4.58; B = 128: 6.60 / 5.24 - below about 100 sequences the one-sequence workgroups leave enough of the chip to the
+  // occupancy launches and the numerator, and their chain is shorter
+  return 64 * a.B >= 25 * device_cu_count();
 }
 // the nnet-output rows of the lazy recursions come in by LDS-direct loads (default wherever a lazy shape fits: on the
 // 16-wave map of C3 it is 2 % faster than rows through registers and bit-identical, and it is what makes rows of

@@ -155,7 +155,7 @@ def test_which_kernel_each_shape_gets():
     cases = [
         # H, K, D, B -> recursion, occupancy
         (3000, 30000, 3456, 64, "den_recursion_lazy_kernel<dma>", "den_gamma2_kernel"),     # C3
-        (3000, 30000, 3456, 128, "den_recursion_pair_kernel", "den_gamma2_kernel"),         # B >= 96: two sequences per workgroup
+        (3000, 30000, 3456, 128, "den_recursion_pair_kernel", "den_gamma2_kernel"),         # B >= 100: two sequences per workgroup
         (200, 2000, 1000, 64, "den_recursion_lazy_kernel<small>", "den_gamma2_kernel"),     # C2: four-wave workgroups
         (20, 60, 40, 2, "den_recursion_lazy_kernel<small>", "den_gamma2_kernel"),           # C1
         (200, 2000, 1000, 256, "den_recursion_lazy_kernel<small>", "den_gamma2_kernel"),    # ... also at batch sizes that pair large graphs
