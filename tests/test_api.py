@@ -366,7 +366,8 @@ def test_policy_queries_answer_without_a_device():
         assert L.pychain_hip_chain_loss_slices(0, hint, 90) == 3
     # time segments: few sequences only, never the fused step at B = 64, never below two burn-ins
     ts = lambda B, T, fused: L.pychain_hip_den_time_segments(0, hint, 3000, 3456, B, T, fused)
-    assert ts(64, 1500, 1) == 1 and ts(16, 1500, 1) == 4 and ts(32, 1500, 1) == 2
+    assert ts(64, 1500, 1) == 1 and ts(16, 1500, 1) == 4 and ts(24, 1500, 1) == 4 and ts(32, 1500, 1) == 2
+    assert ts(40, 1500, 1) == 2 and ts(48, 1500, 1) == 2 and ts(56, 1500, 1) == 1      # (a fused call leaves a quarter of the chip alone)
     assert ts(32, 1500, 0) == 4 and ts(64, 1500, 0) == 2 and ts(128, 1500, 0) == 1 and ts(8, 300, 0) == 1
     with _lib.option("den_tseg", "0"):
         assert ts(16, 1500, 1) == 1
