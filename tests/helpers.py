@@ -302,3 +302,26 @@ class G6Case(object):
 
     def dist_rowsum_ref(self, grad):
         return float(np.abs(np.asarray(grad, dtype=np.float64).sum(-1) - self.ref_rowsum).max())
+
+
+def random_hub_graph(seed):
+    """A random probability-domain graph with a few hub states - many arcs in, many arcs out, self-loops on hubs, hubs
+    feeding hubs, final probabilities from the FST: what makes the plan compiler put states on several lanes
+    (csrc/plan.cpp).  Returns (ChainGraph, num_pdfs)."""
+    from pychain_amd import ChainGraph
+    from pychain_amd.simplefst import StdVectorFst
+    rs = np.random.RandomState(100 + seed)
+    H = int(rs.randint(60, 420))
+    D = int(rs.randint(20, 300))
+    nh = int(rs.randint(1, 6))
+    arcs = [(s, (s + 1) % H, int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for s in range(H)]
+    arcs += [(int(rs.randint(H)), int(rs.randint(H)), int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for _ in range(int(rs.randint(3, 9)) * H)]
+    hubs = rs.choice(H, size=nh, replace=False)
+    for hb in hubs:
+        fan_in, fan_out = int(rs.randint(20, 90)), int(rs.randint(0, 60))
+        arcs += [(int(rs.randint(H)), int(hb), int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for _ in range(fan_in)]
+        arcs += [(int(hb), int(rs.randint(H)), int(rs.randint(D)), float(-0.1 - 2 * rs.rand())) for _ in range(fan_out)]
+        arcs += [(int(hb), int(hb), int(rs.randint(D)), -0.7), (int(hb), int(hubs[0]), int(rs.randint(D)), -1.1)]
+    arcs.sort(key=lambda a: a[0])
+    g = ChainGraph(StdVectorFst.from_arcs(H, 0, arcs, {s: float(-rs.rand()) for s in range(H)}), initial_mode="leaky", final_mode="fst")
+    return g, D

@@ -197,3 +197,31 @@ def test_random_numerators_in_the_reference_arithmetic(seed):
     assert abs(float(o.detach()) - float(ro.sum())) <= 3e-6 * abs(float(ro.sum())) + 1e-5
     rg = np.exp(rlg.astype(np.float64))
     assert rel_err(xx.grad.cpu().numpy(), rg) <= 2e-5, rel_err(xx.grad.cpu().numpy(), rg)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_hub_graphs_states_on_several_lanes(seed):
+    """Random graphs with hub states (helpers.random_hub_graph; the CPU suite emulates the same ten): the plan puts states on
+    several lanes on both sides; the lazy recursions' NC form (four waves or sixteen), the two-barrier kernel and - with the
+    pair kernel asked for, which does not take such plans - whatever runs instead, against the fp64 oracle and against the plan
+    with every state on one lane; ragged lengths, exact zeros in the padding."""
+    from helpers import random_hub_graph
+    from pychain_amd import _plan
+    den, D = random_hub_graph(seed)
+    rng = np.random.RandomState(3000 + seed)
+    B, T = int(rng.randint(2, 7)), int(rng.randint(20, 90))
+    lengths = sorted((int(rng.randint(1, T + 1)) for _ in range(B)), reverse=True)
+    lengths[0] = T
+    x = syn.make_input(B, T, D, seed=70 + seed)
+    L = torch.tensor(lengths)
+    plan = _plan.graph_plan(den, D, torch.device(DEV))
+    assert plan.num_states > den.num_states and (plan.slot_rows >> 28) & 1
+    ro, rg = orc.chain_function(x, L, ChainGraphBatch(den, B), 1e-5, flavour="f64")
+    with _lib.option("plan_split", "0"):
+        o0, g0 = _run(x, L, den, 1, False)
+    for name, lazy, pair in (("lazy", 1, False), ("two-barrier", 0, False), ("pair asked for", 1, True)):
+        o, g = _run(x, L, den, lazy, pair)
+        assert abs(o - ro) <= 1e-5 * abs(ro) and rel_err(g, rg) <= 2e-5, (name, seed, o, ro, rel_err(g, rg))
+        assert abs(o - o0) <= 1e-5 * abs(o0) and rel_err(g, g0) <= 2e-5, (name, seed)
+        for b, l in enumerate(lengths):
+            assert np.all(g[b, l:] == 0.0), (name, b)

@@ -375,3 +375,35 @@ def test_states_on_several_lanes(case):
     assert np.abs(objf - objf0).max() <= 1e-11 * np.abs(objf0).max() and rel_err(grad, grad0) <= 1e-11
     ro, rg, ok = orc.den(ChainGraphBatch(g, 2), np.exp(np.clip(x, -30, 30)), L, 1e-3, flavour="f64")   # (exp(x) rounded to fp32 on its way in)
     assert ok and abs(objf.sum() - ro.sum()) <= 2e-6 * abs(ro.sum()) and rel_err(grad, rg) <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_states_on_several_lanes_random_graphs(seed):
+    """Random graphs with a few hub states (many arcs in, many arcs out, self-loops on hubs, hubs feeding hubs): whatever the
+    compiler decides - states on several lanes on one side, on both, or none - the emulated kernels give the same numbers as
+    with every state on one lane (fp64, 1e-11) and the oracle's, every arc is in each tile once per (position it belongs
+    to, position it gathers), and the per-position vectors add up to the graph's."""
+    from helpers import random_hub_graph
+    g, D = random_hub_graph(seed)
+    H = g.num_states
+    blob = _blob(g, D)
+    with _lib.option("plan_split", "0"):
+        blob0 = _blob(g, D)
+    info, hd, hd0 = _plan.plan_info(blob), emu.parse(blob), emu.parse(blob0)
+    assert info["graph_states"] == H and info["num_states"] == H + info["split_positions"] and hd0["H"] == H
+    if info["split_positions"] == 0:
+        assert bytes(blob) == bytes(blob0)
+    else:
+        assert (info["slot_rows"] & 1023) < (_plan.plan_info(blob0)["slot_rows"] & 1023)
+    for name in ("alpha", "beta"):                       # the probability mass of a tile: every arc once per position it gathers
+        assert hd[name]["p"].astype(np.float64).sum() >= hd0[name]["p"].astype(np.float64).sum() - 1e-9
+    assert abs(hd["leaky_a"].sum() - hd0["leaky_a"].sum()) < 1e-5 and abs(hd["init_a"].sum() - hd0["init_a"].sum()) < 1e-5
+    assert abs(hd["final_b"].sum() - hd0["final_b"].sum()) < 1e-4
+    T = 7
+    x = syn.make_input(2, T, D, seed=200 + seed).numpy()
+    L = np.array([T, T - 2])
+    objf, grad = emu.den_forward_backward(blob, x, L, 1e-3)
+    objf0, grad0 = emu.den_forward_backward(blob0, x, L, 1e-3)
+    assert np.abs(objf - objf0).max() <= 1e-11 * np.abs(objf0).max() and rel_err(grad, grad0) <= 1e-11
+    ro, rg, ok = orc.den(ChainGraphBatch(g, 2), np.exp(np.clip(x, -30, 30)), L, 1e-3, flavour="f64")
+    assert ok and abs(objf.sum() - ro.sum()) <= 2e-6 * abs(ro.sum()) and rel_err(grad, rg) <= 1e-5
