@@ -311,7 +311,7 @@ def other_workloads(dev, steps=6, warmup=3):
             ms = (time.perf_counter() - t0) / steps * 1e3
             frames = int(w["lengths"].sum())
             plan = _plan.graph_plan(w["den_graph"], cfg["D"], dev)
-            rec, occ = _lib.den_kernel_names(plan.slot_rows, plan.num_states, cfg["D"], cfg["B"])
+            rec, occ = _lib.den_kernel_names(plan.slot_rows, plan.num_states, cfg["D"], cfg["B"], fused=bool(cfg["num"]))
             stream = torch.cuda.current_stream(dev)
             # time segments of the call the step makes (totals[5..7] of include/pychain_hip.h: segments per (sequence, direction),
             # speculated rows that did not verify, the worst mismatch seen; 1 / 0 / 0 where the call is not cut)

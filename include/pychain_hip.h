@@ -96,7 +96,8 @@ void        pychain_hip_set_den_lazy(int on);
  * loads), den_recursion_lazy_kernel (16 waves, rows through registers: option den_dma = 0), den_recursion_pair_kernel (two
  * sequences per workgroup, shared plan, B >= 3/8 of the CU count), den_recursion_kernel (everything else),
  * den_general_recursion_kernel (plans in the general format).  Measurement tools and the kernel-selection test label by it.
- * plans_shared = 1: one plan for all sequences (plan stride 0). */
+ * plans_shared: bit 0 = one plan for all sequences (plan stride 0); bit 1 = the call is a fused loss (a numerator runs beside
+ * it: two sequences per recursion workgroup from B >= 100 on 256 CUs; the denominator alone: once 2 B workgroups no longer fit). */
 int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states, int num_pdfs, int B, int plans_shared,
                                          char* buf, size_t buf_bytes);
 /* Settings.  A call reads them ONCE when it starts (process-wide defaults overlaid with the calling thread's
@@ -115,8 +116,9 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *                    exp'd ahead of them on the side stream (bit-identical)
  *   "den_segments"   n >= 1: the occupancy pass in n gated time segments (1 = after the recursions, no overlap) instead of
  *                    the streamed persistent launch
- *   "den_pair"       "1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: from 25/64 of
- *                    the CU count in sequences on, i.e. B >= 100 on 256 CUs - bit-identical to den_recursion_kernel
+ *   "den_pair"       "1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: a fused loss from 25/64
+ *                    of the CU count in sequences on (B >= 100 on 256 CUs), the denominator alone once 2 B one-sequence
+ *                    workgroups no longer fit the chip (B > 128) - bit-identical to den_recursion_kernel
  *   "gamma16"        the one-frame occupancy kernel (and with it the numerator accumulated into the stored gradient
  *                    instead of folded into the occupancy launch) also where the two-frame kernel fits
  *   "debug_corrupt_row" "den,b,t,scale" / "num,b,t,scale": the stored alpha row t of sequence b is scaled between the

@@ -143,11 +143,11 @@ class option(object):
         return False
 
 
-def den_kernel_names(slot_rows, num_states, num_pdfs, batch, plans_shared=True):
-    """("recursion kernel", "occupancy kernel") a denominator call of this shape would launch."""
+def den_kernel_names(slot_rows, num_states, num_pdfs, batch, plans_shared=True, fused=False):
+    """("recursion kernel", "occupancy kernel") a denominator call of this shape would launch (`fused`: as part of a fused loss)."""
     buf = ctypes.create_string_buffer(128)
     check(lib().pychain_hip_den_kernel_names(int(slot_rows), int(num_states), int(num_pdfs), int(batch),
-                                             int(bool(plans_shared)), buf, 128), "pychain_hip_den_kernel_names")
+                                             int(bool(plans_shared)) | (2 if fused else 0), buf, 128), "pychain_hip_den_kernel_names")
     rec, occ = buf.value.decode().split(",")
     return rec, occ
 

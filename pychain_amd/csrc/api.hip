@@ -127,7 +127,8 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
   memset(&a, 0, sizeof(a));
   a.knobs = call_knobs();
   a.H = H; a.Hp = roundup64(H); a.D = D; a.B = B; a.frames_per_block = 32;
-  a.plan_stride = plans_shared ? 0 : 256;
+  a.plan_stride = (plans_shared & 1) ? 0 : 256;
+  a.fused = (plans_shared & 2) ? 1 : 0;                  // (bit 1: the call is a fused loss)
   if (resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) {
     snprintf(buf, buf_bytes, "den_general_recursion_kernel,den_general_gamma_kernel");
     return PYCHAIN_HIP_OK;
@@ -368,10 +369,12 @@ bool den_call_is_pair(const DenArgs& a, int resident_slot_rows) {
   if (a.knobs.den_pair >= 0) return a.knobs.den_pair != 0;
   // small graphs run in four-wave workgroups, several to a CU: nothing to gain from pairing sequences
   if (a.knobs.den_lazy && den_call_is_small(a, resident_slot_rows)) return false;
-  // measured on the C3 graph, fused step (round 5, 256 CUs): B = 96 one-sequence workgroups 4.40 ms, pairs 4.58; B = 104:
+  // measured on the C3 graph (round 5, 256 CUs).  Fused step: B = 96 one-sequence workgroups 4.40 ms, pairs 4.58; B = 104:
   // 5.36 / 4.58; B = 128: 6.60 / 5.24 - below about 100 sequences the one-sequence workgroups leave enough of the chip to the
-  // occupancy launches and the numerator, and their chain is shorter
-  return 64 * a.B >= 25 * device_cu_count();
+  // occupancy launches and the numerator, and their chain is shorter.  The denominator ALONE has the chip to itself: one-
+  // sequence workgroups while they all fit (B = 104: 3.77 against 4.63 with pairs, 112: 3.95 / 4.62, 128: 4.36 / 4.80)
+  if (a.fused) return 64 * a.B >= 25 * device_cu_count();
+  return 2 * a.B > device_cu_count();
 }
 // the nnet-output rows of the lazy recursions come in by LDS-direct loads (default wherever a lazy shape fits: on the
 // 16-wave map of C3 it is 2 % faster than rows through registers and bit-identical, and it is what makes rows of
@@ -676,19 +679,26 @@ extern "C" int pychain_hip_den_time_segments(int64_t plan_stride_bytes, int resi
   memset(&a, 0, sizeof(a));
   a.plan_stride = plan_stride_bytes; a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H); a.frames_per_block = 32;
   a.knobs = call_knobs();
+  a.fused = fused ? 1 : 0;
   a.check_all = a.knobs.verbose >= 1 ? 1 : 0;
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
   return den_time_segments(a, fused != 0);
 }
-extern "C" int pychain_hip_den_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T) {
+namespace {
+int den_half_native_q(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T, int fused) {
   if (B <= 0 || T <= 0 || H <= 0 || D <= 0) return 0;
   DenArgs a;
   memset(&a, 0, sizeof(a));
   a.plan_stride = plan_stride_bytes; a.B = B; a.T = T; a.D = D; a.H = H; a.Hp = roundup64(H); a.frames_per_block = 32;
   a.knobs = call_knobs();
+  a.fused = fused;
   return den_call_half_native(a, resident_slot_rows) ? 1 : 0;
+}
+}  // namespace
+extern "C" int pychain_hip_den_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T) {
+  return den_half_native_q(plan_stride_bytes, resident_slot_rows, H, D, B, T, 0);
 }
 extern "C" int pychain_hip_num_half_native(int H, int K, int D) {
   if (H <= 0 || K <= 0 || D <= 0) return 0;
@@ -699,11 +709,12 @@ extern "C" int pychain_hip_num_half_native(int H, int K, int D) {
 }
 extern "C" int pychain_hip_chain_loss_half_native(int64_t plan_stride_bytes, int resident_slot_rows, int den_H, int D, int B, int T,
                                                   int num_H, int num_K) {
-  if (!pychain_hip_den_half_native(plan_stride_bytes, resident_slot_rows, den_H, D, B, T) || !pychain_hip_num_half_native(num_H, num_K, D)) return 0;
+  if (!den_half_native_q(plan_stride_bytes, resident_slot_rows, den_H, D, B, T, 1) || !pychain_hip_num_half_native(num_H, num_K, D)) return 0;
   DenArgs a;
   memset(&a, 0, sizeof(a));
   a.plan_stride = plan_stride_bytes; a.B = B; a.T = T; a.D = D; a.H = den_H; a.Hp = roundup64(den_H); a.frames_per_block = 32;
   a.knobs = call_knobs();
+  a.fused = 1;
   a.fold_rows = (const float*)1;                          // (the fold's extra LDS counts: gamma2_lds_bytes)
   return den_uses_gamma2(a, (D + 63) / 64, resident_slot_rows) ? 1 : 0;
 }
@@ -902,6 +913,7 @@ int chain_loss_forward_one(
                      grad ? grad : num_ws, bad_count + 1, num_ws, num_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
 
+  da.fused = 1;
   na.watch_nan = 0;              // the denominator's alpha workgroups watch every element of every row (NumArgs::watch_nan)
   // the scalars of ChainLoss.forward from den_finish_kernel's last workgroup (DenArgs::loss_out)
   da.loss_out = totals; da.loss_num_objf = num_objf; da.loss_scale = loss_scale; da.loss_norm_dev = loss_norm_dev; da.bad_words = 2;
@@ -1151,6 +1163,7 @@ int chain_loss_backward_impl(
                          grad_scale, (float*)den_ws, grad, bad_count, den_ws, den_ws_bytes, who);
   if (rc != PYCHAIN_HIP_OK) return rc;
   da.grad_scale_dev = grad_scale_dev;
+  da.fused = 1;                                          // (the forward call that stored the rows decided as a fused call)
   da.lazy = den_call_is_lazy(da, resident_slot_rows) ? 1 : 0;
   da.shape = da.lazy ? den_call_shape(da, resident_slot_rows) : 0;
   NumArgs na;

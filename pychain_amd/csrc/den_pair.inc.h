@@ -8,7 +8,7 @@
 // fma per arc serve both sequences (an LDS gather costs the same for 8 bytes per lane as for 4).  The
 // recursions of B sequences then take B workgroups instead of 2B, 1.4 times as long each (the serial tail of a
 // frame doubles: profiles/r02_pair_phase_timers.txt), and the other CUs run the occupancy launches and the
-// numerator meanwhile: B = 128 7.58 -> 5.85 ms per fused step.  Chosen by api.hip:den_call_is_pair (B >= 100 on 256 CUs).
+// numerator meanwhile: B = 128 7.58 -> 5.85 ms per fused step.  Chosen by api.hip:den_call_is_pair (a fused loss: B >= 100 on 256 CUs; the denominator alone: B > 128).
 //
 // The arithmetic of a sequence is EXACTLY that of den_recursion_kernel (state vector normalised in place, two
 // barriers per frame; packed fp32 lanes are independent and IEEE): same products, same sums in the same order -

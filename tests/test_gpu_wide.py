@@ -30,13 +30,13 @@ def _den(x, L, den, **opts):
     return float(o.detach()), xx.grad
 
 
-def _names(den, D, B, **opts):
+def _names(den, D, B, fused=False, **opts):
     plan = _plan.graph_plan(den, D, torch.device(DEV))
     ctx = [_lib.option(k, v) for k, v in opts.items()]
     for c in ctx:
         c.__enter__()
     try:
-        return _lib.den_kernel_names(plan.slot_rows, plan.num_states, D, B)
+        return _lib.den_kernel_names(plan.slot_rows, plan.num_states, D, B, fused=fused)
     finally:
         for c in reversed(ctx):
             c.__exit__()
@@ -155,7 +155,8 @@ def test_which_kernel_each_shape_gets():
     cases = [
         # H, K, D, B -> recursion, occupancy
         (3000, 30000, 3456, 64, "den_recursion_lazy_kernel<dma>", "den_gamma2_kernel"),     # C3
-        (3000, 30000, 3456, 128, "den_recursion_pair_kernel", "den_gamma2_kernel"),         # B >= 100: two sequences per workgroup
+        (3000, 30000, 3456, 128, "den_recursion_lazy_kernel<dma>", "den_gamma2_kernel"),    # the denominator alone: one-sequence workgroups while 2 B fit the chip
+        (3000, 30000, 3456, 160, "den_recursion_pair_kernel", "den_gamma2_kernel"),         # ... then two sequences per workgroup
         (200, 2000, 1000, 64, "den_recursion_lazy_kernel<small>", "den_gamma2_kernel"),     # C2: four-wave workgroups
         (20, 60, 40, 2, "den_recursion_lazy_kernel<small>", "den_gamma2_kernel"),           # C1
         (200, 2000, 1000, 256, "den_recursion_lazy_kernel<small>", "den_gamma2_kernel"),    # ... also at batch sizes that pair large graphs
@@ -174,6 +175,11 @@ def test_which_kernel_each_shape_gets():
         assert got[0] == rec, (H, K, D, B, got)
         if occ is not None:
             assert got[1] == occ, (H, K, D, B, got)
+    # a fused loss leaves part of the chip to its numerator: pairs from B = 100 on (256 CUs)
+    den = syn.make_den_graph(3000, 30000, 3456, seed=1)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert _names(den, 3456, (25 * cus + 63) // 64, fused=True)[0] == "den_recursion_pair_kernel"
+    assert _names(den, 3456, (25 * cus + 63) // 64 - 4, fused=True)[0] == "den_recursion_lazy_kernel<dma>"
 
 
 def test_structured_phone_lm_like_graph_vs_oracle():
