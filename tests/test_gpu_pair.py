@@ -1,4 +1,4 @@
-"""den_recursion_pair_kernel (two sequences per recursion workgroup, csrc/den_pair.inc.h; chosen from B = 128 on,
+"""den_recursion_pair_kernel (two sequences per recursion workgroup, csrc/den_pair.inc.h; chosen in a fused loss from B = 100 on 256 CUs, in a call of the denominator alone from B > 128;
 option den_pair forces it) against den_recursion_kernel: the arithmetic of a sequence is the same, operation by
 operation, so objective and gradient must agree BIT FOR BIT - for equal and unequal partners, an odd batch, a
 one-frame sequence, every time-segment schedule - and the `ok` conditions must hit the right sequence."""
