@@ -295,8 +295,8 @@ __device__ __forceinline__ void normalise_row(bool fwd, const float* raw, const 
       }
       v = make_float4(r.x * inv + cl.x, r.y * inv + cl.y, r.z * inv + cl.z, r.w * inv + cl.w);
     } else {
-      // (r + add) * inv as one fma per element; a position whose leaky probability has the sign bit set takes no constant
-      // (a state's second lane, padding: plan.cpp, "states on several lanes")
+      // (r + add) * inv as one fma per element; a position whose leaky probability has the sign bit set takes no constant (a
+      // state's lanes after its first - plan.cpp, "states on several lanes" -, marked by the kernel before the first frame)
       const float ai = add * inv;
       const float4 l = *reinterpret_cast<const float4*>(lk + i);
       auto gate = [&](float lv) { return __uint_as_float(__float_as_uint(ai) & ~(uint32_t)((int32_t)__float_as_uint(lv) >> 31)); };

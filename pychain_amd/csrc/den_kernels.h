@@ -30,9 +30,9 @@ struct DenArgs {
   // b(t,.) + c(t), each in a per-frame scale of its own; 0: as den_recursion_kernel (rows normalised).  The
   // occupancy kernels read either form as it is; den_finish_kernel needs to know which scales were divided out.
   int lazy;
+  int fused;                  // the call is a fused loss (a numerator runs beside it): api.hip decides pair / time segments by it
   // 1: the recursions run as den_recursion_pair_kernel (den_pair.inc.h): two sequences per workgroup, ceil(B/2)
   // workgroups per direction; rows as den_recursion_kernel stores them (lazy = 0).  Shared plan only.
-  int fused;                  // the call is a fused loss (a numerator runs beside it): api.hip decides pair / time segments by it
   int pair;
   // which shape the lazy recursions run in (den_lazy.inc.h): kShapeRegs = LzNarrow (16 waves, D <= 4096, rows through
   // registers), kShapeDma = LzNarrowDma / LzDma (16 waves, rows by LDS-direct loads, up to 9216 pdfs), kShapeSmall = LzSmall
