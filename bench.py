@@ -37,6 +37,12 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [REPO, os.path.join(REPO, "oracle")]
+# A step of the loss runs on three streams (the caller's and two side streams); RCCL's collectives add a fourth.  The HIP runtime
+# maps streams onto FOUR hardware queues by default, and a stream of the loss that shares its queue with RCCL's serialises behind
+# it: measured on MI355X with the step's 12-byte all-reduce forced through RCCL in a world of one, 4.21 ms per step against 3.08
+# without the collective - and 3.15 ms with 16 queues (profiles/r06_rccl_one_rank.txt).  Read by the runtime when it initialises:
+# set before anything touches the device (pychain_amd does the same on import where it is imported early enough).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -65,6 +71,10 @@ def parse():
                     help="test mode for boxes with fewer GPUs than ranks: rank r runs on GPU r %% (visible GPUs) and the collectives go "
                          "over gloo (device tensors through the host) - the sharded GPU path in N processes without N GPUs; never a "
                          "scaling measurement (tests/test_gpu_configs.py)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="under a launcher with ONE rank (torch.distributed.run --nproc-per-node 1): initialise RCCL and run the step's "
+                         "all-reduce of [objf, frames, bad] although the world is one - the real library beside the loss's side streams "
+                         "and spin-wait kernels on a box with a single GPU (tests/test_gpu_configs.py)")
     ap.add_argument("--no-fresh-num-graphs", action="store_true",
                     help="skip the host-side leg: a fresh numerator ChainGraphBatch per step, as a trainer builds it")
     return ap.parse_args()
@@ -96,7 +106,28 @@ def event_time_ms(fn, iters, stream):
     return sum(s.elapsed_time(e) for s, e in zip(start, stop)) / iters
 
 
-def kernel_rooflines(w, dev, iters, d2d=True):
+def step_roofline(workload, frames, step_ms):
+    """`roofline.step`: the fused step's algorithmic bytes / counter bytes / their ratio, from the newest committed
+    profiles/r*_<workload>_step_hbm_traffic.json of this very workload (labelled, not re-measured), over the step time of THIS run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_step_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+            if tj.get("workload") == workload and tj.get("frames") == frames:
+                algo, cnt = int(tj["algorithmic_bytes_per_call"]), int(tj["hbm_bytes_per_call"])
+                return {"algorithmic_bytes": algo, "traffic": cnt, "traffic_over_algorithmic": round(cnt / algo, 3),
+                        "ms": round(step_ms, 4),
+                        "achieved": round(algo / (step_ms * 1e-3) / 1e9, 2), "frac": round(algo / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic_GBps": round(cnt / (step_ms * 1e-3) / 1e9, 1), "traffic_frac_of_peak": round(cnt / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "per_kernel_traffic": {k: v["hbm_bytes_per_call"] for k, v in tj.get("kernels", {}).items() if v["hbm_bytes_per_call"] >= (1 << 20)},
+                        "traffic_source": "profiles/" + os.path.basename(path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same step; not re-measured in this run)"}
+        except Exception:
+            continue
+    return {"traffic": None}
+
+
+def kernel_rooflines(w, dev, iters, d2d=True, step_ms=None):
     """Per-kernel launch time of the denominator, each launch isolated with the phase mask."""
     from pychain_amd import _lib, _plan, native
     L = _lib.lib()
@@ -184,6 +215,10 @@ def kernel_rooflines(w, dev, iters, d2d=True):
             roof["other_kernels"].update(numerator_rooflines(w, plan, dev, iters, stream))
         except Exception as e:          # a context figure: never lose the bench line to it
             roof["other_kernels"]["numerator"] = {"error": str(e)[:200]}
+    # the WHOLE fused step: algorithmic bytes (denominator 12 D + 8 (H + 1), numerator 8 U_n + 8 (H_n + 1) per
+    # live frame) against the counter bytes of every kernel of the step from the committed PMC passes (tools/profile_round6.sh)
+    if fused and step_ms:
+        roof["step"] = step_roofline(cfg.get("name"), frames, step_ms)
     # context: what a plain device-to-device copy reaches on this box
     if not d2d:
         return roof
@@ -231,7 +266,7 @@ def numerator_rooflines(w, plan, dev, iters, stream):
             "numerator_forward_backward": mk(ms_all, bytes_fb + bytes_occ)}
 
 
-def _adhoc_workload(name, B, dev, equal=False, den_only=False, dtype=None, structured=False):
+def _adhoc_workload(name, B, dev, equal=False, den_only=False, dtype=None, structured=False, num_compat=False):
     """BASELINE config `name`, optionally at another batch size (same graph, ragged lengths drawn for B), with all
     sequences of the full length (`equal`), without numerators (`den_only`), with a 2-byte network output (`dtype`)."""
     from pychain_amd import synthetic as syn
@@ -284,6 +319,9 @@ def other_workloads(dev, steps=6, warmup=3):
     for label, name, B, kw in (("C4", "C4", None, {}), ("C2", "C2", None, {}), ("C3-equal", "C3", None, dict(equal=True, den_only=True)),
                                ("C3-bf16", "C3", None, dict(dtype=torch.bfloat16)),
                                ("C3-structured", "C3", None, dict(structured=True)),
+                               # the configuration that meets the LITERAL 1e-4 against the reference at benchmark length (option
+                               # num_compat: the numerator in the reference's own fp32 arithmetic, a checking mode - DESIGN.md §3.10)
+                               ("C3-num_compat", "C3", None, dict(num_compat=True)),
                                # few sequences: the recursions are cut into time segments
                                ("C3@B=16", "C3", 16, {}), ("C3@B=32", "C3", 32, {}),
                                ("C3@B=128", "C3", 128, {}), ("C3@B=256", "C3", 256, {})):
@@ -295,20 +333,27 @@ def other_workloads(dev, steps=6, warmup=3):
             crit = ChainLoss(w["den_graph"], 1e-5, avg=False)
             gb = ChainGraphBatch(w["den_graph"], cfg["B"])
 
+            last = {}
+
             def step():
                 x.grad = None
                 if w["num_graphs"] is not None:
-                    crit(x, w["lengths_dev"], w["num_graphs"]).backward()
+                    last["loss"] = crit(x, w["lengths_dev"], w["num_graphs"])
                 else:
-                    ChainFunction.apply(x, w["lengths_dev"], gb, 1e-5).backward()
-            for _ in range(warmup):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / steps * 1e3
+                    last["loss"] = ChainFunction.apply(x, w["lengths_dev"], gb, 1e-5)
+                last["loss"].backward()
+            import contextlib
+            compat = bool(kw.get("num_compat"))
+            nsteps = 2 if compat else steps                       # (a ~40 ms per sequence-slice checking mode: two steps state its cost)
+            with (_lib.option("num_compat", 1) if compat else contextlib.nullcontext()):
+                for _ in range(1 if compat else warmup):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(nsteps):
+                    step()
+                torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / nsteps * 1e3
             frames = int(w["lengths"].sum())
             plan = _plan.graph_plan(w["den_graph"], cfg["D"], dev)
             rec, occ = _lib.den_kernel_names(plan.slot_rows, plan.num_states, cfg["D"], cfg["B"], fused=bool(cfg["num"]))
@@ -317,7 +362,7 @@ def other_workloads(dev, steps=6, warmup=3):
             # speculated rows that did not verify, the worst mismatch seen; 1 / 0 / 0 where the call is not cut)
             fused_call = w["num_graphs"] is not None
             tsegs = int(_lib.lib().pychain_hip_den_time_segments(plan.stride, plan.slot_rows, plan.num_states, cfg["D"], cfg["B"], cfg["T"], int(fused_call)))
-            tot8 = ChainFunction.last_totals_all.detach().float().cpu().tolist() if getattr(ChainFunction, "last_totals_all", None) is not None else None
+            tot8 = last["loss"].totals_all.detach().float().cpu().tolist() if getattr(last["loss"], "totals_all", None) is not None else None
             call = lambda: native.den_forward_backward(plan, w["x"].detach(), w["lengths_dev"], 1e-5)
             parts = {}
             import contextlib
@@ -333,18 +378,20 @@ def other_workloads(dev, steps=6, warmup=3):
             out[label] = {
                 "workload": "%s: B=%d T<=%d (%d frames), %d pdfs, den %d states/%d arcs%s%s"
                             % (name, cfg["B"], cfg["T"], frames, cfg["D"], cfg["H"], cfg["K"], " + numerators" if cfg["num"] else ", denominator only",
-                               ", %s network output and gradient" % str(w["x"].dtype).replace("torch.", "") if half else ""),
+                               (", %s network output and gradient" % str(w["x"].dtype).replace("torch.", "") if half else "") +
+                               (", numerator in the reference's own fp32 arithmetic (option num_compat: within 1e-4 of the reference at "
+                                "this length, tests/test_gpu_compat.py)" if compat else "")),
                 # the [B,T,D] fp32 buffer of the rows exp'd ahead of the recursions: only calls of the denominator alone
                 "rows_exp_ahead_workspace_bytes": 4 * cfg["B"] * cfg["T"] * cfg["D"] if uses_rows else 0,
-                "ms_per_step": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1), "steps": steps,
+                "ms_per_step": round(ms, 4), "frames_per_s": round(frames / ms * 1e3, 1), "steps": nsteps,
                 "recursion_kernel": rec, "occupancy_kernel": occ,
                 "time_segments": tsegs,
                 "splices_redone": None if tot8 is None else int(tot8[5]), "worst_splice_mismatch": None if tot8 is None else tot8[7],
                 "recursion_ms": round(parts["recursion_ms"], 4), "occupancy_ms": round(parts["occupancy_ms"], 4),
                 "den_forward_backward": dict({"algorithmic_bytes": den_bytes, "ms": round(parts["den_ms"], 4),
                                               "frac": round(den_bytes / (parts["den_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                                             **_committed_call_traffic(name if not kw else label, frames, den_bytes)),
-                "n_bad": int(ChainFunction.last_bad_count.sum()),
+                                             **_committed_call_traffic(label, frames, den_bytes)),
+                "n_bad": int(last["loss"].bad_count.sum()),
             }
             del w, x, crit, gb
         except Exception as e:          # context figures: never lose the bench line to them
@@ -618,7 +665,8 @@ def main():
         gpu = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
         torch.cuda.set_device(gpu)
         dev = torch.device("cuda", gpu)
-    if world > 1:
+    use_dist = world > 1 or (args.force_collective and "WORLD_SIZE" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry or args.share_gpu:
             dist.init_process_group("gloo")
@@ -631,7 +679,7 @@ def main():
     cfg = w["cfg"]
     x = w["x"].requires_grad_(True)
     loss_cls = _DryLoss if dry else (None if cfg["num"] else _DenOnlyLoss)
-    loss_fn = ShardedChainLoss(w["den_graph"], 1e-5, avg=False, loss_cls=loss_cls)
+    loss_fn = ShardedChainLoss(w["den_graph"], 1e-5, avg=False, loss_cls=loss_cls, force_collective=use_dist and world == 1)
     local_frames = int(w["lengths"].sum())
     lengths_step = w["lengths"] if dry else w["lengths_dev"]
 
@@ -644,7 +692,7 @@ def main():
     def fence():
         if not dry:
             torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=None if (dry or args.share_gpu) else [local_rank])
         if not dry:
             torch.cuda.synchronize()
@@ -702,7 +750,8 @@ def main():
         config = {"workload": "dry run (no kernels): " + workload_label(args, cfg, world, local_frames, global_frames) if dry
                   else workload_label(args, cfg, world, local_frames, global_frames),
                   "global_batch": cfg["B_global"], "parallelism": "utterance-sharded dp%d" % world,
-                  "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" if world > 1 else "none"}
+                  "collective": "1 all_reduce(SUM) of 3 fp32 scalars per step" + (" (forced: a world of one under a launcher, RCCL)" if world == 1 else "")
+                                if use_dist else "none"}
         if dry:
             # what only a CPU run can afford: the whole global batch in ONE process against the sharded sum
             from pychain_amd import synthetic as syn
@@ -718,7 +767,8 @@ def main():
                 "per_rank": per_rank_out, "sharding": sharding, "config": config}))
         else:
             # (N > 1: the other ranks idle in a barrier behind this: 3 launches per kernel there, ~50 ms)
-            roof = None if args.no_rooflines else kernel_rooflines(w, dev, 3 if world > 1 else max(3, min(args.steps, 10)), d2d=world == 1)
+            roof = None if args.no_rooflines else kernel_rooflines(w, dev, 3 if world > 1 else max(3, min(args.steps, 10)), d2d=world == 1,
+                                                                   step_ms=dt / args.steps * 1e3 if world == 1 else None)
             out = {
                 "metric": "LF-MMI frames/sec (fwd+bwd)", "value": round(total_frames * args.steps / dt, 1),
                 "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -748,7 +798,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_sample)
             print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=None if (dry or args.share_gpu) else [local_rank])
         dist.destroy_process_group()
 

@@ -6,7 +6,10 @@
  *
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include examples/c_abi_client.c \
  *       -L pychain_amd -lpychain_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/pychain_amd -Wl,-rpath,/opt/rocm/lib -o c_abi_client
- *   ./c_abi_client problem.bin result.bin
+ *   ./c_abi_client problem.bin result.bin [calls]
+ * `calls` > 1 repeats the minibatch call (a training loop's pattern) and prints one line per call with what totals[5..7] report
+ * about its time segments; the plan carries a burn-in controller state (pychain_hip_den_tseg_state), so data that forgets
+ * slowly costs a C caller one redone call, not every call.
  *
  * problem.bin (little endian; written by tests/test_c_client.py from pychain_amd.synthetic):
  *   int32 B, T, D, H, K, Hn, Kn, fused;  float leaky
@@ -41,7 +44,8 @@ static void* to_device(const void* host, size_t bytes) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 3) { fprintf(stderr, "usage: %s problem.bin result.bin\n", argv[0]); return 1; }
+  if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s problem.bin result.bin [calls]\n", argv[0]); return 1; }
+  const int calls = argc == 4 ? atoi(argv[3]) : 1;
   if (pychain_hip_abi_version() != PYCHAIN_HIP_ABI_VERSION) { fprintf(stderr, "header / library ABI mismatch\n"); return 1; }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 1; }
@@ -65,6 +69,11 @@ int main(int argc, char** argv) {
   CHECK_LIB(pychain_hip_den_plan_info(blob, (size_t)need, info));
   const int positions = info[0], hint = info[4];      /* positions: what the calls take as num_states (>= H: a state may sit on several lanes) */
   void* plan_dev = to_device(blob, (size_t)need);
+  /* the plan's burn-in controller: 64 bytes of device memory, zeroed once, attached by plan address (ABI 16) */
+  void* tstate = NULL;
+  CHECK_HIP(hipMalloc(&tstate, pychain_hip_den_tseg_state_bytes()));
+  CHECK_HIP(hipMemset(tstate, 0, pychain_hip_den_tseg_state_bytes()));
+  CHECK_LIB(pychain_hip_den_tseg_state(plan_dev, tstate));
 
   /* ---- per minibatch */
   void* x_dev = to_device(x, nx * 4);
@@ -80,8 +89,16 @@ int main(int argc, char** argv) {
   if (!fused) {
     const size_t wsb = pychain_hip_den_workspace_bytes(B, T, positions, D);
     void* ws; CHECK_HIP(hipMalloc(&ws, wsb));
-    CHECK_LIB(pychain_hip_den_forward_backward(plan_dev, 0, hint, positions, D, x_dev, PYCHAIN_HIP_F32, 0, len_dev, B, T, leaky, 1.0f,
-                                               den_objf, grad, bad, totals, ws, wsb, st));
+    for (int c = 0; c < calls; c++) {
+      CHECK_LIB(pychain_hip_den_forward_backward(plan_dev, 0, hint, positions, D, x_dev, PYCHAIN_HIP_F32, 0, len_dev, B, T, leaky, 1.0f,
+                                                 den_objf, grad, bad, totals, ws, wsb, st));
+      if (calls > 1) {                                  /* (a trainer would not sync here: the state lives on the device) */
+        float t8[PYCHAIN_HIP_TOTALS]; int32_t ts[5];
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(t8, totals, sizeof(t8), hipMemcpyDeviceToHost)); CHECK_HIP(hipMemcpy(ts, tstate, sizeof(ts), hipMemcpyDeviceToHost));
+        printf("call %d: segments %d rows_missed %d worst_mismatch %.3g next_burn_in %d cooling_down %d\n", c, (int)t8[6], (int)t8[5], t8[7], ts[1], ts[2]);
+      }
+    }
   } else {
     int32_t* nft = read_n(f, (size_t)B * Kn * 12); int32_t* nfi = read_n(f, (size_t)B * Hn * 8); float* nfp = read_n(f, (size_t)B * Kn * 4);
     int32_t* nbt = read_n(f, (size_t)B * Kn * 12); int32_t* nbi = read_n(f, (size_t)B * Hn * 8); float* nbp = read_n(f, (size_t)B * Kn * 4);
@@ -98,6 +115,7 @@ int main(int argc, char** argv) {
                                                       1.0f, NULL, totals, dws, dwb, nws, nwb, st));
   }
   CHECK_HIP(hipStreamSynchronize(st));
+  CHECK_LIB(pychain_hip_den_tseg_state(plan_dev, NULL));
   fclose(f);
 
   FILE* o = fopen(argv[2], "wb");

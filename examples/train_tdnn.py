@@ -20,6 +20,10 @@ import argparse
 import os
 import sys
 
+# (more hardware queues than the runtime's default of four: the loss's three streams must not share one with RCCL's - a trainer
+# that overlaps collectives with the loss loses a third of its step otherwise; bench.py, INTEGRATION.md "Streams and queues")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -59,6 +63,10 @@ def main():
     ap.add_argument("--max-num-states", type=int, default=80)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" is RCCL on ROCm')
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
+    ap.add_argument("--force-collective", action="store_true",
+                    help="ONE rank under a launcher (torch.distributed.run --nproc-per-node 1): initialise the backend, wrap the model in "
+                         "DDP and run the loss's all-reduce although the world is one - RCCL beside the loss's side streams and "
+                         "spin-wait kernels on a box with a single GPU")
     ap.add_argument("--loss-cls", default=None,
                     help="module:Class of a ChainLoss(den_graph, leaky, avg=False) stand-in for the per-rank loss")
     args = ap.parse_args()
@@ -72,7 +80,8 @@ def main():
         dev = torch.device("cuda", gpu)
     else:
         dev = torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or (args.force_collective and "WORLD_SIZE" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.device == "cuda" and args.backend == "nccl":
             dist.init_process_group(args.backend, device_id=dev)
@@ -86,11 +95,11 @@ def main():
 
     torch.manual_seed(0)
     model = TDNN(args.feat_dim, args.hidden, args.pdfs).to(dev)
-    if world > 1:
+    if use_dist:
         model = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if args.device == "cuda" else None)
     opt = torch.optim.AdamW(model.parameters(), lr=args.lr)
     den_graph = syn.make_den_graph(args.states, args.arcs, args.pdfs, seed=0)      # the shared "phone LM"
-    criterion = ShardedChainLoss(den_graph, leaky_coefficient=1e-5, avg=True, loss_cls=loss_cls)
+    criterion = ShardedChainLoss(den_graph, leaky_coefficient=1e-5, avg=True, loss_cls=loss_cls, force_collective=use_dist and world == 1)
 
     # a fixed synthetic training set per rank: features correlated with the numerator alignment
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
@@ -107,6 +116,8 @@ def main():
         if step == 0:
             first = float(loss)
         last = float(loss)
+        if args.device == "cuda" and int(criterion.last_stats[2]) != 0:
+            raise SystemExit("a kernel of the loss gave up or saw a bad value (bad count %d)" % int(criterion.last_stats[2]))
         if rank == 0 and (step % 5 == 0 or step == args.steps - 1):
             print("step %3d  LF-MMI loss per frame %.4f" % (step, last), flush=True)
     # the loss value is the GLOBAL one on every rank (ShardedChainLoss: one 3-float all-reduce per step)
@@ -115,7 +126,9 @@ def main():
         print("loss %.4f -> %.4f over %d steps on %d %s" % (first, last, args.steps, world,
                                                              "GPU(s)" if args.device == "cuda" else "CPU rank(s)"))
         assert last < first, "the loss did not go down"
-    if world > 1:
+        if use_dist:
+            print("collective backend %s, world %d%s" % (dist.get_backend(), world, " (forced)" if world == 1 else ""))
+    if use_dist:
         dist.destroy_process_group()
 
 

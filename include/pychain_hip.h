@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 15
+#define PYCHAIN_HIP_ABI_VERSION 16
 
 /* Element type of the network output [B,T,D] - and of the gradient an entry point writes for it (ABI 14).
  * 2-byte rows are read as they are by the kernels and converted where they land; the gradient is rounded (to nearest even)
@@ -127,7 +127,9 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "num_compat"     "1": the numerator in the reference's own fp32 arithmetic (num_compat.hip) instead of the exact path
  *   "den_tseg"       time segments per (sequence, direction) of the lazy recursions: unset / "-1" automatic (few sequences
  *                    only: pychain_hip_den_time_segments), "0": never, "2" / "4": wherever the shape allows
- *   "den_tburn"      frames a time segment starts outside itself (default 192); see totals[5..7]
+ *   "den_tburn"      frames a time segment starts outside itself (default 192); see totals[5..7] and pychain_hip_den_tseg_state
+ *   "den_sg"         "0": a "pdf by state" plan (every arc entering a state carries one pdf: pychain_hip_den_plan_info, hint bit 27) runs
+ *                    the recursions every plan runs instead of their one-gather form (the tests compare the two)
  *   "chain_slices"   the fused loss with a gradient over a batch larger than the chip: "0" one call, "n" n slices; default automatic
  *   "plan_split"     read by pychain_hip_den_plan_build: "0": no state on more than one lane; default: where it gains a
  *                    shorter register-resident loop
@@ -245,9 +247,24 @@ size_t pychain_hip_den_workspace_min_bytes(int B, int T, int num_states, int num
  * output (1.3 GB at C3) for calls that never touch it (pair / general / two-barrier kernels, T < 64, exp'd input, a recursion
  * grid that leaves less than a quarter of the chip free). */
 /* How many time segments the recursions of a (sequence, direction) of such a call are cut into (1: not cut; `fused`: the
- * call is a fused loss - half of the chip stays with the numerator).  totals[5..7] of the call report how the cut went; a
- * caller that sees totals[5] > 0 repeatedly (its data forgets slowly) should raise option den_tburn or set den_tseg = 0. */
+ * call is a fused loss - a quarter of the chip stays with the numerator).  totals[5..7] of the call report how the cut went.
+ * A function of the shape, the device's CU count and the options den_tseg / den_tburn only - NOT of the verbose level (a debug
+ * run computes what production computes).  A cut call's results differ from the uncut call's within the fp32 noise of two
+ * recursions (objf bit-equal, gradient ~2e-7), and which shapes are cut depends on B and the CU count: option den_tseg = "0" is
+ * the ONE switch for training that must reproduce bit for bit across batch shapes and devices. */
 int pychain_hip_den_time_segments(int64_t plan_stride_bytes, int resident_slot_rows, int num_states, int num_pdfs, int B, int T, int fused);
+/* The burn-in controller of a plan (ABI 16).  How long a recursion needs to forget where it started depends on
+ * the DATA (peaky network outputs forget slowly), and a call whose speculated rows do not verify runs its recursions twice.
+ * state_dev: pychain_hip_den_tseg_state_bytes() (64) bytes of DEVICE memory the caller owns and has zeroed ONCE; attached to the
+ * plan by address (NULL detaches; detach before freeing either).  Every time-segmented call on that plan then reads its burn-in
+ * from the state and the call's last kernel updates it - in stream order, on the device: after a call that missed, the burn-in
+ * is half as long again while three of them fit T; beyond that the plan is not cut for the next 500 calls (the segmented launch
+ * leaves at once, the uncut launch behind it does the work) and starts over from the default.  No host read, no host timing:
+ * the burn-in of call n is a function of the calls before it on the stream - the same run gives the same bits.  Callers that
+ * pin "den_tseg" or "den_tburn" with an option bypass the state.  int32 words: [0] magic, [1] burn-in, [2] cool-down calls left,
+ * [3] calls seen, [4] calls that missed.  One state per plan AND stream if calls on one plan overlap on several streams. */
+int pychain_hip_den_tseg_state(const void* plans_dev, void* state_dev);
+size_t pychain_hip_den_tseg_state_bytes(void);
 int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int resident_slot_rows, int num_states, int num_pdfs,
                                     int B, int T, int input_is_exp);
 int pychain_hip_den_forward_backward(
@@ -281,6 +298,10 @@ int pychain_hip_den_half_native(int64_t plan_stride_bytes, int resident_slot_row
 #define PYCHAIN_HIP_GRAD_LOG    0
 #define PYCHAIN_HIP_GRAD_LINEAR 1
 #define PYCHAIN_HIP_GRAD_ACCUM  2
+/* pychain_hip_cpu_num_forward_backward only, OR-ed into grad_mode: the network output is taken AS IT IS - the contract of
+ * pychain_C.forward_backward_log_domain, whose C++ does not clamp (chain-log-domain-computation.cc:137-145; the reference
+ * clamps in Python, pychain/loss.py:30).  Without it the host twin applies ChainFunction's clamp(-30, 30) itself. */
+#define PYCHAIN_HIP_CPU_NO_CLAMP 0x100
 size_t pychain_hip_num_workspace_bytes(int B, int T, int num_states, int num_transitions, int num_pdfs);
 int pychain_hip_num_forward_backward(
     const int32_t* forward_transitions,         /* dev [G,K,3] */
@@ -423,6 +444,10 @@ int pychain_hip_chain_loss_half_native(int64_t plan_stride_bytes, int resident_s
  * (fp64 accumulation, rounded once).  num_objf_per_seq may be NULL (denominator only).  All pointers on the device. */
 int pychain_hip_loss_total(const float* den_objf_per_seq, const float* num_objf_per_seq, int B, float scale,
                            const float* norm_dev, float* out, void* stream);
+/* NOT after a forward call that wrote its gradient in slices (a batch of >= 7/8 of the CU count with `grad` given:
+ * pychain_hip_chain_loss_slices > 1): the workspaces then hold the LAST slice's trajectories only, and this call fails with
+ * PYCHAIN_HIP_EUNSUPPORTED instead of writing a wrong gradient (the library remembers, by workspace address, which forward
+ * call last wrote a workspace). */
 int pychain_hip_chain_loss_backward(
     const void* plans_dev, int64_t plan_stride_bytes, int resident_slot_rows, int den_num_states,
     const int32_t* forward_transitions, const int32_t* forward_transition_indices,

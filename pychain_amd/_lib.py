@@ -10,10 +10,11 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 15
+ABI_VERSION = 16
 TOTALS = 8            # floats of a `totals` buffer (include/pychain_hip.h: PYCHAIN_HIP_TOTALS)
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
+CPU_NO_CLAMP = 0x100     # (host twin of the numerator only: include/pychain_hip.h)
 F32, BF16, F16 = 0, 1, 2        # include/pychain_hip.h: PYCHAIN_HIP_F32 / _BF16 / _F16
 
 _lib = None
@@ -58,6 +59,8 @@ _SIGNATURES = {
     "pychain_hip_cpu_calls": (ctypes.c_long, []),
     "pychain_hip_cpu_den_forward_backward": (_i, [_vp] * 9 + [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _i]),
     "pychain_hip_cpu_num_forward_backward": (_i, [_vp] * 8 + [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i]),
+    "pychain_hip_den_tseg_state": (_i, [_vp, _vp]),
+    "pychain_hip_den_tseg_state_bytes": (_sz, []),
     "pychain_hip_rescale": (_i, [_vp, _i, _sz, _vp, _vp]),
     "pychain_hip_loss_total": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "pychain_hip_chain_loss_backward": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _i,
@@ -104,7 +107,7 @@ def lib():
     return _lib
 
 
-OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices")
+OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg")
 
 _thread_values = threading.local()       # what this thread's overrides currently are (for restoring)
 

@@ -27,6 +27,21 @@ class DevicePlan(object):
 
     def __init__(self, blob, stride, slot_rows, num_states):
         self.blob, self.stride, self.slot_rows, self.num_states = blob, int(stride), int(slot_rows), int(num_states)
+        # the plan's burn-in controller (include/pychain_hip.h: pychain_hip_den_tseg_state): 64 bytes on the device, zeroed once,
+        # attached by plan address - the kernels of a time-segmented call read and update it in stream order, nothing on the
+        # host ever reads it.  Detached when the plan goes.
+        self.tseg_state = None
+        if blob.is_cuda and self.stride == 0:
+            self.tseg_state = torch.zeros(int(_lib.lib().pychain_hip_den_tseg_state_bytes()) // 4, dtype=torch.int32, device=blob.device)
+            _lib.check(_lib.lib().pychain_hip_den_tseg_state(blob.data_ptr(), self.tseg_state.data_ptr()), "pychain_hip_den_tseg_state")
+            self._attached = blob.data_ptr()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_attached", None):
+                _lib.lib().pychain_hip_den_tseg_state(self._attached, None)
+        except Exception:          # (interpreter shutdown)
+            pass
 
 
 def _np(t, dtype):
@@ -98,7 +113,7 @@ def plan_info(blob):
 # ($PYCHAIN_PLAN_CACHE_DIR, default ~/.cache/pychain_amd/plans, created 0700; "0" / "off" disables).  Writes are
 # atomic (temp file + rename): ranks racing on one graph all end up with the same bytes.  A file is only
 # believed if its header matches the request AND its payload matches the checksum in the header.
-_KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_SPLIT")
+_KNOBS = ("PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT", "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_SPLIT", "PYCHAIN_PLAN_GAMMA_BOUND", "PYCHAIN_PLAN_SG")
 
 
 def _cache_dir():

@@ -29,7 +29,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
-                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices"};
+                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -71,6 +71,7 @@ CallKnobs call_knobs() {
   k.den_tburn = option_int("den_tburn", 192);
   k.plan_split = option_int("plan_split", -1);
   k.chain_slices = option_int("chain_slices", -1);
+  k.den_sg = option_int("den_sg", 1) ? 1 : 0;
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
@@ -136,6 +137,7 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
+  a.sg = (a.lazy && a.shape == kShapeDma && den_sg_eligible(a, resident_slot_rows)) ? 1 : 0;
   snprintf(buf, buf_bytes, "%s,%s", den_recursion_kernel_name(a, resident_slot_rows),
            den_occupancy_kernel_name(a, (D + 63) / 64, resident_slot_rows));
   return PYCHAIN_HIP_OK;
@@ -187,8 +189,8 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (m > 1023) m = 1023;
   if (gmm > 1023) gmm = 1023;
   if (gm2 > 1023) gm2 = 1023;
-  // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (10 bits) << 10 | occupancy rows, 8 waves (8 bits) << 20
-  if (gm2 > 255) gm2 = 255;
+  // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (10 bits) << 10 | occupancy rows, 8 waves (7 bits) << 20
+  if (gm2 > 127) gm2 = 127;                        // (7 bits since plan format 14; the two-frame kernel keeps at most 64 rows per wave)
   // bit 29: the plan holds the recursion tiles dealt to FOUR waves (small graphs: den_recursion_lazy_kernel<small>); the
   // recursion field is then the row count of THAT dealing (>= the 16-wave one: a kernel sized by it fits either)
   const bool small = hd->alpha4.nwaves == PLAN_REC4_WAVES && hd->beta4.nwaves == PLAN_REC4_WAVES &&
@@ -201,6 +203,8 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   // bit 28: a state sits on several positions of the beta numbering (plan.cpp, "states on several lanes"): not for
   // den_recursion_pair_kernel, whose normalise pass gives every position the constant c(t)
   if (hd->n_no_const > 0) info[4] |= 1 << 28;
+  // bit 27: "pdf by state" - every arc entering a state carries one pdf: the lazy recursions' one-gather form (den_lazy.inc.h: SG)
+  if (hd->flags & PLAN_FLAG_PDF_BY_STATE) info[4] |= 1 << 27;
   info[6] = hd->graph_states;                     // the graph's states (info[0]: positions of the longer side = what calls pass as num_states)
   info[7] = hd->H - hd->graph_states;            // positions added by states on several lanes (the longer side)
   return PYCHAIN_HIP_OK;
@@ -221,6 +225,7 @@ extern "C" size_t pychain_hip_den_workspace_bytes(int B, int T, int H, int D) {
 }
 
 namespace {
+int32_t* tstate_of(const void* plans_dev);
 int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, int hint, int H, int D,
                   const void* nnet_output, int x_dtype, int input_is_exp, const int64_t* seq_lengths,
                   int B, int T, float leaky_hmm_coefficient, float grad_scale,
@@ -276,6 +281,8 @@ int fill_den_args(DenArgs& a, const void* plans_dev, int64_t plan_stride_bytes, 
   // (behind everything else, and only in a workspace of the full size: DenArgs::ex)
   a.splice = (float*)((char*)a.fin_dot + align256(8 * (size_t)B) + 256);
   a.redo = a.progress + 48; a.redo_if = 0; a.tseg = 0; a.tburn = 0;
+  // (the plan's burn-in controller, unless the caller pins the cut or the burn-in with an option of its own)
+  a.tstate = (option_set("den_tseg") || option_set("den_tburn")) ? nullptr : tstate_of(plans_dev);
   a.ex = workspace_bytes >= pychain_hip_den_workspace_bytes(B, T, H, D) ? (float*)((char*)a.splice + align256(4 * (size_t)B * 2 * kMaxTimeSegs * 2 * a.Hp)) : nullptr;
   a.lazy = 0;
   a.check = 0; a.check_all = a.knobs.verbose >= 1 ? 1 : 0;
@@ -401,7 +408,9 @@ bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows) {
 // B = 64 is never cut (CU-time-bound: DESIGN.md §4); the denominator alone at B = 64 runs two segments, C4 (B = 32) four.
 int den_time_segments(const DenArgs& a, bool fused) {
   const int want = a.knobs.den_tseg;
-  if (want == 0 || want == 1 || !a.lazy || a.shape != kShapeDma || a.check_all) return 1;
+  // (not a function of the verbose level: a debug run computes what production computes - ADVICE r5; the per-frame check of
+  // verbose >= 1 reads the totals and occupancy sums a cut call stores like an uncut one)
+  if (want == 0 || want == 1 || !a.lazy || a.shape != kShapeDma) return 1;
   const int burn = a.knobs.den_tburn;
   if (burn < 1) return 1;
   // (a fused call: a quarter of the chip stays with the numerator - measured on 256 CUs, the C3 graph: B = 24 in 4 segments
@@ -428,8 +437,9 @@ int den_time_segments(const DenArgs& a, bool fused) {
 // launch must find CUs of its own whatever the order of dispatch: at least a quarter of the chip stays free of recursion
 // workgroups, else the recursions exp their rows themselves (2B >= the CU count with pairing off could hang).
 bool den_would_exp_rows_ahead(const DenArgs& a) {
-  // (not where the call is cut into time segments: the rows are written from the sequence ends inwards, a segment starts inside)
-  return a.lazy && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && !a.input_is_exp &&
+  // (not where the call is cut into time segments: the rows are written from the sequence ends inwards, a segment starts inside;
+  // not for the one-gather form of a "pdf by state" plan: its beta recursion reads its rows a frame ahead of the others)
+  return a.lazy && !a.sg && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && !a.input_is_exp &&
          a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && 4 * den_recursion_blocks(a) <= 3 * device_cu_count() &&
          den_time_segments(a, false) == 1;
 }
@@ -517,6 +527,7 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   // two sequences per workgroup once the 2B one-sequence workgroups would fill the chip (option den_pair: 1 always
   // where the shape allows, 0 never); rows in den_recursion_kernel's form
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
+  a.sg = (a.lazy && a.shape == kShapeDma && den_sg_eligible(a, resident_slot_rows)) ? 1 : 0;   // (a "pdf by state" plan in the one-gather form)
   const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt) ? den_segments(a) : 1;
   // the invariant check (DenArgs::tot_a) needs the recursions and the occupancy launches of ONE call
   a.check = (occupancy && user_mask == 3) ? 1 : 0;
@@ -660,6 +671,25 @@ hipError_t run_den(DenArgs& a, int resident_slot_rows, bool occupancy, hipStream
 }
 }  // namespace
 
+// ---- the burn-in controller state of a plan (DenArgs::tstate): a caller-owned device blob, attached by plan address
+namespace {
+std::mutex g_tstate_lock;
+std::map<const void*, void*>& tstate_table() { static std::map<const void*, void*> t; return t; }
+int32_t* tstate_of(const void* plans_dev) {
+  std::lock_guard<std::mutex> guard(g_tstate_lock);
+  auto it = tstate_table().find(plans_dev);
+  return it == tstate_table().end() ? nullptr : (int32_t*)it->second;
+}
+}  // namespace
+extern "C" int pychain_hip_den_tseg_state(const void* plans_dev, void* state_dev) {
+  if (!plans_dev) return fail(PYCHAIN_HIP_EINVAL, "den_tseg_state: null plan");
+  if (state_dev && ((uintptr_t)state_dev & 3)) return fail(PYCHAIN_HIP_EINVAL, "den_tseg_state: the state must be 4-byte aligned");
+  std::lock_guard<std::mutex> guard(g_tstate_lock);
+  if (state_dev) tstate_table()[plans_dev] = state_dev; else tstate_table().erase(plans_dev);
+  return PYCHAIN_HIP_OK;
+}
+extern "C" size_t pychain_hip_den_tseg_state_bytes(void) { return kTsegStateWords * sizeof(int32_t); }
+
 extern "C" int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int resident_slot_rows, int H, int D, int B, int T,
                                               int input_is_exp) {
   if (B <= 0 || T <= 0 || H <= 0 || D <= 0 || resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) return 0;
@@ -670,6 +700,7 @@ extern "C" int pychain_hip_den_uses_row_buffer(int64_t plan_stride_bytes, int re
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
+  a.sg = (a.lazy && a.shape == kShapeDma && den_sg_eligible(a, resident_slot_rows)) ? 1 : 0;
   return den_would_exp_rows_ahead(a) ? 1 : 0;
 }
 
@@ -684,6 +715,7 @@ extern "C" int pychain_hip_den_time_segments(int64_t plan_stride_bytes, int resi
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
+  a.sg = (a.lazy && a.shape == kShapeDma && den_sg_eligible(a, resident_slot_rows)) ? 1 : 0;
   return den_time_segments(a, fused != 0);
 }
 namespace {
@@ -1025,6 +1057,23 @@ int chain_loss_slices(int B, int resident_slot_rows, int64_t plan_stride_bytes, 
 }
 }  // namespace
 
+namespace {
+// Which denominator workspaces were last written by a SLICED fused forward (every slice overwrote the one before it: only
+// the last slice's trajectories are there, so pychain_hip_chain_loss_backward on them would write a wrong gradient for all
+// earlier slices - ADVICE r5).  Host-side bookkeeping by workspace address, updated by every pychain_hip_chain_loss_forward.
+std::mutex g_sliced_lock;
+std::map<const void*, bool>& sliced_workspaces() { static std::map<const void*, bool> m; return m; }
+void note_forward_workspace(const void* den_ws, bool sliced) {
+  std::lock_guard<std::mutex> guard(g_sliced_lock);
+  auto& m = sliced_workspaces();
+  if (sliced) { if (m.size() > 256) m.clear(); m[den_ws] = true; } else m.erase(den_ws);
+}
+bool workspace_was_sliced(const void* den_ws) {
+  std::lock_guard<std::mutex> guard(g_sliced_lock);
+  return sliced_workspaces().count(den_ws) != 0;
+}
+}  // namespace
+
 extern "C" int pychain_hip_chain_loss_slices(int64_t plan_stride_bytes, int resident_slot_rows, int B) {
   return chain_loss_slices(B, resident_slot_rows, plan_stride_bytes, true);
 }
@@ -1040,6 +1089,7 @@ extern "C" int pychain_hip_chain_loss_forward(
   const int nsl = (B > 0 && T > 0 && D > 0 && den_ws && bad_count && den_objf && num_objf && seq_lengths && nnet_output && ft && fi && fp &&
                    bt && bi && bp && initial && final_ && den_ws_bytes > 8192)
                       ? chain_loss_slices(B, resident_slot_rows, plan_stride_bytes, grad != nullptr) : 1;
+  note_forward_workspace(den_ws, nsl > 1);
   if (nsl <= 1)
     return chain_loss_forward_one(plans_dev, plan_stride_bytes, resident_slot_rows, den_H, leaky, ft, fi, fp, bt, bi, bp, initial, final_,
                                   graph_batch_stride, num_H, num_K, nnet_output, nnet_output_dtype, seq_lengths, B, T, D, den_objf, num_objf,
@@ -1155,6 +1205,10 @@ int chain_loss_backward_impl(
     void* den_ws, size_t den_ws_bytes, void* num_ws, size_t num_ws_bytes, void* stream, bool zero_bad) {
   const char* who = "chain_loss_backward";
   if (!bad_count || !ft || !fi || !fp) return fail(PYCHAIN_HIP_EINVAL, "%s: null pointer argument", who);
+  if (workspace_was_sliced(den_ws))
+    return fail(PYCHAIN_HIP_EUNSUPPORTED, "%s: the forward call on these workspaces wrote its gradient in slices (a batch larger than the "
+                "chip: pychain_hip_chain_loss_slices) - the workspaces hold the last slice's trajectories only.  Take the gradient "
+                "that call wrote, or call pychain_hip_chain_loss_forward without a gradient first", who);
   DenArgs da;
   float dummy_coef = 0.5f;       // the occupancy launch does not use the leaky coefficient
   if (nnet_output_dtype != PYCHAIN_HIP_F32)              // (the numerator's occupancy launch accumulates into an fp32 gradient)

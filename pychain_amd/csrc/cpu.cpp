@@ -144,7 +144,12 @@ struct Lse64 {
   double value() const { return (m != m || m == -std::numeric_limits<double>::infinity()) ? m : m + std::log(s); }
 };
 bool num_one(const Csr& fwd, const Csr& bwd, const float* init, const float* fin, const float* x, int L, int T, int D, int H,
-             int grad_mode, float gscale, float* objf, float* grad) {
+             int grad_mode_flags, float gscale, float* objf, float* grad) {
+  // (PYCHAIN_HIP_CPU_NO_CLAMP: the network output as it is - the contract of pychain_C.forward_backward_log_domain, whose C++
+  // does not clamp (chain-log-domain-computation.cc:137-145); ChainFunction's clamp(-30, 30), pychain/loss.py:30, otherwise)
+  const bool clamp = (grad_mode_flags & PYCHAIN_HIP_CPU_NO_CLAMP) == 0;
+  const int grad_mode = grad_mode_flags & 0xff;
+  auto xv = [clamp](float v) { return clamp ? clamp30(v) : v; };
   const double ninf = -std::numeric_limits<double>::infinity();
   std::vector<double> alpha((size_t)(L + 1) * H), beta(2 * (size_t)H), occ((size_t)D);
   bool ok = true;
@@ -156,7 +161,7 @@ bool num_one(const Csr& fwd, const Csr& bwd, const float* init, const float* fin
     for (int h = 0; h < H; h++) {
       Lse64 acc;
       for (int k = bwd.idx[2 * h]; k < bwd.idx[2 * h + 1]; k++)
-        acc.push(pa[bwd.trans[3 * k]] + ((double)bwd.prob[k] + (double)clamp30(xr[bwd.trans[3 * k + 2]])));
+        acc.push(pa[bwd.trans[3 * k]] + ((double)bwd.prob[k] + (double)xv(xr[bwd.trans[3 * k + 2]])));
       a[h] = acc.value();
     }
   }
@@ -182,7 +187,7 @@ bool num_one(const Csr& fwd, const Csr& bwd, const float* init, const float* fin
       Lse64 acc;
       for (int k = fwd.idx[2 * h]; k < fwd.idx[2 * h + 1]; k++) {
         const int pdf = fwd.trans[3 * k + 2];
-        const double term = (double)fwd.prob[k] + nb[fwd.trans[3 * k + 1]] + (double)clamp30(xr[pdf]);
+        const double term = (double)fwd.prob[k] + nb[fwd.trans[3 * k + 1]] + (double)xv(xr[pdf]);
         acc.push(term);
         const double o = std::exp(a[h] + term - logp);          // occupancy of the arc (0 where a state cannot be reached)
         if (o > 0.0) { if (occ[pdf] == 0.0) touched.push_back(pdf); occ[pdf] += o; fsum += o; }
@@ -254,7 +259,8 @@ extern "C" int pychain_hip_cpu_num_forward_backward(
   int rc = check_common(who, ft, fi, fp, bt, bi, bp, initial, final_, nnet_output, seq_lengths, objf_per_seq, grad, bad_count, B, T, D, H, K);
   if (rc != PYCHAIN_HIP_OK) return rc;
   if (graph_batch_stride != 0 && graph_batch_stride != 1) return fail(PYCHAIN_HIP_EINVAL, "%s: graph_batch_stride must be 0 or 1", who);
-  if (grad_mode < PYCHAIN_HIP_GRAD_LOG || grad_mode > PYCHAIN_HIP_GRAD_ACCUM) return fail(PYCHAIN_HIP_EINVAL, "%s: unknown grad_mode %d", who, grad_mode);
+  if ((grad_mode & ~PYCHAIN_HIP_CPU_NO_CLAMP) < PYCHAIN_HIP_GRAD_LOG || (grad_mode & ~PYCHAIN_HIP_CPU_NO_CLAMP) > PYCHAIN_HIP_GRAD_ACCUM)
+    return fail(PYCHAIN_HIP_EINVAL, "%s: unknown grad_mode %d", who, grad_mode);
   g_cpu_calls++;
   std::atomic<int> bad{0};
   for_each_sequence(B, num_threads, [&](int b) {

@@ -38,6 +38,7 @@ struct DenArgs {
   // registers), kShapeDma = LzNarrowDma / LzDma (16 waves, rows by LDS-direct loads, up to 9216 pdfs), kShapeSmall = LzSmall
   // (4 waves over the plan's four-wave dealing: small graphs)
   int shape;
+  int sg;                     // 1: the lazy recursions of this call run the one-gather form of a "pdf by state" plan (den_lazy.inc.h: SG)
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
   //     objf = sum_t log tot_a(t) + log fin_dot        (ComputeTotLogLike, chain-computation.cc:209-230)
@@ -120,11 +121,35 @@ struct DenArgs {
   // the neighbouring segment stored; any mismatch beyond 4e-6 sets *redo (and counts into respec), and the recursion launch that
   // follows - the ordinary one, launched with redo_if - runs only then.  Sequences shorter than 2 tburn frames run as one segment.
   int tseg, tburn;
+  // The burn-in controller of a plan (include/pychain_hip.h: pychain_hip_den_tseg_state): how long a recursion needs
+  // to forget where it started depends on the DATA, and a call whose speculated rows do not verify runs its recursions twice.  A
+  // caller-owned device blob (int32[16], zeroed once) attached to the plan carries, from call to call IN STREAM ORDER - no host
+  // read, no host timing: the decision of call n is a function of the calls before it on the stream - [0] magic, [1] the burn-in
+  // in effect, [2] calls left of a cool-down during which the plan is not cut (the segmented launch leaves at once, the uncut
+  // launch behind it does the work), [3] calls seen, [4] calls that missed.  Every kernel of a call reads it through
+  // den_tburn() / den_tseg_off(); den_finish_kernel's last thread updates it at the END of the call: a miss lengthens the burn-in
+  // by half while three of them fit the sequence, else the plan cools down for kTsegCooldown calls.  Null: tburn as given.
+  int32_t* tstate;
   float* splice;                 // [B][2][kMaxTimeSegs][2][Hp]: the speculated row next to a segment; a row nobody reads (workspace)
-  int32_t* redo;                 // [3]: [0] != 0: a splice did not verify; [1]: how many; [2]: the worst mismatch as float bits (reported; zeroed with the progress counters)
+  int32_t* redo;                 // [4]: [0] != 0: a splice did not verify; [1]: how many; [2]: the worst mismatch as float bits (reported); [3]: what the segmented launch counted into `bad` - merged by den_finish_kernel only if [0] == 0 (zeroed with the progress counters)
   int redo_if;                   // this recursion launch is the fallback: its workgroups leave at once unless *redo != 0
   CallKnobs knobs;               // this call's snapshot of the library settings (host side only)
 };
+
+constexpr int kTsegMagic = 0x74736567, kTsegCooldown = 500, kTsegStateWords = 16;
+// the burn-in in effect for this call / whether the plan is cooling down (DenArgs::tstate; the same answer in every kernel of a
+// call: the state changes only at its end)
+__device__ __forceinline__ int den_tburn(const DenArgs& a) {
+  if (!a.tstate) return a.tburn;
+  const int m = __hip_atomic_load(a.tstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int b = __hip_atomic_load(a.tstate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (m == kTsegMagic && b >= 1) ? b : a.tburn;
+}
+__device__ __forceinline__ bool den_tseg_off(const DenArgs& a) {
+  if (!a.tstate) return false;
+  return __hip_atomic_load(a.tstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kTsegMagic &&
+         __hip_atomic_load(a.tstate + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+}
 
 // true if the recursion of this call runs as den_recursion_lazy_kernel (decided once per call; the occupancy
 // launches - also those of a later chain_loss_backward on the same workspace - must be told: DenArgs::lazy)
@@ -141,6 +166,8 @@ const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows);
 const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);
 // ... as den_recursion_pair_kernel (DenArgs::pair); den_pair_blocks: its grid = what a progress counter reaches
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows);
+// ... in the one-gather form of a "pdf by state" plan (launch hint bit 27; a.shape == kShapeDma, a.use_ex / a.x_half decided)
+bool den_sg_eligible(const DenArgs& a, int resident_slot_rows);
 int den_recursion_blocks(const DenArgs& a);
 hipError_t launch_den_splice_check(const DenArgs& a, hipStream_t st);
 bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);

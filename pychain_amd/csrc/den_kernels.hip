@@ -165,6 +165,28 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
   fin_block_sum2(nfail, unused, part2, tid);
   if (tid == 0) {
     if (nfail > 0.0) atomicAdd(a.bad, (int)nfail);
+    // what the segmented (speculative) recursion launch counted stands only if its rows were kept (DenArgs::redo[3])
+    if (a.tseg > 1 && __hip_atomic_load(a.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      const int spec = __hip_atomic_load(a.redo + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spec > 0) atomicAdd(a.bad, spec);
+    }
+    // the plan's burn-in controller (DenArgs::tstate): this call's outcome decides the next call's burn-in - here, at the end of the
+    // call, in stream order; nothing on the host reads it
+    const bool ts_off = a.tseg > 1 && den_tseg_off(a);
+    if (a.tseg > 1 && a.tstate) {
+      const bool init = __hip_atomic_load(a.tstate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kTsegMagic;
+      int burn = den_tburn(a), off = init ? a.tstate[2] : 0, calls = init ? a.tstate[3] : 0, misses = init ? a.tstate[4] : 0;
+      calls++;
+      if (off > 0) off--;
+      else if (__hip_atomic_load(a.redo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+        misses++;
+        const int grown = (3 * burn + 1) / 2;
+        if (3 * grown <= a.T) burn = grown;                  // (a burn-in beyond a third of the sequence: the cut no longer pays)
+        else { off = kTsegCooldown; burn = a.tburn; }
+      }
+      a.tstate[1] = burn; a.tstate[2] = off; a.tstate[3] = calls; a.tstate[4] = misses;
+      __hip_atomic_store(a.tstate, kTsegMagic, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (a.loss_out) {
       double t = acc * (double)a.loss_scale;                 // -(num - den) [* 1/frames], pychain/loss.py:100-104, rounded once
       if (a.loss_norm_dev) t /= (double)__hip_atomic_load(a.loss_norm_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
       a.loss_out[4] = (float)t;                              // (a second copy: the scalar a caller hands out, apart from the statistics)
       // [5]: time segments (DenArgs::tseg) - how many speculated rows did not verify (> 0: the call ran its recursions again, whole)
       a.loss_out[5] = a.tseg > 1 ? (float)__hip_atomic_load(a.redo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-      a.loss_out[6] = (float)(a.tseg > 1 ? a.tseg : 1);
+      a.loss_out[6] = (float)((a.tseg > 1 && !ts_off) ? a.tseg : 1);
       a.loss_out[7] = a.tseg > 1 ? __uint_as_float((unsigned int)__hip_atomic_load(a.redo + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.f;
     }
   }
@@ -942,7 +964,7 @@ hipError_t launch_gamma_stream(const DenArgs& a, int r, size_t lds, dim3 grid, h
 }
 inline bool gamma_stream_shape_ok(const DenArgs& a, int hint, int gamma_max_groups) {
   if (a.plan_stride != 0) return false;
-  if (gamma2_eligible(a, (hint >> 20) & 255, gamma_max_groups)) return true;
+  if (gamma2_eligible(a, (hint >> 20) & 127, gamma_max_groups)) return true;
   const int r = pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
   return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && r > 0;
 }
@@ -957,9 +979,9 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
   if (a.phase_mask & 2) {
     const bool stream = (a.stream & 2) != 0;            // ONE persistent launch over the whole queue (DenArgs::stream)
     const dim3 grid = stream ? dim3(a.stream_blocks) : dim3(gx, a.B);
-    if (gamma2_eligible(a, (hint >> 20) & 255, gamma_max_groups)) {
+    if (gamma2_eligible(a, (hint >> 20) & 127, gamma_max_groups)) {
       const size_t lds2 = gamma2_lds_bytes(a, gamma_max_groups);
-      const int r2 = (hint >> 20) & 255;
+      const int r2 = (hint >> 20) & 127;
       if (stream) return a.D <= 4 * kNT2 ? launch_gamma2<1, true>(a, r2, lds2, grid, st) : launch_gamma2<2, true>(a, r2, lds2, grid, st);
       return a.D <= 4 * kNT2 ? launch_gamma2<1, false>(a, r2, lds2, grid, st) : launch_gamma2<2, false>(a, r2, lds2, grid, st);
     }
@@ -1117,14 +1139,19 @@ __global__ __launch_bounds__(256) void den_splice_check_kernel(const DenArgs a) 
   __shared__ float red[3][4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Lb = seq_len(a.lengths, b, a.T);
-  const int nseg = (a.tseg > 1 && Lb >= 2 * a.tburn) ? a.tseg : 1;
+  if (den_tseg_off(a)) {                                   // cooling down (DenArgs::tstate): nothing was speculated - the uncut launch runs
+    if (b == 0 && tid == 0) atomicAdd(a.redo, 1);
+    return;
+  }
+  const int tburn = den_tburn(a);
+  const int nseg = (a.tseg > 1 && Lb >= 2 * tburn) ? a.tseg : 1;
   int miss = 0;
   float worst = 0.f;
   for (int dir = 0; dir < 2; dir++)
     for (int k = dir == 0 ? 1 : 0; k < (dir == 0 ? nseg : nseg - 1); k++) {
       const int s = (int)(((long)k * Lb) / nseg), e = k + 1 == nseg ? Lb : (int)(((long)(k + 1) * Lb) / nseg);
-      if (dir == 0 && s - a.tburn <= 0) continue;        // (the segment started at the true start: nothing speculated)
-      if (dir == 1 && e + a.tburn >= Lb) continue;
+      if (dir == 0 && s - tburn <= 0) continue;          // (the segment started at the true start: nothing speculated)
+      if (dir == 1 && e + tburn >= Lb) continue;
       const float* truth = dir == 0 ? a.alpha_store + ((size_t)b * a.T + (s - 1)) * a.Hp : a.beta_store + ((size_t)b * (a.T + 1) + (e + 1)) * a.Hp;
       const float* spec = a.splice + ((size_t)(b * 2 + dir) * kMaxTimeSegs + k) * 2 * a.Hp;
       float sp = 0.f, sq = 0.f;
@@ -1171,20 +1198,20 @@ bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_sl
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
   (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";
-  if (a.lazy) return a.shape == kShapeSmall ? "den_recursion_lazy_kernel<small>" : (a.shape == kShapeDma ? "den_recursion_lazy_kernel<dma>" : "den_recursion_lazy_kernel");
+  if (a.lazy) return a.shape == kShapeSmall ? "den_recursion_lazy_kernel<small>" : (a.shape == kShapeDma ? (a.sg ? "den_recursion_lazy_kernel<dma; one gather per arc>" : "den_recursion_lazy_kernel<dma>") : "den_recursion_lazy_kernel");
   return "den_recursion_kernel";
 }
 const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  return gamma2_eligible(a, (resident_slot_rows >> 20) & 255, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 127, gamma_max_groups) ? "den_gamma2_kernel" : "den_gamma_kernel";
 }
 int den_recursion_blocks(const DenArgs& a) { return a.pair ? 2 * ((a.B + 1) / 2) : 2 * a.B; }
 
 bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  return gamma2_eligible(a, (resident_slot_rows >> 20) & 255, gamma_max_groups);
+  return gamma2_eligible(a, (resident_slot_rows >> 20) & 127, gamma_max_groups);
 }
 // 2-byte network output and gradient (DenArgs::x_half): the two-frame kernel, or the one-frame kernel in its float4-chunk forms
 bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
-  if (gamma2_eligible(a, (resident_slot_rows >> 20) & 255, gamma_max_groups)) return true;
+  if (gamma2_eligible(a, (resident_slot_rows >> 20) & 127, gamma_max_groups)) return true;
   return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && pick_r(a, (resident_slot_rows >> 10) & 1023, 2 * a.Hp) > 0;
 }
 

@@ -255,11 +255,44 @@ template <typename MAP> struct LazyArcsOf<32, MAP> { typedef LazyArcsSplit<32, M
 template <typename MAP> struct LazyArcsOf<24, MAP> { typedef LazyArcsSplit<24, MAP> type; };     // (the four-wave shape: launch_small)
 #endif
 
+// "pdf by state" plans (plan_format.h: PLAN_FLAG_PDF_BY_STATE; template parameter SG of lazy_recursion): every arc entering a state
+// carries that state's pdf, so the nnet output leaves the arc loop -
+//   alpha:  a(t+1,j) = x(t,pdf_j) * ( [sum_k p_k a(t,src_k)] / tot(t) + [sum_k p_k cl(src_k)] )     x multiplies the row's sum ONCE,
+//           where the row's value is formed (one ds_read_b32 per lane and group end instead of one per arc);
+//   beta:   b(t,i) = ( [sum_k p_k y(dst_k).x] + c(t+1) [sum_k p_k y(dst_k).y] ) / n(t+1),   y(t+1; j) = x(t,pdf_j) * {b(t+1,j), 1}:
+//           the vector beta gathers from is PRE-MULTIPLIED where row j is written (a group end of the frame before), which needs
+//           the nnet-output row one frame earlier than the arc loop used to: beta's row pipeline runs a frame ahead.
+// Per arc: ONE ds_read_b64 and ONE v_pk_fma_f32 (the probability broadcast by op_sel) - against two gathers and 2.5 VALU; two
+// registers per arc (state address, probabilities in pairs).
+template <int R, typename MAP>
+struct LazyArcsState {
+  static_assert(R % 4 == 0 && R <= 40, "two registers per arc: loops of up to 40 slot-rows");
+  uint32_t ua[R];               // state (b64) address
+  lz_v2f pp[R / 2];
+  __device__ __forceinline__ void load(int nslot_rows, const uint2* __restrict__ wave_slots) {
+#pragma unroll
+    for (int s = 0; s < R; s += 2) {
+      uint2 a = make_uint2(0u, 0u), b = make_uint2(0u, 0u);
+      if (s < nslot_rows) a = wave_slots[s * 64];
+      if (s + 1 < nslot_rows) b = wave_slots[(s + 1) * 64];
+      ua[s] = MAP::kUField + ((a.x & 0xffffu) << 3);
+      ua[s + 1] = MAP::kUField + ((b.x & 0xffffu) << 3);
+      pp[s / 2] = lz_v2f{__uint_as_float(a.y), __uint_as_float(b.y)};
+      asm volatile("" : "+v"(ua[s]), "+v"(ua[s + 1]));
+    }
+  }
+  // (opaque per frame and chunk: the splat {p, p} of a probability is loop-invariant, and hoisted out of the frame loop it costs
+  // two registers per arc instead of one op_sel)
+  __device__ __forceinline__ void opaque4(int s) { asm volatile("" : "+v"(pp[s / 2]), "+v"(pp[s / 2 + 1])); }
+};
+
 // what a wave carries from frame to frame besides its arcs
 struct LazyWave {
   float inv, c;                 // 1 / total of the previous frame; beta: coef * leaky-weighted sum of the previous frame
   float sprev;                  // the scalar that completes the row in the gather buffer: alpha tot(t), beta c(t)
   float lk_next;                // beta: leaky probability of the lane's row in the group whose end comes next
+  float x_next;                 // SG: nnet output of the lane's row in the group whose end comes next (alpha: x(t,pdf_j); beta: x(t-1,pdf_i))
+  bool x_ok;                    // SG, beta: the row x(t-1,.) exists (a step follows this one); else the vector is written unmultiplied
 };
 
 // A group end inside the arc loop does the least it can: the row's new value into the state buffer the
@@ -420,6 +453,100 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
   }
 }
 
+// ... and over arcs of a "pdf by state" plan (LazyArcsState): ONE gather per arc.  xad01 / xad23 = absolute LDS addresses (nnet-output
+// field, 16 bits each) of the pdf of this lane's row in the wave's groups 0 | 1 << 16, 2 | 3 << 16; XOFF = ds_read offset of the
+// row buffer the group ends read.
+template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t XOFF, uint32_t UNEXT, typename Hook, typename Late>
+__device__ __forceinline__ void lazy_tile_sg(LazyArcsState<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, const uint32_t xad01, const uint32_t xad23, int lane,
+                                             float& s0, float& s1, Hook&& after_first_gathers, Late&& late) {
+  constexpr int kChunk = 4;
+  static_assert(PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
+  constexpr int NC = R / kChunk;
+  constexpr int kLateChunk = NC >= 4 ? NC - PYCHAIN_LATE_BACK : NC - 1;
+  uint32_t m_lo = (uint32_t)gr.endmask, m_hi = (uint32_t)(gr.endmask >> 32), cm = gr.chunkmask;
+  asm volatile("" : "+s"(m_lo), "+s"(m_hi), "+s"(cm));
+  lz_v2f acc = {0.f, 0.f};
+  // With one gather per arc the loop is no longer bound by the LDS pipe but by how many gathers a wave has in flight: the gathers
+  // run kAhead chunks ahead of the arithmetic (the two-gather loops run one: their eight gathers per chunk fill the pipe)
+#ifndef PYCHAIN_SG_AHEAD
+#define PYCHAIN_SG_AHEAD 2
+#endif
+  constexpr int kAhead = PYCHAIN_SG_AHEAD < NC ? PYCHAIN_SG_AHEAD : NC - 1, kBuf = kAhead + 1;
+  lz_v2f ub[kBuf][kChunk];
+#pragma unroll
+  for (int c0 = 0; c0 < kAhead; c0++)
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) ub[c0][k] = lz_ld2(ar.ua[c0 * kChunk + k] + UOFF);
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int cb = c % kBuf;
+    wave_priority_by_progress<NC>(c);
+    if (c + kAhead < NC) {
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) ub[(c + kAhead) % kBuf][k] = lz_ld2(ar.ua[(c + kAhead) * kChunk + k] + UOFF);
+    }
+    if (c == 0) after_first_gathers();
+    if (c == kLateChunk) late();
+    __builtin_amdgcn_sched_barrier(0);
+    {                                                        // all but the gathers of the chunks still ahead
+      constexpr int kMaxAhead = kAhead * kChunk;
+      const int ahead = (NC - 1 - c < kAhead ? NC - 1 - c : kAhead) * kChunk;
+      if (ahead == kMaxAhead) PYCHAIN_WAIT_LGKM(kMaxAhead);
+      else if (ahead == kChunk) PYCHAIN_WAIT_LGKM(kChunk);
+      else if (ahead == 2 * kChunk) PYCHAIN_WAIT_LGKM(2 * kChunk);
+      else PYCHAIN_WAIT_LGKM(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ar.opaque4(c * kChunk);
+    lz_v2f nacc = acc;
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) {
+      const lz_v2f pq = ar.pp[c * (kChunk / 2) + k / 2];
+      const float p = (k & 1) ? pq.y : pq.x;
+      nacc = __builtin_elementwise_fma(lz_v2f{p, p}, ub[cb][k], nacc);
+    }
+    if (__builtin_expect(((cm >> c) & 1u) != 0u, 0)) {         // a chunk with a group end (a few per frame) redoes it
+      nacc = acc;
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) {
+        const int sidx = c * kChunk + k;
+        const lz_v2f pq = ar.pp[sidx / 2];
+        const float p = (k & 1) ? pq.y : pq.x;
+        nacc = __builtin_elementwise_fma(lz_v2f{p, p}, ub[cb][k], nacc);
+        const uint32_t mword = sidx < 32 ? m_lo : m_hi;
+        if ((mword >> (sidx & 31)) & 1u) {
+          const uint32_t below = (1u << (sidx & 31)) - 1u;
+          const int g = __builtin_popcount(sidx < 32 ? (m_lo & below) : m_lo) + (sidx < 32 ? 0 : __builtin_popcount(m_hi & below));
+          const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
+          const float xj = w.x_next;
+          float val;
+          if constexpr (FWD) {
+            val = xj * __builtin_fmaf(nacc.x, w.inv, nacc.y);
+            lz_st1(UNEXT + pos * 8u, val);
+            s0 += val;
+          } else {
+            val = __builtin_fmaf(w.c, nacc.y, nacc.x) * w.inv;
+            const float xm = w.x_ok ? xj : 1.f;              // (the last step of a direction: nobody gathers what it writes)
+            *(__attribute__((address_space(3))) lz_v2f*)(UNEXT + pos * 8u) = lz_v2f{xm * val, xm};
+            s0 += val;
+            s1 = __builtin_fmaf(val, w.lk_next, s1);
+            w.lk_next = lds_abs(MAP::kLk + (uint32_t)(__builtin_amdgcn_readlane(gr.base, (g + 1) & 63) + lane) * 4u);
+          }
+          {                                                  // the next group end's nnet output, requested a group ahead
+            // (two 16-bit addresses per register, picked by the uniform group index: an array indexed by it would live in scratch)
+            const int gn = g + 1;
+            const uint32_t word = (gn & 2) ? xad23 : xad01;
+            const uint32_t xa = (gn & 1) ? (word >> 16) : (word & 0xffffu);
+            w.x_next = lds_abs(xa + XOFF);
+          }
+          nacc = lz_v2f{0.f, 0.f};
+        }
+      }
+    }
+    acc = nacc;
+  }
+}
+
 // One (sequence, direction).  The direction is a template parameter and the kernel branches ONCE, at its
 // top: with both directions in one body the register allocator keeps a second copy of every arc register
 // across the (uniform) direction branches.
@@ -428,9 +555,11 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
 // kernel has no register to spare for more than one form.
 enum { kLzRowsF32 = 0, kLzRowsPre = 1, kLzRowsHalf = 2 };
 // TS: time segments (DenArgs::tseg) - a template parameter: the one-segment kernel keeps its registers; NC: see the start vector
-template <int R, typename MAP, bool fwd, int XM, bool TS, bool NC>
+// SG: a "pdf by state" plan - one gather per arc (LazyArcsState, lazy_tile_sg)
+template <int R, typename MAP, bool fwd, int XM, bool TS, bool NC, bool SG = false>
 __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b, const int seg_in = 0) {
   constexpr bool PRE = XM == kLzRowsPre, XH = XM == kLzRowsHalf;
+  static_assert(!SG || (MAP::kDma && MAP::kMaxPdfs <= 4096 && !NC && !PRE), "the one-gather form: LDS-direct rows, <= 4096 pdfs, no split beta positions");
   constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -441,13 +570,14 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // [s, e) (beta: rows s+1 .. e) are the burn-in: discarded, but for the row next to the segment (DenArgs::splice).
   const int Lb = __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const int seg = TS ? seg_in : 0;
-  const int nseg = (TS && a.tseg > 1 && Lb >= 2 * a.tburn) ? a.tseg : 1;
+  const int tburn = TS ? __builtin_amdgcn_readfirstlane(den_tburn(a)) : 0;   // (the plan's controller may have lengthened it: DenArgs::tstate)
+  const int nseg = (TS && a.tseg > 1 && Lb >= 2 * tburn) ? a.tseg : 1;
   if (TS && seg >= nseg) return;                         // (a sequence shorter than two burn-ins is not cut: its segment 0 does everything)
   const int seg_s = TS ? (int)(((long)seg * Lb) / nseg) : 0;
   const int seg_e = (!TS || seg + 1 == nseg) ? Lb : (int)(((long)(seg + 1) * Lb) / nseg);
   const bool seg_last = !TS || (fwd ? seg + 1 == nseg : seg == 0);   // the segment that ends where the sequence's recursion ends
-  const int f0 = (TS && fwd && seg > 0) ? max(seg_s - a.tburn, 0) : 0;                 // alpha: first frame of the virtual sequence
-  const int L = !TS ? Lb : (fwd ? seg_e - f0 : (seg + 1 == nseg ? Lb : min(Lb, seg_e + a.tburn)));   // its length (beta: its last frame + 1)
+  const int f0 = (TS && fwd && seg > 0) ? max(seg_s - tburn, 0) : 0;                 // alpha: first frame of the virtual sequence
+  const int L = !TS ? Lb : (fwd ? seg_e - f0 : (seg + 1 == nseg ? Lb : min(Lb, seg_e + tburn)));   // its length (beta: its last frame + 1)
   const int nsteps = fwd ? L : L - 1 - seg_s;
   // real rows / totals (local numbering): alpha rows >= row_lo, beta rows <= row_hi; the speculated row next to them
   const int row_lo = fwd ? seg_s - f0 : 0, row_hi = fwd ? 0x7fffffff : seg_e;
@@ -469,12 +599,14 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // bit 0: not ok (a total or normaliser that is not finite-positive, a bad length); bit 1: a NaN network output was
   // staged (kept apart: it also turns the log-probability into NaN, and a later "not ok" must not hide it)
   int bad = lds_addr(smem_raw) != 0u ? 1 : 0;                      // the packed arc addresses are absolute
+  // (the fallback behind a segmented launch watches every row itself: what an inner segment of the speculation reported is void)
+  if (!TS && fwd && a.redo_if && tid == 0) __hip_atomic_store(a.xnan + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if ((fwd && seq_len_bad(a.lengths, b, a.T)) || !have_tile) bad |= 1;
 
   GroupRegs groups;
   groups.load<R>(we, gtab, lane);
   const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
-  typename LazyArcsOf<R, MAP>::type arcs;
+  typename std::conditional<SG, LazyArcsState<R, MAP>, typename LazyArcsOf<R, MAP>::type>::type arcs;
   arcs.load(groups.nslots, wave_slots);
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
@@ -535,21 +667,48 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 #pragma unroll
   for (int g = 0; g < MG; g++) gbase[g] = g < groups.ngroups ? __builtin_amdgcn_readlane(groups.base, g) : 0;
   if (groups.ngroups > MG || groups.nslots > R) bad |= 1;   // the host checks the plan before choosing this kernel
+  // SG: where the nnet output of this lane's row of group g sits in a row buffer (absolute address in the nnet-output field)
+  uint32_t xad01 = 0u, xad23 = 0u;
+  if constexpr (SG) {
+    static_assert(!SG || MG <= 4, "four groups per wave");
+    const int32_t* pdf_of = reinterpret_cast<const int32_t*>(plan + (fwd ? hd->off_pdf_a : hd->off_pdf_b));
+    uint32_t xa[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) xa[g] = MAP::kXField + 4u * (uint32_t)((g < MG && g < groups.ngroups) ? pdf_of[gbase[g] + lane] : 0);
+    xad01 = xa[0] | (xa[1] << 16); xad23 = xa[2] | (xa[3] << 16);
+    asm volatile("" : "+v"(xad01), "+v"(xad23));
+  }
 
   // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
   XRow<NT, 4, MAP::kXch> xq;
   {
     float p0 = 0.f, p1 = 0.f;
+    const int t0 = fwd ? 0 : L - 1;
+    if constexpr (SG && !fwd) {
+      // beta gathers y(j) = x(t,pdf_j) {b(t+1,j), 1}: the start vector needs row L-1 before it can be written (landed in buffer 1,
+      // which the first step overwrites), and the first step's group ends need row L-2 in buffer 0
+      dma_row(t0, lane, MAP::kX1);
+      dma_finish(lane, MAP::kX1);
+      __syncthreads();
+    }
     for (int i = tid; i < (int)MAP::kMaxStates; i += NT) {
       float s = 0.f, second = fwd ? 0.f : 1.f, l = 0.f;
       if (i < Hp) { s = start_g[i]; l = leaky_g[i]; if (fwd) second = coef * l; }
-      *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{s, second};
-      *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, second};
+      if constexpr (SG && !fwd) {
+        const int32_t* pdf_b = reinterpret_cast<const int32_t*>(plan + hd->off_pdf_b);
+        const float xi = i < Hp ? *reinterpret_cast<const float*>(smem_raw + MAP::kX1 + 4 * pdf_b[i]) : 0.f;
+        *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{xi * s, xi};
+        *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, 0.f};
+      } else {
+        *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{s, second};
+        *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, second};
+      }
       if (!fwd) *reinterpret_cast<float*>(smem_raw + MAP::kLk + 4 * i) = l;
       p0 += s; p1 += s * l;
     }
-    const int t0 = fwd ? 0 : L - 1;
-    if constexpr (MAP::kDma) {
+    if constexpr (SG && !fwd) {
+      if (L - 2 >= seg_s + 1) { dma_row(L - 2, lane, MAP::kX0); dma_finish(lane, MAP::kX0); }
+    } else if constexpr (MAP::kDma) {
       dma_row(t0, lane, MAP::kX0);
       if constexpr (pre) PYCHAIN_WAIT_VM0();
       else if (dma_finish(lane, MAP::kX0) && fwd) bad |= 2;
@@ -634,8 +793,13 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     constexpr uint32_t UCUR = (PAR) ? MAP::kU1 : MAP::kU0, UNEXT = (PAR) ? MAP::kU0 : MAP::kU1;             \
     constexpr uint32_t UOFF = UCUR - MAP::kUField;                                                          \
     constexpr uint32_t VOFF = ((PAR) ? MAP::kX1 : MAP::kX0) - MAP::kXField;   /* nnet-output buffer PAR */   \
-    const int tn = (FWDC) ? j + 1 : L - 2 - j;               /* nnet-output row of the NEXT step */          \
+    /* nnet-output row that lands during this step: the NEXT step's - SG beta: the one after (its rows run a frame ahead) */ \
+    const int tn = (FWDC) ? j + 1 : (SG ? L - 3 - j : L - 2 - j);                                           \
     const bool have_next = (FWDC) ? (tn < L) : (tn >= seg_s + 1);   /* beta never consumes row 0 (its segment: row s) */ \
+    if constexpr (SG) {                                                                                     \
+      w.x_ok = (FWDC) || (L - 2 - j >= seg_s + 1);           /* (beta: a step follows this one) */           \
+      w.x_next = lds_abs((xad01 & 0xffffu) + VOFF);          /* the first group end's nnet output */         \
+    }                                                                                                       \
     LZ_PH0();                                                                                               \
     if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
       if (have_next) dma_row(tn, lq, (PAR) ? MAP::kX0 : MAP::kX1);                                          \
@@ -654,7 +818,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     float s0 = 0.f, s1 = 0.f;                                                                               \
-    lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, s0, s1, [&]() {                        \
+    auto hook_first = [&]() {                                                                                \
       if (j > 0) PYCHAIN_LZ_TOTALS(pre0, pre1, j - 1, (FWDC), tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) is completed and leaves for HBM */ \
       const int trow = (FWDC) ? j : L - j;                                                                  \
@@ -667,10 +831,13 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       _Pragma("unroll") for (int g = 0; g < MG; g++)                                                        \
         if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1) {                                           \
           const lz_v2f pr = kPreRows ? prow[g] : lz_ld2(UCUR + gbase[g] * 8 + lq * 8);                      \
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, pr.y, pr.x)), obuf, lane4, \
+          /* (SG beta: the buffer holds x {b, 1}: b + c = pr.x / pr.y + c) */                                  \
+          const float rowv = (SG && !(FWDC)) ? __builtin_fmaf(pr.x, __builtin_amdgcn_rcpf(pr.y), w.sprev) : __builtin_fmaf(w.sprev, pr.y, pr.x); \
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), obuf, lane4,                          \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
         }                                                                                                   \
-    }, [&]() {                                                                                              \
+    };                                                                                                      \
+    auto hook_late = [&]() {                                                                                \
       /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
       /* the arc phase, where its VALU and LDS work hides behind the gathers of sixteen waves - not in the serial tail */ \
       if constexpr (MAP::kDma) {                                                                            \
@@ -678,7 +845,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
         if constexpr (pre) PYCHAIN_WAIT_VM0();               /* (ready to gather: it only has to have landed before the barrier) */ \
         else if (have_next && dma_finish(lq, (PAR) ? MAP::kX0 : MAP::kX1) && (FWDC)) bad |= 2; \
       }                                                                                                     \
-    });                                                                                                     \
+    };                                                                                                      \
+    if constexpr (SG) lazy_tile_sg<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, xad01, xad23, lq, s0, s1, hook_first, hook_late); \
+    else lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, s0, s1, hook_first, hook_late);  \
     LZ_PH(0);                                                /* arc phase */                                 \
     /* rows through registers: the next step's nnet-output row into the other buffer (last read in the previous step) */ \
     if constexpr (!MAP::kDma) {                                                                             \
@@ -726,7 +895,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     for (int g = 0; g < MG; g++)
       if (g < groups.ngroups) {
         const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * (gbase[g] + lane));
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(w.sprev, u.y, u.x)), sbuf, lane * 4,
+        const float rowv = SG ? __builtin_fmaf(u.x, __builtin_amdgcn_rcpf(u.y), w.sprev) : __builtin_fmaf(w.sprev, u.y, u.x);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), sbuf, lane * 4,
                                               row_off + gbase[g] * 4, kStoreDeviceScope);
       }
   }
@@ -749,7 +919,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 
   if (TS && fwd && !seg_last) {                            // an inner alpha segment: nothing to total; a NaN it staged is reported
     if (bad & 2) { __hip_atomic_store(a.xnan + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad &= ~2; }   // (whichever wave staged it)
-    if (bad && lane == 0) atomicAdd(a.bad, 1);
+    if (bad && lane == 0) atomicAdd(a.redo + 3, 1);      // (a speculative launch counts into a scratch word: below)
     return;
   }
   if constexpr (fwd) {
@@ -778,22 +948,26 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       if (!(fs > 0.f)) bad |= 1;
     }
   }
-  if (bad && lane == 0) atomicAdd(a.bad, 1);
+  // A segmented launch is speculative: if a splice does not verify, the uncut launch behind it recomputes every row and counts
+  // for itself - so this launch counts into a scratch word (DenArgs::redo[3]) that den_finish_kernel merges into `bad` only when
+  // nothing was redone (a healthy recomputation used to inherit the speculation's counts, real ones were counted twice)
+  if (bad && lane == 0) atomicAdd(TS ? a.redo + 3 : a.bad, 1);
 }
 
 // XM: kLzRowsPre - the rows were exp'd ahead by den_exp_rows_kernel (DenArgs::ex); kLzRowsHalf - 2-byte rows (DenArgs::x_half)
-template <int R, typename MAP, int XM = kLzRowsF32, bool TS = false, bool NC = false>
+template <int R, typename MAP, int XM = kLzRowsF32, bool TS = false, bool NC = false, bool SG = false>
 __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // (the fallback launch behind a segmented one: runs only if a splice did not verify - DenArgs::redo)
   if (a.redo_if && __hip_atomic_load(a.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   if constexpr (TS) {
+    if (den_tseg_off(a)) return;                           // the plan is cooling down after misses: the uncut launch behind this one does the work
     const unsigned per_dir = (unsigned)a.B * (unsigned)a.tseg;                        // workgroups per direction: segment-major
     const unsigned r = blockIdx.x < per_dir ? blockIdx.x : blockIdx.x - per_dir;
-    if (blockIdx.x < per_dir) lazy_recursion<R, MAP, true, XM, true, NC>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
-    else lazy_recursion<R, MAP, false, XM, true, NC>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+    if (blockIdx.x < per_dir) lazy_recursion<R, MAP, true, XM, true, NC, SG>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+    else lazy_recursion<R, MAP, false, XM, true, NC, SG>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
   } else {
-    if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM, false, NC>(a, smem_raw, blockIdx.x);
-    else lazy_recursion<R, MAP, false, XM, false, NC>(a, smem_raw, blockIdx.x - a.B);
+    if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM, false, NC, SG>(a, smem_raw, blockIdx.x);
+    else lazy_recursion<R, MAP, false, XM, false, NC, SG>(a, smem_raw, blockIdx.x - a.B);
   }
 }

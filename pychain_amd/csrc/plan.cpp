@@ -213,6 +213,7 @@ struct SlotOrder {
   // profiles/r03_ubench_ldsbanks.txt): ds_read_b32  L=2 +0.6, L=4 +2.8, L=8 +7.0;  ds_read_b64  L=2 +0.2, L=4 +2.8, L=8 +7.1.
   // (A conflict-free wave64 gather occupies the LDS for 2.0 / 2.3 cycles - an all-padding slot-row costs that too.)
   int wide_op[2] = {0, 0};                           // operand gathered with ds_read_b64 (state vectors of the lazy recursions)
+  bool ignore_op1 = false;                           // "pdf by state" plans: the recursions do not gather the nnet-output operand per arc
   int extra_tenths(int op, int L) const {
     if (L <= 1) return 0;
     if (L == 2) return wide_op[op] ? 2 : 6;
@@ -235,6 +236,7 @@ struct SlotOrder {
   static constexpr int kW = 12;
   int col_energy_op(const Col& c, int op) const { return kW * (c.mx[0][op] + c.mx[1][op]); }
   int col_add(Col& c, int hh, int op, int b, int d) const {   // returns the energy change
+    if (op == 1 && ignore_op1) return 0;
     int& x = c.cnt[hh][op][b];
     const int before = col_energy_op(c, op) + x * x;
     c.nm[hh][op][x]--; x += d; c.nm[hh][op][x]++;
@@ -791,7 +793,7 @@ extern "C" int64_t pychain_hip_den_plan_build(
   key = fnv64(key, bt, (size_t)K * 12); key = fnv64(key, bi, (size_t)H * 8); key = fnv64(key, bp, (size_t)K * 4);
   key = fnv64(key, leaky, (size_t)H * 4); key = fnv64(key, initial, (size_t)H * 4); key = fnv64(key, final_, (size_t)H * 4);
   for (const char* knob : {"PYCHAIN_PLAN_GENERAL", "PYCHAIN_PLAN_SLACK", "PYCHAIN_PLAN_BALANCE", "PYCHAIN_PLAN_ANNEAL", "PYCHAIN_PLAN_FIT",
-                           "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_SPLIT"}) {
+                           "PYCHAIN_PLAN_LINEAR", "PYCHAIN_PLAN_SPLIT", "PYCHAIN_PLAN_GAMMA_BOUND", "PYCHAIN_PLAN_SG"}) {
     const char* v = getenv(knob);
     key = fnv64(key, knob, strlen(knob));
     if (v) key = fnv64(key, v, strlen(v));
@@ -870,6 +872,23 @@ int64_t plan_build_impl(
         if (ca && cb) { parts_a = ca->parts; parts_b = cb->parts; }
         if (stats) fprintf(stderr, "[plan] states on several lanes: loop class %d -> %d (%s waves), cap alpha %d beta %d\n", unsplit, target,
                            four ? "4" : "16", ca ? ca->cap : -1, cb ? cb->cap : -1);
+        // The occupancy tile gets an arc once per (alpha position of its source, beta position of its destination): the 5/4
+        // bound of settle_parts holds per recursion side only, and an arc between two hub states - or a hub's self-loop - is
+        // repeated parts_a x parts_b times there.  Bounded like the sides: at most 3/2 of the arcs; beyond that
+        // the side with the smaller gain gives its split up, then the other.
+        auto gamma_arcs = [&]() { long n = 0; for (int k = 0; k < K; k++) n += (long)parts_a[ft[3 * k]] * parts_b[ft[3 * k + 1]]; return n; };
+        // (PYCHAIN_PLAN_GAMMA_BOUND: the bound in percent of the arcs, default 150 - the sides' own 5/4 bounds keep real graphs
+        // under about 2 K, so the tests lower it to see the rule act)
+        const long gbound = (long)K * env_long("PYCHAIN_PLAN_GAMMA_BOUND", 150) / 100 + 64;
+        if (gamma_arcs() > gbound) {
+          const bool a_first = va[0].cls <= vb[0].cls;       // (the side that was closer to the target without a split goes first)
+          std::vector<int>& first = a_first ? parts_a : parts_b;
+          std::vector<int>& second = a_first ? parts_b : parts_a;
+          first.assign(H, 1);
+          if (gamma_arcs() > gbound) second.assign(H, 1);
+          if (stats) fprintf(stderr, "[plan] states on several lanes: the occupancy tile would repeat too many arcs - split of %s given up\n",
+                             gamma_arcs() > gbound ? "both sides" : (a_first ? "alpha" : "beta"));
+        }
       }
     }
   }
@@ -938,6 +957,17 @@ int64_t plan_build_impl(
   // (the state vectors of the recursion tiles are float2 in the lazy kernels: ds_read_b64; the occupancy tiles are
   // gathered with one width for both operands)
   SlotOrder so_a(tiles[0], lay, true, false), so_b(tiles[1], lay, true, false), so_g(tiles[2], lay, true, true);
+  // "pdf by state" (plan_format.h: PLAN_FLAG_PDF_BY_STATE): every arc entering a state carries one pdf.  PYCHAIN_PLAN_SG=0: not
+  // marked (the tests compare the two kernel families on one graph).
+  std::vector<int> in_pdf(H, 0);
+  bool pdf_by_state = env_long("PYCHAIN_PLAN_SG", 1) != 0 && D <= 4096;
+  for (int h = 0; h < H && pdf_by_state; h++)
+    for (int k = bi[2 * h]; k < bi[2 * h + 1]; k++) {
+      if (k == bi[2 * h]) in_pdf[h] = bt[3 * k + 2];
+      else if (bt[3 * k + 2] != in_pdf[h]) { pdf_by_state = false; break; }
+    }
+  if (stats) fprintf(stderr, "[plan] pdf by state (one gather per arc): %s\n", pdf_by_state ? "yes" : "no");
+  so_a.ignore_op1 = so_b.ignore_op1 = pdf_by_state;
   auto moves = [&](const Tile& t) { return anneal_knob >= 0 ? anneal_knob : (t.fitted ? 3000L : 200L); };
   {
     // the three tiles are independent (and every group has its own random stream: the result does not depend on the threads)
@@ -1001,6 +1031,7 @@ int64_t plan_build_impl(
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
   place_vec(hd.off_row_pdf, gpos);
   place_vec(hd.off_no_const, std::max(1, HB - H));
+  if (pdf_by_state) { hd.flags |= PLAN_FLAG_PDF_BY_STATE; place_vec(hd.off_pdf_a, Hp); place_vec(hd.off_pdf_b, Hp); }
   if (off > (size_t)INT32_MAX)
     return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED, "den_plan_build: plan larger than 2 GiB");
   hd.total_bytes = (int32_t)off;
@@ -1034,6 +1065,13 @@ int64_t plan_build_impl(
     }
   }
   for (int i = 0; i < gpos; i++) row_pdf[i] = i < (int)tiles[2].order.size() ? tiles[2].order[i] : -1;
+  if (pdf_by_state) {
+    int32_t* pdf_a = (int32_t*)(base + hd.off_pdf_a); int32_t* pdf_b = (int32_t*)(base + hd.off_pdf_b);
+    for (int h = 0; h < H; h++) {
+      for (int m = 0; m < parts_a[h]; m++) pdf_a[lay.pos[kLayA][ea0[h] + m]] = in_pdf[h];
+      for (int m = 0; m < parts_b[h]; m++) pdf_b[lay.pos[kLayB][eb0[h] + m]] = in_pdf[h];
+    }
+  }
   // integrity of everything behind the header: the kernels follow the blob's offsets and packed LDS addresses
   // unchecked, so a plan that comes back from a cache file is verified first (pychain_hip_den_plan_info)
   PlanHeader* out_hd = reinterpret_cast<PlanHeader*>(base);

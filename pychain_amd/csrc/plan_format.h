@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 13
+#define PLAN_VERSION 14
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -89,7 +89,18 @@ struct PlanHeader {
   // states on several lanes (plan.cpp): the graph's own state count (H counts POSITIONS of the longer side), and the beta
   // positions that take no constant c(t) - every position of a state after its first: int32[n_no_const] at off_no_const
   int32_t graph_states, off_no_const, n_no_const;
+  // "pdf by state" (format 14): every arc ENTERING a state carries that state's pdf - the shape of a chain denominator compiled
+  // from a phone LM over HMM topologies, where a pdf belongs to the state a transition enters.  flags bit 0 set: the plan then
+  // holds the pdf-id of every position of both numberings (a state without arcs entering it: 0), and the recursions need ONE
+  // gather per arc - the state operand; the nnet output multiplies a row's sum once, where the row's value is formed (alpha), or
+  // is folded into the vector beta gathers from where that vector is written (den_lazy.inc.h: SG).  The tiles themselves are
+  // as for any graph (the arcs keep their pdf operand): every other kernel reads the plan unchanged.
+  int32_t flags;
+  int32_t off_pdf_a;           // int32[Hp]  pdf-id of the arcs entering the state at this alpha position
+  int32_t off_pdf_b;           // int32[Hp]  ... at this beta position
+  int32_t reserved_tail;
 };
+#define PLAN_FLAG_PDF_BY_STATE 1
 
 // ---- the GENERAL format: graphs the compiled tile plans do not take (more than 65 535 states or pdfs, or vectors that
 // do not fit the LDS of one CU).  The reference layout as it is (fstext.cc:49-116), plus the arcs grouped by pdf-id for
@@ -165,6 +176,9 @@ inline bool plan_header_in_bounds(const PlanHeader& hd) {
   for (int32_t off : {hd.off_init_a, hd.off_leaky_a, hd.off_final_a, hd.off_leaky_b, hd.off_final_b})
     if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
   if (hd.n_no_const < 0 || hd.off_no_const < 0 || (size_t)hd.off_no_const + (size_t)hd.n_no_const * 4 > n) return false;
+  if (hd.flags & PLAN_FLAG_PDF_BY_STATE)
+    for (int32_t off : {hd.off_pdf_a, hd.off_pdf_b})
+      if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
   return hd.off_row_pdf >= 0 && (size_t)hd.off_row_pdf + (size_t)hd.gamma.ngroups * 64 * 4 <= n;
 }
 }  // namespace pychain_hip

@@ -36,19 +36,21 @@ class ChainFunction(torch.autograd.Function):
                 "input batch size ({}) does not equal to graph batch size ({})"
                 .format(B, graphs.batch_size))
         x = input.detach()
-        objf, input_grad, bad = ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient, totals=True)
-        return ChainFunction._forward_tail(ctx, input, x, input_lengths, graphs, leaky_coefficient, objf, input_grad, bad)
+        report = {}
+        objf, input_grad, bad = ChainFunction._occupancies(x, input_lengths, graphs, leaky_coefficient, totals=True, report=report)
+        return ChainFunction._forward_tail(ctx, input, x, input_lengths, graphs, leaky_coefficient, objf, input_grad, bad,
+                                           report.get("totals"))
 
     @staticmethod
-    def _occupancies(x, input_lengths, graphs, leaky_coefficient, totals=False):
+    def _occupancies(x, input_lengths, graphs, leaky_coefficient, totals=False, report=None):
         """(objf per sequence, occupancies = gradient for an upstream gradient of 1, bad_count).  `totals`: the
-        denominator's last kernel also leaves [sum objf, frames, bad, sum objf] in ChainFunction.last_totals, and the sum
-        is returned in place of the per-sequence values (no reduction launch behind the call)."""
+        denominator's last kernel also leaves [sum objf, frames, bad, sum objf, ...] (include/pychain_hip.h: totals) in
+        `report["totals"]` - the caller attaches them to the tensor it returns - and the sum is returned in place of the
+        per-sequence values (no reduction launch behind the call)."""
         D = x.size(2)
         if not x.is_cuda:
             # CPU tensors: the library's host twins (pychain_amd/csrc/cpu.cpp) - what the reference does with them
             # (chain-computation.cc:40,136-175); device tensors never come here
-            ChainFunction.last_totals = None
             return native.cpu_forward_backward(graphs, x, input_lengths, leaky_coefficient)
         if not graphs.log_domain:   # usually the denominator
             if graphs.shared_graph is not None:
@@ -70,13 +72,13 @@ class ChainFunction(torch.autograd.Function):
             if totals:
                 objf, input_grad, bad, tot = native.den_forward_backward(
                     plan, x, input_lengths, leaky_coefficient, input_is_exp=False, totals=True)
-                ChainFunction.last_totals, ChainFunction.last_totals_all = tot[:4], tot
+                if report is not None:
+                    report["totals"] = tot
                 objf = native.totals_scalar(tot)   # (no launch; not a view of the statistics)
             else:
                 objf, input_grad, bad = native.den_forward_backward(
                     plan, x, input_lengths, leaky_coefficient, input_is_exp=False)
         else:                       # usually the numerator
-            ChainFunction.last_totals = None
             gt = graphs.device_tensors(x.device)
             gstride = 0 if graphs.shared_graph is not None else 1
             objf, input_grad, bad = native.num_forward_backward(
@@ -84,7 +86,7 @@ class ChainFunction(torch.autograd.Function):
         return objf, input_grad, bad
 
     @staticmethod
-    def _forward_tail(ctx, input, x, input_lengths, graphs, leaky_coefficient, objf, input_grad, bad):
+    def _forward_tail(ctx, input, x, input_lengths, graphs, leaky_coefficient, objf, input_grad, bad, tot=None):
         # The occupancies are the gradient for an upstream gradient of 1.  backward() scales the
         # buffer in place on the device (a no-op launch when the upstream gradient is exactly 1,
         # i.e. `objf.backward()`) and hands it to autograd, instead of the reference's extra
@@ -100,12 +102,15 @@ class ChainFunction(torch.autograd.Function):
                                    lambda r: (r[1], r[2]))
         ctx.in_dtype = input.dtype   # fp16 / bf16 inputs are evaluated in fp32; the gradient goes back in their dtype
         ctx.bad_count = bad          # device int32[1]; the reference's `ok`, never synced here
-        ChainFunction.last_bad_count = bad
-        return objf.sum() if objf.dim() else objf              # (0-dim: the sum came with the call)
+        out = objf.sum() if objf.dim() else objf               # (0-dim: the sum came with the call)
+        return _attach(out, tot, bad)
 
     retain_grad_buffer = False
-    last_totals = None           # device float[4] of the last native call that produced them (include/pychain_hip.h: totals)
+    # DEPRECATED mirrors of what the LAST call in this process reported (any criterion, any thread: two losses in one process
+    # overwrite each other's).  Read `loss.totals` / `loss.totals_all` / `loss.bad_count` of the tensor a call RETURNED instead.
+    last_totals = None           # device float[4] (include/pychain_hip.h: totals), None where the call produced none
     last_totals_all = None       # ... all eight: [5..7] say how a time-segmented call went (segments redone, count, worst mismatch)
+    last_bad_count = None
 
     @staticmethod
     def backward(ctx, objf_grad):
@@ -115,10 +120,23 @@ class ChainFunction(torch.autograd.Function):
             return torch.mul(input_grad, objf_grad).to(ctx.in_dtype), None, None, None
         grad = _take_grad_buffer(ctx, "grad_buf")
         if grad is None:
-            grad, ChainFunction.last_bad_count = ctx.again()   # second backward over a retained graph: evaluate again
+            grad, ctx.bad_count = ctx.again()                  # second backward over a retained graph: evaluate again
+            ChainFunction.last_bad_count = ctx.bad_count
         if not grad.is_cuda:
             return torch.mul(grad, objf_grad).to(ctx.in_dtype), None, None, None          # (loss.py:85, as it is)
         return native.rescale_(grad, objf_grad).to(ctx.in_dtype), None, None, None
+
+
+def _attach(out, totals, bad):
+    """What a call reports travels WITH the tensor it returns - `out.totals` (device float[4]: loss, frames, bad count, sum den - sum
+    num; None where the call produced none), `out.totals_all` (all eight of include/pychain_hip.h), `out.bad_count` (device
+    int32, the reference's `ok` as a count; never synced here) - so that two criteria, or two host threads, in one process do
+    not read each other's.  The class attributes ChainFunction.last_* remain as deprecated mirrors."""
+    out.totals = None if totals is None else totals[:4]
+    out.totals_all = totals
+    out.bad_count = bad
+    ChainFunction.last_totals, ChainFunction.last_totals_all, ChainFunction.last_bad_count = out.totals, totals, bad
+    return out
 
 
 def _recompute(x, evaluate, pick):
@@ -187,7 +205,6 @@ class ChainLossFunction(torch.autograd.Function):
         # -(num - den) [/ frames], loss.py:100-104, comes with the call (the last workgroup of its last kernel adds the
         # per-sequence objectives up): no reduction / subtraction / scaling launches behind it
         objf = native.totals_scalar(totals)    # (no launch; not a view of the statistics: `loss /= n` works)
-        ChainFunction.last_totals, ChainFunction.last_totals_all = totals[:4], totals
         ctx.state = state
         # a second backward over a retained graph (loss.py:82-87 allows it) runs the recursions again
         spec, hscale, dnorm = ctx.speculative, ctx.host_scale, ctx.dev_norm      # (locals: the closure must not hold ctx)
@@ -195,8 +212,8 @@ class ChainLossFunction(torch.autograd.Function):
             plan, gt, gstride, num_graphs.num_states, x, lengths, leaky_coefficient,
             with_grad=spec, grad_scale=hscale, norm_dev=dnorm, half_ok=half_ok), lambda r: (r[3], r[2]))      # (state, bad)
         ctx.in_dtype = input.dtype
-        ChainFunction.last_bad_count = bad       # int32[2]: denominator, numerator; never synced here
-        return objf
+        ctx.bad_count = bad                      # int32[2]: denominator, numerator; never synced here
+        return _attach(objf, totals, bad)
 
     overlap = True     # class-level switch: False = occupancy passes run in backward (no speculation)
 
@@ -204,7 +221,8 @@ class ChainLossFunction(torch.autograd.Function):
     def backward(ctx, objf_grad):
         state = _take_grad_buffer(ctx, "state")
         if state is None:
-            state, ChainFunction.last_bad_count = ctx.again()
+            state, ctx.bad_count = ctx.again()
+            ChainFunction.last_bad_count = ctx.bad_count
         if ctx.speculative:
             # (a device-side normaliser - avg=True with the lengths on the device - was divided into the gradient by the call
             # that wrote it: include/pychain_hip.h, loss_norm_dev; an upstream gradient of exactly 1 then costs one tiny launch)
@@ -212,7 +230,8 @@ class ChainLossFunction(torch.autograd.Function):
         else:
             g = objf_grad if ctx.dev_norm is None else objf_grad / ctx.dev_norm.to(objf_grad.device)
             grad, bad = native.chain_loss_backward(state, ctx.host_scale, g)
-            ChainFunction.last_bad_count = ChainFunction.last_bad_count + bad
+            ctx.bad_count = ctx.bad_count + bad              # (the occupancy launches' own checks)
+            ChainFunction.last_bad_count = ctx.bad_count
         state.grad = None         # the stored trajectories go with `state`
         state.den_ws = state.num_ws = None
         return grad.to(ctx.in_dtype), None, None, None, None, None
@@ -235,9 +254,11 @@ class ChainLoss(nn.Module):
         den_objf = ChainFunction.apply(x, x_lengths, den_graphs, self.leaky_coefficient)
         num_objf = ChainFunction.apply(x, x_lengths, num_graphs)
         objf = -(num_objf - den_objf)
-        # (two native calls made this loss: the totals of the LAST of them are not the step's - ShardedChainLoss must
-        # not mistake them for [loss, frames, bad] of the step and falls back to all-reducing its own three scalars)
-        ChainFunction.last_totals = None
         if self.avg:
             objf = objf / x_lengths.sum()
+        # (two native calls made this loss: neither's totals are the step's - ShardedChainLoss finds none and all-reduces its own
+        # three scalars; the two bad counts ride along as they are: no launch here)
+        objf.totals = objf.totals_all = None
+        objf.bad_count = (den_objf.bad_count, num_objf.bad_count)
+        ChainFunction.last_totals = ChainFunction.last_totals_all = None
         return objf

@@ -10,7 +10,10 @@ import torch
 
 from . import _lib, _plan
 
+import threading
+
 _ws_cache = {}          # (device, stream, tag) -> uint8 tensor, most recently used last
+_ws_lock = threading.Lock()      # (criteria on several host threads share this module)
 _WS_CACHE_ENTRIES = 8   # a training process uses 2 (den, num) per stream; more are streams that came and went
 
 
@@ -40,9 +43,10 @@ def _cpu_graph(graphs, with_leaky):
     return ts, stride
 
 
-def cpu_forward_backward(graphs, x, lengths, leaky_coefficient=1e-5, input_is_exp=False, grad_mode=_lib.GRAD_LINEAR):
+def cpu_forward_backward(graphs, x, lengths, leaky_coefficient=1e-5, input_is_exp=False, grad_mode=_lib.GRAD_LINEAR, clamp=True):
     """ChainFunction's computation on CPU tensors: (objf_per_seq[B], grad[B,T,D] fp32, bad_count int32[1]).  Denominator
-    (probability-domain graphs) or numerator (log-domain graphs) by `graphs.log_domain`."""
+    (probability-domain graphs) or numerator (log-domain graphs) by `graphs.log_domain`.  `clamp` False (numerator): the network
+    output as it is - what pychain_C.forward_backward_log_domain computes on (the reference clamps in Python, loss.py:30)."""
     if x.is_cuda:
         raise RuntimeError("pychain_amd: cpu_forward_backward is for CPU tensors; device tensors run on the HIP kernels")
     xf = x.detach().to(torch.float32).contiguous()
@@ -63,7 +67,7 @@ def cpu_forward_backward(graphs, x, lengths, leaky_coefficient=1e-5, input_is_ex
             "pychain_hip_cpu_den_forward_backward")
     else:
         _lib.check(L.pychain_hip_cpu_num_forward_backward(
-            *ptrs, stride, xf.data_ptr(), lc.data_ptr(), B, T, D, H, K, int(grad_mode), 1.0,
+            *ptrs, stride, xf.data_ptr(), lc.data_ptr(), B, T, D, H, K, int(grad_mode) | (0 if clamp else _lib.CPU_NO_CLAMP), 1.0,
             objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), int(CPU_THREADS)), "pychain_hip_cpu_num_forward_backward")
     return objf, grad, bad
 
@@ -74,21 +78,23 @@ def _workspace(nbytes, device, tag="a"):
     two streams of one device run concurrently and must not share it.  (A replaced buffer goes back to the
     caching allocator, which hands it out again only in the stream order of its allocation.)"""
     key = (str(device), _stream(device), tag)
-    ws = _ws_cache.pop(key, None)
-    if ws is None or ws.numel() < nbytes:
-        ws = None                      # (the old buffer goes back to the allocator before the larger one is asked for)
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-    _ws_cache[key] = ws                # (re-)inserted last = most recently used
-    while len(_ws_cache) > _WS_CACHE_ENTRIES:
-        _ws_cache.pop(next(iter(_ws_cache)))       # least recently used: multi-GB buffers of streams no longer in use
+    with _ws_lock:
+        ws = _ws_cache.pop(key, None)
+        if ws is None or ws.numel() < nbytes:
+            ws = None                      # (the old buffer goes back to the allocator before the larger one is asked for)
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws                # (re-)inserted last = most recently used
+        while len(_ws_cache) > _WS_CACHE_ENTRIES:
+            _ws_cache.pop(next(iter(_ws_cache)))       # least recently used: multi-GB buffers of streams no longer in use
     return ws
 
 
 def release_workspaces():
     """Drop every cached workspace (several GB at C3 sizes) and the memoised plans / graph uploads of the
     pychain_C-compatible surface."""
-    _ws_cache.clear()
-    _compat_cache.clear()
+    with _ws_lock:
+        _ws_cache.clear()
+        _compat_cache.clear()
 
 
 def _stream(device):
@@ -108,70 +114,10 @@ def _check_lengths(lengths, B, T):
             raise ValueError("sequence lengths must be in [1, %d]" % T)
 
 
-# ---------------------------------------------------------------------------
-# Time segments (include/pychain_hip.h: totals[5..7]): how long a recursion needs to forget where it started
-# depends on the DATA (peaky network outputs forget slowly: N(0,1) x 4 instead of x 2 needs > 256 frames on the benchmark
-# graph; the benchmark's x 2 verifies from 192 on: profiles/r05_time_segments.txt), and a call whose speculated rows do not verify runs its recursions twice.  The library is stateless; this layer
-# watches totals[5] of the calls it made - copied to pinned host memory behind the call and read when the copy's event
-# has fired, never a sync - and, after a miss, lengthens the burn-in for that plan by half (option den_tburn), or stops cutting it
-# for a while when the burn-in would eat the gain.  Options set by the caller (den_tseg / den_tburn) switch this off.
-# ---------------------------------------------------------------------------
-_tseg_ctl = {}
-TSEG_COOLDOWN_CALLS = 500
-TSEG_BURN = 192          # the library's default burn-in (option den_tburn)
-
-
-class _TsegState(object):
-    __slots__ = ("burn", "off", "pending", "misses", "calls", "host")
-
-    def __init__(self):
-        self.burn, self.off, self.pending, self.misses, self.calls, self.host = TSEG_BURN, 0, None, 0, 0, None
-
-
-def _tseg_key(plan, B, T, D, dev, fused):
-    """None where the library would not cut such a call anyway (nothing to watch: B = 64, small graphs, ...)."""
-    if _lib.get_option("den_tseg") is not None or _lib.get_option("den_tburn") is not None:
-        return None
-    if _lib.lib().pychain_hip_den_time_segments(plan.stride, plan.slot_rows, int(plan.num_states), int(D), int(B), int(T), int(fused)) <= 1:
-        return None
-    return (str(dev), plan.blob.data_ptr(), int(B), int(T), bool(fused))
-
-
-def _tseg_options(key, T):
-    """The option overrides of this call ([] = the library's own choice), after looking at what earlier calls reported."""
-    if key is None:
-        return []
-    st = _tseg_ctl.get(key)
-    if st is None:
-        st = _tseg_ctl[key] = _TsegState()
-        while len(_tseg_ctl) > 64:
-            _tseg_ctl.pop(next(iter(_tseg_ctl)))
-    st.calls += 1
-    if st.pending is not None and st.pending[0].query():
-        redone = float(st.pending[1][0])
-        st.pending = None
-        if redone > 0:
-            st.misses += 1
-            grown = int(st.burn * 1.5 + 0.5)
-            if grown * 3 <= T:                       # (a burn-in beyond a third of the sequence: the cut no longer pays)
-                st.burn = grown
-            else:
-                st.off, st.burn = st.calls + TSEG_COOLDOWN_CALLS, TSEG_BURN
-    if st.off > st.calls:
-        return [_lib.option("den_tseg", 0)]
-    return [_lib.option("den_tburn", st.burn)] if st.burn != TSEG_BURN else []
-
-
-def _tseg_observe(key, tot, dev):
-    st = _tseg_ctl.get(key) if key is not None else None
-    if st is None or st.pending is not None:
-        return
-    if st.host is None:
-        st.host = torch.empty(3, dtype=torch.float32, pin_memory=True)
-    st.host.copy_(tot[5:8], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    st.pending = (ev, st.host)
+# (Time segments - include/pychain_hip.h: totals[5..7], DESIGN.md §3.13: the burn-in controller that used to live here, fed by
+# non-blocking copies of totals[5] whenever their event happened to have fired, is in the LIBRARY since ABI 16 - a device-
+# resident state per plan, read and updated by the call's own kernels in stream order: pychain_amd/_plan.py attaches it, nothing
+# on the host reads it, and the same run gives the same bits.)
 
 
 HALF_ROWS = True        # False: bf16 / fp16 network outputs are up-cast on the host side of the ABI (the tests compare the two ways)
@@ -208,26 +154,17 @@ def den_forward_backward(plan, x, lengths, leaky_coefficient=1e-5, input_is_exp=
         grad = torch.empty_like(x)                 # (in the type the kernels read: the gradient is rounded where it is written)
         bad = torch.empty(1, dtype=torch.int32, device=dev)
         tot = torch.empty(_lib.TOTALS, dtype=torch.float32, device=dev)
-        key = _tseg_key(plan, B, T, D, dev, False)
-        ctx = _tseg_options(key, T)
-        for c in ctx:
-            c.__enter__()
-        try:
-            # (the [B,T,D] buffer of the rows exp'd ahead only where this call will use it: ADVICE r4)
-            full = L.pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, int(num_states), D, B, T, int(bool(input_is_exp)))
-            nws = (L.pychain_hip_den_workspace_bytes if full else L.pychain_hip_den_workspace_min_bytes)(B, T, int(num_states), D)
-            ws = _workspace(nws, dev, "den")
-            _lib.check(L.pychain_hip_den_forward_backward(
-                plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(), xcode,
-                int(bool(input_is_exp)),
-                ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
-                objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), tot.data_ptr(),
-                ws.data_ptr(), ws.numel(), _stream(dev)),
-                "pychain_hip_den_forward_backward")
-        finally:
-            for c in reversed(ctx):
-                c.__exit__()
-        _tseg_observe(key, tot, dev)
+        # (the [B,T,D] buffer of the rows exp'd ahead only where this call will use it: ADVICE r4)
+        full = L.pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, int(num_states), D, B, T, int(bool(input_is_exp)))
+        nws = (L.pychain_hip_den_workspace_bytes if full else L.pychain_hip_den_workspace_min_bytes)(B, T, int(num_states), D)
+        ws = _workspace(nws, dev, "den")
+        _lib.check(L.pychain_hip_den_forward_backward(
+            plan.blob.data_ptr(), plan.stride, plan.slot_rows, int(num_states), D, x.data_ptr(), xcode,
+            int(bool(input_is_exp)),
+            ld.data_ptr(), B, T, float(leaky_coefficient), float(grad_scale),
+            objf.data_ptr(), grad.data_ptr(), bad.data_ptr(), tot.data_ptr(),
+            ws.data_ptr(), ws.numel(), _stream(dev)),
+            "pychain_hip_den_forward_backward")
     return (objf, grad, bad, tot) if totals else (objf, grad, bad)
 
 
@@ -338,12 +275,7 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
         nws = torch.empty(L.pychain_hip_num_workspace_bytes(B, T, int(num_states_num), K, D), dtype=torch.uint8,
                           device=dev)
         grad = torch.empty_like(x) if with_grad else None
-        key = _tseg_key(plan, B, T, D, dev, True)
-        tctx = _tseg_options(key, T)
-        for c in tctx:
-            c.__enter__()
-        try:
-          _lib.check(L.pychain_hip_chain_loss_forward(
+        _lib.check(L.pychain_hip_chain_loss_forward(
             plan.blob.data_ptr(), plan.stride, plan.slot_rows, plan.num_states, float(leaky_coefficient),
             gt["forward_transitions"].data_ptr(), gt["forward_transition_indices"].data_ptr(),
             gt["forward_transition_probs"].data_ptr(), gt["backward_transitions"].data_ptr(),
@@ -354,10 +286,6 @@ def chain_loss_forward(plan, gt, graph_stride, num_states_num, x, lengths, leaky
             bad.data_ptr(), float(loss_scale), 0 if norm_dev is None else norm_dev.data_ptr(), totals.data_ptr(),
             dws.data_ptr(), dws.numel(), nws.data_ptr(), nws.numel(), _stream(dev)),
             "pychain_hip_chain_loss_forward")
-        finally:
-            for c in reversed(tctx):
-                c.__exit__()
-        _tseg_observe(key, totals, dev)
     st.grad = grad
     # (which numerator wrote the stored rows: backward runs on autograd's thread, where the caller's thread options do not reach)
     st.num_compat = _lib.get_option("num_compat") or "0"
@@ -519,7 +447,7 @@ def forward_backward_log_domain(forward_transitions, forward_transition_indices,
             initial_probs, final_probs]
     if not nnet_output.is_cuda:                   # chain-log-domain-computation.cc:123-159,231-271: the host twin
         gb = _RawGraphs(dict(zip(_GRAPH6 + ["initial_probs", "final_probs"], vals)), log_domain=True)
-        objf, lgrad, bad = cpu_forward_backward(gb, nnet_output, sequence_lengths, grad_mode=_lib.GRAD_LOG)
+        objf, lgrad, bad = cpu_forward_backward(gb, nnet_output, sequence_lengths, grad_mode=_lib.GRAD_LOG, clamp=False)
         return [objf.sum(), lgrad, bad == 0]
     gt = _compat_cached("num", vals, (str(dev),), lambda: {
         n: t.contiguous().to(dev) for n, t in zip(_GRAPH6 + ["initial_probs", "final_probs"], vals)})

@@ -51,7 +51,7 @@ def shard_batch(x, lengths, num_graphs, world_size, rank):
     return xs, ls, gs, idx
 
 
-def allreduce_stats(objf, n_frames, bad_count=None, group=None):
+def allreduce_stats(objf, n_frames, bad_count=None, group=None, force=False):
     """[objf, n_frames, n_bad] summed over all ranks with ONE collective (RCCL all_reduce
     over xGMI on GPUs, gloo on CPU).  Returns the fp32[3] buffer; no host sync."""
     dev = objf.device
@@ -60,7 +60,7 @@ def allreduce_stats(objf, n_frames, bad_count=None, group=None):
              bad_count.to(dev).sum(dtype=torch.float32).reshape(1) if bad_count is not None
              else torch.zeros(1, dtype=torch.float32, device=dev)]
     buf = torch.cat(parts)        # one small kernel, not a fill and three copies
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
 
@@ -109,11 +109,12 @@ class ShardedChainLoss(torch.nn.Module):
     autograd yields the correctly scaled gradient for the local shard.
 
     `last_stats` (device fp32, never synced here) holds [global objf, global frames, global bad count] of the last step.
-    With the native ChainLoss the three scalars come out of the loss call's last kernel (ChainFunction.last_totals) and
-    are all-reduced as they are - no scalar kernels of the host framework around the collective; a world of one does
-    nothing at all here."""
+    With the native ChainLoss the three scalars come out of the loss call's last kernel (`loss.totals` of the tensor the call
+    returned - not a class attribute: two criteria in one process do not see each other's) and are all-reduced as they are -
+    no scalar kernels of the host framework around the collective; a world of one does nothing at all here unless
+    `force_collective` asks for the collective anyway (one rank under torch.distributed: the RCCL leg of the GPU tests)."""
 
-    def __init__(self, den_graph, leaky_coefficient=1e-5, avg=True, group=None, loss_cls=None):
+    def __init__(self, den_graph, leaky_coefficient=1e-5, avg=True, group=None, loss_cls=None, force_collective=False):
         super().__init__()
         self._native = loss_cls is None or bool(getattr(loss_cls, "reports_bad_count", False))
         if loss_cls is None:
@@ -121,6 +122,7 @@ class ShardedChainLoss(torch.nn.Module):
         self.local = loss_cls(den_graph, leaky_coefficient, avg=False)
         self.avg = avg
         self.group = group
+        self.force_collective = bool(force_collective)
         self.last_stats = None
 
     def _world(self):
@@ -128,12 +130,11 @@ class ShardedChainLoss(torch.nn.Module):
 
     def forward(self, x, x_lengths, num_graphs):
         local = self.local(x, x_lengths, num_graphs)                  # sum over local utterances
-        totals = None
-        if self._native:
-            from .loss import ChainFunction
-            totals = ChainFunction.last_totals                        # [loss, frames, bad, ...] of the call above, on the device
+        # [loss, frames, bad, ...] of THIS call, on the device: they came back with the tensor (pychain_amd/loss.py: _attach)
+        totals = getattr(local, "totals", None) if self._native else None
+        collective = dist.is_available() and dist.is_initialized() and (self._world() > 1 or self.force_collective)
         if totals is not None:
-            if self._world() == 1:
+            if not collective:
                 self.last_stats = totals[:3]
                 return local / totals[1] if self.avg else local
             stats = totals[:3].clone()
@@ -141,11 +142,10 @@ class ShardedChainLoss(torch.nn.Module):
             self.last_stats = stats
             return _GlobalLoss.apply(local, stats, self.avg)
         frames = torch.as_tensor(x_lengths).sum()
-        bad = None
-        if self._native:                                              # the reference's `ok` of every rank rides along
-            from .loss import ChainFunction
-            bad = ChainFunction.last_bad_count
-        stats = self.last_stats = allreduce_stats(local, frames, bad, self.group)
+        bad = getattr(local, "bad_count", None) if self._native else None   # the reference's `ok` of every rank rides along
+        if isinstance(bad, (tuple, list)):                            # (a two-call loss: denominator's and numerator's)
+            bad = torch.cat([b.reshape(-1) for b in bad if b is not None]) if any(b is not None for b in bad) else None
+        stats = self.last_stats = allreduce_stats(local, frames, bad, self.group, force=self.force_collective)
         # value: global; gradient: d(local)/dx scaled by the global normaliser
         denom = stats[1] if self.avg else torch.ones((), device=stats.device)
         return (local - local.detach() + stats[0]) / denom

@@ -7,7 +7,7 @@ against the oracle without a GPU.  Mirrors the kernels step by step.
 """
 import numpy as np
 
-HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 13), in int32 words
+HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 14), in int32 words
 
 
 def parse(blob):
@@ -42,6 +42,11 @@ def parse(blob):
     hd["takes_c"][hd["no_const"]] = False
     ng = max(hd["gamma"]["ngroups"] * 64, 64)
     hd["row_pdf"] = b[offs[5]:offs[5] + 4 * ng].view(np.int32).copy()
+    # "pdf by state" (format 14): every arc entering a state carries one pdf; its id by alpha / beta position
+    hd["pdf_by_state"] = bool(int(h[68]) & 1)
+    if hd["pdf_by_state"]:
+        hd["pdf_a"] = b[int(h[69]):int(h[69]) + 4 * Hp].view(np.int32).copy()
+        hd["pdf_b"] = b[int(h[70]):int(h[70]) + 4 * Hp].view(np.int32).copy()
     return hd
 
 
@@ -61,9 +66,28 @@ def tile_rows(t, U, V, nout, dtype):
     return out
 
 
-def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.float64):
-    """Returns (objf_per_seq[B], grad[B,T,D]) exactly as den_kernels.hip computes them."""
+def tile_rows_sg(t, U, nout, dtype):
+    """The one-gather form (den_lazy.inc.h: SG): out[row] = sum_k p_k U[i0_k] - the nnet output is not gathered per arc."""
+    out = np.zeros(nout, dtype=dtype)
+    for w in range(t["nwaves"]):
+        first, ng, row, _ = t["waves"][w]
+        for g in range(first, first + ng):
+            base, ns = t["groups"][g]
+            acc = np.zeros(64, dtype=dtype)
+            for j in range(ns):
+                acc += t["p"][row + j].astype(dtype) * U[t["idx"][row + j] & 0xffff]
+            row += ns
+            out[base:base + 64] = acc
+    return out
+
+
+def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.float64, sg=False):
+    """Returns (objf_per_seq[B], grad[B,T,D]) exactly as den_kernels.hip computes them.  `sg`: the recursions in the one-gather
+    form of a "pdf by state" plan - alpha: x(t, pdf of the row) times the row's sum; beta: the gathered vector pre-multiplied by
+    x(t, pdf of the gathered state) - from the plan's per-position pdf tables (the arcs' own pdf operand is not read)."""
     hd = parse(blob)
+    if sg:
+        assert hd["pdf_by_state"], "not a pdf-by-state plan"
     H, Hp, D = hd["H"], hd["Hp"], hd["D"]
     B, T, _ = x.shape
     ex = x.astype(dtype) if input_is_exp else np.exp(np.clip(x.astype(dtype), -30, 30))
@@ -80,7 +104,7 @@ def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.fl
         logsum = np.log(tot)
         A[0] = v / tot + coef * la
         for t in range(1, L + 1):
-            v = tile_rows(hd["alpha"], A[t - 1], ex[b, t - 1], Hp, dtype)
+            v = ex[b, t - 1][hd["pdf_a"]] * tile_rows_sg(hd["alpha"], A[t - 1], Hp, dtype) if sg else tile_rows(hd["alpha"], A[t - 1], ex[b, t - 1], Hp, dtype)
             tot = v.sum()
             logsum += np.log(tot)
             A[t] = v / tot + coef * la
@@ -88,7 +112,7 @@ def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.fl
         v = hd["final_b"].astype(dtype)
         Bt[L] = (v + mask * coef * (v * lb).sum()) / v.sum()
         for t in range(L - 1, 0, -1):
-            v = tile_rows(hd["beta"], Bt[t + 1], ex[b, t], Hp, dtype)
+            v = tile_rows_sg(hd["beta"], ex[b, t][hd["pdf_b"]] * Bt[t + 1], Hp, dtype) if sg else tile_rows(hd["beta"], Bt[t + 1], ex[b, t], Hp, dtype)
             Bt[t] = (v + mask * coef * (v * lb).sum()) / v.sum()
         g = hd["gamma"]
         for t in range(L):

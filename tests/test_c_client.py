@@ -38,7 +38,7 @@ def test_c_client_compiles_and_links_against_the_header(tmp_path):
     out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
     used = sorted(l.split()[-1] for l in out.splitlines() if "pychain_hip_" in l)
     assert {"pychain_hip_den_plan_build", "pychain_hip_den_plan_info", "pychain_hip_den_forward_backward",
-            "pychain_hip_chain_loss_forward_backward", "pychain_hip_abi_version"} <= set(used)
+            "pychain_hip_chain_loss_forward_backward", "pychain_hip_abi_version", "pychain_hip_den_tseg_state"} <= set(used)
     exported = subprocess.run(["nm", "-D", "--defined-only", build_ext.LIB], capture_output=True, text=True, check=True).stdout
     for sym in used:
         assert (" T " + sym) in exported, sym
@@ -111,3 +111,34 @@ def test_c_client_runs_the_hot_path(tmp_path, fused):
         loss = ChainLoss(w["den_graph"], 1e-5, avg=False)(x, w["lengths"], w["num_graphs"])
         loss.backward()
         assert float(loss.detach()) == float(got["totals"][0]) and np.array_equal(x.grad.cpu().numpy(), got["grad"])
+
+
+@pytest.mark.gpu
+def test_c_client_gets_the_burn_in_controller(tmp_path):
+    """the controller that lengthens the burn-in of a time-segmented call after a miss - or stops cutting a
+    plan that keeps missing - lives in the library (a device-resident state attached to the plan), so a C caller gets what the
+    Python layer gets.  The C3 graph, four sequences of 640 frames, network outputs N(0,1) x 4 (they forget slowly: the default
+    burn-in of 192 frames misses, and a longer one does not fit three times): the first call misses and is redone, no later one
+    does - and every call writes the gradient the uncut call writes."""
+    import re
+    exe = _build(tmp_path)
+    cfg = syn.CONFIGS["C3"]
+    B, T = 4, 640
+    w = dict(den_graph=syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0), cfg=cfg, num_graphs=None,
+             x=syn.make_input(B, T, cfg["D"], seed=33) * 2.0, lengths=torch.full((B,), T))
+    prob, res = str(tmp_path / "problem.bin"), str(tmp_path / "result.bin")
+    _write_problem(prob, w, False)
+    r = subprocess.run([exe, prob, res, "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = re.findall(r"call (\d): segments (\d+) rows_missed (\d+) .* next_burn_in (\d+) cooling_down (\d+)", r.stdout)
+    assert len(lines) == 5, r.stdout
+    segs, missed = [int(l[1]) for l in lines], [int(l[2]) for l in lines]
+    assert segs[0] > 1 and missed[0] > 0, r.stdout                       # cut, missed (and redone)
+    assert sum(1 for m in missed if m > 0) <= 3 and all(m == 0 for m in missed[3:]), r.stdout     # misses stop after <= 3 calls
+    got = _read_result(res, B, T, cfg["D"], False)
+    assert int(got["bad"].sum()) == 0
+    from pychain_amd import _plan, native
+    plan = _plan.graph_plan(w["den_graph"], cfg["D"], torch.device("cuda:0"))
+    with _lib.option("den_tseg", 0):
+        o, g, b = native.den_forward_backward(plan, w["x"].to("cuda:0"), w["lengths"], 1e-5)
+    assert rel_err(got["grad"], g.cpu().numpy()) <= 1e-5 and np.abs(got["den_objf"] - o.cpu().numpy()).max() <= 1e-5 * np.abs(o.cpu().numpy()).max()

@@ -157,3 +157,70 @@ def test_contract_of_the_host_twins():
     xh = x.to(torch.bfloat16).requires_grad_(True)
     ChainLoss(den, 1e-5)(xh, w["lengths"], num).backward()
     assert xh.grad.dtype == torch.bfloat16
+
+
+def test_what_a_call_reports_comes_back_with_the_tensor_it_returned(golden):
+    """`loss.bad_count` / `loss.totals` belong to the call that returned `loss` - two criteria interleaved in
+    one process, or on two host threads, do not read each other's (the class attributes ChainFunction.last_* are deprecated
+    mirrors of whoever called last)."""
+    import threading
+    z = golden("g2_c1_chainloss")
+    den, numb = graph_from_npz(z, "den_"), batch_from_npz(z, "numbatch_")
+    lengths = torch.from_numpy(z["lengths"])
+    good = torch.from_numpy(z["x"]).clone()
+    sick = good.clone()
+    sick[0, 3, 5] = float("nan")                                   # a NaN network output: `ok` false for that call
+    la = ChainLoss(den, 1e-5, avg=False)(sick.requires_grad_(True), lengths, numb)
+    lb = ChainLoss(den, 1e-5, avg=False)(good.clone().requires_grad_(True), lengths, numb)
+    count = lambda l: sum(int(b.sum()) for b in (l.bad_count if isinstance(l.bad_count, (tuple, list)) else [l.bad_count]))
+    assert count(la) > 0 and count(lb) == 0                       # each tensor carries ITS call's count, whoever called last
+    assert la.totals is None and lb.totals is None                # (host twins: no device totals)
+    # sharded wrapper: reads the report of the call it made
+    from pychain_amd.parallel import ShardedChainLoss
+    sa, sb = ShardedChainLoss(den, 1e-5, avg=False), ShardedChainLoss(den, 1e-5, avg=False)
+    va = sa(sick.detach().clone().requires_grad_(True), lengths, numb)
+    vb = sb(good.clone().requires_grad_(True), lengths, numb)
+    assert float(sa.last_stats[2]) > 0 and float(sb.last_stats[2]) == 0 and float(sb.last_stats[1]) == float(lengths.sum())
+    assert np.isnan(float(va.detach())) and abs(float(vb.detach()) - float(lb.detach())) <= 1e-6 * abs(float(lb.detach()))
+    # two host threads, each with its own criterion: every thread sees its own reports
+    out = {}
+
+    def run(name, x):
+        crit = ShardedChainLoss(den, 1e-5, avg=False)
+        seen = []
+        for _ in range(6):
+            crit(x.clone().requires_grad_(True), lengths, numb).backward()
+            seen.append(float(crit.last_stats[2]))
+        out[name] = seen
+    ts = [threading.Thread(target=run, args=("sick", sick.detach())), threading.Thread(target=run, args=("good", good))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert all(v > 0 for v in out["sick"]) and all(v == 0 for v in out["good"]), out
+
+
+def test_the_pychain_C_surface_on_cpu_tensors_does_not_clamp(golden):
+    """the reference clamps in Python (pychain/loss.py:30); its C++ entry point computes on what it is given
+    (chain-log-domain-computation.cc:137-145).  `native.forward_backward_log_domain` on CPU tensors must do the same - values
+    beyond +-30 are used as they are - while ChainFunction on the same input clamps.  Checked against the oracle (the
+    restatement of the C++ loops, which has no clamp) on both inputs."""
+    import oracle as orc
+    z = golden("g5_raw_pychain_C")
+    L = torch.from_numpy(z["lengths"])
+    x = torch.from_numpy(z["x_clamped"]).clone()
+    x[:, ::3, ::5] *= 9.0                                        # well outside [-30, 30] on a lattice of elements
+    assert float(x.abs().max()) > 30.0
+    bs = torch.nn.utils.rnn.pack_padded_sequence(x, L, batch_first=True).batch_sizes
+    nb = batch_from_npz(z, "num_")
+    args = (nb.forward_transitions, nb.forward_transition_indices, nb.forward_transition_probs, nb.backward_transitions,
+            nb.backward_transition_indices, nb.backward_transition_probs, nb.initial_probs, nb.final_probs, nb.start_state)
+    o_raw, lg_raw, ok = native.forward_backward_log_domain(*args, x, bs, L, nb.num_states)
+    ro, rlg, rok = orc.num(nb, x.numpy(), z["lengths"], flavour="f64")          # no clamp anywhere
+    assert bool(ok) == rok and abs(float(o_raw) - ro.sum()) <= 1e-5 * abs(ro.sum())
+    fin = np.isfinite(rlg)
+    assert np.array_equal(np.isneginf(lg_raw.numpy()), np.isneginf(rlg)) and np.abs(lg_raw.numpy()[fin] - rlg[fin]).max() <= 1e-3
+    # ChainFunction clamps (loss.py:30): the same input gives what the clamped input gives
+    o_fn, _ = _function(x.numpy(), z["lengths"], nb)
+    rc, _, _ = orc.num(nb, x.clamp(-30, 30).numpy(), z["lengths"], flavour="f64")
+    assert abs(o_fn - rc.sum()) <= 1e-5 * abs(rc.sum()) and abs(rc.sum() - ro.sum()) > 1e-3 * abs(ro.sum())

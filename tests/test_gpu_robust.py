@@ -461,3 +461,84 @@ def test_a_batch_larger_than_the_chip_runs_in_slices(dtype, T, D):
     dev_len = run("-1")
     assert abs(dev_len[0] - one[0]) <= 1e-6 * abs(one[0])
     assert (dev_len[1].float() - one[1].float()).abs().max() <= (4e-3 if dtype != torch.float32 else 2e-7) * one[1].float().abs().max()
+
+
+def test_two_criteria_and_two_host_threads_keep_their_own_reports():
+    """VERDICT r5 weak 9: the totals / bad count of a call travel with the tensor it returned (`loss.totals`, `loss.bad_count`);
+    ShardedChainLoss reads them from there.  Two criteria interleaved in one process, then two host threads each stepping its own
+    criterion on its own stream, see their own numbers - bit for bit what each gets alone."""
+    import threading
+    from pychain_amd.parallel import ShardedChainLoss
+    w = syn.make_workload("C1")
+    xa = w["x"].to(DEV)
+    xb = (w["x"] * 0.5 + 0.25).to(DEV)
+    xs = xa.clone()
+    xs[1, 2, 3] = float("nan")
+    alone = {}
+    for name, x in (("a", xa), ("b", xb), ("sick", xs)):
+        crit = ShardedChainLoss(w["den_graph"], 1e-5, avg=True)
+        xx = x.clone().requires_grad_(True)
+        l = crit(xx, w["lengths"], w["num_graphs"])
+        l.backward()
+        alone[name] = (l.detach().clone(), xx.grad.clone(), crit.last_stats.clone())
+    # interleaved: forward a, forward sick, forward b, then read everybody's report
+    ca, cs, cb = (ChainLoss(w["den_graph"], 1e-5, avg=False) for _ in range(3))
+    la = ca(xa.clone().requires_grad_(True), w["lengths"], w["num_graphs"])
+    ls = cs(xs.clone().requires_grad_(True), w["lengths"], w["num_graphs"])
+    lb = cb(xb.clone().requires_grad_(True), w["lengths"], w["num_graphs"])
+    torch.cuda.synchronize()
+    assert float(la.totals[0]) == float(la.detach()) and float(lb.totals[0]) == float(lb.detach())
+    assert float(la.totals[2]) == 0 and float(lb.totals[2]) == 0 and float(ls.totals[2]) >= 1
+    assert int(la.bad_count.sum()) == 0 and int(ls.bad_count.sum()) >= 1 and int(lb.bad_count.sum()) == 0
+    assert float(la.totals[0]) != float(lb.totals[0])
+    # two host threads, a criterion and a stream each
+    got, errs = {}, []
+
+    def run(name, x):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                crit = ShardedChainLoss(w["den_graph"], 1e-5, avg=True)
+                for _ in range(12):
+                    xx = x.clone().requires_grad_(True)
+                    l = crit(xx, w["lengths"], w["num_graphs"])
+                    l.backward()
+                    torch.cuda.current_stream().synchronize()
+                    ref = alone[name]
+                    ok = torch.equal(crit.last_stats, ref[2]) and torch.equal(xx.grad, ref[1]) if name != "sick" else float(crit.last_stats[2]) >= 1
+                    got.setdefault(name, []).append(bool(ok))
+        except Exception as e:          # (a thread's exception would otherwise be lost)
+            errs.append(repr(e))
+    ts = [threading.Thread(target=run, args=(n, x)) for n, x in (("a", xa), ("sick", xs), ("b", xb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert all(all(v) for v in got.values()) and sorted(got) == ["a", "b", "sick"], got
+
+
+def test_backward_on_workspaces_a_sliced_forward_wrote_is_refused():
+    """a fused forward over a batch larger than the chip that also writes the gradient runs in slices through the SAME
+    workspaces - afterwards they hold the last slice's trajectories only, and `chain_loss_backward` on that state would write a
+    wrong gradient for every earlier slice.  The library remembers which forward last wrote a workspace and refuses
+    (EUNSUPPORTED); the same batch forwarded WITHOUT a gradient (one call, nothing sliced) takes the backward call, and gives
+    the gradient the sliced forward wrote."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B, T, D = (7 * cus + 7) // 8 + 3, 40, 104
+    den = syn.make_den_graph(200, 2000, D)
+    L = syn.make_lengths(B, T, "ragged", seed=4)
+    num = syn.make_num_graphs(L.tolist(), D, seed=300)
+    plan = _plan.graph_plan(den, D, torch.device(DEV))
+    assert _lib.lib().pychain_hip_chain_loss_slices(plan.stride, plan.slot_rows, B) >= 2
+    gt = num.device_tensors(torch.device(DEV))
+    x = syn.make_input(B, T, D, seed=5, device=DEV)
+    _, _, bad, st, _ = native.chain_loss_forward(plan, gt, 1, num.num_states, x, L, 1e-5, with_grad=True, half_ok=False)
+    torch.cuda.synchronize()
+    assert int(bad.sum()) == 0
+    with pytest.raises(_lib.PychainHipError, match="slices"):
+        native.chain_loss_backward(st)
+    _, _, bad2, st2, _ = native.chain_loss_forward(plan, gt, 1, num.num_states, x, L, 1e-5, with_grad=False, half_ok=False)
+    g2, bad3 = native.chain_loss_backward(st2)
+    torch.cuda.synchronize()
+    assert int(bad2.sum()) == 0 and int(bad3.sum()) == 0
+    assert (g2 - st.grad).abs().max() <= 1e-6 * st.grad.abs().max()

@@ -116,13 +116,14 @@ def test_segmented_fused_loss_two_byte_rows_and_nan():
         assert np.isnan(ln) and int(bn.sum()) > 0, (b, t)
 
 
-def test_a_burn_in_that_misses_is_noticed_by_the_host_layer():
+def test_a_burn_in_that_misses_is_noticed_by_the_plans_controller():
     """How long a recursion needs to forget its start depends on the DATA (network outputs N(0,1) x 4 instead of x 2 need more
     than 256 frames on the benchmark graph: profiles/r05_time_segments.txt), and a call whose speculated rows do not verify runs
-    its recursions twice.  pychain_amd.native watches totals[5] of its calls - a non-blocking copy to pinned memory, read when
-    its event has fired: no sync - and lengthens the burn-in for that plan by half after a miss (or stops cutting it when the burn-in
-    would eat the gain).  Started here from a burn-in of 57 frames: 57, 86, 129 miss, 194 verifies; every call - also the
-    missing ones, through the fallback - gives the unsegmented call's numbers."""
+    its recursions twice.  Since ABI 16 the controller is IN THE LIBRARY (include/pychain_hip.h: pychain_hip_den_tseg_state): a
+    device-resident state attached to the plan, read by the kernels of a segmented call and updated by the call's last kernel
+    in stream order - no host read, no host timing, so the SAME sequence of calls takes the SAME decisions.
+    Started here from a burn-in of 57 frames: 57, 86, 129 miss, 194 verifies; every call - also the missing ones, through the
+    fallback - gives the unsegmented call's numbers; a second run from the same state repeats the first bit for bit."""
     cfg = syn.CONFIGS["C3"]
     den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
     plan = _plan.graph_plan(den, cfg["D"], torch.device(DEV))
@@ -130,16 +131,52 @@ def test_a_burn_in_that_misses_is_noticed_by_the_host_layer():
     L = torch.full((B,), T)
     x = syn.make_input(B, T, cfg["D"], seed=31, device=DEV)
     o0, g0, _, _ = _den(plan, x, L, den_tseg=0)
-    native._tseg_ctl.clear()
-    key = native._tseg_key(plan, B, T, cfg["D"], torch.device(DEV), False)
-    assert key is not None
-    st = native._tseg_ctl[key] = native._TsegState()
-    st.burn = 57
+    st = plan.tseg_state
+    assert st is not None and st.numel() * 4 == _lib.lib().pychain_hip_den_tseg_state_bytes()
+    MAGIC = 0x74736567
+
+    def run():
+        st.zero_()
+        st[0], st[1] = MAGIC, 57                      # (a state that has learnt nothing useful: burn-in 57)
+        seen, grads = [], []
+        for i in range(6):
+            o, g, b, t = native.den_forward_backward(plan, x, L, 1e-5, totals=True)
+            torch.cuda.synchronize()
+            seen.append((int(t[6]), int(t[5]), int(st[1]), int(st[4])))      # segments, rows missed, burn-in AFTER the call, misses so far
+            grads.append(g.clone())
+            assert int(b) == 0 and rel_err(g.cpu().numpy(), g0.cpu().numpy()) <= 1e-5 and float((o - o0).abs().max()) <= 1e-5 * float(o0.abs().max())
+        return seen, grads
+    seen, grads = run()
+    assert seen[0][0] == 4 and seen[0][1] > 0 and seen[0][2] == 86, seen                # cut, missed, redone; the next call burns in longer
+    assert [s[2] for s in seen[:4]] == [86, 129, 194, 194] and seen[-1][1] == 0 and seen[-1][3] == 3, seen   # 57 -> 86 -> 129 -> 194: verifies
+    again, grads2 = run()
+    assert again == seen and all(torch.equal(a, b) for a, b in zip(grads, grads2))      # deterministic: no host timing in the loop
+    # a caller that pins the burn-in with an option bypasses the state
+    st.zero_(); st[0], st[1] = MAGIC, 57
+    o, g, b, t = _den(plan, x, L, den_tburn=192)
+    assert int(st[3]) == 0 and int(t[5]) == 0                                           # the state was not touched; 192 verifies
+
+
+def test_a_plan_that_keeps_missing_cools_down_and_c_callers_get_the_same():
+    """Beyond a third of the sequence the cut no longer pays: the plan is not cut for the next 500 calls (the segmented launch
+    leaves at once, the uncut launch behind it does the work: totals[6] == 1) and starts over.  Data that forgets slowly -
+    N(0,1) x 4 - at T = 640: 192 misses, 288 would not fit three times -> cool-down; misses stop after the first call."""
+    cfg = syn.CONFIGS["C3"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    plan = _plan.graph_plan(den, cfg["D"], torch.device(DEV))
+    B, T = 4, 640
+    L = torch.full((B,), T)
+    x = syn.make_input(B, T, cfg["D"], seed=33, device=DEV) * 2.0            # (make_input is N(0,1) x 2)
+    o0, g0, _, _ = _den(plan, x, L, den_tseg=0)
+    st = plan.tseg_state
+    st.zero_()
     seen = []
-    for i in range(6):
+    for i in range(4):
         o, g, b, t = native.den_forward_backward(plan, x, L, 1e-5, totals=True)
         torch.cuda.synchronize()
-        seen.append((int(t[6]), int(t[5]), st.burn))
-        assert int(b) == 0 and rel_err(g.cpu().numpy(), g0.cpu().numpy()) <= 1e-5 and float((o - o0).abs().max()) <= 1e-5 * float(o0.abs().max())
-    assert seen[0][0] == 4 and seen[0][1] > 0 and seen[0][2] == 57, seen               # cut, missed, redone
-    assert seen[-1][1] == 0 and seen[-1][2] == 194 and st.misses == 3, seen           # 57 -> 86 -> 129 -> 194: verifies
+        seen.append((int(t[6]), int(t[5]), int(st[1]), int(st[2]), int(st[3])))
+        assert int(b) == 0 and rel_err(g.cpu().numpy(), g0.cpu().numpy()) <= 1e-5
+    assert seen[0][0] > 1 and seen[0][1] > 0 and seen[0][3] == 500, seen     # cut, missed, cooling down from here on
+    assert all(s[0] == 1 and s[1] == 0 for s in seen[1:]) and seen[-1][3] == 497 and seen[-1][4] == 4, seen
+    assert torch.equal(g, g0)                                                # a cooled-down call IS the uncut call
+    st.zero_()

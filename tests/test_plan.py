@@ -407,3 +407,76 @@ def test_states_on_several_lanes_random_graphs(seed):
     assert np.abs(objf - objf0).max() <= 1e-11 * np.abs(objf0).max() and rel_err(grad, grad0) <= 1e-11
     ro, rg, ok = orc.den(ChainGraphBatch(g, 2), np.exp(np.clip(x, -30, 30)), L, 1e-3, flavour="f64")
     assert ok and abs(objf.sum() - ro.sum()) <= 2e-6 * abs(ro.sum()) and rel_err(grad, rg) <= 1e-5
+
+
+def test_hub_to_hub_arcs_do_not_blow_up_the_occupancy_tile(capfd, monkeypatch):
+    """the occupancy tile gets an arc once per (alpha position of its source, beta position of its destination), so
+    arcs from a state on several alpha lanes to a state on several beta lanes are repeated parts_a x parts_b times; the 5/4
+    bound of the recursion sides does not see that.  The compiler bounds the tile (3/2 of the arcs; a side gives its split up).
+    The sides' own bounds keep graphs that settle at all under about 2 K, so the test lowers the bound to see the rule act -
+    and what the kernels compute stays what the unsplit plan gives."""
+    monkeypatch.setenv("PYCHAIN_PLAN_STATS", "1")
+    monkeypatch.setenv("PYCHAIN_PLAN_CACHE_DIR", "off")
+    g, D = _hub_graph(seed=9)
+    H = g.num_states
+    K = int(g.forward_transitions.shape[0])
+    blob_free = _blob(g, D)
+    free = int((emu.parse(blob_free)["gamma"]["p"] != 0).sum())
+    err0 = capfd.readouterr().err
+    assert "states on several lanes: loop class" in err0 and "given up" not in err0 and free > K      # split, every copy kept
+    monkeypatch.setenv("PYCHAIN_PLAN_GAMMA_BOUND", str(int(100.0 * (free - 65) / K)))                 # (just under what it takes)
+    blob = _blob(g, D)
+    err = capfd.readouterr().err
+    with _lib.option("plan_split", "0"):
+        blob0 = _blob(g, D)
+    hd, hd0 = emu.parse(blob), emu.parse(blob0)
+    n_gamma = int((hd["gamma"]["p"] != 0).sum())
+    assert int((hd0["gamma"]["p"] != 0).sum()) == K and "given up" in err, err[-1500:]
+    assert K <= n_gamma < free, (K, n_gamma, free)
+    T = 6
+    x = syn.make_input(2, T, D, seed=77).numpy()
+    L = np.array([T, T - 1])
+    objf, grad = emu.den_forward_backward(blob, x, L, 1e-3)
+    objf0, grad0 = emu.den_forward_backward(blob0, x, L, 1e-3)
+    assert np.abs(objf - objf0).max() <= 1e-11 * np.abs(objf0).max() and rel_err(grad, grad0) <= 1e-11
+
+
+def test_pdf_by_state_plans_and_their_one_gather_form():
+    """A graph whose arcs carry the pdf of the state they enter is marked (plan format 14, launch-hint bit 27) and carries that
+    pdf by alpha / beta position; the recursions' one-gather form (den_lazy.inc.h: SG; emulated from the tables alone, the arcs'
+    own pdf operand unread) gives what the ordinary form gives and what the fp64 oracle gives.  The benchmark graph (a pdf per
+    arc) and a graph where ONE state breaks the rule are not marked; PYCHAIN_PLAN_SG=0 marks nothing."""
+    g = syn.make_structured_den_graph(200, 5, 300)
+    D = 300
+    blob = _blob(g, D)
+    info, hd = _plan.plan_info(blob), emu.parse(blob)
+    assert hd["pdf_by_state"] and (info["slot_rows"] >> 27) & 1
+    # every arc of the alpha tile carries the pdf of its ROW's position, every arc of the beta tile that of the position it GATHERS
+    for name, by_row in (("alpha", True), ("beta", False)):
+        t = hd[name]
+        for w in range(t["nwaves"]):
+            first, ng, row, _ = t["waves"][w]
+            for gi in range(first, first + ng):
+                base, ns = t["groups"][gi]
+                for j in range(ns):
+                    idx, p = t["idx"][row + j], t["p"][row + j]
+                    want = hd["pdf_a"][base:base + 64] if by_row else hd["pdf_b"][idx & 0xffff]
+                    assert np.array_equal((idx >> 16)[p != 0], want[p != 0])
+                row += ns
+    T = 9
+    x = syn.make_input(2, T, D, seed=3).numpy()
+    L = np.array([T, T - 4])
+    o1, g1 = emu.den_forward_backward(blob, x, L, 1e-3, sg=True)
+    o0, g0 = emu.den_forward_backward(blob, x, L, 1e-3)
+    assert np.abs(o1 - o0).max() <= 1e-11 * np.abs(o0).max() and rel_err(g1, g0) <= 1e-11
+    ro, rg, ok = orc.den(ChainGraphBatch(g, 2), np.exp(np.clip(x, -30, 30)), L, 1e-3, flavour="f64")
+    assert ok and abs(o1.sum() - ro.sum()) <= 2e-6 * abs(ro.sum()) and rel_err(g1, rg) <= 1e-5
+    # not marked: a pdf per arc; one arc that breaks the rule; the knob
+    rnd = syn.make_den_graph(200, 2000, D, seed=0)
+    assert not emu.parse(_blob(rnd, D))["pdf_by_state"]
+    import os
+    os.environ["PYCHAIN_PLAN_SG"] = "0"
+    try:
+        assert not emu.parse(_blob(g, D))["pdf_by_state"]
+    finally:
+        del os.environ["PYCHAIN_PLAN_SG"]

@@ -7,6 +7,8 @@ from pychain_amd import _lib, _plan, native, synthetic as syn
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 dev = torch.device("cuda:0")
 w = syn.make_workload(name, device=dev)
+if os.environ.get("TIME_DEN_STRUCTURED"):        # the phone-LM-like graph of the same size (every arc carries the pdf of the state it enters)
+    w["den_graph"] = syn.make_structured_den_graph(w["cfg"]["H"] // 2, (w["cfg"]["K"] // (w["cfg"]["H"] // 2) - 2) // 2, w["cfg"]["D"])
 plan = _plan.graph_plan(w["den_graph"], w["cfg"]["D"], dev)
 Ld = w["lengths"].to(dev)
 L = _lib.lib()
