@@ -1220,6 +1220,7 @@ int chain_loss_backward_impl(
   da.fused = 1;                                          // (the forward call that stored the rows decided as a fused call)
   da.lazy = den_call_is_lazy(da, resident_slot_rows) ? 1 : 0;
   da.shape = da.lazy ? den_call_shape(da, resident_slot_rows) : 0;
+  da.sg = (da.lazy && da.shape == kShapeDma && den_sg_eligible(da, resident_slot_rows)) ? 1 : 0;   // (what the stored alpha rows ARE: DenArgs::sg)
   NumArgs na;
   // the occupancy launch reads only the forward transitions / indices / log-probs of the graphs
   rc = fill_num_args(na, ft, fi, fp, ft, fi, fp, fp, fp,

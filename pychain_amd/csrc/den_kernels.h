@@ -38,7 +38,11 @@ struct DenArgs {
   // registers), kShapeDma = LzNarrowDma / LzDma (16 waves, rows by LDS-direct loads, up to 9216 pdfs), kShapeSmall = LzSmall
   // (4 waves over the plan's four-wave dealing: small graphs)
   int shape;
-  int sg;                     // 1: the lazy recursions of this call run the one-gather form of a "pdf by state" plan (den_lazy.inc.h: SG)
+  // 1: a "pdf by state" plan in its own forms (plan_format.h: PLAN_FLAG_PDF_BY_STATE) - the lazy recursions gather ONE operand per arc
+  // (den_lazy.inc.h: SG), the alpha store holds a(t+1,.) at row t instead of alpha'(t,.), and the occupancy kernels sum over
+  // STATES (the plan's gamma_sg tiles) without reading the nnet-output row.  Decided once per call; a later
+  // chain_loss_backward on the same workspaces decides alike (same shape, same options).
+  int sg;
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
   //     objf = sum_t log tot_a(t) + log fin_dot        (ComputeTotLogLike, chain-computation.cc:209-230)

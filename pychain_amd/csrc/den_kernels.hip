@@ -95,7 +95,10 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
   const double logp = sh_total_a + log((double)fin_dot);
   const float objf = (float)logp;
   // (frame 0's side of the check, below)   lazy: PA(0) = 0, SB(0) = sum_{tau>=2} log n(tau);   else: log tot(0), sum_{tau>=1}
-  const double pa_sb0 = (a.lazy ? 0.0 : log((double)ta0)) + sh_total_b - (a.lazy && L >= 1 ? log((double)tb1) : 0.0);
+  // (DenArgs::sg: the occupancy totals are sums of a(t+1,.) beta(t+1,.) - the alpha factor already divided by tot(t): PA(t) then
+  // runs over tau <= t as for normalised rows, SB(t) as for the lazy beta rows)
+  const bool pa_incl = !a.lazy || a.sg;
+  const double pa_sb0 = (pa_incl ? log((double)ta0) : 0.0) + sh_total_b - (a.lazy && L >= 1 ? log((double)tb1) : 0.0);
   // Everything above needs the recursions only; frame 0's occupancy total - the other side of the check - comes from the
   // occupancy launch, which may still be running (DenArgs::occ_done): the sequence's side is left for the last workgroup.
   int bad = 0;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(kFinNT) void den_finish_kernel(const DenArgs a) {
     for (int t = t0; t < t1; t++) {
       const double lt = log((double)ta[t]);
       // cb = sum_{1<=tau<=t} log n(tau)
-      const double pa = a.lazy ? ca : ca + lt;
+      const double pa = pa_incl ? ca + lt : ca;
       const double upto = a.lazy ? cb + (t + 1 <= L ? log((double)tb[t + 1]) : 0.0) : cb;   // sum_{tau<=t+1} / sum_{tau<=t}
       const double est = log((double)g[t]) + pa + (sh_total_b - upto);
       if (!(fabs(est - logp) <= 0.0487901642)) bad = 1;   // log(1.05); NaN counts
@@ -363,11 +366,14 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
-  const TilePlan tp = hd->gamma;
+  // DenArgs::sg ("pdf by state" plans, plan_format.h: gamma_sg): the alpha store holds a(t+1,.) at row t and the occupancies are a
+  // sum over STATES - the tile over states, and no nnet-output row (its rows are "read" as zeros: exp(0) = 1 multiplies)
+  const bool sg = a.sg != 0;
+  const TilePlan tp = sg ? hd->gamma_sg : hd->gamma;
   const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
-  const int32_t* row_pdf = reinterpret_cast<const int32_t*>(plan + hd->off_row_pdf);
+  const int32_t* row_pdf = reinterpret_cast<const int32_t*>(plan + (sg ? hd->off_row_pdf_sg : hd->off_row_pdf));
 
   float* U = reinterpret_cast<float*>(smem_raw);   // alpha'(t,.)   [Hp]
   float* V = U + Hp;                                // beta(t+1,.)   [Hp]
@@ -419,6 +425,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
 #define GAMMA_PREFETCH(t)                                                                     \
   do {                                                                                        \
     if constexpr (XH) xq.load_h(reinterpret_cast<const char*>(xseq) + (size_t)(t) * D * 2, D, tid);   /* (raw) */        \
+    else if (sg) { _Pragma("unroll") for (int i_ = 0; i_ < ((VEC * XCH) > 0 ? (VEC * XCH) : 1); i_++) xq.v[i_] = 0.f; }  \
     else xq.load(xseq + (size_t)(t) * D, D, tid);                                             \
     if (uv_in_regs) {                                                                         \
       const float* ar_ = aseq + (size_t)(t) * Hp;                                             \
@@ -688,11 +695,12 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
   const PlanHeader* hd = reinterpret_cast<const PlanHeader*>(plan);
-  const TilePlan tp = hd->gamma2;
+  const bool sg = a.sg != 0;                          // (the tile over states of a "pdf by state" plan: den_gamma_kernel)
+  const TilePlan tp = sg ? hd->gamma2_sg : hd->gamma2;
   const WaveEntry we = reinterpret_cast<const WaveEntry*>(plan + tp.off_wave_tab)[wave];
   const GroupEntry* gtab = reinterpret_cast<const GroupEntry*>(plan + tp.off_group_tab);
   const uint2* slots = reinterpret_cast<const uint2*>(plan + tp.off_slots);
-  const int32_t* row_pdf = reinterpret_cast<const int32_t*>(plan + hd->off_row_pdf);
+  const int32_t* row_pdf = reinterpret_cast<const int32_t*>(plan + (sg ? hd->off_row_pdf_sg : hd->off_row_pdf));
 
   float* U2 = reinterpret_cast<float*>(smem_raw);    // [Hp] x {alpha'(t0,.), alpha'(t0+1,.)}
   float* V2 = U2 + 2 * Hp;                            // [Hp] x {beta(t0+1,.), beta(t0+2,.)}
@@ -812,6 +820,9 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
       if constexpr (XH) {
         x0.load_h(reinterpret_cast<const char*>(xseq) + (size_t)t0 * D * 2, D, tid);            // (raw: converted behind the arc work)
         x1.load_h(reinterpret_cast<const char*>(xseq) + (size_t)min(t0 + 1, T - 1) * D * 2, D, tid);
+      } else if (sg) {                                   // no nnet-output row: exp(0) = 1 multiplies
+#pragma unroll
+        for (int i_ = 0; i_ < 4 * XCH; i_++) { x0.v[i_] = 0.f; x1.v[i_] = 0.f; }
       } else {
         x0.load(xseq + (size_t)t0 * D, D, tid);
         x1.load(xseq + (size_t)min(t0 + 1, T - 1) * D, D, tid);
@@ -981,11 +992,11 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
     const dim3 grid = stream ? dim3(a.stream_blocks) : dim3(gx, a.B);
     if (gamma2_eligible(a, (hint >> 20) & 127, gamma_max_groups)) {
       const size_t lds2 = gamma2_lds_bytes(a, gamma_max_groups);
-      const int r2 = (hint >> 20) & 127;
+      const int r2 = a.sg ? PLAN_RESIDENT_0 : (hint >> 20) & 127;       // (the tile over states: at most PLAN_RESIDENT_0 rows per wave)
       if (stream) return a.D <= 4 * kNT2 ? launch_gamma2<1, true>(a, r2, lds2, grid, st) : launch_gamma2<2, true>(a, r2, lds2, grid, st);
       return a.D <= 4 * kNT2 ? launch_gamma2<1, false>(a, r2, lds2, grid, st) : launch_gamma2<2, false>(a, r2, lds2, grid, st);
     }
-    const int r = pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
+    const int r = a.sg ? PLAN_RESIDENT_0 : pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
     if (stream) {
       if constexpr (VEC == 4 && XCH > 0) return launch_gamma_stream<XCH>(a, r, lds_gam, grid, st);
       else return hipErrorInvalidValue;                 // (den_stream_eligible said no)

@@ -821,7 +821,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     auto hook_first = [&]() {                                                                                \
       if (j > 0) PYCHAIN_LZ_TOTALS(pre0, pre1, j - 1, (FWDC), tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) is completed and leaves for HBM */ \
-      const int trow = (FWDC) ? j : L - j;                                                                  \
+      /* (SG alpha - DenArgs::sg: the row the occupancy pass reads for frame t is a(t+1,.) ITSELF, without the leaky term, stored as */ \
+      /* row t: step j stores a(j,.) - what step j - 1 produced - as row j - 1, and the last one is flushed after the loop) */ \
+      const int trow = (FWDC) ? ((SG) ? j - 1 : j) : L - j;                                                 \
       /* (time segments: a burn-in row goes to the splice buffer - the one next to the segment to be verified, the others */ \
       /* to a row nobody reads; both choices are uniform: a descriptor and an offset in SGPRs) */            \
       const bool real_row = row_real(trow);                                                                 \
@@ -829,10 +831,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       const int row_off = __builtin_amdgcn_readfirstlane((!TS || real_row) ? trow * Hp * 4 : (trow == spec_row ? 0 : Hp * 4)); \
       const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
       _Pragma("unroll") for (int g = 0; g < MG; g++)                                                        \
-        if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1) {                                           \
+        if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1 && !((SG) && (FWDC) && j == 0)) {            \
           const lz_v2f pr = kPreRows ? prow[g] : lz_ld2(UCUR + gbase[g] * 8 + lq * 8);                      \
           /* (SG beta: the buffer holds x {b, 1}: b + c = pr.x / pr.y + c) */                                  \
-          const float rowv = (SG && !(FWDC)) ? __builtin_fmaf(pr.x, __builtin_amdgcn_rcpf(pr.y), w.sprev) : __builtin_fmaf(w.sprev, pr.y, pr.x); \
+          const float rowv = (SG) ? ((FWDC) ? pr.x : __builtin_fmaf(pr.x, __builtin_amdgcn_rcpf(pr.y), w.sprev)) : __builtin_fmaf(w.sprev, pr.y, pr.x); \
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), obuf, lane4,                          \
                                                 row_off + gbase[g] * 4, kStoreDeviceScope);                 \
         }                                                                                                   \
@@ -882,11 +884,24 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
     PYCHAIN_LZ_SIGNAL(jj + 1);                                // (rows lag one step: after jj + 2 steps the rows of steps < jj + 1 are out)
     // step j stores the row of the frame before it (alpha row j, beta row L - j): after steps 0 .. jj + 1, jj + 2 rows
-    if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2);
+    // (SG alpha stores row j - 1 in step j: one row fewer is out)
+    if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2 - ((SG && fwd) ? 1 : 0));
   }
   if (nsteps > 0) {                                                                  // the last step's
     const float r0 = red[((nsteps - 1) & 1) * 128 + lane], r1 = fwd ? 0.f : red[((nsteps - 1) & 1) * 128 + 64 + lane];
     PYCHAIN_LZ_TOTALS(r0, r1, nsteps - 1, fwd, tid);
+  }
+  if constexpr (SG && fwd) {
+    // the last row of an SG alpha recursion - a(L,.), row L - 1 (DenArgs::sg) - never saw a next step's hook
+    if (nsteps > 0) {
+      const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
+      const int row_off = (nsteps - 1) * Hp * 4;
+      for (int g = 0; g < MG; g++)
+        if (g < groups.ngroups) {
+          const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * (gbase[g] + lane));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(u.x), sbuf, lane * 4, row_off + gbase[g] * 4, kStoreDeviceScope);
+        }
+    }
   }
   if constexpr (!fwd) {
     // the last beta row (row L - nsteps: row 1, or the start row if the sequence has one frame) never saw a next frame

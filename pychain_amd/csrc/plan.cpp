@@ -875,19 +875,14 @@ int64_t plan_build_impl(
         // The occupancy tile gets an arc once per (alpha position of its source, beta position of its destination): the 5/4
         // bound of settle_parts holds per recursion side only, and an arc between two hub states - or a hub's self-loop - is
         // repeated parts_a x parts_b times there.  Bounded like the sides: at most 3/2 of the arcs; beyond that
-        // the side with the smaller gain gives its split up, then the other.
+        // the graph keeps every state on one lane.
         auto gamma_arcs = [&]() { long n = 0; for (int k = 0; k < K; k++) n += (long)parts_a[ft[3 * k]] * parts_b[ft[3 * k + 1]]; return n; };
         // (PYCHAIN_PLAN_GAMMA_BOUND: the bound in percent of the arcs, default 150 - the sides' own 5/4 bounds keep real graphs
         // under about 2 K, so the tests lower it to see the rule act)
         const long gbound = (long)K * env_long("PYCHAIN_PLAN_GAMMA_BOUND", 150) / 100 + 64;
-        if (gamma_arcs() > gbound) {
-          const bool a_first = va[0].cls <= vb[0].cls;       // (the side that was closer to the target without a split goes first)
-          std::vector<int>& first = a_first ? parts_a : parts_b;
-          std::vector<int>& second = a_first ? parts_b : parts_a;
-          first.assign(H, 1);
-          if (gamma_arcs() > gbound) second.assign(H, 1);
-          if (stats) fprintf(stderr, "[plan] states on several lanes: the occupancy tile would repeat too many arcs - split of %s given up\n",
-                             gamma_arcs() > gbound ? "both sides" : (a_first ? "alpha" : "beta"));
+        if (gamma_arcs() > gbound) {                          // (the loop is as long as the longer side's: one side alone gains nothing)
+          parts_a.assign(H, 1); parts_b.assign(H, 1);
+          if (stats) fprintf(stderr, "[plan] states on several lanes: the occupancy tile would repeat too many arcs - split given up\n");
         }
       }
     }
@@ -997,6 +992,29 @@ int64_t plan_build_impl(
   BuiltTile tg2 = emit_tile(tiles[2], so_g, lay, deal_groups(tiles[2].gsl, PLAN_GAM2_WAVES));
   // the recursion tiles once more for four-wave workgroups, where the whole graph fits them (a wave keeps at most
   // PLAN_RESIDENT_2 slot-rows in registers and four groups: den_lazy.inc.h, LzSmall)
+  // "pdf by state": the occupancy tiles over states instead of arcs (plan_format.h: gamma_sg) - one pseudo-arc per alpha position
+  // of a state that has arcs entering it: {that alpha position, the state's beta position, 1}, in the row of the state's pdf
+  BuiltTile tgs, tgs2;
+  std::vector<std::vector<Arc>> rows_gs(D);
+  Tile tile_gs;
+  if (pdf_by_state) {
+    if (HB != H) pdf_by_state = false;                      // (a state on several BETA positions: the kernels' NC form has no one-gather variant)
+    for (int h = 0; h < H && pdf_by_state; h++)
+      if (bi[2 * h + 1] > bi[2 * h])
+        for (int m = 0; m < parts_a[h]; m++) rows_gs[in_pdf[h]].push_back(Arc{ea0[h] + m, eb0[h], 1.0f});
+  }
+  if (pdf_by_state) {
+    std::vector<int> gsdeg(D), gsids;
+    for (int n = 0; n < D; n++) { gsdeg[n] = (int)rows_gs[n].size(); if (gsdeg[n] > 0) gsids.push_back(n); }
+    const int gspos = std::max(((int)gsids.size() + 63) / 64 * 64, 64);
+    init_tile(tile_gs, rows_gs, sort_by_degree(gsdeg, gsids), gspos, kLayA, kLayB, -1, 1, 0, PLAN_GAM_WAVES);
+    SlotOrder so_gs(tile_gs, lay, false, false);
+    so_gs.run(50);
+    tgs = emit_tile(tile_gs, so_gs, lay, deal_groups(tile_gs.gsl, PLAN_GAM_WAVES));
+    tgs2 = emit_tile(tile_gs, so_gs, lay, deal_groups(tile_gs.gsl, PLAN_GAM2_WAVES));
+    if (tgs.max_wave > PLAN_RESIDENT_0 || tgs2.max_wave > PLAN_RESIDENT_0) pdf_by_state = false;   // (one pdf shared by hundreds of states: not the shape this is for)
+    if (stats) fprintf(stderr, "[plan] occupancy tile over states: %d slot-rows (over arcs: %d), max per wave %d / %d\n", tgs.total_slot_rows, tg.total_slot_rows, tgs.max_wave, tgs2.max_wave);
+  }
   BuiltTile ta4, tb4;
   if (small) {
     ta4 = emit_tile(tiles[0], so_a, lay, deal_groups(tiles[0].gsl, PLAN_REC4_WAVES, rec_group_limit(tiles[0].gsl.size(), PLAN_REC4_WAVES)));
@@ -1031,7 +1049,11 @@ int64_t plan_build_impl(
   place_vec(hd.off_leaky_b, Hp); place_vec(hd.off_final_b, Hp);
   place_vec(hd.off_row_pdf, gpos);
   place_vec(hd.off_no_const, std::max(1, HB - H));
-  if (pdf_by_state) { hd.flags |= PLAN_FLAG_PDF_BY_STATE; place_vec(hd.off_pdf_a, Hp); place_vec(hd.off_pdf_b, Hp); }
+  if (pdf_by_state) {
+    hd.flags |= PLAN_FLAG_PDF_BY_STATE; place_vec(hd.off_pdf_a, Hp); place_vec(hd.off_pdf_b, Hp);
+    place_tile(hd.gamma_sg, tgs); place_tile(hd.gamma2_sg, tgs2);
+    place_vec(hd.off_row_pdf_sg, std::max((int)tgs.groups.size() * 64, 64));
+  }
   if (off > (size_t)INT32_MAX)
     return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED, "den_plan_build: plan larger than 2 GiB");
   hd.total_bytes = (int32_t)off;
@@ -1066,6 +1088,9 @@ int64_t plan_build_impl(
   }
   for (int i = 0; i < gpos; i++) row_pdf[i] = i < (int)tiles[2].order.size() ? tiles[2].order[i] : -1;
   if (pdf_by_state) {
+    write_tile(hd.gamma_sg, tgs); write_tile(hd.gamma2_sg, tgs2);
+    int32_t* row_pdf_sg = (int32_t*)(base + hd.off_row_pdf_sg);
+    for (int i = 0; i < std::max((int)tgs.groups.size() * 64, 64); i++) row_pdf_sg[i] = i < (int)tile_gs.order.size() ? tile_gs.order[i] : -1;
     int32_t* pdf_a = (int32_t*)(base + hd.off_pdf_a); int32_t* pdf_b = (int32_t*)(base + hd.off_pdf_b);
     for (int h = 0; h < H; h++) {
       for (int m = 0; m < parts_a[h]; m++) pdf_a[lay.pos[kLayA][ea0[h] + m]] = in_pdf[h];

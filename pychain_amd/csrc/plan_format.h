@@ -98,7 +98,13 @@ struct PlanHeader {
   int32_t flags;
   int32_t off_pdf_a;           // int32[Hp]  pdf-id of the arcs entering the state at this alpha position
   int32_t off_pdf_b;           // int32[Hp]  ... at this beta position
-  int32_t reserved_tail;
+  // ... and the occupancies collapse from a sum over ARCS to a sum over STATES: with a(t+1,j) = x(t,pdf_j) sum_k p_k alpha'(t,src_k)
+  // - the value the alpha recursion forms anyway -  gamma(t,n) ~ sum_{j: pdf_j = n} a(t+1,j) beta(t+1,j).  The alpha recursion of
+  // such a plan stores a(t+1,.) at row t (instead of alpha'(t,.)), and the occupancy kernels walk these tiles - one pseudo-arc per
+  // state position {alpha position, beta position, 1}, rows = pdfs, no nnet-output row read - with the kernels and schedules
+  // they have (DenArgs::sg).  gamma_sg: 16 waves, gamma2_sg: 8 waves; at most PLAN_RESIDENT_0 slot-rows per wave.
+  int32_t off_row_pdf_sg;      // int32[gamma_sg.ngroups*64] natural pdf-id of each row of the *_sg tiles, -1 = padding
+  TilePlan gamma_sg, gamma2_sg;
 };
 #define PLAN_FLAG_PDF_BY_STATE 1
 
@@ -176,9 +182,12 @@ inline bool plan_header_in_bounds(const PlanHeader& hd) {
   for (int32_t off : {hd.off_init_a, hd.off_leaky_a, hd.off_final_a, hd.off_leaky_b, hd.off_final_b})
     if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
   if (hd.n_no_const < 0 || hd.off_no_const < 0 || (size_t)hd.off_no_const + (size_t)hd.n_no_const * 4 > n) return false;
-  if (hd.flags & PLAN_FLAG_PDF_BY_STATE)
+  if (hd.flags & PLAN_FLAG_PDF_BY_STATE) {
     for (int32_t off : {hd.off_pdf_a, hd.off_pdf_b})
       if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
+    if (!tile_in_bounds(hd.gamma_sg, n) || !tile_in_bounds(hd.gamma2_sg, n)) return false;
+    if (hd.off_row_pdf_sg < 0 || (size_t)hd.off_row_pdf_sg + (size_t)hd.gamma_sg.ngroups * 64 * 4 > n) return false;
+  }
   return hd.off_row_pdf >= 0 && (size_t)hd.off_row_pdf + (size_t)hd.gamma.ngroups * 64 * 4 <= n;
 }
 }  // namespace pychain_hip

@@ -7,7 +7,7 @@ against the oracle without a GPU.  Mirrors the kernels step by step.
 """
 import numpy as np
 
-HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 14), in int32 words
+HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4 + 16  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 14), in int32 words
 
 
 def parse(blob):
@@ -47,6 +47,10 @@ def parse(blob):
     if hd["pdf_by_state"]:
         hd["pdf_a"] = b[int(h[69]):int(h[69]) + 4 * Hp].view(np.int32).copy()
         hd["pdf_b"] = b[int(h[70]):int(h[70]) + 4 * Hp].view(np.int32).copy()
+        # ... and the occupancy tiles over states (one pseudo-arc per state position: {alpha position, beta position, 1})
+        hd["gamma_sg"], hd["gamma2_sg"] = tile(72), tile(80)
+        ngs = max(hd["gamma_sg"]["ngroups"] * 64, 64)
+        hd["row_pdf_sg"] = b[int(h[71]):int(h[71]) + 4 * ngs].view(np.int32).copy()
     return hd
 
 
@@ -103,23 +107,27 @@ def den_forward_backward(blob, x, lengths, coef, input_is_exp=False, dtype=np.fl
         tot = v.sum()
         logsum = np.log(tot)
         A[0] = v / tot + coef * la
+        Araw = np.zeros((L + 1, Hp), dtype=dtype)            # a(t,.) before the leaky term (any per-frame scale): what an sg alpha recursion stores
         for t in range(1, L + 1):
             v = ex[b, t - 1][hd["pdf_a"]] * tile_rows_sg(hd["alpha"], A[t - 1], Hp, dtype) if sg else tile_rows(hd["alpha"], A[t - 1], ex[b, t - 1], Hp, dtype)
             tot = v.sum()
             logsum += np.log(tot)
             A[t] = v / tot + coef * la
+            Araw[t] = v
         objf[b] = logsum + np.log((A[L] * hd["final_a"].astype(dtype)).sum())
         v = hd["final_b"].astype(dtype)
         Bt[L] = (v + mask * coef * (v * lb).sum()) / v.sum()
         for t in range(L - 1, 0, -1):
             v = tile_rows_sg(hd["beta"], ex[b, t][hd["pdf_b"]] * Bt[t + 1], Hp, dtype) if sg else tile_rows(hd["beta"], Bt[t + 1], ex[b, t], Hp, dtype)
             Bt[t] = (v + mask * coef * (v * lb).sum()) / v.sum()
-        g = hd["gamma"]
+        g = hd["gamma_sg"] if sg else hd["gamma"]
+        rp = hd["row_pdf_sg"] if sg else hd["row_pdf"]
         for t in range(L):
-            st = tile_rows(g, A[t], Bt[t + 1], max(g["ngroups"] * 64, 64), dtype)
+            # sg: a sum over STATES of a(t+1,j) beta(t+1,j) per pdf - no nnet-output row (DenArgs::sg)
+            st = tile_rows(g, Araw[t + 1] if sg else A[t], Bt[t + 1], max(g["ngroups"] * 64, 64), dtype)
             q = np.zeros(D, dtype=dtype)
-            ok = hd["row_pdf"][:len(st)] >= 0
-            q[hd["row_pdf"][:len(st)][ok]] = st[ok]
-            gm = ex[b, t] * q
+            ok = rp[:len(st)] >= 0
+            q[rp[:len(st)][ok]] = st[ok]
+            gm = q if sg else ex[b, t] * q
             grad[b, t] = gm / gm.sum()
     return objf, grad

@@ -56,9 +56,12 @@ def test_segmented_recursions_agree_with_the_chain(name, B, T, lens):
     if name == "C3" and B == 3:
         ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, B), 1e-5)
         assert abs(float(o.sum()) - ro) <= 1e-4 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-4
-    # verbose >= 1 checks every frame against per-frame scales chained through the whole sequence: not cut
+    # verbose >= 1 checks EVERY frame's invariant (chain-computation.cc:345-391) - on the same cut call, with the same bits: whether a
+    # call is cut is not a function of the verbose level (a debug run must compute what production computes)
     with _lib.option("verbose", 1):
-        assert int(_den(plan, x, L)[3][6]) == 1
+        ov, gv, bv, tv = _den(plan, x, L)
+    assert int(tv[6]) == 4 and int(tv[5]) == 0 and bv == 0
+    assert torch.equal(ov, o) and torch.equal(gv, g)
 
 
 def test_a_burn_in_that_is_too_short_is_caught_and_redone():
