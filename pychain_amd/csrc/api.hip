@@ -29,7 +29,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
-                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg"};
+                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg", "den_cross"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -72,6 +72,7 @@ CallKnobs call_knobs() {
   k.plan_split = option_int("plan_split", -1);
   k.chain_slices = option_int("chain_slices", -1);
   k.den_sg = option_int("den_sg", 1) ? 1 : 0;
+  k.den_cross = option_int("den_cross", 0) ? 1 : 0;   // (off by default: measured slower than the streamed occupancy launch - DESIGN.md 3.15)
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
     char what[8] = ""; int b = 0, t = 0; float sc = 1.f;
@@ -120,6 +121,7 @@ namespace {
 bool den_call_is_pair(const DenArgs& a, int resident_slot_rows);
 bool den_call_is_lazy(const DenArgs& a, int resident_slot_rows);
 int den_call_shape(const DenArgs& a, int resident_slot_rows);
+int device_cu_count();
 }  // namespace
 extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D, int B, int plans_shared,
                                             char* buf, size_t buf_bytes) {
@@ -138,6 +140,9 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
   a.lazy = den_call_is_lazy(a, resident_slot_rows) ? 1 : 0;
   a.shape = a.lazy ? den_call_shape(a, resident_slot_rows) : 0;
   a.sg = (a.lazy && a.shape == kShapeDma && den_sg_eligible(a, resident_slot_rows)) ? 1 : 0;
+  // (the names of a call of the denominator alone that evaluates both launches: the crossing where option den_cross asks for it)
+  { DenArgs long_call = a; long_call.T = 1 << 14;        // (of sequences long enough to have two halves)
+    a.xf = (a.sg && !a.fused && 2 * a.B <= device_cu_count() && den_xf_eligible(long_call, resident_slot_rows)) ? den_xf_band() : 0; }
   snprintf(buf, buf_bytes, "%s,%s", den_recursion_kernel_name(a, resident_slot_rows),
            den_occupancy_kernel_name(a, (D + 63) / 64, resident_slot_rows));
   return PYCHAIN_HIP_OK;
@@ -528,7 +533,12 @@ hipError_t run_den_launches(DenArgs& a, int resident_slot_rows, bool occupancy, 
   // where the shape allows, 0 never); rows in den_recursion_kernel's form
   a.pair = den_call_is_pair(a, resident_slot_rows) ? 1 : 0;
   a.sg = (a.lazy && a.shape == kShapeDma && den_sg_eligible(a, resident_slot_rows)) ? 1 : 0;   // (a "pdf by state" plan in the one-gather form)
-  const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt) ? den_segments(a) : 1;
+  // ... whose recursions emit the occupancies of their own second halves themselves (DenArgs::xf): a call of the denominator alone
+  // that evaluates both launches; the occupancy launch then follows the recursions and handles the bands around the middles
+  // (each direction waits for rows of the other: every workgroup of the launch must be resident at once)
+  a.xf = (a.sg && occupancy && user_mask == 3 && !corrupt && zeroed == nullptr && 2 * a.B <= device_cu_count() &&
+          den_xf_eligible(a, resident_slot_rows)) ? den_xf_band() : 0;
+  const int nseg = (occupancy && user_mask == 3 && !a.check_all && !corrupt && !a.xf) ? den_segments(a) : 1;
   // the invariant check (DenArgs::tot_a) needs the recursions and the occupancy launches of ONE call
   a.check = (occupancy && user_mask == 3) ? 1 : 0;
   hipError_t e = hipSuccess;

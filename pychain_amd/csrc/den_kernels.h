@@ -43,6 +43,12 @@ struct DenArgs {
   // STATES (the plan's gamma_sg tiles) without reading the nnet-output row.  Decided once per call; a later
   // chain_loss_backward on the same workspaces decides alike (same shape, same options).
   int sg;
+  // > 0 ("crossing", den_lazy.inc.h: XF; pdf-by-state plans, calls of the denominator alone): each recursion emits the occupancies of
+  // its own second half itself - alpha the frames from (middle + xf) on, beta those below (middle - xf), per time segment - and the
+  // occupancy launch of the call handles only the band of 2 xf frames around every middle (and the padding); a sequence or segment
+  // shorter than 4 xf + 8 frames is the occupancy launch's whole.  xprog is then the progress table of the crossing
+  // ([2][B][kMaxTimeSegs]: steps whose rows are out), which the peer direction's first landing waits for.
+  int xf;
   // Per-frame totals.  The recursions divide a total out of every frame (alpha: tot(t) = sum_i a(t,i); beta: its
   // own n(t)) and only STORE it; den_finish_kernel turns the stored totals into the log-probability
   //     objf = sum_t log tot_a(t) + log fin_dot        (ComputeTotLogLike, chain-computation.cc:209-230)
@@ -172,6 +178,21 @@ const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, in
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows);
 // ... in the one-gather form of a "pdf by state" plan (launch hint bit 27; a.shape == kShapeDma, a.use_ex / a.x_half decided)
 bool den_sg_eligible(const DenArgs& a, int resident_slot_rows);
+// ... with the crossing (DenArgs::xf); the band half-width it uses
+bool den_xf_eligible(const DenArgs& a, int resident_slot_rows);
+int den_xf_band();
+// is frame t of a length-L sequence one the occupancy launch of a crossing call evaluates (DenArgs::xf)?  `cut`: the call's rows
+// come from its time segments (else from the uncut recursion - also after a splice miss)
+__host__ __device__ inline bool den_xf_band_frame(int t, int L, int nseg, int w) {
+  int k = (int)(((long)t * nseg) / L);
+  if (k >= nseg) k = nseg - 1;
+  while (k > 0 && t < (int)(((long)k * L) / nseg)) k--;
+  while (k + 1 < nseg && t >= (int)(((long)(k + 1) * L) / nseg)) k++;
+  const int s = (int)(((long)k * L) / nseg), e = k + 1 == nseg ? L : (int)(((long)(k + 1) * L) / nseg);
+  if (e - s < 4 * w + 8) return true;
+  const int mid = (s + e) >> 1;
+  return t >= mid - w && t < mid + w;
+}
 int den_recursion_blocks(const DenArgs& a);
 hipError_t launch_den_splice_check(const DenArgs& a, hipStream_t st);
 bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows);

@@ -225,8 +225,21 @@ struct LaunchFrames {
     return need > lo && need <= hi;
   }
 };
-__device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const LaunchFrames& lf) {
-  while (t < t_end && !lf.has(t, L)) t++;
+// "crossing" calls (DenArgs::xf): the occupancy launch evaluates only the band around the middle of every time segment - the
+// recursions emitted the rest themselves.  The segments are those whose rows stand: the call's own, or - after a splice miss, when
+// the uncut launch recomputed everything - the whole sequence.
+struct XfBand {
+  int w, nseg_cut, tburn;
+  __device__ __forceinline__ explicit XfBand(const DenArgs& a) : w(a.xf), nseg_cut(1), tburn(0) {
+    if (w && a.tseg > 1 && __hip_atomic_load(a.redo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && !den_tseg_off(a)) { nseg_cut = a.tseg; tburn = den_tburn(a); }
+  }
+  __device__ __forceinline__ bool has(int t, int L) const {
+    if (!w) return true;
+    return den_xf_band_frame(t, L, (nseg_cut > 1 && L >= 2 * tburn) ? nseg_cut : 1, w);
+  }
+};
+__device__ __forceinline__ int den_next_frame(int t, int t_end, int L, const LaunchFrames& lf, const XfBand& xb) {
+  while (t < t_end && !(lf.has(t, L) && xb.has(t, L))) t++;
   return t;
 }
 
@@ -348,6 +361,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
   int t_first = 0, t_live_end = 0;
   const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
   const LaunchFrames lf(a);
+  const XfBand xband(a);
   if constexpr (!STREAM) {
     const int chunk = den_chunk_of_block(blockIdx.x, L, a);
     if (chunk < 0) return;
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     t_live_end = min(t_end, L);
     // padded tail of a chunk that straddles the sequence end
     if (first_launch && t_live_end < t_end) grad_zero<XH>(gseq0, (size_t)t_live_end * D, (size_t)t_end * D, tid, kNT);
-    t_first = den_next_frame(t_begin, t_live_end, L, lf);
+    t_first = den_next_frame(t_begin, t_live_end, L, lf, xband);
     if (t_first >= t_live_end) return;                // none of this chunk's frames belongs to this launch
   }
   const char* plan = a.plans + (size_t)b * a.plan_stride;
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(kNT) void den_gamma_kernel(const DenArgs a) {
     __syncthreads();
     for (int t = t_first; t < t_live_end;) {
       float* grow = reinterpret_cast<float*>(reinterpret_cast<char*>(gseq) + (size_t)t * D * kXe);
-      const int t_next = STREAM ? t + 1 : den_next_frame(t + 1, t_live_end, L, lf);
+      const int t_next = STREAM ? t + 1 : den_next_frame(t + 1, t_live_end, L, lf, xband);
       const bool have_next = t_next < t_live_end;
       if (have_next) GAMMA_PREFETCH(t_next);
       float s0 = 0.f, s1 = 0.f;
@@ -677,6 +691,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
   int L = STREAM ? 1 : __builtin_amdgcn_readfirstlane(seq_len(a.lengths, b, a.T));
   const bool first_launch = a.gam_nseg == 0 || a.gam_seg == 0;
   const LaunchFrames lf(a);
+  const XfBand xband(a);
   int t0 = 0, t_live_end = 0, t_lo = 0;               // frames [t_lo, t_live_end) of this pass, t0 = first pair (even)
   if constexpr (!STREAM) {
     const int chunk = den_chunk_of_block(blockIdx.x, L, a);
@@ -687,7 +702,8 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     t_live_end = min(t_end, L);
     // pairs (t0, t0+1), t0 even, with at least one frame of this launch
     t0 = t_begin;
-    while (t0 < t_live_end && !den_frame_in_launch(t0, t_live_end, L, lf) && !den_frame_in_launch(t0 + 1, t_live_end, L, lf)) t0 += 2;
+    while (t0 < t_live_end && !(den_frame_in_launch(t0, t_live_end, L, lf) && xband.has(t0, L)) &&
+           !(den_frame_in_launch(t0 + 1, t_live_end, L, lf) && xband.has(t0 + 1, L))) t0 += 2;
     // padding of the first launch is exact zeros: a whole chunk past the end, or the tail of one that straddles it
     if (first_launch && max(t_begin, t_live_end) < t_end)
       grad_zero<XH>(gseq0, (size_t)max(t_begin, t_live_end) * D, (size_t)t_end * D, tid, kNT2);
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(kNT2) void den_gamma2_kernel(const DenArgs a) {
     const float* bseq = a.beta_store + (size_t)b * (T + 1) * Hp;
     const XBuf abuf = make_xbuf(aseq, (size_t)T * Hp * sizeof(float)), bbuf = make_xbuf(bseq, (size_t)(T + 1) * Hp * sizeof(float));
     // which frames of [t0, ..) this pass evaluates
-    auto wanted = [&](int t) { return STREAM ? (t >= t_lo && t < t_live_end) : den_frame_in_launch(t, t_live_end, L, lf); };
+    auto wanted = [&](int t) { return STREAM ? (t >= t_lo && t < t_live_end) : (den_frame_in_launch(t, t_live_end, L, lf) && xband.has(t, L)); };
     // numerator fold: thread u (and u + kNT2) owns the u-th distinct pdf of the sequence; the set of
     // touched pdfs is the same in every frame, so n2 needs no clearing between pairs (only between sequences)
     const int U = fold ? a.fold_ucount[b] : 0;
@@ -1209,7 +1225,7 @@ bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_sl
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
   (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";
-  if (a.lazy) return a.shape == kShapeSmall ? "den_recursion_lazy_kernel<small>" : (a.shape == kShapeDma ? (a.sg ? "den_recursion_lazy_kernel<dma; one gather per arc>" : "den_recursion_lazy_kernel<dma>") : "den_recursion_lazy_kernel");
+  if (a.lazy) return a.shape == kShapeSmall ? "den_recursion_lazy_kernel<small>" : (a.shape == kShapeDma ? (a.sg ? (a.xf ? "den_recursion_lazy_kernel<dma; one gather per arc; crossing>" : "den_recursion_lazy_kernel<dma; one gather per arc>") : "den_recursion_lazy_kernel<dma>") : "den_recursion_lazy_kernel");
   return "den_recursion_kernel";
 }
 const char* den_occupancy_kernel_name(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {

@@ -41,6 +41,15 @@ template <int R, typename M, bool TS>
 hipError_t launch_lz_sg(const DenArgs& a, const dim3 grid, hipStream_t st) {
   return launch_one(den_recursion_lazy_kernel<R, M, kLzRowsF32, TS, false, true>, a, grid, M::kBytes, st, M::kWaves * 64);
 }
+// ... with the crossing (DenArgs::xf; LzCross: state vectors of up to 3072 positions)
+inline bool xf_shape_ok(const DenArgs& a, int hint) {
+  return sg_shape_ok(a, hint) && a.knobs.den_cross != 0 && !a.fused && a.Hp <= (int)LzCross::kMaxStates && a.D % 4 == 0 &&
+         a.D <= (int)LzCross::kMaxPdfs && a.T >= 4 * kCrossBand + 8;
+}
+template <int R, bool TS>
+hipError_t launch_lz_xf(const DenArgs& a, const dim3 grid, hipStream_t st) {
+  return launch_one(den_recursion_lazy_kernel<R, LzCross, kLzRowsF32, TS, false, true, true>, a, grid, LzCross::kBytes, st, LzCross::kWaves * 64);
+}
 template <int R, typename M, int XM, bool TS>
 hipError_t launch_lz(const DenArgs& a, const dim3 grid, hipStream_t st, bool nc) {
   if (nc) return launch_one(den_recursion_lazy_kernel<R, M, XM, TS, true>, a, grid, M::kBytes, st, M::kWaves * 64);
@@ -81,6 +90,10 @@ hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
   if (lazy_shape_ok(a, hint, true) && sg_shape_ok(a, hint)) {            // a "pdf by state" plan: one gather per arc
     const int rows = hint & 1023;
     const dim3 grid(2 * a.B * (a.tseg > 1 ? a.tseg : 1));
+    if (a.xf) {
+      if (a.tseg > 1) return rows <= 32 ? launch_lz_xf<32, true>(a, grid, st) : launch_lz_xf<kMaxResident, true>(a, grid, st);
+      return rows <= 32 ? launch_lz_xf<32, false>(a, grid, st) : launch_lz_xf<kMaxResident, false>(a, grid, st);
+    }
     if (a.tseg > 1) return rows <= 32 ? launch_lz_sg<32, LzNarrowDma, true>(a, grid, st) : launch_lz_sg<kMaxResident, LzNarrowDma, true>(a, grid, st);
     return rows <= 32 ? launch_lz_sg<32, LzNarrowDma, false>(a, grid, st) : launch_lz_sg<kMaxResident, LzNarrowDma, false>(a, grid, st);
   }
@@ -139,6 +152,8 @@ bool den_small_eligible(const DenArgs& a, int resident_slot_rows) { return small
 bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) || dma_shape_ok(a, resident_slot_rows); }
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows) { return pair_shape_ok(a, resident_slot_rows); }
 bool den_sg_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) && sg_shape_ok(a, resident_slot_rows); }
+bool den_xf_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) && xf_shape_ok(a, resident_slot_rows); }
+int den_xf_band() { return kCrossBand; }
 
 // the recursion launch of a call whose DenArgs say pair or lazy (launch_den)
 hipError_t launch_den_lazy_family(const DenArgs& a, int hint, hipStream_t st) {

@@ -78,6 +78,25 @@ struct LzSmall {
   static constexpr uint32_t kMaxStates = 1024, kMaxPdfs = 4096;
   static constexpr uint32_t kRed = 49152, kLk = kRed + 2 * 2 * 64 * 4, kBytes = kLk + kMaxStates * 4;
 };
+// "Crossing" (template parameter XF; pdf-by-state plans only): besides the two state buffers and the two nnet-output rows, two
+// accumulator rows of D words (the occupancies a direction emits itself, fixed point) and two landing rows of Hp floats (the
+// OTHER direction's row of the frame being emitted).  Arcs are LazyArcsState (32-bit state addresses: no 16-bit limit on the
+// state field); the 16-bit addresses are those of a pdf (nnet-output rows AND accumulator rows: one window of 64 KiB from kXField)
+// and of a landing-row position.
+//   [0, 12K) landing 0   [12K, 24K) landing 1   [24K, 40K) x row 0   [40K, 56K) x row 1   [56K, 72K) accumulator 0   [72K, 88K) accumulator 1
+//   [88K, 112K) state buffer 0: float2[<= 3072]   [112K, 136K) state buffer 1   [136K, 148K) beta's leaky probs   partial sums
+struct LzCross {
+  static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
+  static constexpr bool kDma = true;
+  static constexpr uint32_t kLand0 = 0, kLand1 = 12288;
+  static constexpr uint32_t kX0 = 24576, kX1 = 40960, kXField = 24576, kA0 = 57344, kA1 = 73728;
+  static constexpr uint32_t kU0 = 90112, kU1 = 114688, kUField = 90112;
+  static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 4096;
+  static constexpr uint32_t kLk = 139264, kRed = kLk + kMaxStates * 4, kXRed = kRed + 2 * 2 * 64 * 4, kOtot = kXRed + 2 * 16 * 4, kExtra = kOtot + 16, kBytes = kExtra + 8 * PLAN_MAX_EXTRA_A;
+};
+static_assert(LzCross::kBytes <= 160u * 1024u && LzCross::kA1 - LzCross::kXField <= 65535u && LzCross::kXField + 4u * (LzCross::kMaxPdfs - 1) <= 65535u &&
+              LzCross::kLand1 + 4u * (LzCross::kMaxStates - 1) <= 65535u && LzCross::kU1 - LzCross::kUField <= 65535u, "ds offset fields are 16 bits");
+constexpr int kCrossBand = 24;     // frames either side of a segment's middle that stay with the occupancy launch (DenArgs::xf)
 static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzDma>() && lz_map_ok<LzSmall>(), "ds_read offset fields are 16 bits");
 constexpr uint32_t kLzBytes = LzNarrow::kBytes;
 
@@ -96,6 +115,9 @@ __device__ __forceinline__ void lz_st1(uint32_t byte_addr, float v) { *(lz_lds_f
 typedef __attribute__((address_space(3))) void lz_lds_void;
 #ifndef PYCHAIN_LATE_BACK
 #define PYCHAIN_LATE_BACK 2                            /* the late hook of lazy_tile runs this many chunks before the end of the arc phase */
+#endif
+#ifndef PYCHAIN_XF_EXP
+#define PYCHAIN_XF_EXP 0                               /* timing experiments on the crossing (WRONG RESULTS): 1 no adds, 2 no flush, 4 no landing rows, 8 no emission, 16 no totals */
 #endif
 #ifndef PYCHAIN_EXP_NO_ROWSTORE
 #define PYCHAIN_EXP_NO_ROWSTORE 0                      /* timing experiments (WRONG RESULTS): 1 = the rows do not leave for HBM, 2 = they do, but are not re-read from LDS first */
@@ -453,10 +475,13 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
   }
 }
 
+#ifndef PYCHAIN_SG_AHEAD
+#define PYCHAIN_SG_AHEAD 2                             /* chunks the gathers of the one-gather loop run ahead of its arithmetic (measured: 1, 2, 3 alike) */
+#endif
 // ... and over arcs of a "pdf by state" plan (LazyArcsState): ONE gather per arc.  xad01 / xad23 = absolute LDS addresses (nnet-output
 // field, 16 bits each) of the pdf of this lane's row in the wave's groups 0 | 1 << 16, 2 | 3 << 16; XOFF = ds_read offset of the
 // row buffer the group ends read.
-template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t XOFF, uint32_t UNEXT, typename Hook, typename Late>
+template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t XOFF, uint32_t UNEXT, int AHEAD, typename Hook, typename Late>
 __device__ __forceinline__ void lazy_tile_sg(LazyArcsState<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, const uint32_t xad01, const uint32_t xad23, int lane,
                                              float& s0, float& s1, Hook&& after_first_gathers, Late&& late) {
   constexpr int kChunk = 4;
@@ -468,10 +493,7 @@ __device__ __forceinline__ void lazy_tile_sg(LazyArcsState<R, MAP>& ar, const Gr
   lz_v2f acc = {0.f, 0.f};
   // With one gather per arc the loop is no longer bound by the LDS pipe but by how many gathers a wave has in flight: the gathers
   // run kAhead chunks ahead of the arithmetic (the two-gather loops run one: their eight gathers per chunk fill the pipe)
-#ifndef PYCHAIN_SG_AHEAD
-#define PYCHAIN_SG_AHEAD 2
-#endif
-  constexpr int kAhead = PYCHAIN_SG_AHEAD < NC ? PYCHAIN_SG_AHEAD : NC - 1, kBuf = kAhead + 1;
+  constexpr int kAhead = AHEAD < NC ? AHEAD : NC - 1, kBuf = kAhead + 1;
   lz_v2f ub[kBuf][kChunk];
 #pragma unroll
   for (int c0 = 0; c0 < kAhead; c0++)
@@ -556,8 +578,11 @@ __device__ __forceinline__ void lazy_tile_sg(LazyArcsState<R, MAP>& ar, const Gr
 enum { kLzRowsF32 = 0, kLzRowsPre = 1, kLzRowsHalf = 2 };
 // TS: time segments (DenArgs::tseg) - a template parameter: the one-segment kernel keeps its registers; NC: see the start vector
 // SG: a "pdf by state" plan - one gather per arc (LazyArcsState, lazy_tile_sg)
-template <int R, typename MAP, bool fwd, int XM, bool TS, bool NC, bool SG = false>
+// XF: "crossing" - after the two directions of a (sequence[, segment]) have met in the middle, each emits the occupancies of its
+// own second half itself (LzCross): gamma(t, pdf_j) += a(t+1,j) beta(t+1,j) is ONE product per row and lane for a pdf-by-state plan
+template <int R, typename MAP, bool fwd, int XM, bool TS, bool NC, bool SG = false, bool XF = false>
 __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b, const int seg_in = 0) {
+  static_assert(!XF || SG, "crossing: pdf-by-state plans");
   constexpr bool PRE = XM == kLzRowsPre, XH = XM == kLzRowsHalf;
   static_assert(!SG || (MAP::kDma && MAP::kMaxPdfs <= 4096 && !NC && !PRE), "the one-gather form: LDS-direct rows, <= 4096 pdfs, no split beta positions");
   constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
@@ -679,6 +704,183 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     asm volatile("" : "+v"(xad01), "+v"(xad23));
   }
 
+  // ---- crossing (XF).  Real frames [xs, xe) of this workgroup (its segment, or the sequence); alpha emits the frames t >= xMa,
+  // beta the frames t < xMb, the band [xMb, xMa) stays with the occupancy launch (neither direction ever waits for a LATE row of
+  // the other: no deadlock).  The row a hook holds - alpha: a(t+1,.) = row t + 1 of its side, beta: beta(t+1,.) - belongs to frame
+  // t; the other side's row t + 1 of the same states was landed (LDS-direct, device scope) during the step before.
+  const int xs = TS ? seg_s : 0, xe = TS ? seg_e : Lb;
+  const bool xon = XF && a.xf != 0 && (xe - xs >= 4 * kCrossBand + 8);
+  const int xMa = ((xs + xe) >> 1) + kCrossBand, xMb = ((xs + xe) >> 1) - kCrossBand;
+  uint32_t oad01 = 0u, oad23 = 0u;                       // landing-row addresses of this lane's rows (the state's position on the other side)
+  bool xf_pending = false;                               // the previous hook emitted: its accumulator row is flushed by the next one
+  int xf_pending_frame = 0;
+  float xf_gpred_prev = 1.f;                             // ... the total it PREDICTED for its frame (the row is normalised by the measured one)
+  XBuf xf_obuf = sbuf, xf_gbuf = sbuf;
+  const float* xf_ototv = nullptr;
+  int32_t* xf_my = nullptr; const int32_t* xf_peer = nullptr;
+  uint32_t xf_live = 0u; int xf_nextra = 0;
+  int xf_peer_need = 0;                                  // the peer's reported steps that make the FIRST row this side lands complete
+  uint32_t* const xred = reinterpret_cast<uint32_t*>(smem_raw + (XF ? LzCross::kXRed : 0u));   // [2][16] per-wave sums of a hook's products
+  if constexpr (XF) {
+    const int32_t* perm = reinterpret_cast<const int32_t*>(plan + (fwd ? hd->off_a2b : hd->off_b2a));
+    uint32_t oa[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) oa[g] = 4u * (uint32_t)((g < MG && g < groups.ngroups) ? perm[gbase[g] + lane] : 0);
+    oad01 = oa[0] | (oa[1] << 16); oad23 = oa[2] | (oa[3] << 16);
+    asm volatile("" : "+v"(oad01), "+v"(oad23));
+    // (gradient scale x 2^-30, fixed point -> gradient: kept in LDS and read with the tail's other operands - a register held for 1500 frames is one spilled)
+    if (tid == 0) *reinterpret_cast<float*>(smem_raw + LzCross::kOtot + 8) = (a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale) * (1.0f / 1073741824.0f);
+    // alpha lands beta rows (row r of beta_store), beta lands alpha-store rows (index t holds a(t+1,.): DenArgs::sg)
+    xf_obuf = fwd ? make_xbuf(a.beta_store + (size_t)b * (a.T + 1) * Hp, (size_t)(a.T + 1) * Hp * sizeof(float))
+                  : make_xbuf(a.alpha_store + (size_t)b * a.T * Hp, (size_t)a.T * Hp * sizeof(float));
+    xf_gbuf = make_xbuf(a.grad + (size_t)b * a.T * D, (size_t)a.T * D * sizeof(float));
+    xf_ototv = (fwd ? a.tot_b : a.tot_a) + (size_t)b * (a.T + 2);
+    xf_my = a.xprog + ((size_t)(fwd ? 0 : 1) * a.B + b) * kExMaxQ + seg;
+    xf_peer = a.xprog + ((size_t)(fwd ? 1 : 0) * a.B + b) * kExMaxQ + seg;
+    // the first row this side lands: alpha: beta row xMa (frame xMa - 1, its dry run); beta: alpha-store index xMb (frame xMb)
+    if (fwd) {                                           // beta's hook of step j stores row Lvb - j: P steps done => rows >= Lvb - P + 1
+      const int Lvb = (!TS || seg + 1 == nseg) ? Lb : min(Lb, seg_e + tburn);
+      xf_peer_need = Lvb - xMa + 1;
+    } else {                                             // alpha's hook of local step j stores index f0a + j - 1: P steps => indices <= f0a + P - 2
+      const int f0a = (TS && seg > 0) ? max(seg_s - tburn, 0) : 0;
+      xf_peer_need = xMb - f0a + 2;
+    }
+    for (int i = tid; i < 2 * (int)LzCross::kMaxPdfs; i += NT) *reinterpret_cast<uint32_t*>(smem_raw + LzCross::kA0 + 4 * i) = 0u;
+    // what the hooks would otherwise fetch from the plan frame after frame (a load from memory is waited for with every row in
+    // flight): which of this lane's beta positions are states (past them: padding, whose "row" is the leaky constant c(t)); and
+    // the table of a state's further ALPHA positions {8 x beta position | 4 x alpha position << 16, 4 x pdf}, one per thread
+#pragma unroll
+    for (int g = 0; g < MG; g++) if (g < groups.ngroups && (fwd || gbase[g] + lane < hd->graph_states)) xf_live |= 1u << g;
+    if constexpr (!fwd) {
+      const int32_t* ex = reinterpret_cast<const int32_t*>(plan + hd->off_extra_a);
+      const int32_t* pdf_b = reinterpret_cast<const int32_t*>(plan + hd->off_pdf_b);
+      xf_nextra = __builtin_amdgcn_readfirstlane(hd->n_extra_a);
+      if (tid < xf_nextra) {
+        const int pb = ex[2 * tid], pa = ex[2 * tid + 1];
+        *reinterpret_cast<uint2*>(smem_raw + LzCross::kExtra + 8 * tid) = make_uint2(8u * (uint32_t)pb | (4u * (uint32_t)pa) << 16, 4u * (uint32_t)pdf_b[pb]);
+      }
+    }
+    if (tid < 32) xred[tid] = 0u;
+  }
+  // One row's share of the crossing, run in the TAIL of a step - behind the arc phase, where the registers of the gathers are free
+  // and the LDS pipe is no longer queued up by sixteen waves' gathers (in the hook behind the first gathers every dependent LDS
+  // round trip of this chain cost 300+ cycles: profiles/r06_crossing.txt).  The row is the one the step's hook completed (it sits in
+  // the buffer the step gathered from); everything is read first, in one round trip:
+  //   * the row, the other side's row of the same states (landed a step ahead) and the other side's total of it;
+  //   * the per-wave sums of the PREVIOUS row's products (its measured total G') and that row's accumulators, which leave
+  //     for the gradient normalised by the measured total (they were scaled by a PREDICTED one:
+  //     G'(t) = G'(t -+ 1) x the other side's total of row t + 1 / this side's total of the neighbouring row - the invariant
+  //     den_finish_kernel checks, solved for the next frame);
+  // then this row's products go into the accumulator row of their pdfs in fixed point (ds_add_u32: 2^30 / G'_pred).
+  // (the add itself: written out, because the compiler puts a wait for EVERY memory operation in flight - the row stores of this
+  // step's hook among them - in front of an LDS atomic that follows an LDS-direct load it cannot tell apart from it)
+  auto xf_add = [&](uint32_t addr, uint32_t val) { asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(val) : "memory"); };
+  // The accumulator row the previous step's tail filled leaves for the gradient in the HOOK of the next step: early in the step, so
+  // that its store is acknowledged long before the barrier at the step's end waits for this wave's stores (in the tail itself the
+  // barrier waited a memory round trip for it, every emitting frame).  Read first (xf_flush_read), written at the hook's end.
+  struct XfFlush { u32x4 v; float xr, sc; };
+  auto xf_flush_read = [&](XfFlush& f, int par_prev, int tq_, int lq_) {
+    auto& xf_fv = f.v; auto& xf_fxr = f.xr; auto& xf_fsc = f.sc;
+    xf_fv = u32x4{0u, 0u, 0u, 0u};
+    xf_fxr = __uint_as_float(xred[par_prev * 16 + (lq_ & 15)]);
+    xf_fsc = lds_abs(LzCross::kOtot + 8u);
+    if (tq_ * 4 < D) xf_fv = *(const __attribute__((address_space(3))) u32x4*)((par_prev ? LzCross::kA1 : LzCross::kA0) + 16u * (uint32_t)tq_);
+  };
+  auto xf_flush_write = [&](const XfFlush& f, int par_prev, int tq_, int frame, float gpred) {
+    const u32x4 xf_fv = f.v; const float xf_fxr = f.xr, xf_fsc = f.sc;
+    const float gmeas = dpp_row_sum(xf_fxr);
+    if (tq_ * 4 < D && !(PYCHAIN_XF_EXP & 2)) {
+      const float fs = xf_fsc * gpred * __builtin_amdgcn_rcpf(gmeas);
+      *(__attribute__((address_space(3))) u32x4*)((par_prev ? LzCross::kA1 : LzCross::kA0) + 16u * (uint32_t)tq_) = u32x4{0u, 0u, 0u, 0u};
+      u32x4 o;
+      o.x = __float_as_uint((float)xf_fv.x * fs); o.y = __float_as_uint((float)xf_fv.y * fs);
+      o.z = __float_as_uint((float)xf_fv.z * fs); o.w = __float_as_uint((float)xf_fv.w * fs);
+      __builtin_amdgcn_raw_buffer_store_b128(o, xf_gbuf, tq_ * 16, __builtin_amdgcn_readfirstlane(frame * D * 4), 0);
+    }
+    if (a.check && (frame == 0 || a.check_all) && tq_ == 0) den_record_frame_total(a, b, frame, gmeas);
+  };
+  bool xf_do = false; int xf_tfr = 0; float xf_totb = 1.f;   // (what the hook leaves for the tail: the row's frame, this side's total of the row before)
+  auto xf_row = [&](int par, int tfr, float tot_before, uint32_t ucur, int tq_, int lq_) {
+    const bool emit = fwd ? (tfr >= xMa) : (tfr < xMb && tfr >= xs);
+    const bool any = (emit || (fwd ? (tfr == xMa - 1) : (tfr == xMb))) && !(PYCHAIN_XF_EXP & 8);   // (the frame before the first emitted one: a dry run for its total)
+    if (!any && !xf_pending) return;
+    const uint32_t land = par ? LzCross::kLand1 : LzCross::kLand0;
+    const uint32_t acc = par ? LzCross::kA1 : LzCross::kA0;
+    // (the packed addresses as the tail sees them: opaque, or every address derived from them is formed once before the frame loop
+    // and kept - in registers this kernel does not have)
+    uint32_t o01 = oad01, o23 = oad23, x01 = xad01, x23 = xad23;
+    asm volatile("" : "+v"(o01), "+v"(o23), "+v"(x01), "+v"(x23));
+    auto xf_oaddr = [&](int g) { const uint32_t wd = (g & 2) ? o23 : o01; return (g & 1) ? (wd >> 16) : (wd & 0xffffu); };
+    auto xf_xaddr = [&](int g) { const uint32_t wd = (g & 2) ? x23 : x01; return (g & 1) ? (wd >> 16) : (wd & 0xffffu); };
+    lz_v2f pr[MG]; float ld[MG];
+#pragma unroll
+    for (int g = 0; g < MG; g++) pr[g] = lz_ld2(ucur + gbase[g] * 8 + lq_ * 8);          // (gbase = 0 beyond ngroups: masked below)
+#pragma unroll
+    for (int g = 0; g < MG; g++) ld[g] = lds_abs(xf_oaddr(g) + land);
+    const float ot = lds_abs(LzCross::kOtot + 4u * (uint32_t)par);
+    uint2 ex = make_uint2(0u, 0u);
+    const bool has_extra = !fwd && tq_ < xf_nextra;          // a state on several ALPHA positions: its beta lane took the first one
+    if (has_extra) { const lz_v2f e2 = lz_ld2(LzCross::kExtra + 8u * (uint32_t)tq_); ex = make_uint2(__float_as_uint(e2.x), __float_as_uint(e2.y)); }
+    XfFlush f;
+    xf_flush_read(f, par ^ 1, tq_, lq_);                     // (the previous row's measured total is needed either way)
+    const float gprev = dpp_row_sum(f.xr);
+    const bool flush = xf_pending;
+    const int flush_frame = xf_pending_frame;
+    const float flush_pred = xf_gpred_prev;
+    xf_pending = emit && any; xf_pending_frame = tfr;
+    if (any) {
+      const float gpred = gprev * ot * __builtin_amdgcn_rcpf(tot_before);
+      const float sc = 1073741824.0f * __builtin_amdgcn_rcpf(gpred);
+      if (emit && !(gpred > 0.f && sc - sc == 0.f)) bad |= 1;
+      xf_gpred_prev = gpred;
+      float gs = 0.f;
+#pragma unroll
+      for (int g = 0; g < MG; g++) {
+        const float rowv = fwd ? pr[g].x : __builtin_fmaf(pr[g].x, __builtin_amdgcn_rcpf(pr[g].y), w.sprev);
+        const float pq = ((xf_live >> g) & 1u) ? rowv * ld[g] : 0.f;     // (not a state: a group the wave does not own, a beta padding position)
+        gs += pq;
+        if (emit && !(PYCHAIN_XF_EXP & 1) && ((xf_live >> g) & 1u))
+          xf_add(xf_xaddr(g) + (acc - LzCross::kXField), (uint32_t)__builtin_fmaf(pq, sc, 0.5f));
+      }
+      if constexpr (!fwd) {
+        if (xf_nextra > 0) {                                   // (uniform; a few per plan, one per thread)
+          float pq = 0.f;
+          if (has_extra) {
+            const lz_v2f pe = lz_ld2(ucur + (ex.x & 0xffffu));
+            pq = __builtin_fmaf(pe.x, __builtin_amdgcn_rcpf(pe.y), w.sprev) * lds_abs(land + (ex.x >> 16));
+            if (emit && !(PYCHAIN_XF_EXP & 1))
+              xf_add(acc + ex.y, (uint32_t)__builtin_fmaf(pq, sc, 0.5f));
+          }
+          gs += pq;
+        }
+      }
+      gs = wave_sum(gs);
+      if (lq_ == 0) xred[par * 16 + wave] = __float_as_uint(gs);
+    }
+    // (last: the previous row's accumulators leave for the gradient - nothing of this step touches LDS after this store)
+    if (flush) xf_flush_write(f, par ^ 1, tq_, flush_frame, flush_pred);
+  };
+  // what a step lands for the NEXT step's hook: the other side's row of the frame that hook handles (if it emits, or dry-runs)
+  auto xf_land = [&](int j, int lq_) {
+    const int tnx = fwd ? f0 + j : L - j - 2;              // the frame of the next hook's row
+    const bool want = fwd ? (tnx >= xMa - 1 && tnx < xe) : (tnx <= xMb && tnx >= xs);
+    if (!want) return;
+    if (fwd ? tnx == xMa - 1 : tnx == xMb) {               // the first one: the peer must have stored it (later ones it stored EARLIER)
+      const unsigned long long t0 = wall_clock64();        // 100 MHz
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(xf_peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < xf_peer_need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 2000000000ull) { bad |= 1; break; }   // 20 s: the peer died
+      }
+    }
+    const int row = fwd ? tnx + 1 : tnx;                   // beta row / alpha-store index
+    if (!(PYCHAIN_XF_EXP & 4)) lz_dma_row<NW, ((int)LzCross::kMaxStates / 256 + NW - 1) / NW, kStoreDeviceScope>(xf_obuf, row, Hp, wave, lq_, ((j + 1) & 1) ? LzCross::kLand1 : LzCross::kLand0);
+    // ... and its total, by the same route: a load into a REGISTER would be waited for where the compiler next touches the register -
+    // at the top of the arc phase, with every row just requested in flight (measured: +1 ms per call)
+    if (!(PYCHAIN_XF_EXP & 16) && wave == 0 && lq_ == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xf_ototv + tnx + 1),
+                                       (lz_lds_void*)(LzCross::kOtot + (((j + 1) & 1) ? 4u : 0u)), 4, 0, kStoreDeviceScope);
+  };
+
   // ---- frame 0 (alpha: chain-computation.cc:92-95) / frame L (beta: :232-245): un-normalised start vector
   XRow<NT, 4, MAP::kXch> xq;
   {
@@ -741,7 +943,10 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     w.c = coef * wtot;
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad |= 1;
     w.sprev = fwd ? tot : w.c;                         // the start row (alpha row 0 / beta row L) goes out at the end of frame 0
-    if (tid == 0 && tot_real(fwd ? 0 : L)) totv[fwd ? 0 : L] = tot;
+    if (tid == 0 && tot_real(fwd ? 0 : L)) {
+      if constexpr (XF) __hip_atomic_store(totv + (fwd ? 0 : L), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else totv[fwd ? 0 : L] = tot;
+    }
     __syncthreads();                                                 // red is rewritten by the first frame (its first 4 NW entries per sum)
   }
 
@@ -760,11 +965,15 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   // -DPYCHAIN_PROFILE_PHASES: cycles per phase of a frame step, per wave (s_memtime: the sums live in SGPRs), printed
   // for sequence 0 when the kernel ends (tools/phase_timers.sh; the table of DESIGN.md §4)
 #ifdef PYCHAIN_PROFILE_PHASES
-  unsigned long long lzph[6] = {0, 0, 0, 0, 0, 0}, lzt = 0;
+  unsigned long long lzph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lzt = 0;
 #define LZ_PH0() lzt = PH_T()
 #define LZ_PH(i) do { const unsigned long long t_ = PH_T(); lzph[i] += t_ - lzt; lzt = t_; } while (0)
 #define LZ_VMWAIT() do { const unsigned long long t_ = PH_T(); PYCHAIN_WAIT_VM0(); lzph[5] += PH_T() - t_; } while (0)   /* (inside the arc phase) */
+#define LZ_HK0() const unsigned long long hk0_ = PH_T()
+#define LZ_HK(i) do { lzph[i] += PH_T() - hk0_; } while (0)     /* (inside the hook: cumulative from its start) */
 #else
+#define LZ_HK0() (void)0
+#define LZ_HK(i) (void)0
 #define LZ_VMWAIT() (void)0
 #define LZ_PH0() (void)0
 #define LZ_PH(i) (void)0
@@ -778,7 +987,11 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if (!(tot > 0.f) || !(w.inv > 0.f)) bad |= 1;                                                           \
     if (FWDC) w.sprev = tot;                                                                                \
     else { w.c = coef * wave_sum(R1); w.sprev = w.c; }                                                      \
-    if ((TQ) == 0 && tot_real((FWDC) ? (JP) + 1 : L - 1 - (JP))) totv[(FWDC) ? (JP) + 1 : L - 1 - (JP)] = tot;   \
+    if ((TQ) == 0 && tot_real((FWDC) ? (JP) + 1 : L - 1 - (JP))) {                                           \
+      /* (crossing: the other direction reads this total while the kernel runs - device scope) */           \
+      if constexpr (XF) __hip_atomic_store(totv + ((FWDC) ? (JP) + 1 : L - 1 - (JP)), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+      else totv[(FWDC) ? (JP) + 1 : L - 1 - (JP)] = tot;                                                    \
+    }                                                                                                       \
     last_tot = tot;                                                                                         \
   } while (0)
   // One frame step j: alpha produces a(j+1,.) from a(j,.) and x(j); beta produces b(t,.), t = L-1-j, from b(t+1,.) and x(t).
@@ -804,6 +1017,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     if constexpr (MAP::kDma) {                               /* straight into the other buffer, in flight during the arc work */ \
       if (have_next) dma_row(tn, lq, (PAR) ? MAP::kX0 : MAP::kX1);                                          \
     } else if (have_next) xq.load_row(xbuf, tn, D, tq);      /* in flight during the arc work */             \
+    if constexpr (XF) { if (xon) xf_land(j, lq); }           /* crossing: the other side's row for the NEXT step's tail */ \
     /* What the hook behind the first gathers needs from LDS - the previous step's partial sums and the row it produced (it */ \
     /* sits in the buffer this step gathers from) - is requested HERE, ahead of the gathers: behind them the reads queue up */ \
     /* after sixteen waves' first two chunks, and a wave that waits for them issues nothing meanwhile (C3 recursion -4 %: */ \
@@ -811,7 +1025,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     float pre0 = 0.f, pre1 = 0.f;                                                                           \
     if (j > 0) { pre0 = red[((PAR) ^ 1) * 128 + lq]; if (!(FWDC)) pre1 = red[((PAR) ^ 1) * 128 + 64 + lq]; } \
     if constexpr (MAP::kMaxPdfs <= 4096 && !(FWDC)) w.lk_next = lds_abs(MAP::kLk + gbase[0] * 4 + lq * 4);          \
-    constexpr bool kPreRows = MAP::kMaxPdfs <= 4096;         /* (the map of C4 has no registers to spare: the rows are read in the hook) */ \
+    constexpr bool kPreRows = MAP::kMaxPdfs <= 4096 && !(XF);       /* (the map of C4 has no registers to spare: the rows are read in the hook) */ \
     lz_v2f prow[MG];                                                                                        \
     if constexpr (kPreRows) {                                                                               \
       _Pragma("unroll") for (int g = 0; g < MG; g++) prow[g] = lz_ld2(UCUR + gbase[g] * 8 + lq * 8);   /* (gbase = 0 beyond ngroups) */ \
@@ -819,6 +1033,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     float s0 = 0.f, s1 = 0.f;                                                                               \
     auto hook_first = [&]() {                                                                                \
+      LZ_HK0();                                                                                             \
+      const float tot_before = last_tot;                     /* (crossing: this side's total of the row before the one in this hook) */ \
       if (j > 0) PYCHAIN_LZ_TOTALS(pre0, pre1, j - 1, (FWDC), tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) is completed and leaves for HBM */ \
       /* (SG alpha - DenArgs::sg: the row the occupancy pass reads for frame t is a(t+1,.) ITSELF, without the leaky term, stored as */ \
@@ -830,14 +1046,22 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       const XBuf obuf = (!TS || real_row) ? sbuf : spbuf;                                                   \
       const int row_off = __builtin_amdgcn_readfirstlane((!TS || real_row) ? trow * Hp * 4 : (trow == spec_row ? 0 : Hp * 4)); \
       const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
-      _Pragma("unroll") for (int g = 0; g < MG; g++)                                                        \
+      /* crossing: the frame this hook's row belongs to; a direction stores only the rows the other one (or the band's occupancy */ \
+      /* launch) reads - alpha those of the frames below xMa, beta those from xMb on */                     \
+      const int tfr = (FWDC) ? f0 + j - 1 : L - j - 1;                                                      \
+      const bool xstore = !(XF) || !xon || ((FWDC) ? tfr < xMa : tfr >= xMb);                               \
+      if constexpr (XF) { xf_do = xon && !((FWDC) && j == 0); xf_tfr = tfr; xf_totb = tot_before; }         /* (the crossing's share: the step's tail) */ \
+      LZ_HK(6);                                                                                             \
+      _Pragma("unroll") for (int g = 0; g < MG; g++) {                                                      \
         if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1 && !((SG) && (FWDC) && j == 0)) {            \
           const lz_v2f pr = kPreRows ? prow[g] : lz_ld2(UCUR + gbase[g] * 8 + lq * 8);                      \
           /* (SG beta: the buffer holds x {b, 1}: b + c = pr.x / pr.y + c) */                                  \
           const float rowv = (SG) ? ((FWDC) ? pr.x : __builtin_fmaf(pr.x, __builtin_amdgcn_rcpf(pr.y), w.sprev)) : __builtin_fmaf(w.sprev, pr.y, pr.x); \
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), obuf, lane4,                          \
-                                                row_off + gbase[g] * 4, kStoreDeviceScope);                 \
+          if (xstore) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), obuf, lane4,              \
+                                                            row_off + gbase[g] * 4, kStoreDeviceScope);     \
         }                                                                                                   \
+      }                                                                                                     \
+      LZ_HK(7);                                                                                             \
     };                                                                                                      \
     auto hook_late = [&]() {                                                                                \
       /* LDS-direct rows: the next step's row (requested above, landed by now) is clamped / exp'd in place HERE, late in */ \
@@ -848,7 +1072,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
         else if (have_next && dma_finish(lq, (PAR) ? MAP::kX0 : MAP::kX1) && (FWDC)) bad |= 2; \
       }                                                                                                     \
     };                                                                                                      \
-    if constexpr (SG) lazy_tile_sg<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, xad01, xad23, lq, s0, s1, hook_first, hook_late); \
+    if constexpr (SG) lazy_tile_sg<R, MAP, (FWDC), UOFF, VOFF, UNEXT, (XF) ? 1 : PYCHAIN_SG_AHEAD>(arcs, groups, w, xad01, xad23, lq, s0, s1, hook_first, hook_late); \
     else lazy_tile<R, MAP, (FWDC), UOFF, VOFF, UNEXT>(arcs, groups, w, lq, s0, s1, hook_first, hook_late);  \
     LZ_PH(0);                                                /* arc phase */                                 \
     /* rows through registers: the next step's nnet-output row into the other buffer (last read in the previous step) */ \
@@ -866,6 +1090,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       if (!(FWDC)) { const float r1 = dpp_row_sum(s1); red[(PAR) * 128 + 64 + wave * 4 + (lq >> 4)] = r1; } \
     }                                                                                                       \
     LZ_PH(2);                                                /* previous row completed and stored, row sums */ \
+    /* (crossing: the step's last LDS work; its one store to memory is the last instruction before the barrier, and the barrier */ \
+    /* is then one that does NOT wait for stores to be acknowledged - __syncthreads() does, a memory round trip per emitting frame) */ \
+    if constexpr (XF) {                                                                                     \
+      LZ_HK0(); if (xf_do) xf_row((PAR), xf_tfr, xf_totb, UCUR, tq, lq); LZ_HK(8);                          \
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
+    } else                                                                                                  \
     __syncthreads();                                         /* every gather of this frame is done; the new vector is complete */ \
     LZ_PH(3);                                                /* wait at the barrier */                       \
     /* (this frame's totals: reduced by the next step behind its first gathers, or after the loop) */       \
@@ -879,6 +1109,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     __syncthreads();                                                                                        \
     if (tid == 0) __hip_atomic_store(my_progress, (P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         \
   } while (0)
+#define PYCHAIN_XF_REPORT(P)                                                                                \
+  do {                                                                                                      \
+    __builtin_amdgcn_s_waitcnt(0);                                                                          \
+    __syncthreads();                                                                                        \
+    if (tid == 0) __hip_atomic_store(xf_my, (P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+  } while (0)
   for (int jj = 0; jj < nsteps; jj += 2) {
     PYCHAIN_LZ_STEP(jj, 0, fwd);
     if (jj + 1 < nsteps) PYCHAIN_LZ_STEP(jj + 1, 1, fwd);
@@ -886,14 +1122,37 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     // step j stores the row of the frame before it (alpha row j, beta row L - j): after steps 0 .. jj + 1, jj + 2 rows
     // (SG alpha stores row j - 1 in step j: one row fewer is out)
     if (a.stream && stream_report_due(a.T, jj + 2) && jj + 2 < nsteps) PYCHAIN_LZ_REPORT(jj + 2 - ((SG && fwd) ? 1 : 0));
+    // crossing: how many steps' hooks are done and their rows visible device-wide, for the peer that lands them
+    if constexpr (XF) { if (xon && ((jj + 2) & 15) == 0 && jj + 2 < nsteps) PYCHAIN_XF_REPORT(jj + 2); }
   }
+  const float tot_before_last = last_tot;
   if (nsteps > 0) {                                                                  // the last step's
     const float r0 = red[((nsteps - 1) & 1) * 128 + lane], r1 = fwd ? 0.f : red[((nsteps - 1) & 1) * 128 + 64 + lane];
     PYCHAIN_LZ_TOTALS(r0, r1, nsteps - 1, fwd, tid);
   }
+  // crossing: the last row of either direction belongs to a frame its own side emits - the hook no step is left to run
+  bool xf_last_done = false;
+  if constexpr (XF) {
+    if (xon && nsteps > 0) {
+      const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
+#pragma unroll
+      for (int g = 0; g < MG; g++) {
+        if (g < groups.ngroups) {
+          const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * (gbase[g] + lane));
+          const float rowv = fwd ? u.x : __builtin_fmaf(u.x, __builtin_amdgcn_rcpf(u.y), w.sprev);
+          // (it is also the TRUE row the neighbouring time segment's speculated one is verified against: stored as ever)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), sbuf, lane * 4, (fwd ? nsteps - 1 : L - nsteps) * Hp * 4 + gbase[g] * 4, kStoreDeviceScope);
+        }
+      }
+      xf_row(nsteps & 1, fwd ? f0 + nsteps - 1 : L - nsteps - 1, tot_before_last, ul, tid, lane);
+      __syncthreads();                                       // every wave's products are in the accumulator row
+      if (xf_pending) { XfFlush f; xf_flush_read(f, nsteps & 1, tid, lane); xf_flush_write(f, nsteps & 1, tid, xf_pending_frame, xf_gpred_prev); }
+      xf_last_done = true;
+    }
+  }
   if constexpr (SG && fwd) {
     // the last row of an SG alpha recursion - a(L,.), row L - 1 (DenArgs::sg) - never saw a next step's hook
-    if (nsteps > 0) {
+    if (nsteps > 0 && !xf_last_done) {
       const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
       const int row_off = (nsteps - 1) * Hp * 4;
       for (int g = 0; g < MG; g++)
@@ -903,7 +1162,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
         }
     }
   }
-  if constexpr (!fwd) {
+  if constexpr (XF) { if (xon) PYCHAIN_XF_REPORT(0x3fffffff); }   // (a peer still waiting never waits for more)
+#undef PYCHAIN_XF_REPORT
+  if (!fwd && !xf_last_done) {
     // the last beta row (row L - nsteps: row 1, or the start row if the sequence has one frame) never saw a next frame
     const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
     const int row_off = (L - nsteps) * Hp * 4;
@@ -924,8 +1185,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 #ifdef PYCHAIN_PROFILE_PHASES
   if (lane == 0 && b == 0) {
     const unsigned long long n = (unsigned long long)max(1, nsteps);
-    printf("lazy dir %d wave %2d rows %2d steps %d cycles/step: arcs %llu rereads+x %llu rowstore+sums %llu barrier %llu totals %llu vmwait-in-arcs %llu\n",
-           (int)fwd, wave, groups.nslots, nsteps, lzph[0] / n, lzph[1] / n, lzph[2] / n, lzph[3] / n, lzph[4] / n, lzph[5] / n);
+    printf("lazy dir %d wave %2d rows %2d steps %d cycles/step: arcs %llu rereads+x %llu rowstore+sums %llu barrier %llu totals %llu vmwait-in-arcs %llu hook: totals %llu rows %llu crossing-tail %llu - %llu\n",
+           (int)fwd, wave, groups.nslots, nsteps, lzph[0] / n, lzph[1] / n, lzph[2] / n, lzph[3] / n, lzph[4] / n, lzph[5] / n, lzph[6] / n, lzph[7] / n, lzph[8] / n, lzph[9] / n);
   }
 #endif
 #undef LZ_PH
@@ -970,7 +1231,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
 }
 
 // XM: kLzRowsPre - the rows were exp'd ahead by den_exp_rows_kernel (DenArgs::ex); kLzRowsHalf - 2-byte rows (DenArgs::x_half)
-template <int R, typename MAP, int XM = kLzRowsF32, bool TS = false, bool NC = false, bool SG = false>
+template <int R, typename MAP, int XM = kLzRowsF32, bool TS = false, bool NC = false, bool SG = false, bool XF = false>
 __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(const DenArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // (the fallback launch behind a segmented one: runs only if a splice did not verify - DenArgs::redo)
@@ -979,10 +1240,10 @@ __global__ __launch_bounds__(MAP::kWaves * 64) void den_recursion_lazy_kernel(co
     if (den_tseg_off(a)) return;                           // the plan is cooling down after misses: the uncut launch behind this one does the work
     const unsigned per_dir = (unsigned)a.B * (unsigned)a.tseg;                        // workgroups per direction: segment-major
     const unsigned r = blockIdx.x < per_dir ? blockIdx.x : blockIdx.x - per_dir;
-    if (blockIdx.x < per_dir) lazy_recursion<R, MAP, true, XM, true, NC, SG>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
-    else lazy_recursion<R, MAP, false, XM, true, NC, SG>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+    if (blockIdx.x < per_dir) lazy_recursion<R, MAP, true, XM, true, NC, SG, XF>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
+    else lazy_recursion<R, MAP, false, XM, true, NC, SG, XF>(a, smem_raw, (int)(r % (unsigned)a.B), (int)(r / (unsigned)a.B));
   } else {
-    if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM, false, NC, SG>(a, smem_raw, blockIdx.x);
-    else lazy_recursion<R, MAP, false, XM, false, NC, SG>(a, smem_raw, blockIdx.x - a.B);
+    if (blockIdx.x < (unsigned)a.B) lazy_recursion<R, MAP, true, XM, false, NC, SG, XF>(a, smem_raw, blockIdx.x);
+    else lazy_recursion<R, MAP, false, XM, false, NC, SG, XF>(a, smem_raw, blockIdx.x - a.B);
   }
 }

@@ -999,6 +999,7 @@ int64_t plan_build_impl(
   Tile tile_gs;
   if (pdf_by_state) {
     if (HB != H) pdf_by_state = false;                      // (a state on several BETA positions: the kernels' NC form has no one-gather variant)
+    if (HA - H > PLAN_MAX_EXTRA_A) pdf_by_state = false;    // (the crossing keeps a state's further ALPHA positions in a fixed table: den_lazy.inc.h, LzCross)
     for (int h = 0; h < H && pdf_by_state; h++)
       if (bi[2 * h + 1] > bi[2 * h])
         for (int m = 0; m < parts_a[h]; m++) rows_gs[in_pdf[h]].push_back(Arc{ea0[h] + m, eb0[h], 1.0f});
@@ -1053,6 +1054,9 @@ int64_t plan_build_impl(
     hd.flags |= PLAN_FLAG_PDF_BY_STATE; place_vec(hd.off_pdf_a, Hp); place_vec(hd.off_pdf_b, Hp);
     place_tile(hd.gamma_sg, tgs); place_tile(hd.gamma2_sg, tgs2);
     place_vec(hd.off_row_pdf_sg, std::max((int)tgs.groups.size() * 64, 64));
+    place_vec(hd.off_a2b, Hp); place_vec(hd.off_b2a, Hp);
+    hd.n_extra_a = HA - H;
+    place_vec(hd.off_extra_a, std::max(2, 2 * (HA - H)));
   }
   if (off > (size_t)INT32_MAX)
     return pychain_hip::fail(PYCHAIN_HIP_EUNSUPPORTED, "den_plan_build: plan larger than 2 GiB");
@@ -1091,6 +1095,16 @@ int64_t plan_build_impl(
     write_tile(hd.gamma_sg, tgs); write_tile(hd.gamma2_sg, tgs2);
     int32_t* row_pdf_sg = (int32_t*)(base + hd.off_row_pdf_sg);
     for (int i = 0; i < std::max((int)tgs.groups.size() * 64, 64); i++) row_pdf_sg[i] = i < (int)tile_gs.order.size() ? tile_gs.order[i] : -1;
+    int32_t* a2b = (int32_t*)(base + hd.off_a2b); int32_t* b2a = (int32_t*)(base + hd.off_b2a); int32_t* extra = (int32_t*)(base + hd.off_extra_a);
+    int n_ex = 0;
+    for (int h = 0; h < H; h++) {                            // (HB == H: one beta position per state)
+      const int pb = lay.pos[kLayB][eb0[h]];
+      b2a[pb] = lay.pos[kLayA][ea0[h]];
+      for (int m = 0; m < parts_a[h]; m++) {
+        a2b[lay.pos[kLayA][ea0[h] + m]] = pb;
+        if (m > 0) { extra[2 * n_ex] = pb; extra[2 * n_ex + 1] = lay.pos[kLayA][ea0[h] + m]; n_ex++; }
+      }
+    }
     int32_t* pdf_a = (int32_t*)(base + hd.off_pdf_a); int32_t* pdf_b = (int32_t*)(base + hd.off_pdf_b);
     for (int h = 0; h < H; h++) {
       for (int m = 0; m < parts_a[h]; m++) pdf_a[lay.pos[kLayA][ea0[h] + m]] = in_pdf[h];

@@ -67,6 +67,7 @@ struct GroupEntry {
   int32_t nslots;              // slot-rows in this group (may be 0)
 };
 
+constexpr int PLAN_MAX_EXTRA_A = 1024;   // a pdf-by-state plan's states on several alpha positions: at most this many further positions
 struct PlanHeader {
   int32_t magic, version;
   int32_t H, K, D, Hp;
@@ -105,6 +106,12 @@ struct PlanHeader {
   // they have (DenArgs::sg).  gamma_sg: 16 waves, gamma2_sg: 8 waves; at most PLAN_RESIDENT_0 slot-rows per wave.
   int32_t off_row_pdf_sg;      // int32[gamma_sg.ngroups*64] natural pdf-id of each row of the *_sg tiles, -1 = padding
   TilePlan gamma_sg, gamma2_sg;
+  // ... and each recursion can emit the occupancies of its own second half ("crossing", den_lazy.inc.h: XF): a workgroup holds
+  // its side's value of a position and needs the OTHER side's value of the same state -
+  int32_t off_a2b;             // int32[Hp]  alpha position -> the state's beta position
+  int32_t off_b2a;             // int32[Hp]  beta position  -> the state's FIRST alpha position
+  int32_t off_extra_a;         // int32[2 n_extra_a]  {beta position, alpha position}: the alpha positions of a state after its first
+  int32_t n_extra_a;           // <= PLAN_MAX_EXTRA_A
 };
 #define PLAN_FLAG_PDF_BY_STATE 1
 
@@ -187,6 +194,9 @@ inline bool plan_header_in_bounds(const PlanHeader& hd) {
       if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
     if (!tile_in_bounds(hd.gamma_sg, n) || !tile_in_bounds(hd.gamma2_sg, n)) return false;
     if (hd.off_row_pdf_sg < 0 || (size_t)hd.off_row_pdf_sg + (size_t)hd.gamma_sg.ngroups * 64 * 4 > n) return false;
+    for (int32_t off : {hd.off_a2b, hd.off_b2a})
+      if (off < 0 || (size_t)off + (size_t)hd.Hp * 4 > n) return false;
+    if (hd.n_extra_a < 0 || hd.n_extra_a > PLAN_MAX_EXTRA_A || hd.off_extra_a < 0 || (size_t)hd.off_extra_a + (size_t)hd.n_extra_a * 8 > n) return false;
   }
   return hd.off_row_pdf >= 0 && (size_t)hd.off_row_pdf + (size_t)hd.gamma.ngroups * 64 * 4 <= n;
 }

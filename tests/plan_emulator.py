@@ -7,7 +7,7 @@ against the oracle without a GPU.  Mirrors the kernels step by step.
 """
 import numpy as np
 
-HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4 + 16  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 14), in int32 words
+HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4 + 16 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 14), in int32 words
 
 
 def parse(blob):
@@ -51,6 +51,11 @@ def parse(blob):
         hd["gamma_sg"], hd["gamma2_sg"] = tile(72), tile(80)
         ngs = max(hd["gamma_sg"]["ngroups"] * 64, 64)
         hd["row_pdf_sg"] = b[int(h[71]):int(h[71]) + 4 * ngs].view(np.int32).copy()
+        # the crossing's tables: alpha position -> the state's beta position, beta position -> its FIRST alpha position, and
+        # the further alpha positions of states on several {beta position, alpha position}
+        hd["a2b"] = b[int(h[88]):int(h[88]) + 4 * Hp].view(np.int32).copy()
+        hd["b2a"] = b[int(h[89]):int(h[89]) + 4 * Hp].view(np.int32).copy()
+        hd["extra_a"] = b[int(h[90]):int(h[90]) + 8 * int(h[91])].view(np.int32).reshape(-1, 2).copy()
     return hd
 
 

@@ -202,9 +202,10 @@ def test_random_numerators_in_the_reference_arithmetic(seed):
 @pytest.mark.parametrize("seed", range(8))
 def test_random_hub_graphs_states_on_several_lanes(seed):
     """Random graphs with hub states (helpers.random_hub_graph; the CPU suite emulates the same ten): the plan puts states on
-    several lanes on both sides; the lazy recursions' NC form (four waves or sixteen), the two-barrier kernel and - with the
-    pair kernel asked for, which does not take such plans - whatever runs instead, against the fp64 oracle and against the plan
-    with every state on one lane; ragged lengths, exact zeros in the padding."""
+    several lanes on both sides - or, where hubs feed hubs so much that the occupancy tile would repeat its arcs beyond 3/2 of
+    them (plan.cpp: the gamma-arc bound; seed 1), on neither; the lazy recursions' NC form (four waves or sixteen), the two-barrier
+    kernel and - with the pair kernel asked for, which does not take such plans - whatever runs instead, against the fp64 oracle
+    and against the plan with every state on one lane; ragged lengths, exact zeros in the padding."""
     from helpers import random_hub_graph
     from pychain_amd import _plan
     den, D = random_hub_graph(seed)
@@ -215,7 +216,8 @@ def test_random_hub_graphs_states_on_several_lanes(seed):
     x = syn.make_input(B, T, D, seed=70 + seed)
     L = torch.tensor(lengths)
     plan = _plan.graph_plan(den, D, torch.device(DEV))
-    assert plan.num_states > den.num_states and (plan.slot_rows >> 28) & 1
+    split = plan.num_states > den.num_states
+    assert split == bool((plan.slot_rows >> 28) & 1) and (split or seed == 1)
     ro, rg = orc.chain_function(x, L, ChainGraphBatch(den, B), 1e-5, flavour="f64")
     with _lib.option("plan_split", "0"):
         o0, g0 = _run(x, L, den, 1, False)

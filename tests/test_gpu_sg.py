@@ -139,3 +139,63 @@ def test_a_graph_where_only_some_states_qualify_runs_the_ordinary_kernels():
     o, g, bad, _ = _call(mixed, x, L)
     ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(mixed, 4), 1e-5, flavour="f64")
     assert bad == 0 and abs(o - ro) <= 1e-5 * abs(ro) and rel_err(g.cpu().numpy(), rg) <= 1e-5
+
+
+@pytest.mark.parametrize("lens,opts", [([700, 651, 512, 333, 104, 103, 2, 1], {}), ([1500, 1400, 900, 300], {}),
+                                       ([900, 820, 400], dict(den_tseg=2, den_tburn=192)), ([1500, 1211], dict(den_tseg=4, den_tburn=160))])
+def test_crossing_recursions_vs_the_streamed_occupancy_launch(den, lens, opts):
+    """Option den_cross = 1 (off by default - measured slower): each recursion emits the occupancies of its own
+    second half - a(t+1,j) b(t+1,j) against the other side's row, landed a step ahead, into fixed-point accumulators per pdf - and the
+    occupancy launch handles a band of 48 frames around every middle.  Same objective, same gradient to 1e-6 of its largest entry
+    (fixed point at 2^30 / G': 3e-7 measured) and rows that sum to 1 as they do without it; sequences too short to have two halves
+    (< 104 frames) are left to the occupancy launch whole; uncut and cut into time segments (a segment has its own middle)."""
+    T, B = max(lens), len(lens)
+    L = torch.tensor(lens)
+    x = syn.make_input(B, T, D, seed=90 + T, device=DEV)
+    with _lib.option("den_cross", 1):
+        assert "crossing" in _name(den, B) and "crossing" not in _name(den, B, fused=True)
+    assert "crossing" not in _name(den, B)
+    o, g, bad, tot = _call(den, x, L, den_cross=1, **opts)
+    o0, g0, bad0, tot0 = _call(den, x, L, **opts)
+    assert bad == 0 and bad0 == 0 and o == o0
+    assert torch.equal(tot[5:7], tot0[5:7])                                # the same segments, the same (zero) misses
+    gm = float(g0.abs().max())
+    err = float((g - g0).abs().max()) / gm
+    rows = g.sum(dim=2)
+    for b, Lb in enumerate(lens):
+        assert float((rows[b, :Lb] - g0.sum(dim=2)[b, :Lb]).abs().max()) <= 2e-6 and float(g[b, Lb:].abs().max() if Lb < T else 0.0) == 0.0
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, B), 1e-5, flavour="f64")
+    record_parity("crossing_T%d_B%d_%s" % (T, B, "tseg%d" % opts["den_tseg"] if opts else "uncut"), grad_vs_streamed_occupancies=err,
+                  grad_vs_f64=rel_err(g.cpu().numpy(), rg), bound=1e-6)
+    assert err <= 1e-6 and rel_err(g.cpu().numpy(), rg) <= 1e-5, err
+    o2, g2, _, _ = _call(den, x, L, den_cross=1, **opts)                   # integer accumulation: the same bits every time
+    assert o2 == o and torch.equal(g2, g)
+
+
+def test_crossing_with_states_on_several_alpha_positions_and_the_per_frame_check():
+    """A hub state with more arcs than a slot-row group holds is dealt to several ALPHA positions (plan.cpp): its beta lane pairs
+    with the first, the table of further positions (PlanHeader::off_extra_a) with the rest.  And verbose = 1: the 5 % invariant of
+    chain-computation.cc:363-390 is checked on every frame, on the totals the crossing measures itself."""
+    n, fan = 600, 6
+    base = syn.make_structured_den_graph(n, fan, D)
+    ft = base.forward_transitions
+    src, dst, pdf = ft[:, 0].numpy().copy(), ft[:, 1].numpy().copy(), ft[:, 2].numpy().copy()
+    lp = np.log(base.forward_transition_probs.numpy())
+    rng = np.random.default_rng(3)
+    hub, hub_pdf = 11, int(pdf[np.nonzero(dst == 11)[0][0]])
+    extra = rng.choice(2 * n, size=200, replace=False)                     # 200 more arcs ENTER the hub, all with its pdf
+    src = np.concatenate([src, extra]); dst = np.concatenate([dst, np.full(200, hub)]); pdf = np.concatenate([pdf, np.full(200, hub_pdf)])
+    lp = np.concatenate([lp, np.full(200, np.log(0.01))])
+    fst = StdVectorFst.from_arrays(2 * n, 0, src, dst, pdf, lp, np.zeros(2 * n))
+    g_hub = ChainGraph(fst, initial_mode="leaky", final_mode="ones", log_domain=False)
+    plan = _plan.graph_plan(g_hub, D, torch.device(DEV))
+    assert (plan.slot_rows >> 27) & 1 and plan.num_states > 2 * n          # (positions of the longer side: the hub sits on several)
+    L = torch.tensor([420, 333, 209])
+    x = syn.make_input(3, 420, D, seed=31, device=DEV)
+    o, g, bad, _ = _call(g_hub, x, L, den_cross=1)
+    o0, g0, bad0, _ = _call(g_hub, x, L)
+    ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(g_hub, 3), 1e-5, flavour="f64")
+    assert bad == 0 and bad0 == 0 and o == o0
+    assert float((g - g0).abs().max()) <= 1e-6 * float(g0.abs().max()) and rel_err(g.cpu().numpy(), rg) <= 1e-5
+    o1, g1, bad1, _ = _call(g_hub, x, L, den_cross=1, verbose=1)
+    assert bad1 == 0 and o1 == o and torch.equal(g1, g)

@@ -10,7 +10,8 @@ import oracle as orc
 import plan_emulator as emu
 from helpers import graph_from_npz, rel_err
 from pychain_amd import _lib, _plan, synthetic as syn
-from pychain_amd.graph import ChainGraphBatch
+from pychain_amd.graph import ChainGraph, ChainGraphBatch
+from pychain_amd.simplefst import StdVectorFst
 
 
 def _blob(g, D):
@@ -480,3 +481,33 @@ def test_pdf_by_state_plans_and_their_one_gather_form():
         assert not emu.parse(_blob(g, D))["pdf_by_state"]
     finally:
         del os.environ["PYCHAIN_PLAN_SG"]
+
+
+def test_pdf_by_state_plans_carry_the_tables_of_the_crossing():
+    """For the crossing (den_lazy.inc.h: XF, option den_cross) a pdf-by-state plan maps every alpha position to its state's beta
+    position and back (the FIRST alpha position), and lists the further alpha positions of states dealt to several
+    (PlanHeader::off_a2b / off_b2a / off_extra_a): a pair of positions is one state - same pdf; a beta position and its first alpha
+    position the same leaky probability - and the
+    further positions are exactly those the round trip does not return to."""
+    D = 300
+    base = syn.make_structured_den_graph(200, 5, D)
+    ft = base.forward_transitions
+    src, dst, pdf = ft[:, 0].numpy().copy(), ft[:, 1].numpy().copy(), ft[:, 2].numpy().copy()
+    lp = np.log(base.forward_transition_probs.numpy())
+    rng = np.random.default_rng(5)
+    hub, hub_pdf = 7, int(pdf[np.nonzero(dst == 7)[0][0]])
+    more = rng.choice(400, size=300, replace=False)                         # a hub: 300 more arcs enter state 7, with its pdf
+    fst = StdVectorFst.from_arrays(400, 0, np.concatenate([src, more]), np.concatenate([dst, np.full(300, hub)]),
+                                   np.concatenate([pdf, np.full(300, hub_pdf)]), np.concatenate([lp, np.full(300, np.log(0.01))]), np.zeros(400))
+    for g in (base, ChainGraph(fst, initial_mode="leaky", final_mode="ones", log_domain=False)):
+        hd = emu.parse(_blob(g, D))
+        assert hd["pdf_by_state"]
+        S, a2b, b2a, ex = hd["graph_states"], hd["a2b"], hd["b2a"], hd["extra_a"]
+        HA = S + len(ex)                                                    # alpha positions: the states + their further positions
+        assert np.all((a2b[:HA] >= 0) & (a2b[:HA] < S)) and np.all((b2a[:S] >= 0) & (b2a[:S] < HA))
+        assert np.array_equal(a2b[b2a[:S]], np.arange(S))                   # beta -> first alpha -> the same beta position
+        assert np.array_equal(hd["pdf_a"][:HA], hd["pdf_b"][a2b[:HA]]) and np.array_equal(hd["leaky_a"][b2a[:S]], hd["leaky_b"][:S])
+        back = b2a[a2b[:HA]]
+        further = np.nonzero(back != np.arange(HA))[0]
+        assert sorted(further.tolist()) == sorted(ex[:, 1].tolist()) and np.array_equal(a2b[ex[:, 1]], ex[:, 0])
+    assert len(ex) > 0                                                      # (the hub graph has such states)

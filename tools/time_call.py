@@ -23,6 +23,8 @@ elif label == "C3-equal":
     kw = dict(equal=True, den_only=True)
 elif label.startswith("C3@B="):
     B = int(label.split("=")[1])
+elif label.startswith("C3-structured@B="):       # the structured graph's denominator alone at that batch
+    B, kw = int(label.split("=")[1]), dict(structured=True)
 else:
     name = label
 w = bench._adhoc_workload(name, B, dev, **kw)
