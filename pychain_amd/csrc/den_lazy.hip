@@ -43,7 +43,8 @@ hipError_t launch_lz_sg(const DenArgs& a, const dim3 grid, hipStream_t st) {
 }
 // ... with the crossing (DenArgs::xf; LzCross: state vectors of up to 3072 positions)
 inline bool xf_shape_ok(const DenArgs& a, int hint) {
-  return sg_shape_ok(a, hint) && a.knobs.den_cross != 0 && !a.fused && a.Hp <= (int)LzCross::kMaxStates && a.D % 4 == 0 &&
+  // (at most 32 slot-rows per wave: the 40-row form of this kernel spills thirty registers inside its loop)
+  return sg_shape_ok(a, hint) && (hint & 1023) <= 32 && a.knobs.den_cross != 0 && !a.fused && a.Hp <= (int)LzCross::kMaxStates && a.D % 4 == 0 &&
          a.D <= (int)LzCross::kMaxPdfs && a.T >= 4 * kCrossBand + 8;
 }
 template <int R, bool TS>
@@ -91,8 +92,7 @@ hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
     const int rows = hint & 1023;
     const dim3 grid(2 * a.B * (a.tseg > 1 ? a.tseg : 1));
     if (a.xf) {
-      if (a.tseg > 1) return rows <= 32 ? launch_lz_xf<32, true>(a, grid, st) : launch_lz_xf<kMaxResident, true>(a, grid, st);
-      return rows <= 32 ? launch_lz_xf<32, false>(a, grid, st) : launch_lz_xf<kMaxResident, false>(a, grid, st);
+      return a.tseg > 1 ? launch_lz_xf<32, true>(a, grid, st) : launch_lz_xf<32, false>(a, grid, st);   // (xf_shape_ok: rows <= 32)
     }
     if (a.tseg > 1) return rows <= 32 ? launch_lz_sg<32, LzNarrowDma, true>(a, grid, st) : launch_lz_sg<kMaxResident, LzNarrowDma, true>(a, grid, st);
     return rows <= 32 ? launch_lz_sg<32, LzNarrowDma, false>(a, grid, st) : launch_lz_sg<kMaxResident, LzNarrowDma, false>(a, grid, st);

@@ -1034,7 +1034,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     float s0 = 0.f, s1 = 0.f;                                                                               \
     auto hook_first = [&]() {                                                                                \
       LZ_HK0();                                                                                             \
-      const float tot_before = last_tot;                     /* (crossing: this side's total of the row before the one in this hook) */ \
+      float tot_before = 0.f;                                /* (crossing: this side's total of the row before the one in this hook) */ \
+      if constexpr (XF) tot_before = last_tot;                                                              \
       if (j > 0) PYCHAIN_LZ_TOTALS(pre0, pre1, j - 1, (FWDC), tq);   /* (step 0: the start vector's, above) */ \
       /* ... and with them the row of the PREVIOUS frame (alpha row j, beta row L - j) is completed and leaves for HBM */ \
       /* (SG alpha - DenArgs::sg: the row the occupancy pass reads for frame t is a(t+1,.) ITSELF, without the leaky term, stored as */ \
@@ -1048,9 +1049,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       const int lane4 = lq * 4;                              /* one VGPR of addresses, the group in the SGPR offset */ \
       /* crossing: the frame this hook's row belongs to; a direction stores only the rows the other one (or the band's occupancy */ \
       /* launch) reads - alpha those of the frames below xMa, beta those from xMb on */                     \
-      const int tfr = (FWDC) ? f0 + j - 1 : L - j - 1;                                                      \
-      const bool xstore = !(XF) || !xon || ((FWDC) ? tfr < xMa : tfr >= xMb);                               \
-      if constexpr (XF) { xf_do = xon && !((FWDC) && j == 0); xf_tfr = tfr; xf_totb = tot_before; }         /* (the crossing's share: the step's tail) */ \
+      bool xstore = true;                                                                                   \
+      if constexpr (XF) { const int tfr = (FWDC) ? f0 + j - 1 : L - j - 1; xstore = !xon || ((FWDC) ? tfr < xMa : tfr >= xMb); } \
+      if constexpr (XF) { xf_do = xon && !((FWDC) && j == 0); xf_tfr = (FWDC) ? f0 + j - 1 : L - j - 1; xf_totb = tot_before; } \
       LZ_HK(6);                                                                                             \
       _Pragma("unroll") for (int g = 0; g < MG; g++) {                                                      \
         if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1 && !((SG) && (FWDC) && j == 0)) {            \
@@ -1164,7 +1165,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   }
   if constexpr (XF) { if (xon) PYCHAIN_XF_REPORT(0x3fffffff); }   // (a peer still waiting never waits for more)
 #undef PYCHAIN_XF_REPORT
-  if (!fwd && !xf_last_done) {
+  if (!fwd && (!XF || !xf_last_done)) {
     // the last beta row (row L - nsteps: row 1, or the start row if the sequence has one frame) never saw a next frame
     const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
     const int row_off = (L - nsteps) * Hp * 4;
