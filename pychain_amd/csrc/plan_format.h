@@ -29,7 +29,7 @@
 #include <stdint.h>
 
 #define PLAN_MAGIC 0x4C504843  // "CHPL"
-#define PLAN_VERSION 14
+#define PLAN_VERSION 15
 #ifndef PLAN_REC_WAVES
 #define PLAN_REC_WAVES 16      // waves per workgroup the alpha/beta plans are scheduled for
 #define PLAN_GAM_WAVES 16      // same for the gamma plan
@@ -106,7 +106,7 @@ struct PlanHeader {
   // they have (DenArgs::sg).  gamma_sg: 16 waves, gamma2_sg: 8 waves; at most PLAN_RESIDENT_0 slot-rows per wave.
   int32_t off_row_pdf_sg;      // int32[gamma_sg.ngroups*64] natural pdf-id of each row of the *_sg tiles, -1 = padding
   TilePlan gamma_sg, gamma2_sg;
-  // ... and each recursion can emit the occupancies of its own second half ("crossing", den_lazy.inc.h: XF): a workgroup holds
+  // ... and (format 15) each recursion can emit the occupancies of its own second half ("crossing", den_lazy.inc.h: XF): a workgroup holds
   // its side's value of a position and needs the OTHER side's value of the same state -
   int32_t off_a2b;             // int32[Hp]  alpha position -> the state's beta position
   int32_t off_b2a;             // int32[Hp]  beta position  -> the state's FIRST alpha position

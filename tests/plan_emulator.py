@@ -7,7 +7,7 @@ against the oracle without a GPU.  Mirrors the kernels step by step.
 """
 import numpy as np
 
-HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4 + 16 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 14), in int32 words
+HDR_INTS = 8 + 3 * 8 + 8 + 3 * 8 + 4 + 4 + 16 + 4  # PlanHeader of csrc/plan_format.h (PLAN_VERSION 15), in int32 words
 
 
 def parse(blob):
