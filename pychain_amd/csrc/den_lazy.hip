@@ -30,11 +30,13 @@ inline bool lazy_shape_ok(const DenArgs& a, int hint, bool dma = false) {
 // (launch hint bit 28: the plan has beta positions that take no constant - the kernels' NC form, den_lazy.inc.h)
 inline bool hint_no_const(int hint) { return hint >= 0 && ((hint >> 28) & 1); }   // (negative: PYCHAIN_HIP_HINT_GENERAL)
 // (launch hint bit 27: a "pdf by state" plan - the one-gather form of the recursions, den_lazy.inc.h: SG.  Taken where the form
-// is instantiated: the 16-wave map of C3 with LDS-direct fp32 rows the kernel clamps / exp's itself, loops of 32 or 40 rows, no
+// is instantiated: the 16-wave map of C3 with LDS-direct fp32 rows the kernel clamps / exp's itself, loops of up to 32 rows, no
 // beta position without the constant; everything else runs such a plan like any other.)
 inline bool hint_pdf_by_state(int hint) { return hint >= 0 && ((hint >> 27) & 1); }
 inline bool sg_shape_ok(const DenArgs& a, int hint) {
-  return hint_pdf_by_state(hint) && !hint_no_const(hint) && a.knobs.den_sg != 0 && !a.input_is_exp && !a.x_half && !a.use_ex &&
+  // (at most 32 slot-rows per wave: with two registers per arc the 40-row loop does not fit 128 registers - it compiled to 300
+  // reloads from scratch per frame; such a plan runs the ordinary kernels)
+  return hint_pdf_by_state(hint) && (hint & 1023) <= 32 && !hint_no_const(hint) && a.knobs.den_sg != 0 && !a.input_is_exp && !a.x_half && !a.use_ex &&
          a.plan_stride == 0 && a.D <= (int)LzNarrow::kMaxPdfs;
 }
 template <int R, typename M, bool TS>
@@ -89,13 +91,11 @@ hipError_t launch_dma_x(const DenArgs& a, int rows, hipStream_t st, bool nc) {
 hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
   // the map of C3 where the shape fits it, else the one for rows of up to 9216 pdfs
   if (lazy_shape_ok(a, hint, true) && sg_shape_ok(a, hint)) {            // a "pdf by state" plan: one gather per arc
-    const int rows = hint & 1023;
-    const dim3 grid(2 * a.B * (a.tseg > 1 ? a.tseg : 1));
+    const dim3 grid(2 * a.B * (a.tseg > 1 ? a.tseg : 1));         // (sg_shape_ok: rows <= 32)
     if (a.xf) {
       return a.tseg > 1 ? launch_lz_xf<32, true>(a, grid, st) : launch_lz_xf<32, false>(a, grid, st);   // (xf_shape_ok: rows <= 32)
     }
-    if (a.tseg > 1) return rows <= 32 ? launch_lz_sg<32, LzNarrowDma, true>(a, grid, st) : launch_lz_sg<kMaxResident, LzNarrowDma, true>(a, grid, st);
-    return rows <= 32 ? launch_lz_sg<32, LzNarrowDma, false>(a, grid, st) : launch_lz_sg<kMaxResident, LzNarrowDma, false>(a, grid, st);
+    return a.tseg > 1 ? launch_lz_sg<32, LzNarrowDma, true>(a, grid, st) : launch_lz_sg<32, LzNarrowDma, false>(a, grid, st);
   }
   if (lazy_shape_ok(a, hint, true)) return launch_dma_x<LzNarrowDma>(a, hint & 1023, st, hint_no_const(hint));
   return launch_dma_x<LzDma>(a, hint & 1023, st, hint_no_const(hint));
