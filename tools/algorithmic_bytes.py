@@ -6,8 +6,8 @@ sys.path[:0] = [REPO]
 import torch
 from pychain_amd import synthetic as syn
 label = sys.argv[1]
-name, B, equal, fused = "C3", None, False, label in ("C3", "C3-num_compat")
-if label == "C3-equal":
+name, B, equal, fused = "C3", None, False, label in ("C3", "C3-num_compat", "C3-structured")
+if label in ("C3-equal", "C3-structured-den"):           # (the structured graph has the sizes of C3's)
     equal = True
 elif label.startswith("C3@B="):
     B = int(label.split("=")[1])

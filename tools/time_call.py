@@ -23,6 +23,8 @@ elif label == "C3-equal":
     kw = dict(equal=True, den_only=True)
 elif label.startswith("C3@B="):
     B = int(label.split("=")[1])
+elif label.startswith("C3-fused@B="):             # the fused step at that batch (bench.py: other_workloads C3@B=...)
+    B, fused = int(label.split("=")[1]), True
 elif label.startswith("C3-structured@B="):       # the structured graph's denominator alone at that batch
     B, kw = int(label.split("=")[1]), dict(structured=True)
 else:
