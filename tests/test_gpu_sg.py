@@ -199,3 +199,17 @@ def test_crossing_with_states_on_several_alpha_positions_and_the_per_frame_check
     assert float((g - g0).abs().max()) <= 1e-6 * float(g0.abs().max()) and rel_err(g.cpu().numpy(), rg) <= 1e-5
     o1, g1, bad1, _ = _call(g_hub, x, L, den_cross=1, verbose=1)
     assert bad1 == 0 and o1 == o and torch.equal(g1, g)
+
+
+def test_crossing_after_a_splice_miss_is_the_uncut_crossing(den):
+    """Time segments with 16 frames of burn-in do not verify: the call runs its recursions again uncut - with the
+    crossing on, the uncut crossing, whose middles are the sequences' and not the segments'; the occupancy launch must then handle
+    THOSE bands.  Same bits as the uncut crossing asked for directly; the misses are reported; nothing is `bad`."""
+    L = torch.tensor([900, 640, 300])
+    x = syn.make_input(3, 900, D, seed=23, device=DEV)
+    o0, g0, b0, t0 = _call(den, x, L, den_cross=1, den_tseg=0)
+    o, g, b, t = _call(den, x, L, den_cross=1, den_tseg=4, den_tburn=16)
+    assert b == 0 and b0 == 0 and int(t[6]) == 4 and int(t[5]) >= 1
+    assert o == o0 and torch.equal(g, g0)
+    o1, g1, b1, _ = _call(den, x, L, den_tseg=0)
+    assert b1 == 0 and float((g - g1).abs().max()) <= 1e-6 * float(g1.abs().max())
