@@ -85,6 +85,8 @@ struct LzSmall {
 // and of a landing-row position.
 //   [0, 12K) landing 0   [12K, 24K) landing 1   [24K, 40K) x row 0   [40K, 56K) x row 1   [56K, 72K) accumulator 0   [72K, 88K) accumulator 1
 //   [88K, 112K) state buffer 0: float2[<= 3072]   [112K, 136K) state buffer 1   [136K, 148K) beta's leaky probs   partial sums
+//   then: partial sums, the per-wave sums of a row's products [2][16], the other side's totals [2] and the gradient scale, the table
+//   of a state's further alpha positions (<= PLAN_MAX_EXTRA_A x 8 bytes): 160 912 bytes in all
 struct LzCross {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
   static constexpr bool kDma = true;
@@ -864,7 +866,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     // (last: the previous row's accumulators leave for the gradient - nothing of this step touches LDS after this store)
     if (flush) xf_flush_write(f, par ^ 1, tq_, flush_frame, flush_pred);
   };
-  // what a step lands for the NEXT step's hook: the other side's row of the frame that hook handles (if it emits, or dry-runs)
+  // what a step lands for the NEXT step's tail: the other side's row of the frame that tail handles (if it emits, or dry-runs)
   auto xf_land = [&](int j, int lq_) {
     const int tnx = fwd ? f0 + j : L - j - 2;              // the frame of the next hook's row
     const bool want = fwd ? (tnx >= xMa - 1 && tnx < xe) : (tnx <= xMb && tnx >= xs);
