@@ -173,8 +173,14 @@ def kernel_rooflines(w, dev, iters, d2d=True, step_ms=None):
             with open(path) as f:
                 tj = json.load(f)
             base = rec_name.split("<")[0]           # (the lazy recursion's shapes share their counters' kernel name)
-            if tj.get("workload") == cfg.get("name") and tj.get("frames") == frames and base in tj:
+            if tj.get("workload") != cfg.get("name") or tj.get("frames") != frames:
+                continue
+            kn = tj.get("kernels", {}).get(base)    # (round 6: the passes over the whole step, every kernel - tools/step_traffic_json.py)
+            if kn is not None and kn.get("dispatches_per_call"):
+                traffic = int(kn["hbm_bytes_per_call"] / kn["dispatches_per_call"])
+            elif base in tj:
                 traffic = tj[base]["hbm_bytes_per_launch"]
+            if traffic is not None:
                 traffic_source = "profiles/" + os.path.basename(path) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch; not re-measured in this run)"
                 break
         except Exception:

@@ -69,7 +69,7 @@ out["algorithmic_bytes_per_call"] = algo
 out["traffic_over_algorithmic"] = round(total / algo, 3) if algo else None
 if not label.startswith("C3-num") and label not in ("C3", "C3-structured"):
     out["den_call_hbm_bytes"] = total            # (a call of the denominator alone: what bench.py's other_workloads look up)
-elif label == "C3-structured":                   # (a fused step looked up by other_workloads: its denominator's kernels)
+elif label in ("C3", "C3-structured"):           # (a fused step: its denominator's kernels)
     out["den_call_hbm_bytes"] = sum(v["hbm_bytes_per_call"] for k, v in out["kernels"].items() if k.startswith("den_") or k.startswith("zero_words"))
 with open(sys.argv[7], "w") as fo:
     json.dump(out, fo, indent=1)
