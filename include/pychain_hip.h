@@ -133,7 +133,9 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "den_cross"      "1": the recursions of a pdf-by-state plan emit occupancies themselves (calls of the denominator alone with at
  *                    most one workgroup per CU: each direction emits those of its own second half, the occupancy launch handles the
  *                    band around every middle).  Off by default: same results to 3e-7, but measured slower than the streamed
- *                    occupancy launch it replaces (profiles/r06_crossing.txt)
+ *                    occupancy launch it replaces (profiles/r06_crossing.txt).  Each direction waits for rows of
+ *                    the other, so every workgroup of the launch must be resident: not beside other work on the same GPU (a
+ *                    workgroup that waits 20 s for its peer gives up and the call reports `ok` false)
  *   "chain_slices"   the fused loss with a gradient over a batch larger than the chip: "0" one call, "n" n slices; default automatic
  *   "plan_split"     read by pychain_hip_den_plan_build: "0": no state on more than one lane; default: where it gains a
  *                    shorter register-resident loop
