@@ -213,3 +213,26 @@ def test_crossing_after_a_splice_miss_is_the_uncut_crossing(den):
     assert o == o0 and torch.equal(g, g0)
     o1, g1, b1, _ = _call(den, x, L, den_tseg=0)
     assert b1 == 0 and float((g - g1).abs().max()) <= 1e-6 * float(g1.abs().max())
+
+
+def test_crossing_at_full_size_every_workgroup_waits_for_a_peer():
+    """64 sequences of 1500 frames on the C3-sized pdf-by-state graph - the shape the option is for: 128 recursion workgroups (256 in
+    two time segments), each landing rows of a peer from the middle on; against the streamed path on the same input, and the
+    size-independent properties: rows of the gradient sum to the gradient scale, zeros in the padding, the objective bit-identical."""
+    den = syn.make_structured_den_graph()
+    B, T = 64, 1500
+    lens = [T] * 40 + [1500 - 37 * i for i in range(1, 25)]               # 40 full-length sequences, 24 ragged ones down to 612 frames
+    L = torch.tensor(lens)
+    x = syn.make_input(B, T, D, seed=4, device=DEV)
+    for opts in ({"den_tseg": 0}, {"den_tseg": 2}):
+        o, g, bad, tot = _call(den, x, L, den_cross=1, **opts)
+        o0, g0, bad0, tot0 = _call(den, x, L, **opts)
+        assert bad == 0 and bad0 == 0 and o == o0 and int(tot[5]) == 0
+        gm = float(g0.abs().max())
+        err = float((g - g0).abs().max()) / gm
+        record_parity("crossing_full_size_%s" % ("tseg2" if opts["den_tseg"] else "uncut"), grad_vs_streamed_occupancies=err, bound=1e-6)
+        assert err <= 1e-6, err
+        rows = g.sum(dim=2)
+        for b in (0, 39, 40, 63):
+            assert float((rows[b, :lens[b]] - 1.0).abs().max()) <= 2e-5 and (lens[b] == T or float(g[b, lens[b]:].abs().max()) == 0.0)
+        del g, g0
