@@ -83,18 +83,22 @@ struct LzSmall {
 // OTHER direction's row of the frame being emitted).  Arcs are LazyArcsState (32-bit state addresses: no 16-bit limit on the
 // state field); the 16-bit addresses are those of a pdf (nnet-output rows AND accumulator rows: one window of 64 KiB from kXField)
 // and of a landing-row position.
-//   [0, 12K) landing 0   [12K, 24K) landing 1   [24K, 40K) x row 0   [40K, 56K) x row 1   [56K, 72K) accumulator 0   [72K, 88K) accumulator 1
-//   [88K, 112K) state buffer 0: float2[<= 3072]   [112K, 136K) state buffer 1   [136K, 148K) beta's leaky probs   partial sums
-//   then: partial sums, the per-wave sums of a row's products [2][16], the other side's totals [2] and the gradient scale, the table
-//   of a state's further alpha positions (<= PLAN_MAX_EXTRA_A x 8 bytes): 160 912 bytes in all
+//   landing 0 (12K + 64 B of zeros)   landing 1 (12K + 64)   x row 0 (16K)   x row 1   accumulator 0 (16K)   accumulator 1
+//   state buffer 0: float2[<= 3072] (24K)   state buffer 1   beta's leaky probs (12K)   partial sums   the per-wave sums of a row's
+//   products [2][16]   the other side's totals [2], this side's predicted totals [2], the gradient scale   the table of a state's
+//   further alpha positions (<= PLAN_MAX_EXTRA_A x 8 bytes): 161 056 bytes in all
 struct LzCross {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
   static constexpr bool kDma = true;
-  static constexpr uint32_t kLand0 = 0, kLand1 = 12288;
-  static constexpr uint32_t kX0 = 24576, kX1 = 40960, kXField = 24576, kA0 = 57344, kA1 = 73728;
-  static constexpr uint32_t kU0 = 90112, kU1 = 114688, kUField = 90112;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 4096;
-  static constexpr uint32_t kLk = 139264, kRed = kLk + kMaxStates * 4, kXRed = kRed + 2 * 2 * 64 * 4, kOtot = kXRed + 2 * 16 * 4, kExtra = kOtot + 16, kBytes = kExtra + 8 * PLAN_MAX_EXTRA_A;
+  // (64 bytes of zeros behind each landing row: a lane whose position is no state - a group its wave does not own, padding - reads
+  // its "other side's value" there, at offset kZero of either row, and needs no mask)
+  static constexpr uint32_t kZero = kMaxStates * 4, kLand0 = 0, kLand1 = kZero + 64;
+  static constexpr uint32_t kX0 = kLand1 + kZero + 64, kX1 = kX0 + 16384, kXField = kX0, kA0 = kX1 + 16384, kA1 = kA0 + 16384;
+  static constexpr uint32_t kU0 = kA1 + 16384, kU1 = kU0 + 8 * kMaxStates, kUField = kU0;
+  static constexpr uint32_t kLk = kU1 + 8 * kMaxStates, kRed = kLk + kMaxStates * 4, kXRed = kRed + 2 * 2 * 64 * 4;
+  // [2] the other side's totals, [2] this side's predicted totals (by step parity), the gradient scale x 2^-30
+  static constexpr uint32_t kOtot = kXRed + 2 * 16 * 4, kPred = kOtot + 8, kScale = kOtot + 16, kExtra = kOtot + 32, kBytes = kExtra + 8 * PLAN_MAX_EXTRA_A;
 };
 static_assert(LzCross::kBytes <= 160u * 1024u && LzCross::kA1 - LzCross::kXField <= 65535u && LzCross::kXField + 4u * (LzCross::kMaxPdfs - 1) <= 65535u &&
               LzCross::kLand1 + 4u * (LzCross::kMaxStates - 1) <= 65535u && LzCross::kU1 - LzCross::kUField <= 65535u, "ds offset fields are 16 bits");
@@ -718,28 +722,37 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   const bool xon = XF && a.xf != 0 && (xe - xs >= 4 * kCrossBand + 8);
   const int xMa = ((xs + xe) >> 1) + kCrossBand, xMb = ((xs + xe) >> 1) - kCrossBand;
   uint32_t oad01 = 0u, oad23 = 0u;                       // landing-row addresses of this lane's rows (the state's position on the other side)
-  bool xf_pending = false;                               // the previous hook emitted: its accumulator row is flushed by the next one
-  int xf_pending_frame = 0;
-  float xf_gpred_prev = 1.f;                             // ... the total it PREDICTED for its frame (the row is normalised by the measured one)
-  XBuf xf_obuf = sbuf, xf_gbuf = sbuf;
+  XBuf xf_obuf = sbuf;
+  float* xf_grad = nullptr;
   const float* xf_ototv = nullptr;
   int32_t* xf_my = nullptr; const int32_t* xf_peer = nullptr;
-  uint32_t xf_live = 0u; int xf_nextra = 0;
+  int xf_nextra = 0;
   int xf_peer_need = 0;                                  // the peer's reported steps that make the FIRST row this side lands complete
-  uint32_t* const xred = reinterpret_cast<uint32_t*>(smem_raw + (XF ? LzCross::kXRed : 0u));   // [2][16] per-wave sums of a hook's products
+  uint32_t* const xred = reinterpret_cast<uint32_t*>(smem_raw + (XF ? LzCross::kXRed : 0u));   // [2][16] per-wave sums of a row's products
   if constexpr (XF) {
+    // (a position that is no state - a group this wave does not own, a beta position past the graph's states, whose "row" is the
+    // leaky constant c(t) - reads the zeros behind the landing row: its product vanishes without a mask)
     const int32_t* perm = reinterpret_cast<const int32_t*>(plan + (fwd ? hd->off_a2b : hd->off_b2a));
     uint32_t oa[4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) oa[g] = 4u * (uint32_t)((g < MG && g < groups.ngroups) ? perm[gbase[g] + lane] : 0);
+    for (int g = 0; g < 4; g++)
+      oa[g] = (g < MG && g < groups.ngroups && (fwd || gbase[g] + lane < hd->graph_states)) ? 4u * (uint32_t)perm[gbase[g] + lane] : LzCross::kZero;
     oad01 = oa[0] | (oa[1] << 16); oad23 = oa[2] | (oa[3] << 16);
     asm volatile("" : "+v"(oad01), "+v"(oad23));
-    // (gradient scale x 2^-30, fixed point -> gradient: kept in LDS and read with the tail's other operands - a register held for 1500 frames is one spilled)
-    if (tid == 0) *reinterpret_cast<float*>(smem_raw + LzCross::kOtot + 8) = (a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale) * (1.0f / 1073741824.0f);
+    if (tid < 32) {
+      *reinterpret_cast<uint32_t*>(smem_raw + LzCross::kLand0 + LzCross::kZero + 4 * (tid & 15) + (tid >> 4) * (LzCross::kLand1 - LzCross::kLand0)) = 0u;
+      xred[tid] = 0u;
+    }
+    // (gradient scale x 2^-30, fixed point -> gradient: kept in LDS and read with the tail's other operands - a register held for
+    // 1500 frames is one spilled)
+    if (tid == 0) {
+      *reinterpret_cast<float*>(smem_raw + LzCross::kScale) = (a.grad_scale_dev ? a.grad_scale * *a.grad_scale_dev : a.grad_scale) * (1.0f / 1073741824.0f);
+      *reinterpret_cast<float*>(smem_raw + LzCross::kPred) = 1.f; *reinterpret_cast<float*>(smem_raw + LzCross::kPred + 4) = 1.f;
+    }
     // alpha lands beta rows (row r of beta_store), beta lands alpha-store rows (index t holds a(t+1,.): DenArgs::sg)
     xf_obuf = fwd ? make_xbuf(a.beta_store + (size_t)b * (a.T + 1) * Hp, (size_t)(a.T + 1) * Hp * sizeof(float))
                   : make_xbuf(a.alpha_store + (size_t)b * a.T * Hp, (size_t)a.T * Hp * sizeof(float));
-    xf_gbuf = make_xbuf(a.grad + (size_t)b * a.T * D, (size_t)a.T * D * sizeof(float));
+    xf_grad = a.grad + (size_t)b * a.T * D;
     xf_ototv = (fwd ? a.tot_b : a.tot_a) + (size_t)b * (a.T + 2);
     xf_my = a.xprog + ((size_t)(fwd ? 0 : 1) * a.B + b) * kExMaxQ + seg;
     xf_peer = a.xprog + ((size_t)(fwd ? 1 : 0) * a.B + b) * kExMaxQ + seg;
@@ -752,11 +765,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       xf_peer_need = xMb - f0a + 2;
     }
     for (int i = tid; i < 2 * (int)LzCross::kMaxPdfs; i += NT) *reinterpret_cast<uint32_t*>(smem_raw + LzCross::kA0 + 4 * i) = 0u;
-    // what the hooks would otherwise fetch from the plan frame after frame (a load from memory is waited for with every row in
-    // flight): which of this lane's beta positions are states (past them: padding, whose "row" is the leaky constant c(t)); and
-    // the table of a state's further ALPHA positions {8 x beta position | 4 x alpha position << 16, 4 x pdf}, one per thread
-#pragma unroll
-    for (int g = 0; g < MG; g++) if (g < groups.ngroups && (fwd || gbase[g] + lane < hd->graph_states)) xf_live |= 1u << g;
+    // the table of a state's further ALPHA positions {8 x beta position | 4 x alpha position << 16, 4 x pdf}, one per thread (read
+    // from the plan frame after frame, a load from memory would be waited for with every row in flight)
     if constexpr (!fwd) {
       const int32_t* ex = reinterpret_cast<const int32_t*>(plan + hd->off_extra_a);
       const int32_t* pdf_b = reinterpret_cast<const int32_t*>(plan + hd->off_pdf_b);
@@ -766,105 +776,108 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
         *reinterpret_cast<uint2*>(smem_raw + LzCross::kExtra + 8 * tid) = make_uint2(8u * (uint32_t)pb | (4u * (uint32_t)pa) << 16, 4u * (uint32_t)pdf_b[pb]);
       }
     }
-    if (tid < 32) xred[tid] = 0u;
   }
-  // One row's share of the crossing, run in the TAIL of a step - behind the arc phase, where the registers of the gathers are free
-  // and the LDS pipe is no longer queued up by sixteen waves' gathers (in the hook behind the first gathers every dependent LDS
-  // round trip of this chain cost 300+ cycles: profiles/r06_crossing.txt).  The row is the one the step's hook completed (it sits in
-  // the buffer the step gathered from); everything is read first, in one round trip:
-  //   * the row, the other side's row of the same states (landed a step ahead) and the other side's total of it;
-  //   * the per-wave sums of the PREVIOUS row's products (its measured total G') and that row's accumulators, which leave
-  //     for the gradient normalised by the measured total (they were scaled by a PREDICTED one:
-  //     G'(t) = G'(t -+ 1) x the other side's total of row t + 1 / this side's total of the neighbouring row - the invariant
-  //     den_finish_kernel checks, solved for the next frame);
-  // then this row's products go into the accumulator row of their pdfs in fixed point (ds_add_u32: 2^30 / G'_pred).
   // (the add itself: written out, because the compiler puts a wait for EVERY memory operation in flight - the row stores of this
   // step's hook among them - in front of an LDS atomic that follows an LDS-direct load it cannot tell apart from it)
   auto xf_add = [&](uint32_t addr, uint32_t val) { asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(val) : "memory"); };
-  // The accumulator row the previous step's tail filled leaves for the gradient in the HOOK of the next step: early in the step, so
-  // that its store is acknowledged long before the barrier at the step's end waits for this wave's stores (in the tail itself the
-  // barrier waited a memory round trip for it, every emitting frame).  Read first (xf_flush_read), written at the hook's end.
-  struct XfFlush { u32x4 v; float xr, sc; };
-  auto xf_flush_read = [&](XfFlush& f, int par_prev, int tq_, int lq_) {
-    auto& xf_fv = f.v; auto& xf_fxr = f.xr; auto& xf_fsc = f.sc;
-    xf_fv = u32x4{0u, 0u, 0u, 0u};
-    xf_fxr = __uint_as_float(xred[par_prev * 16 + (lq_ & 15)]);
-    xf_fsc = lds_abs(LzCross::kOtot + 8u);
-    if (tq_ * 4 < D) xf_fv = *(const __attribute__((address_space(3))) u32x4*)((par_prev ? LzCross::kA1 : LzCross::kA0) + 16u * (uint32_t)tq_);
-  };
-  auto xf_flush_write = [&](const XfFlush& f, int par_prev, int tq_, int frame, float gpred) {
-    const u32x4 xf_fv = f.v; const float xf_fxr = f.xr, xf_fsc = f.sc;
-    const float gmeas = dpp_row_sum(xf_fxr);
-    if (tq_ * 4 < D && !(PYCHAIN_XF_EXP & 2)) {
-      const float fs = xf_fsc * gpred * __builtin_amdgcn_rcpf(gmeas);
-      *(__attribute__((address_space(3))) u32x4*)((par_prev ? LzCross::kA1 : LzCross::kA0) + 16u * (uint32_t)tq_) = u32x4{0u, 0u, 0u, 0u};
-      u32x4 o;
-      o.x = __float_as_uint((float)xf_fv.x * fs); o.y = __float_as_uint((float)xf_fv.y * fs);
-      o.z = __float_as_uint((float)xf_fv.z * fs); o.w = __float_as_uint((float)xf_fv.w * fs);
-      __builtin_amdgcn_raw_buffer_store_b128(o, xf_gbuf, tq_ * 16, __builtin_amdgcn_readfirstlane(frame * D * 4), 0);
-    }
-    if (a.check && (frame == 0 || a.check_all) && tq_ == 0) den_record_frame_total(a, b, frame, gmeas);
-  };
-  bool xf_do = false; int xf_tfr = 0; float xf_totb = 1.f;   // (what the hook leaves for the tail: the row's frame, this side's total of the row before)
+  // which frames a direction emits; the frame before its first one is a dry run (its products are only summed: the first emitted
+  // frame's scale needs the measured total of its neighbour)
+  auto xf_emits = [&](int tfr) { return fwd ? (tfr >= xMa && tfr < xe) : (tfr < xMb && tfr >= xs); };
+  // One row's share of the crossing, run in the TAIL of a step - behind the arc phase, where the registers of the gathers are free
+  // and the LDS pipe is no longer queued up by sixteen waves' gathers (in the hook behind the first gathers every dependent LDS
+  // round trip of this chain cost 300+ cycles: profiles/r06_crossing.txt).  `tfr`: the frame of the row the step's hook completed
+  // (it sits in the buffer the step gathered from); everything is read first, in one round trip:
+  //   * the row, the other side's row of the same states (landed a step ahead) and the other side's total of it;
+  //   * the per-wave sums of the PREVIOUS row's products (its measured total G'), the total PREDICTED for it, and - if it was
+  //     emitted - its accumulators, which leave for the gradient normalised by the measured total:
+  //     G'(t) = G'(t -+ 1) x the other side's total of row t + 1 / this side's total of the neighbouring row - the invariant
+  //     den_finish_kernel checks, solved for the next frame;
+  // then this row's products go into the accumulator row of their pdfs in fixed point (ds_add_u32: 2^30 / G'_pred).  The store of
+  // the flush is the tail's last instruction, and the step's barrier does not wait for it.
+  float xf_totb = 1.f;                                   // (what the hook leaves for the tail: this side's total of the row before)
+#ifdef PYCHAIN_PROFILE_PHASES
+  unsigned long long xft[5] = {0, 0, 0, 0, 0};
+#define XF_T(i) do { const unsigned long long t_ = PH_T(); xft[i] += t_ - xt0_; xt0_ = t_; } while (0)
+#define XF_T0() unsigned long long xt0_ = PH_T()
+#else
+#define XF_T(i) (void)0
+#define XF_T0() (void)0
+#endif
   auto xf_row = [&](int par, int tfr, float tot_before, uint32_t ucur, int tq_, int lq_) {
-    const bool emit = fwd ? (tfr >= xMa) : (tfr < xMb && tfr >= xs);
-    const bool any = (emit || (fwd ? (tfr == xMa - 1) : (tfr == xMb))) && !(PYCHAIN_XF_EXP & 8);   // (the frame before the first emitted one: a dry run for its total)
-    if (!any && !xf_pending) return;
+    const bool emit = xf_emits(tfr), dry = fwd ? tfr == xMa - 1 : tfr == xMb;
+    const int tprev = fwd ? tfr - 1 : tfr + 1;           // the row of the step before: emitted => its accumulators leave now
+    const bool flush = xf_emits(tprev) && !(fwd && tprev < f0) ;
+    if (!(emit || dry || flush) || (PYCHAIN_XF_EXP & 8)) return;
+    XF_T0();
     const uint32_t land = par ? LzCross::kLand1 : LzCross::kLand0;
-    const uint32_t acc = par ? LzCross::kA1 : LzCross::kA0;
+    const uint32_t acc = par ? LzCross::kA1 : LzCross::kA0, acc_prev = par ? LzCross::kA0 : LzCross::kA1;
     // (the packed addresses as the tail sees them: opaque, or every address derived from them is formed once before the frame loop
     // and kept - in registers this kernel does not have)
     uint32_t o01 = oad01, o23 = oad23, x01 = xad01, x23 = xad23;
     asm volatile("" : "+v"(o01), "+v"(o23), "+v"(x01), "+v"(x23));
-    auto xf_oaddr = [&](int g) { const uint32_t wd = (g & 2) ? o23 : o01; return (g & 1) ? (wd >> 16) : (wd & 0xffffu); };
-    auto xf_xaddr = [&](int g) { const uint32_t wd = (g & 2) ? x23 : x01; return (g & 1) ? (wd >> 16) : (wd & 0xffffu); };
+    auto oaddr = [&](int g) { const uint32_t wd = (g & 2) ? o23 : o01; return (g & 1) ? (wd >> 16) : (wd & 0xffffu); };
+    auto xaddr = [&](int g) { const uint32_t wd = (g & 2) ? x23 : x01; return (g & 1) ? (wd >> 16) : (wd & 0xffffu); };
     lz_v2f pr[MG]; float ld[MG];
 #pragma unroll
-    for (int g = 0; g < MG; g++) pr[g] = lz_ld2(ucur + gbase[g] * 8 + lq_ * 8);          // (gbase = 0 beyond ngroups: masked below)
+    for (int g = 0; g < MG; g++) pr[g] = lz_ld2(ucur + gbase[g] * 8 + lq_ * 8);          // (gbase = 0 beyond ngroups: times zero below)
 #pragma unroll
-    for (int g = 0; g < MG; g++) ld[g] = lds_abs(xf_oaddr(g) + land);
+    for (int g = 0; g < MG; g++) ld[g] = lds_abs(oaddr(g) + land);
+    const float xr = __uint_as_float(xred[(par ^ 1) * 16 + (lq_ & 15)]);
     const float ot = lds_abs(LzCross::kOtot + 4u * (uint32_t)par);
-    uint2 ex = make_uint2(0u, 0u);
+    const float pred_prev = lds_abs(LzCross::kPred + 4u * (uint32_t)(par ^ 1));
+    const float gscale = lds_abs(LzCross::kScale);
+    const bool fl = flush && tq_ * 4 < D && !(PYCHAIN_XF_EXP & 2);
+    u32x4 fv = u32x4{0u, 0u, 0u, 0u};
+    if (fl) fv = *(const __attribute__((address_space(3))) u32x4*)(acc_prev + 16u * (uint32_t)tq_);
+    lz_v2f ex = lz_v2f{0.f, 0.f};
     const bool has_extra = !fwd && tq_ < xf_nextra;          // a state on several ALPHA positions: its beta lane took the first one
-    if (has_extra) { const lz_v2f e2 = lz_ld2(LzCross::kExtra + 8u * (uint32_t)tq_); ex = make_uint2(__float_as_uint(e2.x), __float_as_uint(e2.y)); }
-    XfFlush f;
-    xf_flush_read(f, par ^ 1, tq_, lq_);                     // (the previous row's measured total is needed either way)
-    const float gprev = dpp_row_sum(f.xr);
-    const bool flush = xf_pending;
-    const int flush_frame = xf_pending_frame;
-    const float flush_pred = xf_gpred_prev;
-    xf_pending = emit && any; xf_pending_frame = tfr;
-    if (any) {
+    if (has_extra) ex = lz_ld2(LzCross::kExtra + 8u * (uint32_t)tq_);
+    const float gprev = dpp_row_sum(xr);                     // the previous row's MEASURED total
+    const float rgprev = __builtin_amdgcn_rcpf(gprev);
+    XF_T(0);                                                 /* (operands read, the previous row's total) */
+    if (emit || dry) {
       const float gpred = gprev * ot * __builtin_amdgcn_rcpf(tot_before);
       const float sc = 1073741824.0f * __builtin_amdgcn_rcpf(gpred);
       if (emit && !(gpred > 0.f && sc - sc == 0.f)) bad |= 1;
-      xf_gpred_prev = gpred;
       float gs = 0.f;
 #pragma unroll
       for (int g = 0; g < MG; g++) {
-        const float rowv = fwd ? pr[g].x : __builtin_fmaf(pr[g].x, __builtin_amdgcn_rcpf(pr[g].y), w.sprev);
-        const float pq = ((xf_live >> g) & 1u) ? rowv * ld[g] : 0.f;     // (not a state: a group the wave does not own, a beta padding position)
-        gs += pq;
-        if (emit && !(PYCHAIN_XF_EXP & 1) && ((xf_live >> g) & 1u))
-          xf_add(xf_xaddr(g) + (acc - LzCross::kXField), (uint32_t)__builtin_fmaf(pq, sc, 0.5f));
+        if (g < groups.ngroups) {                            // (uniform: sixty-four adds of zero to ONE address would cost 255 cycles)
+          const float rowv = fwd ? pr[g].x : __builtin_fmaf(pr[g].x, __builtin_amdgcn_rcpf(pr[g].y), w.sprev);
+          const float pq = rowv * ld[g];
+          gs += pq;
+          if (emit && !(PYCHAIN_XF_EXP & 1)) xf_add(xaddr(g) + (acc - LzCross::kXField), (uint32_t)__builtin_fmaf(pq, sc, 0.5f));
+        }
       }
       if constexpr (!fwd) {
-        if (xf_nextra > 0) {                                   // (uniform; a few per plan, one per thread)
+        if (xf_nextra > 0) {                                 // (uniform; a few per plan, one per thread)
           float pq = 0.f;
           if (has_extra) {
-            const lz_v2f pe = lz_ld2(ucur + (ex.x & 0xffffu));
-            pq = __builtin_fmaf(pe.x, __builtin_amdgcn_rcpf(pe.y), w.sprev) * lds_abs(land + (ex.x >> 16));
-            if (emit && !(PYCHAIN_XF_EXP & 1))
-              xf_add(acc + ex.y, (uint32_t)__builtin_fmaf(pq, sc, 0.5f));
+            const uint32_t e0 = __float_as_uint(ex.x), e1 = __float_as_uint(ex.y);
+            const lz_v2f pe = lz_ld2(ucur + (e0 & 0xffffu));
+            pq = __builtin_fmaf(pe.x, __builtin_amdgcn_rcpf(pe.y), w.sprev) * lds_abs(land + (e0 >> 16));
+            if (emit && !(PYCHAIN_XF_EXP & 1)) xf_add(acc + e1, (uint32_t)__builtin_fmaf(pq, sc, 0.5f));
           }
           gs += pq;
         }
       }
+      XF_T(1);                                               /* (products, adds) */
       gs = wave_sum(gs);
       if (lq_ == 0) xred[par * 16 + wave] = __float_as_uint(gs);
+      if (tq_ == 0) *reinterpret_cast<float*>(smem_raw + LzCross::kPred + 4 * par) = gpred;
+      XF_T(2);                                               /* (the row's sum) */
     }
-    // (last: the previous row's accumulators leave for the gradient - nothing of this step touches LDS after this store)
-    if (flush) xf_flush_write(f, par ^ 1, tq_, flush_frame, flush_pred);
+    if (flush) {
+      // (last: the previous row's accumulators leave for the gradient - nothing of this step touches LDS after this store)
+      if (fl) {
+        const float fs = gscale * pred_prev * rgprev;
+        *(__attribute__((address_space(3))) u32x4*)(acc_prev + 16u * (uint32_t)tq_) = u32x4{0u, 0u, 0u, 0u};
+        lz_v4 o = lz_v4{(float)fv.x * fs, (float)fv.y * fs, (float)fv.z * fs, (float)fv.w * fs};
+        *reinterpret_cast<lz_v4*>(xf_grad + (size_t)tprev * D + 4 * tq_) = o;
+      }
+      if (a.check && (tprev == 0 || a.check_all) && tq_ == 0) den_record_frame_total(a, b, tprev, gprev);
+    }
+    XF_T(3);                                                 /* (flush) */
   };
   // what a step lands for the NEXT step's tail: the other side's row of the frame that tail handles (if it emits, or dry-runs)
   auto xf_land = [&](int j, int lq_) {
@@ -1057,7 +1070,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       /* launch) reads - alpha those of the frames below xMa, beta those from xMb on */                     \
       bool xstore = true;                                                                                   \
       if constexpr (XF) { const int tfr = (FWDC) ? f0 + j - 1 : L - j - 1; xstore = !xon || ((FWDC) ? tfr < xMa : tfr >= xMb); } \
-      if constexpr (XF) { xf_do = xon && !((FWDC) && j == 0); xf_tfr = (FWDC) ? f0 + j - 1 : L - j - 1; xf_totb = tot_before; } \
+      if constexpr (XF) xf_totb = tot_before;                /* (the crossing's share of this row: the step's tail) */ \
       LZ_HK(6);                                                                                             \
       _Pragma("unroll") for (int g = 0; g < MG; g++) {                                                      \
         if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1 && !((SG) && (FWDC) && j == 0)) {            \
@@ -1077,6 +1090,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
         LZ_VMWAIT();                                                                                        \
         if constexpr (pre) PYCHAIN_WAIT_VM0();               /* (ready to gather: it only has to have landed before the barrier) */ \
         else if (have_next && dma_finish(lq, (PAR) ? MAP::kX0 : MAP::kX1) && (FWDC)) bad |= 2; \
+        /* (crossing: the row landed for the next tail has no nnet-output row beside it in the last steps - and the step's barrier */ \
+        /* does not wait for loads) */                                                                      \
+        if constexpr (XF) { if (!have_next) PYCHAIN_WAIT_VM0(); }                                           \
       }                                                                                                     \
     };                                                                                                      \
     if constexpr (SG) lazy_tile_sg<R, MAP, (FWDC), UOFF, VOFF, UNEXT, (XF) ? 1 : PYCHAIN_SG_AHEAD>(arcs, groups, w, xad01, xad23, lq, s0, s1, hook_first, hook_late); \
@@ -1100,7 +1116,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* (crossing: the step's last LDS work; its one store to memory is the last instruction before the barrier, and the barrier */ \
     /* is then one that does NOT wait for stores to be acknowledged - __syncthreads() does, a memory round trip per emitting frame) */ \
     if constexpr (XF) {                                                                                     \
-      LZ_HK0(); if (xf_do) xf_row((PAR), xf_tfr, xf_totb, UCUR, tq, lq); LZ_HK(8);                          \
+      LZ_HK0(); if (xon && !((FWDC) && j == 0)) xf_row((PAR), (FWDC) ? f0 + j - 1 : L - j - 1, xf_totb, UCUR, tq, lq); LZ_HK(8); \
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
     } else                                                                                                  \
     __syncthreads();                                         /* every gather of this frame is done; the new vector is complete */ \
@@ -1153,7 +1169,8 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
       }
       xf_row(nsteps & 1, fwd ? f0 + nsteps - 1 : L - nsteps - 1, tot_before_last, ul, tid, lane);
       __syncthreads();                                       // every wave's products are in the accumulator row
-      if (xf_pending) { XfFlush f; xf_flush_read(f, nsteps & 1, tid, lane); xf_flush_write(f, nsteps & 1, tid, xf_pending_frame, xf_gpred_prev); }
+      // (one more pass: a frame outside the direction's range, after an emitted one - its accumulators leave)
+      xf_row((nsteps & 1) ^ 1, fwd ? f0 + nsteps : L - nsteps - 2, 1.f, ul, tid, lane);
       xf_last_done = true;
     }
   }
@@ -1194,6 +1211,7 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const unsigned long long n = (unsigned long long)max(1, nsteps);
     printf("lazy dir %d wave %2d rows %2d steps %d cycles/step: arcs %llu rereads+x %llu rowstore+sums %llu barrier %llu totals %llu vmwait-in-arcs %llu hook: totals %llu rows %llu crossing-tail %llu - %llu\n",
            (int)fwd, wave, groups.nslots, nsteps, lzph[0] / n, lzph[1] / n, lzph[2] / n, lzph[3] / n, lzph[4] / n, lzph[5] / n, lzph[6] / n, lzph[7] / n, lzph[8] / n, lzph[9] / n);
+    if constexpr (XF) printf("xf tail dir %d wave %2d: reads %llu products %llu sum %llu flush %llu\n", (int)fwd, wave, xft[0] / n, xft[1] / n, xft[2] / n, xft[3] / n);
   }
 #endif
 #undef LZ_PH

@@ -21,7 +21,7 @@ def call(**o):
     finally:
         for c in reversed(ctx): c.__exit__()
     return float(out.detach()), xx.grad, int(out.bad_count.sum()), out.totals_all.cpu()
-o1, g1, b1, t1 = call(**opts)
+o1, g1, b1, t1 = call(**dict(dict(den_cross=1), **opts))
 o0, g0, b0, t0 = call(den_cross=0, **opts)
 print("objf", o1, o0, "bad", b1, b0, "totals", t1.tolist()[5:], t0.tolist()[5:])
 gm = float(g0.abs().max())
