@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PYCHAIN_HIP_ABI_VERSION 16
+#define PYCHAIN_HIP_ABI_VERSION 17
 
 /* Element type of the network output [B,T,D] - and of the gradient an entry point writes for it (ABI 14).
  * 2-byte rows are read as they are by the kernels and converted where they land; the gradient is rounded (to nearest even)
@@ -130,6 +130,12 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "den_tburn"      frames a time segment starts outside itself (default 192); see totals[5..7] and pychain_hip_den_tseg_state
  *   "den_sg"         "0": a "pdf by state" plan (every arc entering a state carries one pdf: pychain_hip_den_plan_info, hint bit 27) runs
  *                    the recursions every plan runs instead of their one-gather form (the tests compare the two)
+ *   "den_q"          "1": the lazy recursions keep ONE-WORD state vectors where the plan allows them (every leaky probability
+ *                    positive, one position per state: pychain_hip_den_plan_info, hint bit 19; fp32 rows, uncut sequences, loops of
+ *                    17 .. 32 slot-rows): alpha gathers a / (coef leaky), both directions two ds_read_b32 per arc instead of a
+ *                    ds_read_b64 and a ds_read_b32.  Off by default: a quarter less LDS time per frame, same results to 3e-7 - and
+ *                    measured 6 % slower with rows the recursions clamp / exp themselves, 7 % faster with rows exp'd ahead (the
+ *                    frame is bound by VALU issue: DESIGN.md 3.16, profiles/r06_one_word_states.txt)
  *   "den_cross"      "1": the recursions of a pdf-by-state plan emit occupancies themselves (calls of the denominator alone with at
  *                    most one workgroup per CU: each direction emits those of its own second half, the occupancy launch handles the
  *                    band around every middle).  Off by default: same results to 3e-7, but measured slower than the streamed
@@ -195,8 +201,10 @@ int64_t pychain_hip_den_plan_build(
  * device at call time and is never read back):
  *   info[0] num_states (positions: see "States on several lanes")  info[1] num_transitions  info[2] num_pdfs  info[3] plan bytes, low 31 bits (info[5]: the rest)
  *   info[4] launch hint: slot-rows per wave (= arcs a wave keeps in registers), three
- *           fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-19)
+ *           fields: recursion plans (bits 0-9), occupancy plan for 16 waves (10-18; ABI 17: nine bits)
  *           and for 8 waves (20-27); combine several plans by taking the max of each field
+ *           bit 19: (ABI 17) every state sits on one position of either numbering and every leaky probability is positive: the
+ *                   lazy recursions may keep ONE-WORD state vectors (alpha gathers a / (coef leaky); option "den_q") (AND)
  *           bit 28: a state sits on several positions of the beta numbering: the lazy recursions' NC form; not for
  *                   den_recursion_pair_kernel (OR)
  *           bit 29: the plan also holds its recursion tiles dealt to FOUR waves (small graphs: 256-thread recursion

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PYCHAIN_HIP_LIB") or os.path.join(_HERE, "libpychain_hip.so")  # env: kernel experiments only
-ABI_VERSION = 16
+ABI_VERSION = 17
 TOTALS = 8            # floats of a `totals` buffer (include/pychain_hip.h: PYCHAIN_HIP_TOTALS)
 
 GRAD_LOG, GRAD_LINEAR, GRAD_ACCUM = 0, 1, 2
@@ -107,7 +107,7 @@ def lib():
     return _lib
 
 
-OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg", "den_cross")
+OPTIONS = ("verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16", "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg", "den_cross", "den_q")
 
 _thread_values = threading.local()       # what this thread's overrides currently are (for restoring)
 

@@ -217,10 +217,10 @@ def batch_plans(tensors, num_pdfs, device):
         assert all(h == HINT_GENERAL for h in hints)
         slot_rows = HINT_GENERAL
     else:
-        slot_rows = sum(max((h >> sh) & mask for h in hints) << sh for sh, mask in ((0, 1023), (10, 1023), (20, 255)))
+        slot_rows = sum(max((h >> sh) & mask for h in hints) << sh for sh, mask in ((0, 1023), (10, 511), (20, 255)))
         if any((h >> 28) & 1 for h in hints):      # a state on several beta positions: not for the pair kernel
             slot_rows |= 1 << 28
-        for bit in (29, 30):                       # every plan holds four-wave tiles / fits the lazy recursion (<= 4 groups per wave)
+        for bit in (19, 29, 30):                   # every plan takes one-word state vectors / holds four-wave tiles / fits the lazy recursion (<= 4 groups per wave)
             if all((h >> bit) & 1 for h in hints):
                 slot_rows |= 1 << bit
     if same:

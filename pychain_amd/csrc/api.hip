@@ -29,7 +29,7 @@ typedef std::map<std::string, std::string> OptionTable;
 OptionTable& process_options() { static OptionTable t; return t; }
 OptionTable& thread_options() { static thread_local OptionTable t; return t; }     // "" = unset for this thread
 const char* const kKnownOptions[] = {"verbose", "den_phase_mask", "den_lazy", "den_dma", "den_segments", "den_pair", "gamma16",
-                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg", "den_cross"};
+                                     "debug_corrupt_row", "num_compat", "den_tseg", "den_tburn", "plan_split", "chain_slices", "den_sg", "den_cross", "den_q"};
 bool known_option(const char* name) {
   if (!name) return false;
   for (const char* k : kKnownOptions) if (strcmp(k, name) == 0) return true;
@@ -72,6 +72,7 @@ CallKnobs call_knobs() {
   k.plan_split = option_int("plan_split", -1);
   k.chain_slices = option_int("chain_slices", -1);
   k.den_sg = option_int("den_sg", 1) ? 1 : 0;
+  k.den_q = option_int("den_q", 0) ? 1 : 0;          // (off by default: the frame is bound by VALU issue, not by the LDS time it saves - DESIGN.md 3.16)
   k.den_cross = option_int("den_cross", 0) ? 1 : 0;   // (off by default: measured slower than the streamed occupancy launch - DESIGN.md 3.15)
   std::string v;
   if (option_value("debug_corrupt_row", &v)) {   // "den,b,t,scale" / "num,b,t,scale"
@@ -132,6 +133,7 @@ extern "C" int pychain_hip_den_kernel_names(int resident_slot_rows, int H, int D
   a.H = H; a.Hp = roundup64(H); a.D = D; a.B = B; a.frames_per_block = 32;
   a.plan_stride = (plans_shared & 1) ? 0 : 256;
   a.fused = (plans_shared & 2) ? 1 : 0;                  // (bit 1: the call is a fused loss)
+  a.coef = 1e-5f;                                        // (the usual leaky-HMM coefficient: option den_q asks for one in [1e-8, 1])
   if (resident_slot_rows == PYCHAIN_HIP_HINT_GENERAL) {
     snprintf(buf, buf_bytes, "den_general_recursion_kernel,den_general_gamma_kernel");
     return PYCHAIN_HIP_OK;
@@ -192,9 +194,9 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   if (hd->beta.max_wave_slot_rows > m) m = hd->beta.max_wave_slot_rows;
   int gmm = hd->gamma.max_wave_slot_rows, gm2 = hd->gamma2.max_wave_slot_rows;
   if (m > 1023) m = 1023;
-  if (gmm > 1023) gmm = 1023;
+  if (gmm > 511) gmm = 511;                        // (9 bits since ABI 17: anything beyond the resident row counts means "stream the tail")
   if (gm2 > 1023) gm2 = 1023;
-  // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (10 bits) << 10 | occupancy rows, 8 waves (7 bits) << 20
+  // launch hint: recursion rows (10 bits) | occupancy rows, 16 waves (9 bits) << 10 | occupancy rows, 8 waves (7 bits) << 20
   if (gm2 > 127) gm2 = 127;                        // (7 bits since plan format 14; the two-frame kernel keeps at most 64 rows per wave)
   // bit 29: the plan holds the recursion tiles dealt to FOUR waves (small graphs: den_recursion_lazy_kernel<small>); the
   // recursion field is then the row count of THAT dealing (>= the 16-wave one: a kernel sized by it fits either)
@@ -208,6 +210,14 @@ extern "C" int pychain_hip_den_plan_info(const void* host_blob, size_t blob_byte
   // bit 28: a state sits on several positions of the beta numbering (plan.cpp, "states on several lanes"): not for
   // den_recursion_pair_kernel, whose normalise pass gives every position the constant c(t)
   if (hd->n_no_const > 0) info[4] |= 1 << 28;
+  // bit 19: every state sits on ONE position of either numbering and every leaky probability is positive (>= 1e-12): the lazy
+  // recursions' one-word state vectors (den_lazy.inc.h: MAP::kQ - alpha gathers a / cl, which needs cl > 0 everywhere)
+  if (hd->n_no_const == 0 && hd->H == hd->graph_states) {
+    const float* lk = (const float*)((const char*)host_blob + hd->off_leaky_a);
+    bool pos = true;
+    for (int i = 0; i < hd->H; i++) pos = pos && lk[i] >= 1e-12f && lk[i] <= 1e12f;
+    if (pos) info[4] |= 1 << 19;
+  }
   // bit 27: "pdf by state" - every arc entering a state carries one pdf: the lazy recursions' one-gather form (den_lazy.inc.h: SG)
   if (hd->flags & PLAN_FLAG_PDF_BY_STATE) info[4] |= 1 << 27;
   info[6] = hd->graph_states;                     // the graph's states (info[0]: positions of the longer side = what calls pass as num_states)

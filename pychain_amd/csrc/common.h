@@ -31,6 +31,7 @@ struct CallKnobs {
   int den_tseg;               // time segments per (sequence, direction) of the lazy recursions: -1 automatic, 0 / 1 never, 2 or 4 wherever the shape allows
   int den_tburn;              // frames a segment starts outside itself (its burn-in); default 192
   int den_sg;                 // 0: never the one-gather form of the lazy recursions for "pdf by state" plans (den_lazy.inc.h: SG); default 1
+  int den_q;                  // 0: never the one-word state vectors of the lazy recursions (den_lazy.inc.h: MAP::kQ; launch hint bit 19); default 0
   int den_cross;              // 0: the recursions of a pdf-by-state plan never emit occupancies themselves (den_lazy.inc.h: XF); default 1
   int chain_slices;           // the fused loss over a batch larger than the chip: -1 automatic, 0 / 1 one call, n >= 2 that many slices (api.hip)
   int plan_split;             // pychain_hip_den_plan_build: 0 = no state on more than one lane (plans of one batch with a stride must have

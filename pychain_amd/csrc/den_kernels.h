@@ -180,6 +180,7 @@ bool den_pair_eligible(const DenArgs& a, int resident_slot_rows);
 bool den_sg_eligible(const DenArgs& a, int resident_slot_rows);
 // ... with the crossing (DenArgs::xf); the band half-width it uses
 bool den_xf_eligible(const DenArgs& a, int resident_slot_rows);
+bool den_q_eligible(const DenArgs& a, int resident_slot_rows);    // one-word state vectors (option den_q; den_lazy.inc.h: MAP::kQ)
 int den_xf_band();
 // is frame t of a length-L sequence one the occupancy launch of a crossing call evaluates (DenArgs::xf)?  `cut`: the call's rows
 // come from its time segments (else from the uncut recursion - also after a splice miss)

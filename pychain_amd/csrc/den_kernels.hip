@@ -992,7 +992,7 @@ hipError_t launch_gamma_stream(const DenArgs& a, int r, size_t lds, dim3 grid, h
 inline bool gamma_stream_shape_ok(const DenArgs& a, int hint, int gamma_max_groups) {
   if (a.plan_stride != 0) return false;
   if (gamma2_eligible(a, (hint >> 20) & 127, gamma_max_groups)) return true;
-  const int r = pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
+  const int r = pick_r(a, (hint >> 10) & 511, 2 * a.Hp);
   return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && r > 0;
 }
 
@@ -1012,7 +1012,7 @@ hipError_t launch_r(const DenArgs& a, int hint, size_t lds_rec, size_t lds_gam, 
       if (stream) return a.D <= 4 * kNT2 ? launch_gamma2<1, true>(a, r2, lds2, grid, st) : launch_gamma2<2, true>(a, r2, lds2, grid, st);
       return a.D <= 4 * kNT2 ? launch_gamma2<1, false>(a, r2, lds2, grid, st) : launch_gamma2<2, false>(a, r2, lds2, grid, st);
     }
-    const int r = a.sg ? PLAN_RESIDENT_0 : pick_r(a, (hint >> 10) & 1023, 2 * a.Hp);
+    const int r = a.sg ? PLAN_RESIDENT_0 : pick_r(a, (hint >> 10) & 511, 2 * a.Hp);
     if (stream) {
       if constexpr (VEC == 4 && XCH > 0) return launch_gamma_stream<XCH>(a, r, lds_gam, grid, st);
       else return hipErrorInvalidValue;                 // (den_stream_eligible said no)
@@ -1223,8 +1223,8 @@ bool den_stream_eligible(const DenArgs& a, int gamma_max_groups, int resident_sl
   return (a.lazy || a.pair) && gamma_stream_shape_ok(a, resident_slot_rows, gamma_max_groups);
 }
 const char* den_recursion_kernel_name(const DenArgs& a, int resident_slot_rows) {
-  (void)resident_slot_rows;
   if (a.pair) return "den_recursion_pair_kernel";
+  if (a.lazy && a.shape == kShapeDma && !a.sg && den_q_eligible(a, resident_slot_rows)) return "den_recursion_lazy_kernel<dma; one-word states>";
   if (a.lazy) return a.shape == kShapeSmall ? "den_recursion_lazy_kernel<small>" : (a.shape == kShapeDma ? (a.sg ? (a.xf ? "den_recursion_lazy_kernel<dma; one gather per arc; crossing>" : "den_recursion_lazy_kernel<dma; one gather per arc>") : "den_recursion_lazy_kernel<dma>") : "den_recursion_lazy_kernel");
   return "den_recursion_kernel";
 }
@@ -1239,7 +1239,7 @@ bool den_uses_gamma2(const DenArgs& a, int gamma_max_groups, int resident_slot_r
 // 2-byte network output and gradient (DenArgs::x_half): the two-frame kernel, or the one-frame kernel in its float4-chunk forms
 bool den_occupancy_half_ok(const DenArgs& a, int gamma_max_groups, int resident_slot_rows) {
   if (gamma2_eligible(a, (resident_slot_rows >> 20) & 127, gamma_max_groups)) return true;
-  return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && pick_r(a, (resident_slot_rows >> 10) & 1023, 2 * a.Hp) > 0;
+  return a.D % 4 == 0 && a.D <= 4 * 4 * kNT && pick_r(a, (resident_slot_rows >> 10) & 511, 2 * a.Hp) > 0;
 }
 
 hipError_t launch_den(const DenArgs& a, int gamma_max_groups, int resident_slot_rows, hipStream_t st,

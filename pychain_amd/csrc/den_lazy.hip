@@ -53,9 +53,18 @@ template <int R, bool TS>
 hipError_t launch_lz_xf(const DenArgs& a, const dim3 grid, hipStream_t st) {
   return launch_one(den_recursion_lazy_kernel<R, LzCross, kLzRowsF32, TS, false, true, true>, a, grid, LzCross::kBytes, st, LzCross::kWaves * 64);
 }
+// (launch hint bit 19: one position per state on both sides, every leaky probability positive - the one-word state vectors of
+// den_lazy.inc.h: MAP::kQ.  Instantiated for the 32-row loop of the 16-wave map with LDS-direct fp32 rows, uncut sequences; coef >= 1e-8
+// keeps 1 / (coef leaky) <= 1e20.  Option den_q, off by default: measured, it does not pay - DESIGN.md 3.16.)
+inline bool hint_one_word(int hint) { return hint >= 0 && ((hint >> 19) & 1); }
+inline bool q_shape_ok(const DenArgs& a, int hint) {
+  const int rows = hint & 1023;
+  return hint_one_word(hint) && !hint_no_const(hint) && rows > 16 && rows <= 32 && a.knobs.den_q != 0 && a.coef >= 1e-8f && a.coef <= 1.f &&
+         a.tseg <= 1 && !a.x_half;
+}
 template <int R, typename M, int XM, bool TS>
 hipError_t launch_lz(const DenArgs& a, const dim3 grid, hipStream_t st, bool nc) {
-  if (nc) return launch_one(den_recursion_lazy_kernel<R, M, XM, TS, true>, a, grid, M::kBytes, st, M::kWaves * 64);
+  if constexpr (!M::kQ) { if (nc) return launch_one(den_recursion_lazy_kernel<R, M, XM, TS, true>, a, grid, M::kBytes, st, M::kWaves * 64); }
   return launch_one(den_recursion_lazy_kernel<R, M, XM, TS, false>, a, grid, M::kBytes, st, M::kWaves * 64);
 }
 hipError_t launch_lazy(const DenArgs& a, int hint, hipStream_t st) {
@@ -96,6 +105,12 @@ hipError_t launch_dma(const DenArgs& a, int hint, hipStream_t st) {
       return a.tseg > 1 ? launch_lz_xf<32, true>(a, grid, st) : launch_lz_xf<32, false>(a, grid, st);   // (xf_shape_ok: rows <= 32)
     }
     return a.tseg > 1 ? launch_lz_sg<32, LzNarrowDma, true>(a, grid, st) : launch_lz_sg<32, LzNarrowDma, false>(a, grid, st);
+  }
+  if (lazy_shape_ok(a, hint, true) && q_shape_ok(a, hint)) {         // one-word state vectors (rows <= 32: the 32-row loop)
+    const dim3 grid(2 * a.B);                             // (q_shape_ok: fp32 rows, the sequence in one piece)
+    typedef LzNarrowDmaQ M;
+    if (a.use_ex) return launch_lz<32, M, kLzRowsPre, false>(a, grid, st, false);
+    return launch_lz<32, M, kLzRowsF32, false>(a, grid, st, false);
   }
   if (lazy_shape_ok(a, hint, true)) return launch_dma_x<LzNarrowDma>(a, hint & 1023, st, hint_no_const(hint));
   return launch_dma_x<LzDma>(a, hint & 1023, st, hint_no_const(hint));
@@ -153,6 +168,9 @@ bool den_dma_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_sh
 bool den_pair_eligible(const DenArgs& a, int resident_slot_rows) { return pair_shape_ok(a, resident_slot_rows); }
 bool den_sg_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) && sg_shape_ok(a, resident_slot_rows); }
 bool den_xf_eligible(const DenArgs& a, int resident_slot_rows) { return lazy_shape_ok(a, resident_slot_rows, true) && xf_shape_ok(a, resident_slot_rows); }
+bool den_q_eligible(const DenArgs& a, int resident_slot_rows) {
+  return lazy_shape_ok(a, resident_slot_rows, true) && !sg_shape_ok(a, resident_slot_rows) && q_shape_ok(a, resident_slot_rows);
+}
 int den_xf_band() { return kCrossBand; }
 
 // the recursion launch of a call whose DenArgs say pair or lazy (launch_den)

@@ -45,20 +45,32 @@ struct LzNarrow {
   //   [64K, 80K)  nnet-output buffer 0 (exp'd row)      [80K, 96K)  nnet-output buffer 1
   //   [96K, ...)  partial sums, beta's leaky probs
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 1;
-  static constexpr bool kDma = false;
+  static constexpr bool kDma = false, kQ = false;
   static constexpr uint32_t kU0 = 0, kU1 = 32768, kX0 = 65536, kX1 = 81920, kUField = 0, kXField = 49152;
   static constexpr uint32_t kRed = 98304, kLk = kRed + 2 * 2 * 64 * 4, kMaxStates = 4096, kMaxPdfs = 4096;
   static constexpr uint32_t kBytes = kLk + kMaxStates * 4;
 };
 // the same map with the nnet-output rows brought in by LDS-direct loads (lazy_recursion: kDma): the default of C1-C3
 struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static constexpr int kXch = 0; };
+// ... and with ONE-WORD state vectors (template parameter MAP::kQ, "Q" below; plans whose leaky probabilities are all positive and
+// whose states sit on one position each - launch hint bit 19).  The second word of the float2 {a, cl} / {b, 1} is a constant of the
+// STATE, so it can leave the gathered vector:
+//   alpha:  gather a^(i) = a(i) / cl(i) and keep q_k = p_k cl(src_k) in the arc's register instead of p_k:
+//           sum_k w_k a(src_k) = sum_k q_k x_k a^(src_k),   sum_k w_k cl(src_k) = sum_k q_k x_k  - no operand at all;
+//   beta:   gather b(i); the second sum is sum_k p_k x_k.
+// Per arc: TWO ds_read_b32 (state, nnet output) instead of a ds_read_b64 and a ds_read_b32 - a third less LDS time per gather
+// pair - and the same 2.5 VALU (per pair of rows: 2 unpacks, v_pk_mul q x, v_pk_fma into {sum1 of row 2i, sum1 of row 2i+1},
+// v_pk_add into {sum2, sum2}); a group end writes a^(j) = a(j) / cl(j) (1 / cl from LDS, requested a group ahead like beta's
+// leaky probability), the row that leaves for HBM is cl (a^ + tot) = a + tot cl.  Same LDS map; the state buffers use their first
+// 16 KiB, alpha keeps cl(.) in the upper half of buffer 0 and 1 / cl(.) where beta keeps its leaky probabilities.
+struct LzNarrowDmaQ : LzNarrowDma { static constexpr bool kQ = true; static constexpr uint32_t kCl = kU0 + 16384; };
 // 16 waves x 128 VGPRs AND nnet-output rows of up to 9216 pdfs (C4): the rows never pass through registers.  Every wave
 // requests its 1 KiB chunks of the NEXT step's raw row with `buffer_load_dwordx4 ... lds` (lane l's 16 bytes land at
 // chunk base + 16 l: tools/ubench/ldsdma.hip) at the start of a frame, straight into the buffer the next frame gathers
 // from, and clamps / exp's its own chunks IN PLACE at the end of the frame.
 struct LzDma {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
-  static constexpr bool kDma = true;
+  static constexpr bool kDma = true, kQ = false;
   static constexpr uint32_t kX0 = 0, kX1 = 36864, kU0 = 73728, kU1 = 98304, kUField = 32776, kXField = 0;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 9216;
   static constexpr uint32_t kLk = 122880, kRed = kLk + kMaxStates * 4, kBytes = kRed + 2 * 2 * 64 * 4;
@@ -73,7 +85,7 @@ template <typename MAP> constexpr bool lz_map_ok() {
 //   [48K, ...) partial sums, beta's leaky probs
 struct LzSmall {
   static constexpr int kWaves = 4, kMaxGroups = 4, kXch = 0;
-  static constexpr bool kDma = true;
+  static constexpr bool kDma = true, kQ = false;
   static constexpr uint32_t kU0 = 0, kU1 = 8192, kX0 = 16384, kX1 = 32768, kUField = 0, kXField = 16384;
   static constexpr uint32_t kMaxStates = 1024, kMaxPdfs = 4096;
   static constexpr uint32_t kRed = 49152, kLk = kRed + 2 * 2 * 64 * 4, kBytes = kLk + kMaxStates * 4;
@@ -89,7 +101,7 @@ struct LzSmall {
 //   further alpha positions (<= PLAN_MAX_EXTRA_A x 8 bytes): 161 056 bytes in all
 struct LzCross {
   static constexpr int kWaves = 16, kMaxGroups = 4, kXch = 0;
-  static constexpr bool kDma = true;
+  static constexpr bool kDma = true, kQ = false;
   static constexpr uint32_t kMaxStates = 3072, kMaxPdfs = 4096;
   // (64 bytes of zeros behind each landing row: a lane whose position is no state - a group its wave does not own, padding - reads
   // its "other side's value" there, at offset kZero of either row, and needs no mask)
@@ -105,6 +117,7 @@ static_assert(LzCross::kBytes <= 160u * 1024u && LzCross::kA1 - LzCross::kXField
 constexpr int kCrossBand = 24;     // frames either side of a segment's middle that stay with the occupancy launch (DenArgs::xf)
 static_assert(lz_map_ok<LzNarrow>() && lz_map_ok<LzDma>() && lz_map_ok<LzSmall>(), "ds_read offset fields are 16 bits");
 constexpr uint32_t kLzBytes = LzNarrow::kBytes;
+template <typename MAP, bool Q> constexpr uint32_t lz_cl_of() { if constexpr (Q) return MAP::kCl; else return 0u; }
 
 typedef float lz_v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const lz_v2f lz_lds_cv2f;
@@ -121,6 +134,15 @@ __device__ __forceinline__ void lz_st1(uint32_t byte_addr, float v) { *(lz_lds_f
 typedef __attribute__((address_space(3))) void lz_lds_void;
 #ifndef PYCHAIN_LATE_BACK
 #define PYCHAIN_LATE_BACK 2                            /* the late hook of lazy_tile runs this many chunks before the end of the arc phase */
+#endif
+#ifndef PYCHAIN_Q_REDO
+#define PYCHAIN_Q_REDO 1                                /* group ends of the one-word form: 1 row by row, 2 pair by pair (packed) */
+#endif
+#ifndef PYCHAIN_Q_ALPHA
+#define PYCHAIN_Q_ALPHA 1                               /* 0: one-word state vectors in the beta recursions only */
+#endif
+#ifndef PYCHAIN_Q_ASMLK
+#define PYCHAIN_Q_ASMLK 0                               /* the group ends' LDS operand requested with an instruction the compiler does not count */
 #endif
 #ifndef PYCHAIN_XF_EXP
 #define PYCHAIN_XF_EXP 0                               /* timing experiments on the crossing (WRONG RESULTS): 1 no adds, 2 no flush, 4 no landing rows, 8 no emission, 16 no totals */
@@ -143,7 +165,13 @@ __device__ __forceinline__ void lz_dma_row(XBuf buf, int t, int D, int wave, int
       // a lane that starts inside the row reads its 16 bytes as they are (D % 4 != 0: the last one runs a few floats
       // into the next row or, at the end of the slab, into the zeros of the buffer's range check); one that starts past
       // the row's end re-reads the row's last 16 bytes
-      const int voff = ch * 1024 + lane * 16 < row_bytes ? lane * 16 : max(0, row_bytes - 16 - ch * 1024);
+      // (rows of whole 16-byte pieces: the last piece's offset inside the chunk is uniform, one v_min instead of compare / select)
+      const int last = __builtin_amdgcn_readfirstlane(min(1008, max(0, row_bytes - 16 - ch * 1024)));
+      int voff = min(lane * 16, last);
+      if (__builtin_expect((row_bytes & 15) != 0, 0)) {      // (uniform, rare, and kept a BRANCH: the asm keeps it from becoming selects)
+        asm volatile("" ::: "memory");
+        voff = ch * 1024 + lane * 16 < row_bytes ? lane * 16 : max(0, row_bytes - 16 - ch * 1024);
+      }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(buf, (lz_lds_void*)(xbase + (uint32_t)ch * 1024u), 16, voff,
                                                soff + ch * 1024, 0, AUX);
     }
@@ -169,7 +197,18 @@ __device__ __forceinline__ bool lz_dma_finish(int D, int wave, int lane, uint32_
         const int e = ch * 256 + lane * 4;
         nan = nan || (e < D && q.x != q.x) || (e + 1 < D && q.y != q.y) || (e + 2 < D && q.z != q.z) || (e + 3 < D && q.w != q.w);
       }
+#if PYCHAIN_EXP_OPS == 2
+      if (is_exp == kXExpClamp) {
+        // (clamp_exp element by element, the product with log2 e as two v_pk_mul_f32: the same bits, two VALU instructions less
+        // per wave and frame - each one is ~0.5 % of a frame that sits on its VALU issue)
+        const lz_v2f l2e = lz_v2f{1.44269502162933349609375f, 1.44269502162933349609375f};
+        const lz_v2f t0 = lz_v2f{__builtin_amdgcn_fmed3f(q.x, -30.f, 30.f), __builtin_amdgcn_fmed3f(q.y, -30.f, 30.f)} * l2e;
+        const lz_v2f t1 = lz_v2f{__builtin_amdgcn_fmed3f(q.z, -30.f, 30.f), __builtin_amdgcn_fmed3f(q.w, -30.f, 30.f)} * l2e;
+        q = lz_v4{__builtin_amdgcn_exp2f(t0.x), __builtin_amdgcn_exp2f(t0.y), __builtin_amdgcn_exp2f(t1.x), __builtin_amdgcn_exp2f(t1.y)};
+      }
+#else
       if (is_exp == kXExpClamp) q = lz_v4{clamp_exp(q.x, kXExpClamp), clamp_exp(q.y, kXExpClamp), clamp_exp(q.z, kXExpClamp), clamp_exp(q.w, kXExpClamp)};
+#endif
       *(__attribute__((address_space(3))) lz_v4*)(addr) = q;
     }
   }
@@ -286,6 +325,42 @@ template <typename MAP> struct LazyArcsOf<16, MAP> { typedef LazyArcsSplit<16, M
 template <typename MAP> struct LazyArcsOf<32, MAP> { typedef LazyArcsSplit<32, MAP> type; };
 template <typename MAP> struct LazyArcsOf<24, MAP> { typedef LazyArcsSplit<24, MAP> type; };     // (the four-wave shape: launch_small)
 #endif
+
+// One-word state vectors (MAP::kQ): the split form with a b32 state address; alpha's probabilities are q_k = p_k cl(src_k).
+template <int R, typename MAP>
+struct LazyArcsQ {
+  static_assert(R % 4 == 0 && R <= 32, "2.5 registers per arc fit for loops of up to 32 slot-rows");
+  uint32_t ua[R];               // state (b32) address
+  uint32_t xp[R / 2];           // nnet-output (b32) addresses of rows 2i | 2i + 1 << 16
+  lz_v2f pp[R / 2];
+  // cl_g: alpha - the leaky probabilities in the numbering of the gathered vector (q = p coef leaky(src)); beta: nullptr
+  __device__ __forceinline__ void load(int nslot_rows, const uint2* __restrict__ wave_slots, const float* __restrict__ cl_g, float coef) {
+#pragma unroll
+    for (int s = 0; s < R; s += 2) {
+      uint2 a = make_uint2(0u, 0u), b = make_uint2(0u, 0u);
+      if (s < nslot_rows) a = wave_slots[s * 64];
+      if (s + 1 < nslot_rows) b = wave_slots[(s + 1) * 64];
+      ua[s] = MAP::kUField + ((a.x & 0xffffu) << 2);
+      ua[s + 1] = MAP::kUField + ((b.x & 0xffffu) << 2);
+      xp[s / 2] = (MAP::kXField + ((a.x >> 16) << 2)) | ((MAP::kXField + ((b.x >> 16) << 2)) << 16);
+      float qa = __uint_as_float(a.y), qb = __uint_as_float(b.y);
+      if (cl_g) { qa *= coef * cl_g[a.x & 0xffffu]; qb *= coef * cl_g[b.x & 0xffffu]; }
+      pp[s / 2] = lz_v2f{qa, qb};
+      asm volatile("" : "+v"(ua[s]), "+v"(ua[s + 1]));
+    }
+  }
+  __device__ __forceinline__ void opaque4(int s) { asm volatile("" : "+v"(xp[s / 2]), "+v"(xp[s / 2 + 1])); }
+  // rows s, s + 1 (s even): u = {state word of row s, of row s + 1}
+  template <uint32_t UOFF, uint32_t VOFF>
+  __device__ __forceinline__ void gather2(int s, lz_v2f& u, lz_v2f& v) {
+    u.x = lds_abs(ua[s] + UOFF);
+    u.y = lds_abs(ua[s + 1] + UOFF);
+    v.x = lds_abs((xp[s / 2] & 0xffffu) + VOFF);
+    v.y = lds_abs((xp[s / 2] >> 16) + VOFF);
+  }
+};
+template <int R, typename MAP, bool Q = MAP::kQ> struct LazyArcsFor { typedef typename LazyArcsOf<R, MAP>::type type; };
+template <int R, typename MAP> struct LazyArcsFor<R, MAP, true> { typedef LazyArcsQ<R, MAP> type; };
 
 // "pdf by state" plans (plan_format.h: PLAN_FLAG_PDF_BY_STATE; template parameter SG of lazy_recursion): every arc entering a state
 // carries that state's pdf, so the nnet output leaves the arc loop -
@@ -485,6 +560,114 @@ __device__ __forceinline__ void lazy_tile(LazyArcsSplit<R, MAP>& ar, const Group
   }
 }
 
+// ... and over arcs with one-word states (LazyArcsQ): the sums of a pair of rows live in the two halves of {acc1.x, acc1.y} /
+// {acc2.x, acc2.y} - a row's sums are the halves added up where its group ends
+template <int R, typename MAP, bool FWD, uint32_t UOFF, uint32_t VOFF, uint32_t UNEXT, typename Hook, typename Late>
+__device__ __forceinline__ void lazy_tile(LazyArcsQ<R, MAP>& ar, const GroupRegs& gr, LazyWave& w, int lane, float& s0, float& s1, Hook&& after_first_gathers, Late&& late) {
+  constexpr int kChunk = 4;
+  static_assert(PYCHAIN_CHUNK == 4, "chunk mask of GroupRegs is built for chunks of 4");
+  constexpr int NC = R / kChunk;
+  constexpr int kLateChunk = NC >= 4 ? NC - PYCHAIN_LATE_BACK : NC - 1;
+  uint32_t m_lo = (uint32_t)gr.endmask, cm = gr.chunkmask;
+  asm volatile("" : "+s"(m_lo), "+s"(cm));
+  lz_v2f acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+  lz_v2f ub[2][kChunk / 2];
+  lz_v2f vb[2][kChunk / 2];
+  ar.opaque4(0);
+#pragma unroll
+  for (int k = 0; k < kChunk; k += 2) ar.template gather2<UOFF, VOFF>(k, ub[0][k / 2], vb[0][k / 2]);
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int cb = c & 1;
+    wave_priority_by_progress<NC>(c);
+    if (c + 1 < NC) {
+      ar.opaque4((c + 1) * kChunk);
+#pragma unroll
+      for (int k = 0; k < kChunk; k += 2)
+        ar.template gather2<UOFF, VOFF>((c + 1) * kChunk + k, ub[cb ^ 1][k / 2], vb[cb ^ 1][k / 2]);
+    }
+    if (c == 0) after_first_gathers();
+    if (c == kLateChunk) late();                       // (the next frame's nnet-output row: lazy_recursion)
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < NC) PYCHAIN_WAIT_LGKM(2 * kChunk); else PYCHAIN_WAIT_LGKM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    lz_v2f wk[kChunk / 2];
+#pragma unroll
+    for (int k = 0; k < kChunk / 2; k++) wk[k] = ar.pp[c * (kChunk / 2) + k] * vb[cb][k];
+    lz_v2f n1 = acc1, n2 = acc2;
+#pragma unroll
+    for (int k = 0; k < kChunk / 2; k++) {
+      n1 = __builtin_elementwise_fma(wk[k], ub[cb][k], n1);
+      n2 = n2 + wk[k];
+    }
+    if (__builtin_expect(((cm >> c) & 1u) != 0u, 0)) {         // a chunk with a group end (about every other chunk of a C3 wave)
+      bool lk_fresh = false;                                   // (a second group end in this chunk: its operand was requested in it)
+      auto group_end = [&](int sidx, float r1, float r2) {
+        const int g = __builtin_popcount(m_lo & ((1u << sidx) - 1u));
+        const uint32_t pos = (uint32_t)(__builtin_amdgcn_readlane(gr.base, g) + lane);
+#if PYCHAIN_Q_ASMLK
+        if (lk_fresh) PYCHAIN_WAIT_LGKM(0);
+#endif
+        float val;
+        if constexpr (FWD) {
+          val = __builtin_fmaf(r1, w.inv, r2);
+          lz_st1(UNEXT + pos * 4u, val * w.lk_next);           // a^(j) = a(j) / cl(j)
+          s0 += val;
+        } else {
+          val = __builtin_fmaf(w.c, r2, r1) * w.inv;
+          lz_st1(UNEXT + pos * 4u, val);
+          s0 += val;
+          s1 = __builtin_fmaf(val, w.lk_next, s1);
+        }
+        // (alpha: 1 / cl, beta: the leaky probability - of the lane's row in the group whose end comes next)
+        const uint32_t lka = MAP::kLk + (uint32_t)(__builtin_amdgcn_readlane(gr.base, (g + 1) & 63) + lane) * 4u;
+#if PYCHAIN_Q_ASMLK
+        // Requested with an instruction the compiler does not count: it would wait for EVERY LDS operation in flight - the next
+        // chunk's gathers - before the next group end reads it, although the wait at the top of that chunk's arithmetic (all but
+        // the gathers issued after this) has long covered it.  (An uncounted operation in the queue only makes the compiler's
+        // own waits wait for one more.)
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w.lk_next) : "v"(lka) : "memory");
+        lk_fresh = true;
+#else
+        w.lk_next = lds_abs(lka);
+        (void)lk_fresh;
+#endif
+      };
+#if PYCHAIN_Q_REDO == 2
+      n1 = acc1; n2 = acc2;
+#pragma unroll
+      for (int kp = 0; kp < kChunk / 2; kp++) {
+        const int se = c * kChunk + 2 * kp;
+        const bool e0 = ((m_lo >> se) & 1u) != 0u, e1 = ((m_lo >> (se + 1)) & 1u) != 0u;   // (uniform)
+        if (!e0) {
+          n1 = __builtin_elementwise_fma(wk[kp], ub[cb][kp], n1);
+          n2 = n2 + wk[kp];
+          if (e1) { group_end(se + 1, n1.x + n1.y, n2.x + n2.y); n1 = lz_v2f{0.f, 0.f}; n2 = lz_v2f{0.f, 0.f}; }
+        } else {
+          group_end(se, __builtin_fmaf(wk[kp].x, ub[cb][kp].x, n1.x + n1.y), n2.x + n2.y + wk[kp].x);
+          const float o1 = wk[kp].y * ub[cb][kp].y, o2 = wk[kp].y;
+          if (e1) { group_end(se + 1, o1, o2); n1 = lz_v2f{0.f, 0.f}; n2 = lz_v2f{0.f, 0.f}; }
+          else { n1 = lz_v2f{0.f, o1}; n2 = lz_v2f{0.f, o2}; }
+        }
+      }
+#else
+      float r1 = acc1.x + acc1.y, r2 = acc2.x + acc2.y;
+#pragma unroll
+      for (int k = 0; k < kChunk; k++) {
+        const int sidx = c * kChunk + k;
+        const float x = (k & 1) ? wk[k / 2].y : wk[k / 2].x;
+        const float u = (k & 1) ? ub[cb][k / 2].y : ub[cb][k / 2].x;
+        r1 = __builtin_fmaf(x, u, r1);
+        r2 += x;
+        if ((m_lo >> sidx) & 1u) { group_end(sidx, r1, r2); r1 = 0.f; r2 = 0.f; }
+      }
+      n1 = lz_v2f{r1, 0.f}; n2 = lz_v2f{r2, 0.f};
+#endif
+    }
+    acc1 = n1; acc2 = n2;
+  }
+}
+
 #ifndef PYCHAIN_SG_AHEAD
 #define PYCHAIN_SG_AHEAD 2                             /* chunks the gathers of the one-gather loop run ahead of its arithmetic (measured: 1, 2, 3 alike) */
 #endif
@@ -594,6 +777,7 @@ template <int R, typename MAP, bool fwd, int XM, bool TS, bool NC, bool SG = fal
 __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw, const int b, const int seg_in = 0) {
   static_assert(!XF || SG, "crossing: pdf-by-state plans");
   constexpr bool PRE = XM == kLzRowsPre, XH = XM == kLzRowsHalf;
+  constexpr bool kQd = MAP::kQ && (PYCHAIN_Q_ALPHA || !fwd);   // one-word state vectors in this direction
   static_assert(!SG || (MAP::kDma && MAP::kMaxPdfs <= 4096 && !NC && !PRE), "the one-gather form: LDS-direct rows, <= 4096 pdfs, no split beta positions");
   constexpr int NW = MAP::kWaves, NT = NW * 64, MG = MAP::kMaxGroups;
   const int tid = threadIdx.x;
@@ -641,8 +825,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
   GroupRegs groups;
   groups.load<R>(we, gtab, lane);
   const uint2* wave_slots = slots + (size_t)__builtin_amdgcn_readfirstlane(we.slot_row_begin) * 64 + lane;
-  typename std::conditional<SG, LazyArcsState<R, MAP>, typename LazyArcsOf<R, MAP>::type>::type arcs;
-  arcs.load(groups.nslots, wave_slots);
+  typename std::conditional<SG, LazyArcsState<R, MAP>, typename LazyArcsFor<R, MAP, kQd>::type>::type arcs;
+  if constexpr (kQd) arcs.load(groups.nslots, wave_slots, fwd ? reinterpret_cast<const float*>(plan + hd->off_leaky_a) : nullptr, a.coef);
+  else arcs.load(groups.nslots, wave_slots);
 
   const float* leaky_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_leaky_a : hd->off_leaky_b));
   const float* start_g = reinterpret_cast<const float*>(plan + (fwd ? hd->off_init_a : hd->off_final_b));
@@ -920,6 +1105,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
         const float xi = i < Hp ? *reinterpret_cast<const float*>(smem_raw + MAP::kX1 + 4 * pdf_b[i]) : 0.f;
         *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{xi * s, xi};
         *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, 0.f};
+      } else if constexpr (kQd) {
+        // one-word states: alpha's vector is a / cl (a position without a state - padding - has cl = 0 and stays 0)
+        const float rcl = (fwd && second > 0.f) ? 1.0f / second : 0.f;
+        *reinterpret_cast<float*>(smem_raw + MAP::kU0 + 4 * i) = fwd ? s * rcl : s;
+        *reinterpret_cast<float*>(smem_raw + MAP::kU1 + 4 * i) = 0.f;
+        if (fwd) { *reinterpret_cast<float*>(smem_raw + MAP::kCl + 4 * i) = second; *reinterpret_cast<float*>(smem_raw + MAP::kLk + 4 * i) = rcl; }
       } else {
         *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU0 + 8 * i) = lz_v2f{s, second};
         *reinterpret_cast<lz_v2f*>(smem_raw + MAP::kU1 + 8 * i) = lz_v2f{0.f, second};
@@ -1043,11 +1234,17 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     /* profiles/r04_n_*; registers: live exactly as long as in the hook before) */                          \
     float pre0 = 0.f, pre1 = 0.f;                                                                           \
     if (j > 0) { pre0 = red[((PAR) ^ 1) * 128 + lq]; if (!(FWDC)) pre1 = red[((PAR) ^ 1) * 128 + 64 + lq]; } \
-    if constexpr (MAP::kMaxPdfs <= 4096 && !(FWDC)) w.lk_next = lds_abs(MAP::kLk + gbase[0] * 4 + lq * 4);          \
+    if constexpr (kQd && PYCHAIN_Q_ASMLK) {                /* (uncounted, like the group ends' own requests: lazy_tile) */ \
+      asm volatile("ds_read_b32 %0, %1" : "=v"(w.lk_next) : "v"((uint32_t)(MAP::kLk + gbase[0] * 4 + lq * 4)) : "memory"); \
+    } else                                                                                                  \
+    if constexpr (MAP::kMaxPdfs <= 4096 && (!(FWDC) || kQd)) w.lk_next = lds_abs(MAP::kLk + gbase[0] * 4 + lq * 4);   \
     constexpr bool kPreRows = MAP::kMaxPdfs <= 4096 && !(XF);       /* (the map of C4 has no registers to spare: the rows are read in the hook) */ \
     lz_v2f prow[MG];                                                                                        \
     if constexpr (kPreRows) {                                                                               \
-      _Pragma("unroll") for (int g = 0; g < MG; g++) prow[g] = lz_ld2(UCUR + gbase[g] * 8 + lq * 8);   /* (gbase = 0 beyond ngroups) */ \
+      _Pragma("unroll") for (int g = 0; g < MG; g++) {       /* (gbase = 0 beyond ngroups) */                \
+        if constexpr (kQd) prow[g] = lz_v2f{lds_abs(UCUR + gbase[g] * 4 + lq * 4), (FWDC) ? lds_abs(lz_cl_of<MAP, kQd>() + gbase[g] * 4 + lq * 4) : 1.f}; \
+        else prow[g] = lz_ld2(UCUR + gbase[g] * 8 + lq * 8);                                                 \
+      }                                                                                                     \
     }                                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     float s0 = 0.f, s1 = 0.f;                                                                               \
@@ -1076,7 +1273,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
         if (g < groups.ngroups && PYCHAIN_EXP_NO_ROWSTORE != 1 && !((SG) && (FWDC) && j == 0)) {            \
           const lz_v2f pr = kPreRows ? prow[g] : lz_ld2(UCUR + gbase[g] * 8 + lq * 8);                      \
           /* (SG beta: the buffer holds x {b, 1}: b + c = pr.x / pr.y + c) */                                  \
-          const float rowv = (SG) ? ((FWDC) ? pr.x : __builtin_fmaf(pr.x, __builtin_amdgcn_rcpf(pr.y), w.sprev)) : __builtin_fmaf(w.sprev, pr.y, pr.x); \
+          /* (one-word states: alpha's buffer holds a / cl, the row is cl (a / cl + tot); beta's b, the row b + c) */ \
+          const float rowv = (SG) ? ((FWDC) ? pr.x : __builtin_fmaf(pr.x, __builtin_amdgcn_rcpf(pr.y), w.sprev)) \
+                                  : (kQd ? ((FWDC) ? pr.y * (pr.x + w.sprev) : pr.x + w.sprev) : __builtin_fmaf(w.sprev, pr.y, pr.x)); \
           if (xstore) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), obuf, lane4,              \
                                                             row_off + gbase[g] * 4, kStoreDeviceScope);     \
         }                                                                                                   \
@@ -1194,7 +1393,9 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const int row_off = (L - nsteps) * Hp * 4;
     for (int g = 0; g < MG; g++)
       if (g < groups.ngroups) {
-        const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * (gbase[g] + lane));
+        lz_v2f u;
+        if constexpr (kQd) u = lz_v2f{*reinterpret_cast<const float*>(smem_raw + ul + 4 * (gbase[g] + lane)), 1.f};
+        else u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * (gbase[g] + lane));
         const float rowv = SG ? __builtin_fmaf(u.x, __builtin_amdgcn_rcpf(u.y), w.sprev) : __builtin_fmaf(w.sprev, u.y, u.x);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowv), sbuf, lane * 4,
                                               row_off + gbase[g] * 4, kStoreDeviceScope);
@@ -1230,8 +1431,12 @@ __device__ __forceinline__ void lazy_recursion(const DenArgs& a, char* smem_raw,
     const uint32_t ul = (nsteps & 1) ? MAP::kU1 : MAP::kU0;
     float f = 0.f;
     for (int i = tid; i < Hp; i += NT) {
-      const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * i);
-      f += __builtin_fmaf(last_tot, u.y, u.x) * fin[i];
+      if constexpr (kQd) {
+        f += *reinterpret_cast<const float*>(smem_raw + lz_cl_of<MAP, kQd>() + 4 * i) * (*reinterpret_cast<const float*>(smem_raw + ul + 4 * i) + last_tot) * fin[i];
+      } else {
+        const lz_v2f u = *reinterpret_cast<const lz_v2f*>(smem_raw + ul + 8 * i);
+        f += __builtin_fmaf(last_tot, u.y, u.x) * fin[i];
+      }
     }
     f = wave_sum(f);
     __syncthreads();

@@ -43,13 +43,28 @@ __device__ __forceinline__ float dpp_row_sum(float v) {
   return v;
 }
 // sum over the wave, same value (an SGPR-derived one) in every lane
+// (the four row sums r0 .. r3 are combined by two more DPP steps - row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3:
+// lane 63 then holds (r3 + r2) + (r1 + r0), bit for bit the (r0 + r1) + (r2 + r3) of four readlanes and three adds - and ONE
+// readlane: 7 VALU instructions instead of 13.  The recursion frames sit on their VALU issue - DESIGN.md 3.16 - and every wave
+// reduces one or two such sums per frame.)
+#ifndef PYCHAIN_WAVE_SUM_BCAST
+#define PYCHAIN_WAVE_SUM_BCAST 1
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
   v = dpp_row_sum(v);
+#if PYCHAIN_WAVE_SUM_BCAST
+  // (written out: from the builtin the compiler makes v_mov 0, v_mov_dpp, v_add of each step; the s_nop is the two wait states a
+  // DPP read needs after the VALU write of its source, which the compiler cannot see into the asm to insert)
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));   // rows 1, 3 += lane 15 of rows 0, 2
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));   // rows 2, 3 += lane 31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#else
   const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
   const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
   const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
   const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
   return (r0 + r1) + (r2 + r3);
+#endif
 }
 
 // exp(c) for |c| <= 30.  PYCHAIN_EXP_OPS == 5 (rounds 1-2): v_exp_f32 on c*log2(e) with the rounding error of that product

@@ -511,3 +511,18 @@ def test_pdf_by_state_plans_carry_the_tables_of_the_crossing():
         further = np.nonzero(back != np.arange(HA))[0]
         assert sorted(further.tolist()) == sorted(ex[:, 1].tolist()) and np.array_equal(a2b[ex[:, 1]], ex[:, 0])
     assert len(ex) > 0                                                      # (the hub graph has such states)
+
+
+def test_hint_bit_19_one_word_state_vectors():
+    """ABI 17: bit 19 of the launch hint = every leaky probability positive and one position per state on either side (the lazy
+    recursions' one-word state vectors, option den_q); the occupancy field beside it has nine bits."""
+    D = 64
+    g = syn.make_den_graph(40, 200, D, seed=3)
+    t = [getattr(g, n) for n in _plan._NAMES]
+    info = _plan.plan_info(_plan.build_plan_blob(*t, D, use_cache=False))
+    assert (info["slot_rows"] >> 19) & 1 and ((info["slot_rows"] >> 10) & 511) > 0
+    lk = g.leaky_probs.clone()
+    lk[7] = 0.0                                                             # a state no leak enters: alpha cannot gather a / (coef leaky)
+    t[_plan._NAMES.index("leaky_probs")] = lk
+    info0 = _plan.plan_info(_plan.build_plan_blob(*t, D, use_cache=False))
+    assert not (info0["slot_rows"] >> 19) & 1
