@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for v in short0 shortA shortB short0; do PYCHAIN_HIP_LIB=$GRAFT_REPO_ROOT/tools/variants/$v.so python tools/q_variants.py 2>&1 | grep -v amdgpu.ids | grep "q=0\|objf"; done > gpurun_out/short_waves.txt 2>&1
-cat gpurun_out/short_waves.txt
+python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -3 > gpurun_out/final_smoke.txt
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/full_gpu_suite.txt
+cat gpurun_out/final_smoke.txt gpurun_out/full_gpu_suite.txt
+timeout 600 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 200 gpurun_out/bench_final.json
