@@ -133,9 +133,10 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "den_q"          "1": the lazy recursions keep ONE-WORD state vectors where the plan allows them (every leaky probability
  *                    positive, one position per state: pychain_hip_den_plan_info, hint bit 19; fp32 rows, uncut sequences, loops of
  *                    17 .. 32 slot-rows): alpha gathers a / (coef leaky), both directions two ds_read_b32 per arc instead of a
- *                    ds_read_b64 and a ds_read_b32.  Off by default: a quarter less LDS time per frame, same results to 3e-7 - and
+ *                    ds_read_b64 and a ds_read_b32.  Off by default: a third fewer LDS bytes per gather pair, same results to 3e-7 - and
  *                    measured 6 % slower with rows the recursions clamp / exp themselves, 7 % faster with rows exp'd ahead (the
- *                    frame is bound by VALU issue: DESIGN.md 3.16, profiles/r06_one_word_states.txt)
+ *                    LDS pipe is as busy as before - a b64 gather occupies it about as long as a b32 one - and the group ends add 12 %
+ *                    VALU: DESIGN.md 3.16, profiles/r06_one_word_states.txt)
  *   "den_cross"      "1": the recursions of a pdf-by-state plan emit occupancies themselves (calls of the denominator alone with at
  *                    most one workgroup per CU: each direction emits those of its own second half, the occupancy launch handles the
  *                    band around every middle).  Off by default: same results to 3e-7, but measured slower than the streamed

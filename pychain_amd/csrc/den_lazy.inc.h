@@ -58,8 +58,9 @@ struct LzNarrowDma : LzNarrow { static constexpr bool kDma = true; static conste
 //   alpha:  gather a^(i) = a(i) / cl(i) and keep q_k = p_k cl(src_k) in the arc's register instead of p_k:
 //           sum_k w_k a(src_k) = sum_k q_k x_k a^(src_k),   sum_k w_k cl(src_k) = sum_k q_k x_k  - no operand at all;
 //   beta:   gather b(i); the second sum is sum_k p_k x_k.
-// Per arc: TWO ds_read_b32 (state, nnet output) instead of a ds_read_b64 and a ds_read_b32 - a third less LDS time per gather
-// pair - and the same 2.5 VALU (per pair of rows: 2 unpacks, v_pk_mul q x, v_pk_fma into {sum1 of row 2i, sum1 of row 2i+1},
+// Per arc: TWO ds_read_b32 (state, nnet output) instead of a ds_read_b64 and a ds_read_b32 - a third fewer LDS bytes per gather
+// pair, which the counters show to buy NO LDS time (SQ_LDS_IDX_ACTIVE unchanged: a b64 gather occupies the pipe about as long as
+// a b32 one; bank conflicts -11 %; VALU +12 % for the group ends: profiles/r06_one_word_states.txt) - and the same 2.5 VALU (per pair of rows: 2 unpacks, v_pk_mul q x, v_pk_fma into {sum1 of row 2i, sum1 of row 2i+1},
 // v_pk_add into {sum2, sum2}); a group end writes a^(j) = a(j) / cl(j) (1 / cl from LDS, requested a group ahead like beta's
 // leaky probability), the row that leaves for HBM is cl (a^ + tot) = a + tot cl.  Same LDS map; the state buffers use their first
 // 16 KiB, alpha keeps cl(.) in the upper half of buffer 0 and 1 / cl(.) where beta keeps its leaky probabilities.
