@@ -23,7 +23,7 @@ struct CallKnobs {
                               // n >= 1: the gated schedule with n time segments (1 = no overlap)
   int gamma16;                // 1: the one-frame occupancy kernel also where the two-frame one fits
   int den_pair;               // -1 automatic, 0 never, 1 wherever the shape allows
-  int den_dma;                // 0: nnet-output rows of the lazy recursions through registers, else by LDS-direct loads; 2: never exp'd ahead (DenArgs::ex)
+  int den_dma;                // 0: nnet-output rows of the lazy recursions through registers, else by LDS-direct loads; 2: never exp'd ahead (DenArgs::ex), 3: exp'd ahead wherever the shape allows
   // debug_corrupt_row = "den|num,b,t,scale": one stored alpha row is scaled before the occupancy pass reads it,
   // so that the reference's 5 % invariant (chain-computation.cc:363-390, chain-log-domain-computation.cc:289-303)
   // can be seen to fire

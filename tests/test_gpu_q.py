@@ -65,7 +65,7 @@ def test_one_word_states_vs_oracle_and_vs_the_two_word_kernels(den, lens, ahead)
     T, B = max(lens), len(lens)
     L = torch.tensor(lens)
     x = syn.make_input(B, T, D, seed=190 + T, device=DEV)
-    dma = {} if ahead else {"den_dma": 2}
+    dma = {"den_dma": 3} if ahead else {"den_dma": 2}
     o, g, bad = _call(den, x, L, den_q=1, den_tseg=0, **dma)
     o0, g0, bad0 = _call(den, x, L, den_q=0, den_tseg=0, **dma)
     ro, rg = orc.chain_function(x.cpu(), L, ChainGraphBatch(den, B), 1e-5, flavour="f64")

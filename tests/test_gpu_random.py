@@ -93,7 +93,7 @@ def test_random_shapes_rows_exp_ahead(seed):
         return float(o.detach()), xx.grad
     o0, g0 = run(den_dma=2)
     for _ in range(3):
-        o, g = run()
+        o, g = run(den_dma=3)
         assert o == o0 and torch.equal(g, g0), (H, K, D, B, T, lengths[:8])
 
 

@@ -133,7 +133,7 @@ def test_rows_exp_ahead_of_the_recursions_are_the_same_rows(name, H, K, D, T, le
     x = syn.make_input(len(lens), T, D, seed=29, device=DEV)
     for extra in ({}, {"den_segments": 3}, {"den_segments": 1}):
         o, g = _den(x, L, den, den_dma=2, **extra)
-        o2, g2 = _den(x, L, den, **extra)
+        o2, g2 = _den(x, L, den, den_dma=3, **extra)       # (3: also where the default no longer exp's ahead - rows of <= 4096 pdfs)
         assert o == o2 and torch.equal(g, g2), extra
     for (b, t, d) in ((0, 0, 5), (0, lens[0] // 2, D - 1), (1, lens[1] - 1, 0), (2, 7, 33)):
         xn = x.clone()
