@@ -114,7 +114,7 @@ int         pychain_hip_den_kernel_names(int resident_slot_rows, int num_states,
  *   "den_dma"        "0": nnet-output rows of the lazy recursion through registers instead of LDS-direct loads; "2": LDS-direct,
  *                    and the recursions clamp / exp every row themselves instead of gathering from rows den_exp_rows_kernel
  *                    exp'd ahead of them on the side stream (bit-identical); "3": rows exp'd ahead wherever the shape allows - by
- *                    default only four-wave workgroups and rows beyond 4096 pdfs take them
+ *                    default only four-wave workgroups take them
  *   "den_segments"   n >= 1: the occupancy pass in n gated time segments (1 = after the recursions, no overlap) instead of
  *                    the streamed persistent launch
  *   "den_pair"       "1": two sequences per recursion workgroup wherever the shape allows, "0": never; default: a fused loss from 25/64

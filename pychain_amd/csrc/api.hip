@@ -454,11 +454,12 @@ int den_time_segments(const DenArgs& a, bool fused) {
 bool den_would_exp_rows_ahead(const DenArgs& a) {
   // (not where the call is cut into time segments: the rows are written from the sequence ends inwards, a segment starts inside;
   // not for the one-gather form of a "pdf by state" plan: its beta recursion reads its rows a frame ahead of the others)
-  // (round 6: NOT for the 16-wave map of rows up to 4096 pdfs any more - since the rows' clamp / exp sits late in the arc phase and
-  // the frame lost a dozen instructions, the recursions with their own rows are the faster ones there: C3 graph, denominator alone,
-  // B = 80: 3.35 -> 3.23 ms, B = 96: 4.0 -> 3.6 ms (profiles/r06_rows_ahead.txt); four-wave workgroups (C2: 0.208 against 0.214 ms) and
-  // rows beyond 4096 pdfs (C4's map: three chunks of row work per wave) keep them; option den_dma = 3: wherever the shape allows)
-  const bool pays = a.shape == kShapeSmall || a.D > 4096 || a.knobs.den_dma == 3;
+  // (round 6: NOT for the 16-wave maps any more - since the rows' clamp / exp sits late in the arc phase and the frame lost a dozen
+  // instructions, the recursions with their own rows are the faster ones in the only calls that still took them, the uncut ones of
+  // 65 .. 96 sequences: C3 graph, denominator alone, B = 80: 3.35 -> 3.23 ms, B = 96: 4.0 -> 3.6 ms; C4's graph and rows, B = 80,
+  // T <= 1000: 4.25 -> 3.25 ms (profiles/r06_rows_ahead.txt); four-wave workgroups keep them (C2: 0.208 against 0.214 ms); option
+  // den_dma = 3: wherever the shape allows)
+  const bool pays = a.shape == kShapeSmall || a.knobs.den_dma == 3;
   return a.lazy && !a.sg && (a.shape == kShapeDma || a.shape == kShapeSmall) && a.knobs.den_dma != 2 && pays && !a.input_is_exp &&
          a.D % 4 == 0 && a.D <= 4 * 5 * 512 && a.T >= 64 && 4 * den_recursion_blocks(a) <= 3 * device_cu_count() &&
          den_time_segments(a, false) == 1;

@@ -99,7 +99,7 @@ def test_two_byte_rows_of_8408_pdfs():
     den = syn.make_den_graph(3000, 30000, 8408, seed=0)
     L = torch.tensor([120, 119, 64])
     x = syn.make_input(3, 120, 8408, seed=3, device=DEV).to(torch.bfloat16)
-    for opts in ({}, {"den_dma": 2}):
+    for opts in ({"den_dma": 3}, {"den_dma": 2}):          # (rows exp'd ahead - no longer a default of this map - and by the recursions)
         ctx = [_lib.option(k, v) for k, v in opts.items()]
         for c in ctx:
             c.__enter__()

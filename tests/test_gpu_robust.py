@@ -351,14 +351,14 @@ def test_recursion_grid_that_fills_the_chip_does_not_wait_for_rows_nobody_can_wr
     x = syn.make_input(B, T, D, seed=5, device=DEV)
     plan = _plan.graph_plan(den, D, torch.device(DEV))
     outs = []
-    for opts in ({"den_pair": 0}, {"den_pair": 0, "den_dma": 2}):
+    for opts in ({"den_pair": 0, "den_dma": 3}, {"den_pair": 0, "den_dma": 2}):     # (3: rows exp'd ahead wherever the shape allows)
         ctx = [_lib.option(k, v) for k, v in opts.items()]
         for c in ctx:
             c.__enter__()
         try:
             assert _lib.den_kernel_names(plan.slot_rows, den.num_states, D, B)[0] == "den_recursion_lazy_kernel<dma>"
             assert _lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, den.num_states, D, B, T, 0) == 0
-            assert _lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, den.num_states, D, 8, T, 0) == (0 if "den_dma" in opts else 1)
+            assert _lib.lib().pychain_hip_den_uses_row_buffer(plan.stride, plan.slot_rows, den.num_states, D, 8, T, 0) == (1 if opts["den_dma"] == 3 else 0)
             objf, grad, bad = native.den_forward_backward(plan, x, L)
             torch.cuda.synchronize()
         finally:

@@ -14,6 +14,12 @@ if name == "C3":
     L = syn.make_lengths(B, 1500, "ragged", seed=2)
     x = syn.make_input(B, 1500, 3456, seed=1, device=dev)
     D = 3456; tag = "C3@B=%d" % B
+elif name == "C4" and len(sys.argv) > 2:                 # C4's graph and rows (8408 pdfs) at another batch size, uncut
+    B = int(sys.argv[2]); cfg = syn.CONFIGS["C4"]
+    den = syn.make_den_graph(cfg["H"], cfg["K"], cfg["D"], seed=0)
+    L = syn.make_lengths(B, 1000, "ragged", seed=2)
+    x = syn.make_input(B, 1000, cfg["D"], seed=1, device=dev)
+    D = cfg["D"]; tag = "C4@B=%d,T<=1000" % B
 else:
     w = syn.make_workload(name, device=dev)
     den, L, x, D, tag = w["den_graph"], w["lengths"], w["x"], w["cfg"]["D"], name
@@ -28,8 +34,8 @@ def med(f, n=9):
     return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
 call = lambda: native.den_forward_backward(plan, x, Ld, 1e-5)
 for rep in range(2):
-    for label, opts in (("rows exp'd ahead (default)", {}), ("rows exp'd by the recursions", {"den_dma": 2}),
-                        ("one-word states, rows exp'd ahead", {"den_q": 1}), ("one-word states, rows by the recursions", {"den_q": 1, "den_dma": 2})):
+    for label, opts in (("default", {}), ("rows exp'd ahead (den_dma = 3)", {"den_dma": 3}), ("rows exp'd by the recursions (den_dma = 2)", {"den_dma": 2}),
+                        ("one-word states, rows exp'd ahead", {"den_q": 1, "den_dma": 3}), ("one-word states, rows by the recursions", {"den_q": 1, "den_dma": 2})):
         ctx = [_lib.option(k, v) for k, v in opts.items()]
         for c in ctx: c.__enter__()
         try:
