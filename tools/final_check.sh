@@ -1,3 +1,6 @@
+#!/bin/bash
+# What the driver runs at round end, in one gpurun call: build() + smoke(), the whole GPU suite, the default bench line (gpurun_out/final_smoke.txt,
+# full_gpu_suite.txt, bench_final.json).  usage: gpurun --timeout 3000 -- bash tools/final_check.sh
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/final_smoke.txt
